@@ -1,0 +1,132 @@
+"""K2/K3/K4: oriented bounding box frame + head-end detection (oracle; test infrastructure).
+
+Restates reference `src/shoulder/humerus/mesh.py:63-125` (`FullObb._obb`).  The
+arithmetic lives in third-party packages absent from this image -- parity UNPINNED:
+  * `Trimesh.apply_obb()` (mesh.py:82) = trimesh 3.23.5 `bounds.oriented_bounds`
+    (convex hull -> one candidate per hull face normal -> 2-D minimum-area
+    rectangle of the projected hull by rotating calipers over 2-D hull edges ->
+    minimum volume -> box centred at the origin -> axes ordered by ascending
+    extent, x shortest, z longest);
+  * `circle_fit.least_squares_circle` 0.1.3 (mesh.py:102): scipy `leastsq` on
+    R_i - mean(R) from the barycentre, residu = sum (R_i - mean R)^2.
+Canonical rules: every hull face normal is a candidate (trimesh
+bins directions at 0.1 rad and keeps one representative per bin, which depends on
+qhull's face order); axis signs are fixed physically: first merged vertex has
+x >= 0 and z >= 0 (before the head-end flip), y = z x x.
+"""
+import numpy as np
+import scipy.optimize
+import scipy.spatial
+
+from .section import ZSlicer
+from .xform import transform_pts
+
+
+def _basis(n):
+    k = int(np.argmin(np.abs(n)))
+    e = np.zeros(3)
+    e[k] = 1.0
+    u = np.cross(n, e)
+    u /= np.linalg.norm(u)
+    return u, np.cross(n, u)
+
+
+def min_area_rect_2d(p2: np.ndarray):
+    """Minimum-area enclosing rectangle over 2-D hull edge directions.
+    -> (area, unit edge direction (2,), extent along it, extent across it)."""
+    h = scipy.spatial.ConvexHull(p2)
+    hp = p2[h.vertices]
+    e = np.roll(hp, -1, axis=0) - hp
+    ln = np.linalg.norm(e, axis=1)
+    e = e[ln > 0] / ln[ln > 0][:, None]
+    a = hp @ e.T
+    b = hp @ np.c_[-e[:, 1], e[:, 0]].T
+    ea = a.max(axis=0) - a.min(axis=0)
+    eb = b.max(axis=0) - b.min(axis=0)
+    area = ea * eb
+    i = int(np.argmin(area))
+    return float(area[i]), e[i], float(ea[i]), float(eb[i])
+
+
+def hull(verts: np.ndarray):
+    """-> (hull vertex ids, hull triangles (ids into verts), unit normals)."""
+    h = scipy.spatial.ConvexHull(verts, qhull_options="QbB Pp Qt")
+    tri = h.simplices
+    a, b, c = verts[tri[:, 0]], verts[tri[:, 1]], verts[tri[:, 2]]
+    n = np.cross(b - a, c - a)
+    ln = np.linalg.norm(n, axis=1)
+    ok = ln > 1e-12 * ln.max()
+    return h.vertices, tri[ok], n[ok] / ln[ok][:, None]
+
+
+def oriented_bounds(verts: np.ndarray):
+    """-> (T 4x4 CT->OBB, extents (3,) ascending, min volume)."""
+    verts = np.asarray(verts, dtype=np.float64)
+    hv_ids, _, normals = hull(verts)
+    hv = verts[hv_ids]
+    best = (np.inf, None)
+    for n in normals:
+        u, v = _basis(n)
+        h = hv @ n
+        height = h.max() - h.min()
+        area, e2, ea, eb = min_area_rect_2d(np.c_[hv @ u, hv @ v])
+        vol = area * height
+        if vol < best[0]:
+            e = e2[0] * u + e2[1] * v
+            best = (vol, (n, e, np.cross(n, e), np.array([height, ea, eb])))
+    vol, (a0, a1, a2, ext) = best
+    order = np.argsort(ext, kind="stable")
+    A = np.stack([a0, a1, a2])[order]
+    R = A.copy()
+    p = verts @ R.T
+    c = 0.5 * (p.min(axis=0) + p.max(axis=0))
+    if p[0, 0] - c[0] < 0:
+        R[0] = -R[0]
+    if p[0, 2] - c[2] < 0:
+        R[2] = -R[2]
+    R[1] = np.cross(R[2], R[0])
+    p = verts @ R.T
+    c = 0.5 * (p.min(axis=0) + p.max(axis=0))
+    T = np.identity(4)
+    T[:3, :3] = R
+    T[:3, 3] = -c
+    return T, ext[order], vol
+
+
+def least_squares_circle(xy: np.ndarray):
+    """circle_fit 0.1.3 `least_squares_circle` -> (xc, yc, R, residu)."""
+    x, y = xy[:, 0], xy[:, 1]
+
+    def f(c):
+        ri = np.sqrt((x - c[0]) ** 2 + (y - c[1]) ** 2)
+        return ri - ri.mean()
+
+    center, _ = scipy.optimize.leastsq(f, (x.mean(), y.mean()))
+    ri = np.sqrt((x - center[0]) ** 2 + (y - center[1]) ** 2)
+    r = ri.mean()
+    return center[0], center[1], r, float(np.sum((ri - r) ** 2))
+
+
+FLIP = np.array([[-1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]])
+
+
+def full_obb(verts: np.ndarray, faces: np.ndarray):
+    """mesh.py:63-125 -> dict(transform, z_bounds, z_length, verts_obb, flipped, residus)."""
+    T_obb, ext, vol = oriented_bounds(verts)
+    v = transform_pts(verts, T_obb)
+    z_bounds = (float(v[:, 2].min()), float(v[:, 2].max()))      # mesh.py:85
+    z_length = abs(z_bounds[0]) + abs(z_bounds[1])               # mesh.py:86
+    sl = ZSlicer(v, faces)
+    humeral_end, residu_init, residus = 0.0, np.inf, []
+    for z_limit in z_bounds:                                     # mesh.py:91-107
+        pts = sl.points(0.95 * z_limit)
+        residu = least_squares_circle(pts)[3]
+        residus.append(residu)
+        if residu < residu_init:
+            residu_init, humeral_end = residu, z_limit
+    flipped = humeral_end < 0                                    # mesh.py:112
+    flip = FLIP if flipped else np.identity(4)
+    if flipped:
+        v = transform_pts(v, flip)
+    return dict(transform=np.matmul(flip, T_obb), z_bounds=z_bounds, z_length=z_length,
+                verts_obb=v, flipped=bool(flipped), residus=residus, extents=ext, volume=vol)
