@@ -1,0 +1,120 @@
+"""The oracle against golden vectors captured from the reference's own code
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import anp, groove, slices, xform
+
+
+def _g(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def test_utils_golden():
+    g = _g("utils_golden.npz")
+    np.testing.assert_array_equal(xform.transform_pts(g["pts"], g["T"]), g["transform_pts"])
+    np.testing.assert_array_equal(xform.inv_transform(g["T"]), g["inv_transform"])
+    np.testing.assert_array_equal(xform.construct_csys(g["vz"], g["vy"]), g["construct_csys"])
+    np.testing.assert_array_equal(xform.construct_csys(g["vz"], g["vy"][::-1]), g["construct_csys_swapped"])
+    np.testing.assert_array_equal(xform.translate_transform(g["t"]), g["translate_transform"])
+    np.testing.assert_array_equal(xform.unit_vector(g["vz"][0], g["vz"][1]), g["unit_vector"])
+
+
+def test_rect_helpers_golden():
+    from oracle import te
+    g = _g("utils_golden.npz")
+    r = te.min_area_rect(g["rect"][:-1])
+    assert abs(r["L"] - float(g["major_axis_dist"])) < 1e-12
+    # azimuth of the long side, degrees clockwise from +y in (0,180] (utils.py:36-55)
+    az = np.degrees(np.arctan2(r["major"][0], r["major"][1]))
+    az = az if az > 0 else az + 180
+    assert abs((az - float(g["rect_azimuth"]) + 90) % 180 - 90) < 1e-9
+
+
+def test_cutoff_golden():
+    g = _g("slice_golden.npz")
+    for (n, c0, c1), (a, b) in zip(g["cutoff_cases"], g["cutoff_ranges"]):
+        assert slices.cutoff_range(int(n), (c0, c1)) == (a, b)
+    # the exact index ranges the path relies on
+    assert slices.cutoff_range(200, (0.35, 0.75)) == (50, 130)
+    assert slices.cutoff_range(200, (0.70, 0.99)) == (2, 60)
+    assert slices.cutoff_range(600, (0.2, 0.75)) == (150, 480)
+    assert slices.cutoff_range(600, (0.0, 0.852)) == (88, 600)
+    assert slices.cutoff_range(200, (0.8, 0.99)) == (2, 39)
+
+
+def test_resample_polar_golden():
+    g = _g("slice_golden.npz")
+    np.testing.assert_array_equal(slices.resample_polygon(g["poly"], 100), g["resample_100"])
+    np.testing.assert_array_equal(slices.resample_polygon(g["poly"], 512), g["resample_512"])
+    np.testing.assert_array_equal(slices.cart2pol_no_sort(g["poly"][:, 0], g["poly"][:, 1]), g["cart2pol_no_sort"])
+    c = _g("contours_left.npz")
+    ixy = c["ixy"].astype(np.float64)
+    cen = c["centroids"].astype(np.float64)
+    rows = g["rows"]
+    cent = ixy[rows] - cen[rows][:, :, None]
+    np.testing.assert_array_equal(cent, g["ixy_centered_rows"])
+    for k, r in enumerate(rows):
+        np.testing.assert_array_equal(slices.roll_to_argmin_theta(slices.cart2pol_no_sort(ixy[r][0], ixy[r][1])),
+                                      g["itr_start_rows"][k])
+        np.testing.assert_array_equal(slices.roll_to_argmin_theta(slices.cart2pol_no_sort(cent[k][0], cent[k][1])),
+                                      g["itr_centered_start_rows"][k])
+
+
+def _polar_centered_start(ixy, cen):
+    return np.stack([slices.roll_to_argmin_theta(slices.cart2pol_no_sort(p[0], p[1])) for p in ixy - cen[:, :, None]])
+
+
+def _synthetic_contours(n=600, m=512, seed=99):
+    rng = np.random.default_rng(seed)
+    zs = np.linspace(170.0, 128.0, n)
+    ixy = np.zeros((n, 2, m))
+    cents = np.zeros((n, 2))
+    ph = rng.uniform(-0.1, 0.1, n)
+    for i in range(n):
+        t = np.linspace(-np.pi, np.pi, 400)
+        f = i / (n - 1)
+        r = 22 - 6 * f + 1.5 * np.cos(2 * t + ph[i]) - 2.2 * np.exp(-((t - 0.9) / 0.12) ** 2) \
+            - 1.1 * np.exp(-((t + 1.7) / 0.15) ** 2)
+        xy = np.c_[3 + r * np.cos(t), -2 + r * np.sin(t)]
+        xy[-1] = xy[0]
+        ixy[i] = slices.resample_polygon(xy, m).T
+        cents[i] = 0.5 * (xy.min(axis=0) + xy.max(axis=0))
+    return zs, ixy, cents
+
+
+@pytest.mark.parametrize("tag", ["left", "synth"])
+def test_groove_golden(tag, rfc_tables):
+    g = _g(f"groove_golden_{tag}.npz")
+    if tag == "left":
+        c = _g("contours_left.npz")
+        ixy, cen, zs = c["ixy"].astype(np.float64), c["centroids"].astype(np.float64), c["zs"].astype(np.float64)
+    else:
+        zs, ixy, cen = _synthetic_contours()
+    a, b = slices.cutoff_range(600, (0.2, 0.75))
+    polar = _polar_centered_start(ixy, cen)[a:b]
+    out = groove.groove_points(polar, zs[a:b], cen[a:b], g["canal_axis_ct"], g["T_obb"], rfc_tables)
+    assert out["bg_theta"] == float(g["bg_theta"])
+    # rows of X may be ordered differently only when a slice has > 7 peaks (argpartition order, B-5)
+    assert out["X"].shape == g["X"].shape
+    np.testing.assert_allclose(np.sort(out["X"], axis=0), np.sort(g["X"], axis=0), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(np.sort(out["peak_theta"]), np.sort(g["peak_theta"]), rtol=0, atol=0)
+    np.testing.assert_array_equal(out["points_obb"], g["points_obb"])
+    np.testing.assert_array_equal(out["points_ct"], g["points_ct"])
+
+
+def test_anp_golden():
+    g = _g("anp_golden_left.npz")
+    c = _g("contours_left.npz")
+    ixy, zs = c["ixy"].astype(np.float64), c["zs"].astype(np.float64)
+    a, b = slices.cutoff_range(600, (0.0, 0.852))
+    itr = np.stack([slices.roll_to_argmin_theta(slices.cart2pol_no_sort(p[0], p[1])) for p in ixy])[a:b]
+    img, shft, _ = anp.anp_image(itr, float(g["bg_theta"]))
+    np.testing.assert_array_equal(img.astype(np.float32), g["image_f32"])
+    m = anp.mask_points(g["logits_f32"], shft, zs[a:b])
+    np.testing.assert_array_equal(m["points_obb"], g["points_obb"])
+    assert len(m["articular_obb"]) == int(g["n_articular"])
+    np.testing.assert_array_equal(anp.to_ct(m["points_obb"], c["T_obb"]), g["points_ct"])
