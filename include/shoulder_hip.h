@@ -1,0 +1,149 @@
+/* shoulder_hip.h -- C-ABI of libshoulder_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the `shoulder.Humerus` landmark path of gregspangenberg/shoulder.
+ * The reference has no FFI of its own (pure Python over NumPy/trimesh/onnxruntime); the
+ * Python facade `shoulder_amd.Humerus` keeps the reference's accessor API and calls these
+ * entry points through ctypes.  Each entry point names the reference code it replaces
+ * (paths relative to src/shoulder/).
+ *
+ * Conventions: every function returns 0 (SH_OK) or a negative sh_status and never throws or
+ * aborts across the boundary; sh_last_error() gives the text.  The caller owns every host
+ * buffer; the library owns all device memory inside sh_ctx.  One sh_ctx per HIP device /
+ * stream; a ctx is NOT thread-safe; distinct ctxs may run concurrently.  All work is
+ * enqueued on the ctx's HIP stream; functions that return host data synchronise that stream.
+ * Matrices are 4x4 row-major float64, points are xyz float64, vertices are float32 (as in
+ * an STL file).
+ */
+#ifndef SHOULDER_HIP_H
+#define SHOULDER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sh_ctx sh_ctx;
+
+typedef enum sh_status {
+  SH_OK = 0,
+  SH_ERR_ARG = -1,      /* bad argument / shape */
+  SH_ERR_HIP = -2,      /* HIP runtime error (text in sh_last_error) */
+  SH_ERR_STATE = -3,    /* call order: meshes / parameters not loaded */
+  SH_ERR_CAPACITY = -4, /* a per-slice or per-mesh capacity was exceeded */
+  SH_ERR_GEOMETRY = -5, /* degenerate input: open contour, empty slice, ray miss, ... */
+  SH_ERR_NOMEM = -6
+} sh_status;
+
+/* Stages of sh_run, in evaluation order (bone.py:110-157). */
+enum {
+  SH_STAGE_OBB      = 1u << 0, /* mesh.py:63-125  FullObb._obb (hull, min-volume box, head-end flip) */
+  SH_STAGE_FULL     = 1u << 1, /* slice.py:209-224 + :21-60  FullSlices sections, centroids, areas   */
+  SH_STAGE_NECK     = 1u << 2, /* surgical_neck.py:22-56  kernel change point -> neck_z              */
+  SH_STAGE_CANAL    = 1u << 3, /* canal.py:19-85                                                     */
+  SH_STAGE_PROXIMAL = 1u << 4, /* slice.py:227-253 + :65-147 ProximalSlices, resample, polar images  */
+  SH_STAGE_GROOVE   = 1u << 5, /* bicipital_groove.py:26-265                                         */
+  SH_STAGE_ANP      = 1u << 6, /* anatomic_neck.py:31-236 (image, UNet, edge points, plane, axes)    */
+  SH_STAGE_DISTAL   = 1u << 7, /* slice.py:256-276 DistalSlices sections                             */
+  SH_STAGE_TE       = 1u << 8, /* epicondyle.py:29-101                                               */
+  SH_STAGE_CSYS     = 1u << 9, /* bone.py:146-157 construct_csys + re-expression of landmarks        */
+  SH_STAGE_ALL      = 0x3FFu
+};
+
+enum { SH_UNET_F32 = 0, SH_UNET_BF16 = 1 };
+
+#define SH_GROOVE_ROWS 330   /* rows 150..479 of 600 proximal slices (slice.py:157-164) */
+#define SH_ANP_MAX_PTS 4096  /* capacity of the padded edge-point list                  */
+
+/* Fixed-size result per humerus; everything in CT coordinates unless noted.
+ * Row order of every (2,3) axis follows the reference accessor it mirrors. */
+typedef struct sh_landmarks {
+  double obb_transform[16];   /* FullObb.transform, CT -> OBB incl. head-end flip (mesh.py:124) */
+  double z_length;            /* mesh.py:86 */
+  double neck_z;              /* SurgicalNeck.neck_z, OBB frame (surgical_neck.py:34) */
+  double canal_axis[6];       /* Canal.axis(): [proximal, distal] (canal.py:58-85) */
+  double te_axis[6];          /* TransEpicondylar.axis(): [medial, lateral] (epicondyle.py:29-101) */
+  double groove_axis[6];      /* DeepGroove.axis() (bicipital_groove.py:244-265) */
+  double bg_theta;            /* DeepGroove.bg_theta (bicipital_groove.py:188) */
+  double anp_plane_point[3];  /* AnatomicNeck.plane().point  (anatomic_neck.py:123-153) */
+  double anp_plane_normal[3]; /* AnatomicNeck.plane().normal */
+  double anp_axis_normal[6];  /* AnatomicNeck.axis_normal(): [upper, lower] (anatomic_neck.py:174-200) */
+  double anp_axis_central[6]; /* AnatomicNeck.axis_central(): [upper, lower] (anatomic_neck.py:202-236) */
+  double csys[16];            /* apply_csys_canal_transepiconylar() matrix, CT -> canal/TE (bone.py:146-157) */
+  double groove_points[SH_GROOVE_ROWS * 3]; /* DeepGroove.points() (bicipital_groove.py:26-242) */
+  double anp_points[SH_ANP_MAX_PTS * 3];    /* AnatomicNeck.points(), first n_anp rows valid (anatomic_neck.py:31-121) */
+  int32_t n_anp;              /* number of edge points (K) */
+  int32_t n_articular;        /* number of mask pixels (anatomic_neck.py:104-112) */
+  int32_t neck_index;         /* change-point index into areas1((0.70,0.99)) (surgical_neck.py:33) */
+  int32_t flipped;            /* 1 if the head end was at -z of the raw box (mesh.py:112) */
+  int32_t status;             /* 0 or a negative sh_status for this mesh */
+  int32_t pad_;
+} sh_landmarks;
+
+/* Tunables the reference exposes as keyword defaults (SURVEY 5 "config / flags"). */
+typedef struct sh_params {
+  double canal_cutoff[2];     /* canal.py:19          default (0.35, 0.75) */
+  double groove_cutoff[2];    /* bicipital_groove.py:26 default (0.2, 0.75); rows must stay 330 */
+  double groove_deg_window;   /* bicipital_groove.py:26 default 7 */
+  int32_t unet_dtype;         /* SH_UNET_F32 (parity) or SH_UNET_BF16 (throughput) */
+  int32_t pad_;
+} sh_params;
+
+/* ---- context ------------------------------------------------------------------------ */
+int  sh_ctx_create(int device, void* hip_stream /* nullable: e.g. torch's current stream */, sh_ctx** out);
+void sh_ctx_destroy(sh_ctx*);
+const char* sh_last_error(const sh_ctx*);      /* owned by ctx, valid until the next call */
+int  sh_default_params(sh_params* out);
+int  sh_set_params(sh_ctx*, const sh_params*);
+
+/* ---- parameters (replace the ONNX files read at bicipital_groove.py:174-180 and
+ *      anatomic_neck.py:62-69; host pointers, copied) ---------------------------------- */
+int  sh_load_rfc(sh_ctx*, const int32_t* feat, const float* thr, const int32_t* true_idx,
+                 const int32_t* false_idx, const float* leaf_weight, int n_nodes,
+                 const int32_t* roots, int n_trees);
+/* UNet: `packed` = concatenation, in this order, of enc{i}a_w,enc{i}a_b,enc{i}b_w,enc{i}b_b (i=0..depth-1),
+ * bota_w,bota_b,botb_w,botb_b, then for i=depth-1..0: up{i}_w,up{i}_b,dec{i}a_w,dec{i}a_b,dec{i}b_w,dec{i}b_b,
+ * then head_w, head_b; conv weights laid out [ky][kx][cin][cout] float32. */
+int  sh_load_unet(sh_ctx*, int base_channels, int depth, const float* packed, size_t n_floats);
+/* Device address + size of the packed parameter block (UNet then RFC), for a collective
+ * broadcast by the caller (torch.distributed over RCCL); valid until the next sh_load_*. */
+int  sh_param_block(sh_ctx*, void** dev_ptr, size_t* nbytes);
+
+/* ---- meshes (replace MeshLoader, mesh.py:14-41; vertices already merged) ------------- */
+int  sh_upload_meshes(sh_ctx*, const float* verts /* sumV x 3 */, const int32_t* faces /* sumF x 3, per-mesh local ids */,
+                      const int64_t* v_off /* B+1 */, const int64_t* f_off /* B+1 */, int B);
+/* Synthetic batch (BASELINE config 3/4): mesh i = similarity transform T[i] (4x4, float64)
+ * of uploaded mesh 0, evaluated on the device in float64 and stored as float32. */
+int  sh_synth_batch(sh_ctx*, const double* T /* B x 16 */, int B);
+int  sh_batch_size(const sh_ctx*);
+
+/* ---- the hot path -------------------------------------------------------------------- */
+int  sh_run(sh_ctx*, uint32_t stage_mask, sh_landmarks* out /* B, host, nullable */);
+/* Device address of the B result structs of the last sh_run (for a collective gather). */
+int  sh_landmarks_device(sh_ctx*, void** dev_ptr, size_t* nbytes);
+
+/* utils.transform_pts (utils.py:172-188) for B point sets on the device:
+ * out[off[b]..off[b+1]) = T[b] * in[...]; in/out are DEVICE pointers to float64 xyz. */
+int  sh_affine_apply(sh_ctx*, const double* T /* host, B x 16 */, const void* dev_in, void* dev_out,
+                     const int64_t* off /* host, B+1 */, int B);
+/* Trimesh.apply_transform of mesh b (bone.py:155): transformed float64 vertices -> host. */
+int  sh_mesh_transformed(sh_ctx*, int b, const double* T /* 16 */, double* out_verts /* V x 3 */);
+
+/* ---- stage-level access for parity tests: named intermediate device buffers ----------
+ * names: "verts_obb" "obb_transform" "full.zs" "full.centroids" "full.areas" "full.nloops"
+ * "distal.*" "prox.*" "prox.ixy" "prox.itr_start" "prox.itr_centered_start" "canal.points"
+ * "groove.X" "groove.nX" "groove.proba" "anp.image" "anp.logits" "anp.roll" ... (see sh_buffer_info) */
+int  sh_buffer_info(sh_ctx*, const char* name, size_t* nbytes, int* elem_size);
+int  sh_fetch(sh_ctx*, const char* name, void* host, size_t nbytes);
+int  sh_store(sh_ctx*, const char* name, const void* host, size_t nbytes);
+
+/* Average duration (ms) of the named kernel over the launches since the last reset, measured
+ * with HIP events on the ctx stream (bench.py roofline); name NULL resets all timers. */
+int  sh_kernel_time_ms(sh_ctx*, const char* kernel, double* avg_ms, int* launches);
+int  sh_enable_timing(sh_ctx*, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHOULDER_HIP_H */

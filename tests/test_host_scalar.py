@@ -1,0 +1,214 @@
+"""The SH_HD scalar stages (shoulder_amd/csrc/sh_scalar.h, the exact source the GPU kernels
+run) instantiated on the host by tests/hostcheck and compared against scipy / the oracle.
+CPU only; builds the shim with g++ on first use."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.signal
+
+from conftest import GOLDEN, ROOT
+from oracle import cpd, fits, groove, obb, slices, te, xform
+
+HC = os.path.join(ROOT, "tests", "hostcheck")
+D = ctypes.POINTER(ctypes.c_double)
+I = ctypes.POINTER(ctypes.c_int)
+
+
+def dp(a):
+    return a.ctypes.data_as(D)
+
+
+@pytest.fixture(scope="module")
+def hc():
+    so = os.path.join(HC, "libhostcheck.so")
+    src = os.path.join(HC, "hostcheck.cpp")
+    hdrs = [os.path.join(ROOT, "shoulder_amd", "csrc", h) for h in ("sh_scalar.h", "sh_common.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    lib.hc_circle.restype = ctypes.c_double
+    lib.hc_rfc.restype = ctypes.c_float
+    lib.hc_interp.restype = ctypes.c_double
+    lib.hc_linspace.restype = ctypes.c_double
+    return lib
+
+
+def test_savgol(hc):
+    rng = np.random.default_rng(0)
+    for n in (512, 64, 21):
+        x = rng.standard_normal(n).cumsum()
+        y = np.zeros(n)
+        hc.hc_savgol(dp(x), n, dp(y))
+        ref = scipy.signal.savgol_filter(x, 10, 1)
+        np.testing.assert_allclose(y, ref, rtol=0, atol=2e-13)   # scipy's taps are 0.1 +- 3e-17 (lstsq)
+
+
+def _fp(hc, x, h=-10.0, p=0.6, w=0.1, cap=1024):
+    idx = np.zeros(cap, dtype=np.int32)
+    prom, wid, wh = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+    k = hc.hc_find_peaks(dp(x), len(x), ctypes.c_double(h), ctypes.c_double(p), ctypes.c_double(w),
+                         idx.ctypes.data_as(I), dp(prom), dp(wid), dp(wh), cap)
+    return idx[:k], prom[:k], wid[:k], wh[:k]
+
+
+def test_find_peaks(hc):
+    rng = np.random.default_rng(1)
+    for trial in range(200):
+        n = int(rng.integers(12, 600))
+        x = rng.standard_normal(n).cumsum() * rng.uniform(0.2, 2)
+        if trial % 3 == 0:                      # plateaus and exact ties
+            x = np.round(x, 0)
+        if trial % 5 == 0:
+            x = np.round(x * 2) / 2
+        pmin = [0.6, 0.0, 1.5][trial % 3]
+        idx, prom, wid, wh = _fp(hc, x, p=pmin)
+        ref, pr = scipy.signal.find_peaks(x, height=-10, prominence=pmin, width=0.1)
+        np.testing.assert_array_equal(idx, ref)
+        np.testing.assert_array_equal(prom, pr["prominences"])
+        np.testing.assert_array_equal(wid, pr["widths"])
+        np.testing.assert_array_equal(wh, pr["width_heights"])
+
+
+def test_cpd(hc):
+    rng = np.random.default_rng(2)
+    for trial in range(30):
+        n = int(rng.integers(8, 64))
+        k = int(rng.integers(2, n - 2))
+        x = np.r_[rng.normal(1700, 60, k), rng.normal(700, 80, n - k)] + np.linspace(0, 50, n)
+        assert hc.hc_cpd(dp(x), n) == cpd.kernel_cpd_one_bkp(x)
+    x = np.full(20, 3.0)                       # median 0 -> gamma 1; every t ties (rounding decides)
+    assert 2 <= hc.hc_cpd(dp(x), 20) <= 18
+
+
+def test_circle_fit(hc):
+    rng = np.random.default_rng(3)
+    for trial in range(20):
+        t = np.sort(rng.uniform(0, 2 * np.pi, 150))
+        r = 20 + rng.normal(0, 0.5 + trial * 0.2, 150) + 3 * np.cos(2 * t) * (trial % 2)
+        xy = np.ascontiguousarray(np.c_[5 + r * np.cos(t), -7 + 1.3 * r * np.sin(t)])
+        c = np.zeros(2)
+        res = hc.hc_circle(dp(xy), len(xy), dp(c))
+        xc, yc, _, ref = obb.least_squares_circle(xy)
+        assert abs(res - ref) <= 1e-9 * ref
+        assert abs(c[0] - xc) < 1e-4 and abs(c[1] - yc) < 1e-4   # scipy leastsq stops at xtol 1.5e-8
+
+
+def test_groove_rows_and_local_min(hc, rfc_tables):
+    c = np.load(os.path.join(GOLDEN, "contours_left.npz"))
+    ixy, cen, zs = c["ixy"].astype(np.float64), c["centroids"].astype(np.float64), c["zs"].astype(np.float64)
+    a, b = slices.cutoff_range(600, (0.2, 0.75))
+    polar = np.stack([slices.roll_to_argmin_theta(slices.cart2pol_no_sort(p[0], p[1]))
+                      for p in (ixy - cen[:, :, None])[a:b]])
+    zc = zs[a:b]
+    canal = c["canal_axis_ct"]
+    out = groove.groove_points(polar, zc, cen[a:b], canal, c["T_obb"], rfc_tables)
+    cu = xform.unit_vector(canal[0], canal[1])
+    # MinMaxScaler on zs: (z - min) * (1/(max-min)) ... sklearn: X*scale + min_
+    scale = 1.0 / (zc.max() - zc.min())
+    zsc = zc * scale + (0.0 - zc.min() * scale)
+    Xraw, pth = [], []
+    for i in range(len(zc)):
+        X = np.zeros((7, 9))
+        th = np.zeros(7)
+        pidx = np.zeros(7, dtype=np.int32)
+        k = hc.hc_groove_row(dp(np.ascontiguousarray(polar[i, 0])), dp(np.ascontiguousarray(polar[i, 1])), 512,
+                             ctypes.c_double(zc[i]), ctypes.c_double(zsc[i]), dp(cu), dp(X), dp(th), pidx.ctypes.data_as(I))
+        Xraw.append(X[:k])
+        pth.append(th[:k])
+    Xraw, pth = np.concatenate(Xraw), np.concatenate(pth)
+    assert Xraw.shape == out["X_raw"].shape
+    np.testing.assert_array_equal(pth, out["peak_theta"])
+    np.testing.assert_allclose(Xraw, out["X_raw"], rtol=0, atol=1e-12)
+    # RFC on the oracle's scaled X
+    t = rfc_tables
+    ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    pr = np.array([hc.hc_rfc(ip(t["feat"]), fp(t["thr"]), ip(t["true_idx"]), ip(t["false_idx"]), fp(t["leaf_weight"]),
+                             ip(t["roots"]), len(t["roots"]), dp(np.ascontiguousarray(x))) for x in out["X"]], dtype=np.float32)
+    np.testing.assert_array_equal(pr, out["proba"])
+    # local minima
+    polar_0 = polar.copy()
+    polar_0[:, 1, :] = np.apply_along_axis(lambda x: x - np.mean(x), axis=1, arr=polar[:, 1, :])
+    for bg in (out["bg_theta"], -3.13, 3.14, 0.0):
+        for i in range(0, len(zc), 7):
+            got = hc.hc_local_min(dp(np.ascontiguousarray(polar_0[i, 0])), dp(np.ascontiguousarray(polar_0[i, 1])), 512,
+                                  ctypes.c_double(bg), 10)
+            esti = groove.find_nearest_idx(polar_0[i, 0, :], bg)
+            if 10 > esti:
+                rng_ = np.concatenate((polar_0[i, :, (esti - 10):], polar_0[i, :, :(esti + 10)]), axis=1)
+            else:
+                rng_ = polar_0[i, :, (esti - 10):(esti + 10)]
+            assert got == int(np.argmin(rng_[1, :])) + (esti - 10)
+
+
+def test_ellipse_center(hc):
+    rng = np.random.default_rng(4)
+    for trial in range(20):
+        t = rng.uniform(0, 2 * np.pi, 400)
+        a, b, ph = rng.uniform(15, 30), rng.uniform(8, 15), rng.uniform(0, np.pi)
+        x = a * np.cos(t) * np.cos(ph) - b * np.sin(t) * np.sin(ph) + rng.normal(0, 0.3, 400) + 4
+        y = a * np.cos(t) * np.sin(ph) + b * np.sin(t) * np.cos(ph) + rng.normal(0, 0.3, 400) - 9
+        Dm = np.c_[x * x, x * y, y * y, x, y, np.ones_like(x)]
+        S = np.ascontiguousarray(Dm.T @ Dm)
+        c = np.zeros(2)
+        assert hc.hc_ellipse(dp(S), dp(c)) == 0
+        np.testing.assert_allclose(c, fits.ellipse_center(np.c_[x, y]), rtol=0, atol=1e-8)
+
+
+def test_mrr_and_clip(hc):
+    rng = np.random.default_rng(5)
+    for trial in range(30):
+        n = int(rng.integers(20, 300))
+        t = np.sort(rng.uniform(0, 2 * np.pi, n))
+        r = 30 + 8 * np.cos(2 * t + trial) + 3 * np.sin(5 * t) + rng.uniform(-0.3, 0.3, n)
+        xy = np.ascontiguousarray(np.c_[r * np.cos(t) * 1.6 + 2, r * np.sin(t) - 3])
+        out = np.zeros(7)
+        nh = hc.hc_mrr(dp(xy), n, dp(out))
+        ref = te.min_area_rect(xy)
+        assert nh == len(te.convex_hull_2d(xy))
+        np.testing.assert_allclose(out[4:7], [ref["L"], ref["W"], ref["area"]], rtol=1e-13)
+        np.testing.assert_allclose(out[0:2], ref["center"], atol=1e-10)
+        assert abs(abs(out[2] * ref["major"][0] + out[3] * ref["major"][1]) - 1) < 1e-12
+        ring = np.r_[xy, xy[:1]]
+        for sgn in (1, -1):
+            m = ref["major"] * sgn
+            for frac in (0.999, 0.9, 0.5):
+                w0 = 0.5 * frac * ref["L"]
+                pcs = te.clip_halfplane_pieces(ring, ref["center"], m, w0)
+                cents = np.zeros(2 * 16)
+                k = hc.hc_clip(dp(xy), n, ctypes.c_double(ref["center"][0]), ctypes.c_double(ref["center"][1]),
+                               ctypes.c_double(m[0]), ctypes.c_double(m[1]), ctypes.c_double(w0), dp(cents), 16)
+                assert k == len(pcs)
+                got = sorted(map(tuple, cents[:2 * k].reshape(-1, 2).round(9)))
+                exp = sorted(map(tuple, np.array([p[0] for p in pcs]).reshape(-1, 2).round(9)))
+                np.testing.assert_allclose(got, exp, atol=1e-8)
+
+
+def test_csys_eig_interp(hc):
+    g = np.load(os.path.join(GOLDEN, "utils_golden.npz"))
+    out = np.zeros(16)
+    assert hc.hc_construct_csys(dp(np.ascontiguousarray(g["vz"])), dp(np.ascontiguousarray(g["vy"])), dp(out)) == 0
+    np.testing.assert_allclose(out.reshape(4, 4), g["construct_csys"], rtol=0, atol=1e-11)
+    assert hc.hc_inv_transform(dp(np.ascontiguousarray(g["T"])), dp(out)) == 0
+    np.testing.assert_allclose(out.reshape(4, 4), g["inv_transform"], rtol=0, atol=1e-11)
+    rng = np.random.default_rng(6)
+    for _ in range(20):
+        P = rng.standard_normal((50, 3)) * np.array([40, 3, 0.5]) @ np.linalg.qr(rng.standard_normal((3, 3)))[0]
+        C = np.ascontiguousarray(np.cov(P.T))
+        w, V, v = np.zeros(3), np.zeros(9), np.zeros(3)
+        hc.hc_eig_sym3(dp(C), dp(w), dp(V))
+        wr, Vr = np.linalg.eigh(C)
+        np.testing.assert_allclose(w, wr, rtol=0, atol=1e-14 * wr.max())
+        assert abs(abs(V.reshape(3, 3)[:, 0] @ Vr[:, 0]) - 1) < 1e-12
+        hc.hc_dominant(dp(C), dp(v))
+        assert abs(abs(v @ Vr[:, 2]) - 1) < 1e-13
+    xp = np.sort(rng.uniform(0, 10, 40))
+    xp[5] = xp[4]
+    fp_ = rng.standard_normal(40)
+    for x in np.r_[rng.uniform(-1, 11, 200), xp]:
+        assert hc.hc_interp(ctypes.c_double(x), dp(xp), dp(fp_), 40) == np.interp(x, xp, fp_)
+    for k in range(200):
+        assert hc.hc_linspace(ctypes.c_double(171.3), ctypes.c_double(-169.2), 200, k) == np.linspace(171.3, -169.2, 200)[k]
