@@ -1,0 +1,109 @@
+"""ctypes binding of libshoulder_hip.so (include/shoulder_hip.h).  Fails loudly when the HIP
+library is missing -- there is no CPU fallback on the product path."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+GROOVE_ROWS = 330
+ANP_MAX_PTS = 4096
+
+STAGE_OBB, STAGE_FULL, STAGE_NECK, STAGE_CANAL, STAGE_PROXIMAL = 1, 2, 4, 8, 16
+STAGE_GROOVE, STAGE_ANP, STAGE_DISTAL, STAGE_TE, STAGE_CSYS = 32, 64, 128, 256, 512
+STAGE_ALL = 0x3FF
+UNET_F32, UNET_BF16 = 0, 1
+
+
+class Landmarks(ctypes.Structure):
+    _fields_ = [
+        ("obb_transform", ctypes.c_double * 16),
+        ("z_length", ctypes.c_double),
+        ("neck_z", ctypes.c_double),
+        ("canal_axis", ctypes.c_double * 6),
+        ("te_axis", ctypes.c_double * 6),
+        ("groove_axis", ctypes.c_double * 6),
+        ("bg_theta", ctypes.c_double),
+        ("anp_plane_point", ctypes.c_double * 3),
+        ("anp_plane_normal", ctypes.c_double * 3),
+        ("anp_axis_normal", ctypes.c_double * 6),
+        ("anp_axis_central", ctypes.c_double * 6),
+        ("csys", ctypes.c_double * 16),
+        ("groove_points", ctypes.c_double * (GROOVE_ROWS * 3)),
+        ("anp_points", ctypes.c_double * (ANP_MAX_PTS * 3)),
+        ("n_anp", ctypes.c_int32),
+        ("n_articular", ctypes.c_int32),
+        ("neck_index", ctypes.c_int32),
+        ("flipped", ctypes.c_int32),
+        ("status", ctypes.c_int32),
+        ("pad_", ctypes.c_int32),
+    ]
+
+
+LANDMARKS_DTYPE = np.dtype([
+    ("obb_transform", "<f8", (4, 4)), ("z_length", "<f8"), ("neck_z", "<f8"), ("canal_axis", "<f8", (2, 3)),
+    ("te_axis", "<f8", (2, 3)), ("groove_axis", "<f8", (2, 3)), ("bg_theta", "<f8"), ("anp_plane_point", "<f8", (3,)),
+    ("anp_plane_normal", "<f8", (3,)), ("anp_axis_normal", "<f8", (2, 3)), ("anp_axis_central", "<f8", (2, 3)),
+    ("csys", "<f8", (4, 4)), ("groove_points", "<f8", (GROOVE_ROWS, 3)), ("anp_points", "<f8", (ANP_MAX_PTS, 3)),
+    ("n_anp", "<i4"), ("n_articular", "<i4"), ("neck_index", "<i4"), ("flipped", "<i4"), ("status", "<i4"), ("pad_", "<i4")])
+assert LANDMARKS_DTYPE.itemsize == ctypes.sizeof(Landmarks)
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("canal_cutoff", ctypes.c_double * 2), ("groove_cutoff", ctypes.c_double * 2),
+                ("groove_deg_window", ctypes.c_double), ("unet_dtype", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+EXPORTS = ["sh_ctx_create", "sh_ctx_destroy", "sh_last_error", "sh_default_params", "sh_set_params", "sh_load_rfc",
+           "sh_load_unet", "sh_param_block", "sh_upload_meshes", "sh_synth_batch", "sh_batch_size", "sh_run",
+           "sh_landmarks_device", "sh_affine_apply", "sh_mesh_transformed", "sh_buffer_info", "sh_fetch", "sh_store",
+           "sh_kernel_time_ms", "sh_enable_timing"]
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load (building in-tree first if the .so is absent or stale and hipcc is present)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if build_if_missing and _build.is_stale():
+        try:
+            _build.build_lib(verbose=False)
+        except Exception as e:  # no hipcc: use a prebuilt .so if there is one
+            if not os.path.exists(path):
+                raise RuntimeError(f"libshoulder_hip.so is not built and cannot be built here: {e}") from e
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} missing: run `python -m shoulder_amd.build` (needs hipcc / ROCm)")
+    L = ctypes.CDLL(path)
+    vp, cp = ctypes.c_void_p, ctypes.c_char_p
+    L.sh_ctx_create.argtypes = [ctypes.c_int, vp, ctypes.POINTER(vp)]
+    L.sh_ctx_destroy.argtypes = [vp]
+    L.sh_ctx_destroy.restype = None
+    L.sh_last_error.argtypes = [vp]
+    L.sh_last_error.restype = cp
+    L.sh_default_params.argtypes = [ctypes.POINTER(Params)]
+    L.sh_set_params.argtypes = [vp, ctypes.POINTER(Params)]
+    L.sh_load_rfc.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_int]
+    L.sh_load_unet.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t]
+    L.sh_param_block.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    L.sh_upload_meshes.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int]
+    L.sh_synth_batch.argtypes = [vp, vp, ctypes.c_int]
+    L.sh_batch_size.argtypes = [vp]
+    L.sh_run.argtypes = [vp, ctypes.c_uint32, vp]
+    L.sh_landmarks_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    L.sh_affine_apply.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int]
+    L.sh_mesh_transformed.argtypes = [vp, ctypes.c_int, vp, vp]
+    L.sh_buffer_info.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
+    L.sh_fetch.argtypes = [vp, cp, vp, ctypes.c_size_t]
+    L.sh_store.argtypes = [vp, cp, vp, ctypes.c_size_t]
+    L.sh_kernel_time_ms.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    L.sh_enable_timing.argtypes = [vp, ctypes.c_int]
+    _lib = L
+    return L

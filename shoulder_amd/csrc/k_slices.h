@@ -1,0 +1,455 @@
+// k_slices.h -- the slice layer on the device (reference src/shoulder/humerus/slice.py, K3/K5-K9).
+//
+// Data layout in HBM (per ctx, B meshes, set = full/distal/proximal with N planes):
+//   verts      float32 [sumV][3]        CT vertices as in the STL
+//   verts_obb  float64 [sumV][3]        T_obb * v   (mesh.py:82,117: the mutated `obb.mesh`)
+//   zs, zeff   float64 [B][N]           linspace z of each plane, and z_orig + (zs - z_orig)
+//   seg_count  int32   [B][N]
+//   segs       Seg     [B][N][SH_MAXSEG] crossing segments, slot order = atomic arrival order
+//   centroids  float64 [B][N][2], areas float64 [B][N], nloops int32 [B][N]
+//   ring_n     int32   [B][N]           vertices of the largest loop (open count)
+//   ring       float64 [B][N][SH_MAXSEG+1][2]  largest loop, CCW, canonical start, closed
+//   ixy / itr_start / itr_centered_start  float64 [B][N][2][M]   (proximal set only)
+// All kernels are HBM/latency bound integer + fp64 work; no MFMA here.
+#pragma once
+#include "sh_scalar.h"
+
+namespace sh {
+
+struct __attribute__((aligned(16))) Seg {
+  uint32_t s_lo, s_hi, e_lo, e_hi;  // mesh-edge keys (min vid, max vid) of the start / end crossing
+  double px, py;                    // start crossing point (OBB xy)
+};
+static_assert(sizeof(Seg) == 32, "Seg must be 32 bytes");
+
+// order-preserving double <-> uint64 for atomic min/max
+__device__ inline unsigned long long enc_f64(double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ inline double dec_f64(unsigned long long e) {
+  unsigned long long b = (e & 0x8000000000000000ull) ? (e & 0x7FFFFFFFFFFFFFFFull) : ~e;
+  return __longlong_as_double((long long)b);
+}
+
+// ---- verts_obb = T_b * v, plus z bounds (mesh.py:85 `mesh.bounds[:, -1]`) -------------------
+__global__ void k_transform_verts(const float* __restrict__ verts, const long long* __restrict__ voff,
+                                  const double* __restrict__ T, double* __restrict__ vobb,
+                                  unsigned long long* __restrict__ zb_enc /*[B][2] min,max*/) {
+  int b = blockIdx.y;
+  long long v0 = voff[b], nv = voff[b + 1] - v0;
+  const double* Tb = T + 16 * b;
+  double zmin = 1e300, zmax = -1e300;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    const float* p = verts + 3 * (v0 + i);
+    double o[3];
+    xform_pt(Tb, (double)p[0], (double)p[1], (double)p[2], o);
+    double* q = vobb + 3 * (v0 + i);
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+    zmin = fmin(zmin, o[2]); zmax = fmax(zmax, o[2]);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    zmin = fmin(zmin, __shfl_down(zmin, off));
+    zmax = fmax(zmax, __shfl_down(zmax, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&zb_enc[2 * b], enc_f64(zmin));
+    atomicMax(&zb_enc[2 * b + 1], enc_f64(zmax));
+  }
+}
+
+__global__ void k_decode_bounds(const unsigned long long* zb_enc, double* zb, int B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * B) zb[i] = dec_f64(zb_enc[i]);
+}
+
+// NumPy pairwise summation (np.add.reduce on a contiguous float64 vector)
+__device__ inline double np_pairwise_sum(const double* a, int n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += a[i];
+    return r;
+  } else if (n <= 128) {
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  } else {
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+  }
+}
+
+// ---- plane heights of one slice set (slice.py:16-19, :219-224, :248-253, :271-276) -----------
+// kind 0: full  linspace(.99 zmax, .99 zmin, N)   kind 1: proximal linspace(.99 zmax, neck_z, N)
+// kind 2: distal linspace(.99 zmin, 0, N)
+__global__ void k_make_planes(int kind, int N, const double* __restrict__ zb /*[B][2]*/, const double* __restrict__ neck_z,
+                              double* __restrict__ zs, double* __restrict__ zeff, int B) {
+  int b = blockIdx.x;
+  if (b >= B) return;
+  double zmin = zb[2 * b], zmax = zb[2 * b + 1];
+  double a, e;
+  if (kind == 0) { a = 0.99 * zmax; e = 0.99 * zmin; }
+  else if (kind == 1) { a = 0.99 * zmax; e = neck_z[b]; }
+  else { a = 0.99 * zmin; e = 0.0; }
+  double* z = zs + (size_t)b * N;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) z[k] = linspace_at(a, e, N, k);
+  __syncthreads();
+  __shared__ double z_orig;
+  if (threadIdx.x == 0) z_orig = np_pairwise_sum(z, N) / (double)N;   // slice.py:18 np.mean
+  __syncthreads();
+  for (int k = threadIdx.x; k < N; k += blockDim.x) zeff[(size_t)b * N + k] = z_orig + (z[k] - z_orig);  // :19 + section_multiplane
+}
+
+// ---- K5: triangle-centric multi-plane section ------------------------------------------------
+// One lane per triangle; each crossing (triangle, plane) appends one Seg to that plane's slot
+// range.  Sign rule and crossing-point formula: oracle/section.py (canonical rules).
+__global__ void k_slice_emit(const double* __restrict__ vobb, const int* __restrict__ faces,
+                             const long long* __restrict__ voff, const long long* __restrict__ foff,
+                             const double* __restrict__ zeff, int N, int* __restrict__ seg_count,
+                             Seg* __restrict__ segs, int* __restrict__ err) {
+  int b = blockIdx.y;
+  long long f0 = foff[b], nf = foff[b + 1] - f0;
+  const double* vb = vobb + 3 * voff[b];
+  const double* zp = zeff + (size_t)b * N;
+  double z_first = zp[0], z_last = zp[N - 1];
+  double inv_step = (double)(N - 1) / (z_last - z_first);
+  for (long long fi = blockIdx.x * (long long)blockDim.x + threadIdx.x; fi < nf; fi += (long long)gridDim.x * blockDim.x) {
+    const int* f = faces + 3 * (f0 + fi);
+    int id[3] = {f[0], f[1], f[2]};
+    double X[3], Y[3], Z[3];
+    for (int k = 0; k < 3; ++k) { X[k] = vb[3 * (size_t)id[k]]; Y[k] = vb[3 * (size_t)id[k] + 1]; Z[k] = vb[3 * (size_t)id[k] + 2]; }
+    double fzmin = fmin(Z[0], fmin(Z[1], Z[2])), fzmax = fmax(Z[0], fmax(Z[1], Z[2]));
+    double ka = (fzmin - z_first) * inv_step, kb = (fzmax - z_first) * inv_step;
+    double klo = fmin(ka, kb), khi = fmax(ka, kb);
+    if (khi < -1.0 || klo > (double)N) continue;
+    int lo = (int)floor(fmax(klo, 0.0)) - 1, hi = (int)ceil(fmin(khi, (double)(N - 1))) + 1;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > N - 1 ? N - 1 : hi;
+    for (int k = lo; k <= hi; ++k) {
+      double z = zp[k];
+      double d[3];
+      int s[3];
+      for (int j = 0; j < 3; ++j) { d[j] = Z[j] - z; s[j] = d[j] < -SH_SECTION_TOL ? -1 : 1; }
+      if (s[0] == s[1] && s[1] == s[2]) continue;
+      int up = 0, dn = 0;
+      for (int j = 0; j < 3; ++j) {
+        int jn = (j + 1) % 3;
+        if (s[j] == -1 && s[jn] == 1) up = j;
+        if (s[j] == 1 && s[jn] == -1) dn = j;
+      }
+      Seg sg;
+      {  // start = crossing on the edge walked downwards (+ -> -)
+        int a = dn, c = (dn + 1) % 3;
+        int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
+        double t = d[l] / (d[l] - d[h]);
+        sg.s_lo = (uint32_t)id[l]; sg.s_hi = (uint32_t)id[h];
+        sg.px = X[l] + t * (X[h] - X[l]);
+        sg.py = Y[l] + t * (Y[h] - Y[l]);
+      }
+      {
+        int a = up, c = (up + 1) % 3;
+        int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
+        sg.e_lo = (uint32_t)id[l]; sg.e_hi = (uint32_t)id[h];
+      }
+      int slot = atomicAdd(&seg_count[(size_t)b * N + k], 1);
+      if (slot < SH_MAXSEG) segs[((size_t)b * N + k) * SH_MAXSEG + slot] = sg;
+      else atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
+    }
+  }
+}
+
+// ---- K5b-K7: join segments into loops, orient, areas, AABB centre, largest loop --------------
+// One workgroup per (mesh, plane).  LDS hash join on edge keys -> successor list -> pointer
+// jumping for (a) the minimum edge key of each loop (canonical start, B-1) and (b) the rank of
+// every segment from that start.
+#define SH_LINK_THREADS 256
+#define SH_HASH 2048
+#define SH_MAXLOOPS 32
+
+__device__ inline uint32_t hash_key(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33;
+  return (uint32_t)k & (SH_HASH - 1);
+}
+
+// select: 0 = largest loop (slice.py:53-59), 1 = loop whose closed-ring vertex mean is nearest
+// the origin in L1 (surgical_neck.py:40-48)
+__global__ void __launch_bounds__(SH_LINK_THREADS)
+k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
+             double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops,
+             int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err) {
+  __shared__ unsigned long long skey[SH_MAXSEG];
+  __shared__ unsigned long long bufA[SH_MAXSEG];   // ekey, then label ping, then ring x
+  __shared__ unsigned long long bufB[SH_MAXSEG];   // label pong, then ring y
+  __shared__ double px[SH_MAXSEG], py[SH_MAXSEG];
+  __shared__ int nxt[SH_MAXSEG], jmpA[SH_MAXSEG], jmpB[SH_MAXSEG], rnkA[SH_MAXSEG], rnkB[SH_MAXSEG];
+  __shared__ int table[SH_HASH];
+  __shared__ int l_start[SH_MAXLOOPS], l_len[SH_MAXLOOPS], l_off[SH_MAXLOOPS];
+  __shared__ double l_area[SH_MAXLOOPS], l_sel[SH_MAXLOOPS];
+  __shared__ int n_loops, bad, best_loop;
+  __shared__ unsigned long long bb[4];
+
+  const int pl = blockIdx.x;           // b*N + k
+  const int b = pl / N;
+  const int tid = threadIdx.x;
+  int cnt = seg_count[pl];
+  const int n = cnt > SH_MAXSEG ? SH_MAXSEG : cnt;
+  if (tid == 0) { n_loops = 0; bad = 0; best_loop = 0; bb[0] = bb[2] = ~0ull; bb[1] = bb[3] = 0ull; }
+  for (int i = tid; i < SH_HASH; i += SH_LINK_THREADS) table[i] = -1;
+  const Seg* sp = segs + (size_t)pl * SH_MAXSEG;
+  for (int i = tid; i < n; i += SH_LINK_THREADS) {
+    Seg s = sp[i];
+    skey[i] = ((unsigned long long)s.s_lo << 32) | s.s_hi;
+    bufA[i] = ((unsigned long long)s.e_lo << 32) | s.e_hi;
+    px[i] = s.px; py[i] = s.py;
+  }
+  __syncthreads();
+  if (n < 3) {
+    if (tid == 0) {
+      centroids[2 * (size_t)pl] = 0; centroids[2 * (size_t)pl + 1] = 0; areas[pl] = 0; nloops[pl] = 0; ring_n[pl] = 0;
+      atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+    }
+    return;
+  }
+  for (int i = tid; i < n; i += SH_LINK_THREADS) {
+    uint32_t h = hash_key(skey[i]);
+    while (atomicCAS(&table[h], -1, i) != -1) h = (h + 1) & (SH_HASH - 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += SH_LINK_THREADS) {
+    unsigned long long k = bufA[i];
+    uint32_t h = hash_key(k);
+    int t, found = -1;
+    while ((t = table[h]) != -1) {
+      if (skey[t] == k) { found = t; break; }
+      h = (h + 1) & (SH_HASH - 1);
+    }
+    if (found < 0) { found = i; bad = 1; }   // open contour: self-loop keeps the walk bounded
+    nxt[i] = found;
+  }
+  __syncthreads();
+  // (a) loop label = min start key over the loop
+  unsigned long long* labA = bufA;
+  unsigned long long* labB = bufB;
+  for (int i = tid; i < n; i += SH_LINK_THREADS) { labA[i] = skey[i]; jmpA[i] = nxt[i]; }
+  __syncthreads();
+  int* ja = jmpA; int* jb = jmpB;
+  for (int span = 1; span < n; span <<= 1) {
+    for (int i = tid; i < n; i += SH_LINK_THREADS) {
+      int j = ja[i];
+      unsigned long long a = labA[i], c = labA[j];
+      labB[i] = a < c ? a : c;
+      jb[i] = ja[j];
+    }
+    __syncthreads();
+    unsigned long long* tl = labA; labA = labB; labB = tl;
+    int* tj = ja; ja = jb; jb = tj;
+  }
+  // (b) forward distance to the loop's start node (absorbing)
+  int* ra = rnkA; int* rb = rnkB;
+  for (int i = tid; i < n; i += SH_LINK_THREADS) {
+    bool st = skey[i] == labA[i];
+    ja[i] = st ? i : nxt[i];
+    ra[i] = st ? 0 : 1;
+    if (st) {
+      int l = atomicAdd(&n_loops, 1);
+      if (l < SH_MAXLOOPS) l_start[l] = i;
+    }
+  }
+  __syncthreads();
+  for (int span = 1; span < n; span <<= 1) {
+    for (int i = tid; i < n; i += SH_LINK_THREADS) {
+      int j = ja[i];
+      rb[i] = ra[i] + ra[j];
+      jb[i] = ja[j];
+    }
+    __syncthreads();
+    int* t1 = ra; ra = rb; rb = t1;
+    int* t2 = ja; ja = jb; jb = t2;
+  }
+  // now ja[i] = start node of i's loop, ra[i] = forward steps from i to it
+  const int nl = n_loops > SH_MAXLOOPS ? SH_MAXLOOPS : n_loops;
+  if (tid == 0) {
+    if (n_loops > SH_MAXLOOPS) atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
+    // canonical loop order: ascending start key
+    for (int a = 1; a < nl; ++a) {
+      int v = l_start[a]; int c = a - 1;
+      while (c >= 0 && skey[l_start[c]] > skey[v]) { l_start[c + 1] = l_start[c]; --c; }
+      l_start[c + 1] = v;
+    }
+    int off = 0;
+    for (int l = 0; l < nl; ++l) {
+      int s = l_start[l];
+      int L = ra[nxt[s]] + 1;
+      l_len[l] = L; l_off[l] = off; off += L;
+      table[s] = l;               // start node -> loop id (table no longer needed as a hash)
+    }
+    if (off != n) bad = 1;        // some segments are on no closed loop
+  }
+  __syncthreads();
+  // ring placement: position from start = (L - r) mod L
+  // label buffers are dead from here on: reuse them for the ordered ring
+  double* rx = (double*)bufA;
+  double* ry = (double*)bufB;
+  int my_pos[ (SH_MAXSEG + SH_LINK_THREADS - 1) / SH_LINK_THREADS ];
+  {
+    int c = 0;
+    for (int i = tid; i < n; i += SH_LINK_THREADS, ++c) {
+      int s = ja[i];
+      int l = table[s];
+      int L = l_len[l];
+      int r = ra[i];
+      int pos = r == 0 ? 0 : L - r;
+      my_pos[c] = (l < 0 || l >= nl) ? -1 : l_off[l] + pos;
+    }
+  }
+  __syncthreads();
+  {
+    int c = 0;
+    for (int i = tid; i < n; i += SH_LINK_THREADS, ++c)
+      if (my_pos[c] >= 0 && my_pos[c] < n) { rx[my_pos[c]] = px[i]; ry[my_pos[c]] = py[i]; }
+  }
+  __syncthreads();
+  // AABB over every loop vertex (trimesh Path2D.centroid, slice.py:38)
+  {
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    for (int i = tid; i < n; i += SH_LINK_THREADS) {
+      x0 = fmin(x0, px[i]); x1 = fmax(x1, px[i]); y0 = fmin(y0, py[i]); y1 = fmax(y1, py[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      x0 = fmin(x0, __shfl_down(x0, off)); x1 = fmax(x1, __shfl_down(x1, off));
+      y0 = fmin(y0, __shfl_down(y0, off)); y1 = fmax(y1, __shfl_down(y1, off));
+    }
+    if ((tid & 63) == 0) {
+      atomicMin(&bb[0], enc_f64(x0)); atomicMax(&bb[1], enc_f64(x1));
+      atomicMin(&bb[2], enc_f64(y0)); atomicMax(&bb[3], enc_f64(y1));
+    }
+  }
+  // per-loop shoelace area (ring order, one lane per loop) and the selection score
+  if (tid < nl) {
+    int o = l_off[tid], L = l_len[tid];
+    double a2 = 0.0, mx = 0.0, my = 0.0;
+    for (int q = 0; q < L; ++q) {
+      int qn = q + 1 == L ? 0 : q + 1;
+      a2 += rx[o + q] * ry[o + qn] - rx[o + qn] * ry[o + q];
+      mx += rx[o + q]; my += ry[o + q];
+    }
+    l_area[tid] = 0.5 * a2;
+    // surgical_neck.py:43-46: mean over the CLOSED ring (first vertex counted twice)
+    mx = (mx + rx[o]) / (double)(L + 1); my = (my + ry[o]) / (double)(L + 1);
+    l_sel[tid] = fabs(mx) + fabs(my);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int best = 0;
+    for (int l = 1; l < nl; ++l) {
+      if (select == 0) { if (fabs(l_area[l]) > fabs(l_area[best])) best = l; }
+      else { if (l_sel[l] < l_sel[best]) best = l; }
+    }
+    best_loop = best;
+    double x0 = dec_f64(bb[0]), x1 = dec_f64(bb[1]), y0 = dec_f64(bb[2]), y1 = dec_f64(bb[3]);
+    centroids[2 * (size_t)pl] = 0.5 * (x0 + x1);
+    centroids[2 * (size_t)pl + 1] = 0.5 * (y0 + y1);
+    int amax = 0;
+    for (int l = 1; l < nl; ++l) if (fabs(l_area[l]) > fabs(l_area[amax])) amax = l;
+    areas[pl] = fabs(l_area[amax]);
+    nloops[pl] = nl;
+    ring_n[pl] = l_len[best];
+    if (bad) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+  }
+  __syncthreads();
+  if (ring) {
+    int l = best_loop, o = l_off[l], L = l_len[l];
+    bool rev = l_area[l] < 0;           // clockwise loop: traverse backwards from the same start
+    double* out = ring + (size_t)pl * (SH_MAXSEG + 1) * 2;
+    for (int q = tid; q <= L; q += SH_LINK_THREADS) {
+      int qq = q == L ? 0 : q;
+      int src = rev ? (qq == 0 ? 0 : L - qq) : qq;
+      out[2 * q] = rx[o + src];
+      out[2 * q + 1] = ry[o + src];
+    }
+  }
+}
+
+// ---- K8/K9: arclength resampling + polar images (slice.py:65-147, :166-206) -------------------
+// One workgroup per (mesh, plane).  cumsum is sequential (np.cumsum order); each sample is one
+// np.interp evaluation; theta = atan2(y,x), r = sqrt(x^2+y^2); rows rolled to argmin(theta).
+#define SH_RS_THREADS 256
+__global__ void __launch_bounds__(SH_RS_THREADS)
+k_resample_polar(int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring,
+                 const double* __restrict__ centroids, double* __restrict__ ixy,
+                 double* __restrict__ itr_start, double* __restrict__ itr_cs) {
+  __shared__ double rx[SH_MAXSEG + 1], ry[SH_MAXSEG + 1], d[SH_MAXSEG + 1];
+  __shared__ double sx[SH_MPROX], sy[SH_MPROX], th[SH_MPROX], rr[SH_MPROX];
+  __shared__ unsigned long long amin_enc;   // (enc(theta) high bits | index) is not exact; use 2-step
+  __shared__ int amin_idx;
+  __shared__ double wmin[SH_RS_THREADS / 64];
+  __shared__ int widx[SH_RS_THREADS / 64];
+  const int pl = blockIdx.x, tid = threadIdx.x;
+  const int L = ring_n[pl];
+  const double* rp = ring + (size_t)pl * (SH_MAXSEG + 1) * 2;
+  for (int q = tid; q <= L; q += SH_RS_THREADS) { rx[q] = rp[2 * q]; ry[q] = rp[2 * q + 1]; }
+  __syncthreads();
+  if (tid == 0) {
+    double acc = 0.0;
+    d[0] = 0.0;
+    for (int q = 1; q <= L; ++q) {
+      double dx = rx[q] - rx[q - 1], dy = ry[q] - ry[q - 1];
+      acc += sqrt(dx * dx + dy * dy);
+      d[q] = acc;
+    }
+  }
+  __syncthreads();
+  const double dmax = d[L];
+  for (int j = tid; j < M; j += SH_RS_THREADS) {
+    double t = linspace_at(0.0, dmax, M, j);
+    sx[j] = interp1(t, d, rx, L + 1);
+    sy[j] = interp1(t, d, ry, L + 1);
+  }
+  __syncthreads();
+  double* oxy = ixy + (size_t)pl * 2 * M;
+  for (int j = tid; j < M; j += SH_RS_THREADS) { oxy[j] = sx[j]; oxy[M + j] = sy[j]; }
+  const double cx = centroids[2 * (size_t)pl], cy = centroids[2 * (size_t)pl + 1];
+  for (int pass = 0; pass < 2; ++pass) {
+    double ox = pass ? cx : 0.0, oy = pass ? cy : 0.0;
+    double best = 1e300;
+    int bi = 0x7fffffff;
+    for (int j = tid; j < M; j += SH_RS_THREADS) {
+      double x = sx[j] - ox, y = sy[j] - oy;
+      double t = atan2(y, x);
+      th[j] = t;
+      rr[j] = sqrt(x * x + y * y);
+      if (t < best || (t == best && j < bi)) { best = t; bi = j; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      double ob = __shfl_down(best, off);
+      int oi = __shfl_down(bi, off);
+      if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((tid & 63) == 0) { wmin[tid >> 6] = best; widx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      double bv = wmin[0]; int bx = widx[0];
+      for (int w = 1; w < SH_RS_THREADS / 64; ++w)
+        if (wmin[w] < bv || (wmin[w] == bv && widx[w] < bx)) { bv = wmin[w]; bx = widx[w]; }
+      amin_idx = bx;
+    }
+    __syncthreads();
+    const int k0 = amin_idx;
+    double* o = (pass ? itr_cs : itr_start) + (size_t)pl * 2 * M;
+    for (int j = tid; j < M; j += SH_RS_THREADS) {
+      int src = j + k0; if (src >= M) src -= M;
+      o[j] = th[src];
+      o[M + j] = rr[src];
+    }
+    __syncthreads();
+  }
+  (void)amin_enc;
+}
+
+}  // namespace sh

@@ -1,0 +1,117 @@
+// k_stages.h -- per-mesh stages around the slice layer: synthetic batch, affine apply, surgical
+// neck, canal.  Small fp64 work; one wave (or one lane) per humerus.
+#pragma once
+#include "k_slices.h"
+
+namespace sh {
+
+// BASELINE config 3/4: mesh i = T[i] * template (float64 arithmetic, stored float32 like an STL)
+__global__ void k_synth_batch(const float* __restrict__ tv, const int* __restrict__ tf, long long V, long long F,
+                              const double* __restrict__ T, float* __restrict__ verts, int* __restrict__ faces) {
+  int b = blockIdx.y;
+  const double* Tb = T + 16 * b;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < V; i += (long long)gridDim.x * blockDim.x) {
+    double o[3];
+    xform_pt(Tb, (double)tv[3 * i], (double)tv[3 * i + 1], (double)tv[3 * i + 2], o);
+    float* q = verts + 3 * (V * b + i);
+    q[0] = (float)o[0]; q[1] = (float)o[1]; q[2] = (float)o[2];
+  }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < 3 * F; i += (long long)gridDim.x * blockDim.x)
+    faces[3 * F * b + i] = tf[i];
+}
+
+// utils.transform_pts (utils.py:172-188), B point sets, float64 xyz
+__global__ void k_affine_f64(const double* __restrict__ T, const double* __restrict__ in, double* __restrict__ out,
+                             const long long* __restrict__ off) {
+  int b = blockIdx.y;
+  const double* Tb = T + 16 * b;
+  long long o0 = off[b], n = off[b + 1] - o0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double* p = in + 3 * (o0 + i);
+    double o[3];
+    xform_pt(Tb, p[0], p[1], p[2], o);
+    double* q = out + 3 * (o0 + i);
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+  }
+}
+
+// Trimesh.apply_transform (bone.py:155) on float32 vertices -> float64
+__global__ void k_affine_f32in(const double* __restrict__ T, const float* __restrict__ in, double* __restrict__ out, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    double o[3];
+    xform_pt(T, (double)in[3 * i], (double)in[3 * i + 1], (double)in[3 * i + 2], o);
+    out[3 * i] = o[0]; out[3 * i + 1] = o[1]; out[3 * i + 2] = o[2];
+  }
+}
+
+__global__ void k_init_bounds(unsigned long long* zb_enc, int B) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * B) zb_enc[i] = (i & 1) ? 0ull : ~0ull;
+}
+
+// surgical_neck.py:22-34: KernelCPD on areas1((0.70,0.99)) -> neck_z = zs_cut[bkp]
+__global__ void k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* __restrict__ scratch,
+                       double* __restrict__ neck_z, int* __restrict__ neck_index, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int a, e;
+  cutoff_range(SH_NFULL, 0.70, 0.99, &a, &e);
+  int t = cpd_one_bkp(areas + (size_t)b * SH_NFULL + a, e - a, scratch + (size_t)b * 6144);
+  neck_index[b] = t;
+  neck_z[b] = zs[(size_t)b * SH_NFULL + a + t];
+}
+
+__device__ inline double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  return __shfl(v, 0);
+}
+
+// Mean + covariance of n xyz points by one wave (lane-strided loads, shuffle reduction), then
+// the dominant direction by power iteration (K11 `Line.best_fit`, canal.py:66).
+__device__ inline void wave_line_fit(const double* p, int n, int stride, double* mean, double* dir) {
+  int lane = threadIdx.x & 63;
+  double s[3] = {0, 0, 0};
+  for (int i = lane; i < n; i += 64) { s[0] += p[(size_t)i * stride]; s[1] += p[(size_t)i * stride + 1]; s[2] += p[(size_t)i * stride + 2]; }
+  for (int k = 0; k < 3; ++k) mean[k] = wave_sum(s[k]) / (double)n;
+  double c[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = lane; i < n; i += 64) {
+    double x = p[(size_t)i * stride] - mean[0], y = p[(size_t)i * stride + 1] - mean[1], z = p[(size_t)i * stride + 2] - mean[2];
+    c[0] += x * x; c[1] += x * y; c[2] += x * z; c[3] += y * y; c[4] += y * z; c[5] += z * z;
+  }
+  for (int k = 0; k < 6; ++k) c[k] = wave_sum(c[k]);
+  double C[9] = {c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
+  dominant_eigvec3(C, dir);   // every lane computes the same 3x3 problem
+}
+
+// canal.py:19-85
+__global__ void k_canal(const double* __restrict__ centroids, const double* __restrict__ zs, const double* __restrict__ zb,
+                        const double* __restrict__ T_obb, double c0, double c1, double* __restrict__ pts_obb,
+                        double* __restrict__ axis_obb, double* __restrict__ axis_ct) {
+  int b = blockIdx.x, lane = threadIdx.x;
+  int a, e;
+  cutoff_range(SH_NFULL, c0, c1, &a, &e);
+  int n = e - a;
+  if (n > 80) n = 80;
+  double* P = pts_obb + (size_t)b * 80 * 3;
+  for (int i = lane; i < n; i += 64) {
+    P[3 * i] = centroids[2 * ((size_t)b * SH_NFULL + a + i)];
+    P[3 * i + 1] = centroids[2 * ((size_t)b * SH_NFULL + a + i) + 1];
+    P[3 * i + 2] = zs[(size_t)b * SH_NFULL + a + i];
+  }
+  __syncthreads();
+  double mean[3], d[3];
+  wave_line_fit(P, n, 3, mean, d);
+  if (lane == 0) {
+    if (d[2] < 0) { d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+    double z_length = fabs(zb[2 * b]) + fabs(zb[2 * b + 1]);
+    double half = (z_length * ((c0 + c1) / 2.0)) / 2.0;
+    double* A = axis_obb + 6 * b;
+    for (int k = 0; k < 3; ++k) { A[k] = mean[k] + d[k] * half; A[3 + k] = mean[k] - d[k] * half; }
+    double Ti[16];
+    inv_transform(T_obb + 16 * b, Ti);
+    xform_pt(Ti, A[0], A[1], A[2], axis_ct + 6 * b);
+    xform_pt(Ti, A[3], A[4], A[5], axis_ct + 6 * b + 3);
+  }
+}
+
+}  // namespace sh

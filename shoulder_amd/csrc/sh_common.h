@@ -24,6 +24,8 @@
 #define SH_GROOVE_NROWS 330
 #define SH_MAXPEAK 7        // bicipital_groove.py:122
 #define SH_SECTION_TOL 1e-8 // trimesh tol.merge used by intersections.mesh_plane
+#define SH_ERR_CAPACITY_DEV (-4)
+#define SH_ERR_GEOMETRY_DEV (-5)
 
 namespace sh {
 

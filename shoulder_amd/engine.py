@@ -1,0 +1,158 @@
+"""Engine: one HIP context (device + stream) behind the C-ABI, NumPy in / NumPy out.
+
+Host-side glue only -- every numeric stage runs in libshoulder_hip.so.  A missing library or a
+failing call raises; nothing falls back to the CPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import LANDMARKS_DTYPE
+
+
+class ShoulderHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libshoulder_hip error {code}: {msg}")
+        self.code = code
+
+
+_MODELS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
+
+UNET_ORDER = None
+
+
+def unet_pack_order(depth):
+    names = []
+    for i in range(depth):
+        names += [f"enc{i}a_w", f"enc{i}a_b", f"enc{i}b_w", f"enc{i}b_b"]
+    names += ["bota_w", "bota_b", "botb_w", "botb_b"]
+    for i in reversed(range(depth)):
+        names += [f"up{i}_w", f"up{i}_b", f"dec{i}a_w", f"dec{i}a_b", f"dec{i}b_w", f"dec{i}b_b"]
+    names += ["head_w", "head_b"]
+    return names
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class Engine:
+    def __init__(self, device=0, stream=None):
+        self.L = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self.L.sh_ctx_create(int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
+        if rc != 0:
+            raise ShoulderHipError(rc, f"sh_ctx_create(device={device}) failed (is a HIP device visible?)")
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sh_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise ShoulderHipError(rc, self.L.sh_last_error(self.h).decode())
+
+    # ---- parameters ----------------------------------------------------------------------------
+    def load_rfc(self, npz_path=None):
+        z = np.load(npz_path or os.path.join(_MODELS, "rfc_bg3.npz"))
+        c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+        feat, thr = c(z["feat"], np.int32), c(z["thr"], np.float32)
+        ti, fi = c(z["true_idx"], np.int32), c(z["false_idx"], np.int32)
+        lw, roots = c(z["leaf_weight"], np.float32), c(z["roots"], np.int32)
+        self._chk(self.L.sh_load_rfc(self.h, _ptr(feat), _ptr(thr), _ptr(ti), _ptr(fi), _ptr(lw), len(feat), _ptr(roots), len(roots)))
+
+    def load_unet(self, weights, base, depth):
+        packed = np.concatenate([np.asarray(weights[k], dtype=np.float32).ravel() for k in unet_pack_order(depth)])
+        packed = np.ascontiguousarray(packed)
+        self._chk(self.L.sh_load_unet(self.h, int(base), int(depth), _ptr(packed), packed.size))
+
+    def set_params(self, canal_cutoff=(0.35, 0.75), groove_cutoff=(0.2, 0.75), groove_deg_window=7.0, unet_dtype=_lib.UNET_F32):
+        p = _lib.Params()
+        self.L.sh_default_params(ctypes.byref(p))
+        p.canal_cutoff[0], p.canal_cutoff[1] = canal_cutoff
+        p.groove_cutoff[0], p.groove_cutoff[1] = groove_cutoff
+        p.groove_deg_window = groove_deg_window
+        p.unet_dtype = unet_dtype
+        self._chk(self.L.sh_set_params(self.h, ctypes.byref(p)))
+
+    def param_block(self):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._chk(self.L.sh_param_block(self.h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    # ---- meshes ----------------------------------------------------------------------------------
+    def upload(self, meshes):
+        """meshes: list of (verts float32 (V,3), faces int32 (F,3))."""
+        verts = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float32).reshape(-1, 3) for v, _ in meshes]))
+        faces = np.ascontiguousarray(np.concatenate([np.asarray(f, dtype=np.int32).reshape(-1, 3) for _, f in meshes]))
+        voff = np.zeros(len(meshes) + 1, dtype=np.int64)
+        foff = np.zeros(len(meshes) + 1, dtype=np.int64)
+        voff[1:] = np.cumsum([len(v) for v, _ in meshes])
+        foff[1:] = np.cumsum([len(f) for _, f in meshes])
+        self._chk(self.L.sh_upload_meshes(self.h, _ptr(verts), _ptr(faces), _ptr(voff), _ptr(foff), len(meshes)))
+        self.voff, self.foff = voff, foff
+
+    def synth_batch(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(-1, 16)
+        V, F = int(self.voff[1] - self.voff[0]), int(self.foff[1] - self.foff[0])
+        self._chk(self.L.sh_synth_batch(self.h, _ptr(T), len(T)))
+        self.voff = np.arange(len(T) + 1, dtype=np.int64) * V
+        self.foff = np.arange(len(T) + 1, dtype=np.int64) * F
+
+    @property
+    def B(self):
+        return self.L.sh_batch_size(self.h)
+
+    # ---- run ---------------------------------------------------------------------------------------
+    def run(self, stages=_lib.STAGE_ALL, fetch=True):
+        out = np.zeros(self.B, dtype=LANDMARKS_DTYPE) if fetch else None
+        self._chk(self.L.sh_run(self.h, int(stages), _ptr(out) if fetch else None))
+        return out
+
+    def landmarks_device(self):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._chk(self.L.sh_landmarks_device(self.h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def mesh_transformed(self, b, T):
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        out = np.empty((int(self.voff[b + 1] - self.voff[b]), 3), dtype=np.float64)
+        self._chk(self.L.sh_mesh_transformed(self.h, int(b), _ptr(T), _ptr(out)))
+        return out
+
+    # ---- named buffers -----------------------------------------------------------------------------
+    def fetch(self, name, dtype, shape=None):
+        n, e = ctypes.c_size_t(), ctypes.c_int()
+        self._chk(self.L.sh_buffer_info(self.h, name.encode(), ctypes.byref(n), ctypes.byref(e)))
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape)) if shape is not None else n.value // dtype.itemsize
+        out = np.empty(count, dtype=dtype)
+        self._chk(self.L.sh_fetch(self.h, name.encode(), _ptr(out), out.nbytes))
+        return out.reshape(shape) if shape is not None else out
+
+    def store(self, name, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.sh_store(self.h, name.encode(), _ptr(arr), arr.nbytes))
+
+    # ---- timing --------------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        self._chk(self.L.sh_enable_timing(self.h, 1 if on else 0))
+
+    def reset_timers(self):
+        self._chk(self.L.sh_kernel_time_ms(self.h, None, None, None))
+
+    def kernel_time_ms(self, name):
+        ms, n = ctypes.c_double(), ctypes.c_int()
+        self._chk(self.L.sh_kernel_time_ms(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value

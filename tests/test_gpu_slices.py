@@ -1,0 +1,86 @@
+"""GPU parity, slice layer + neck + canal: HIP path (through the C-ABI) vs the oracle on the
+reference's STL fixtures, with the oracle's OBB transform injected so that this stage is judged
+on its own.  Integer results exact; coordinates to 1e-9 mm (budget: 1e-4 mm)."""
+import numpy as np
+import pytest
+
+from shoulder_amd import _lib
+
+pytestmark = pytest.mark.gpu
+NAMES = ["humerus_left", "humerus_left_trab", "humerus_right"]
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ran(engine, oracle_bones):
+    hs = [oracle_bones(n) for n in NAMES]
+    engine.upload([(h.verts, h.faces) for h in hs])
+    engine.store("obb_transform", np.stack([h.T_obb for h in hs]))
+    engine.run(_lib.STAGE_FULL | _lib.STAGE_DISTAL | _lib.STAGE_NECK | _lib.STAGE_CANAL | _lib.STAGE_PROXIMAL, fetch=False)
+    return hs
+
+
+def test_verts_obb_and_bounds(engine, ran):
+    vo = engine.fetch("verts_obb", np.float64).reshape(-1, 3)
+    zb = engine.fetch("z_bounds", np.float64, (len(ran), 2))
+    for b, h in enumerate(ran):
+        got = vo[engine.voff[b]:engine.voff[b + 1]]
+        np.testing.assert_allclose(got, h.verts_obb, rtol=0, atol=1e-10)
+        assert abs(zb[b, 0] - h.verts_obb[:, 2].min()) < 1e-10 and abs(zb[b, 1] - h.verts_obb[:, 2].max()) < 1e-10
+
+
+@pytest.mark.parametrize("pfx,attr,N", [("full", "full", 200), ("distal", "distal", 200), ("prox", "proximal", 600)])
+def test_slice_sets(engine, ran, pfx, attr, N):
+    B = len(ran)
+    zs = engine.fetch(pfx + ".zs", np.float64, (B, N))
+    cen = engine.fetch(pfx + ".centroids", np.float64, (B, N, 2))
+    areas = engine.fetch(pfx + ".areas", np.float64, (B, N))
+    nl = engine.fetch(pfx + ".nloops", np.int32, (B, N))
+    cnt = engine.fetch(pfx + ".seg_count", np.int32, (B, N))
+    ring_n = engine.fetch(pfx + ".ring_n", np.int32, (B, N))
+    for b, h in enumerate(ran):
+        s = getattr(h, attr)
+        np.testing.assert_allclose(zs[b], s.zs_all, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(nl[b], s.n_loops)                                   # loop count: exact
+        np.testing.assert_array_equal(cnt[b], [sum(len(r) - 1 for r in rings) for rings in s.loops])   # crossing triangles: exact
+        np.testing.assert_array_equal(ring_n[b], [len(r) - 1 for r in s.largest])
+        np.testing.assert_allclose(cen[b], s.centroids_all, rtol=0, atol=TOL)
+        np.testing.assert_allclose(areas[b], s.areas1_all, rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("pfx,attr,N", [("distal", "distal", 200), ("prox", "proximal", 600)])
+def test_rings_canonical(engine, ran, pfx, attr, N):
+    B = len(ran)
+    ring = engine.fetch(pfx + ".ring", np.float64, (B, N, 1025, 2))
+    for b, h in enumerate(ran):
+        s = getattr(h, attr)
+        for k in range(0, N, 7):
+            r = s.largest[k]
+            np.testing.assert_allclose(ring[b, k, :len(r)], r, rtol=0, atol=TOL)          # same start, same direction
+
+
+def test_resample_and_polar(engine, ran):
+    B = len(ran)
+    ixy = engine.fetch("prox.ixy", np.float64, (B, 600, 2, 512))
+    its = engine.fetch("prox.itr_start", np.float64, (B, 600, 2, 512))
+    itc = engine.fetch("prox.itr_centered_start", np.float64, (B, 600, 2, 512))
+    for b, h in enumerate(ran):
+        p = h.proximal
+        np.testing.assert_allclose(ixy[b], p.ixy_all, rtol=0, atol=TOL)
+        for got, exp in ((its[b], p.itr_start_all), (itc[b], p.itr_centered_start_all)):
+            # theta rows: the roll index (argmin theta) is an integer decision -> must match exactly
+            np.testing.assert_array_equal(np.argmin(np.abs(got[:, 0, :] - exp[:, 0, :1]), axis=1), 0)
+            np.testing.assert_allclose(got, exp, rtol=0, atol=TOL)
+
+
+def test_neck_and_canal(engine, ran):
+    B = len(ran)
+    nz = engine.fetch("neck_z", np.float64, (B,))
+    ni = engine.fetch("neck_index", np.int32, (B,))
+    ax = engine.fetch("canal.axis_ct", np.float64, (B, 2, 3))
+    pts = engine.fetch("canal.points_obb", np.float64, (B, 80, 3))
+    for b, h in enumerate(ran):
+        assert ni[b] == h.neck["bkp"]
+        assert nz[b] == pytest.approx(h.neck["neck_z"], abs=1e-12)
+        np.testing.assert_allclose(pts[b], h.canal["points_obb"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(ax[b], h.canal["axis_ct"], rtol=0, atol=1e-8)
