@@ -1,0 +1,238 @@
+// k_anp.h -- anatomic neck around the UNet (reference src/shoulder/humerus/anatomic_neck.py).
+//   k_anp_rows    :40-54   even-theta re-interpolation + roll to the groove angle (one lane per row)
+//   k_anp_minmax  :56-58   global min-max (sklearn MinMaxScaler arithmetic) -> float32 image (:73-75)
+//   k_anp_edges   :79-118  mask = logit > 0, |diff(mask, prepend=0)| along theta, compaction -> points
+//   k_anp_plane   :123-153 plane fit (covariance, smallest eigenvector) + LSQ-ellipse centre
+//   k_rays        :174-236 4 rays (+-normal, +-central) vs all triangles, nearest hit (B-6)
+// Buffers: anp.raw [B][512][512] f64, anp.shft_theta [B][512][512] f64, anp.roll [B][512] i32,
+// anp.image [B][512][512] f32, anp.logits [B][512][512] f32, anp.points_obb [B][ANP_CAP][3] f64,
+// anp.counts [B][2] i32 (edge points, mask pixels), anp.plane [B][6] f64, anp.axes_obb [B][4][3] f64.
+#pragma once
+#include "k_groove.h"
+
+namespace sh {
+
+#define SH_ANP_CAP 65536
+#define SH_IMG (SH_ANP_ROWS * SH_MPROX)
+
+__global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][512]*/, const double* __restrict__ bg_theta,
+                           double* __restrict__ raw, double* __restrict__ shft_theta, int* __restrict__ roll, int B) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * SH_ANP_ROWS) return;
+  int b = gid / SH_ANP_ROWS, i = gid % SH_ANP_ROWS;
+  const int M = SH_MPROX;
+  const double* th = itr_start + ((size_t)b * SH_NPROX + SH_ANP_ROW0 + i) * 2 * M;
+  const double* r = th + M;
+  double t0 = th[0], t1 = th[M - 2];
+  double bg = bg_theta[b];
+  // pass 1: argmin |t_sampling - bg_theta| (first minimum)
+  int kbest = 0;
+  double dbest = 1e300;
+  for (int j = 0; j < M; ++j) {
+    double d = fabs(linspace_at(t0, t1, M, j) - bg);
+    if (d < dbest) { dbest = d; kbest = j; }
+  }
+  roll[gid] = kbest;
+  // pass 2: np.interp(t_sampling, theta[:-1], r[:-1]) in sample order (guess carried), rolled on write
+  double* o_r = raw + (size_t)gid * M;
+  double* o_t = shft_theta + (size_t)gid * M;
+  int jg = 0;
+  for (int j = 0; j < M; ++j) {
+    double t = linspace_at(t0, t1, M, j);
+    double v = np_interp_step(t, th, r, M - 1, &jg);
+    int dst = j - kbest; if (dst < 0) dst += M;
+    o_r[dst] = v;
+    o_t[dst] = t;
+  }
+}
+
+__global__ void k_anp_minmax(const double* __restrict__ raw, float* __restrict__ image) {
+  __shared__ double smin[4], smax[4];
+  __shared__ double g_scale, g_min;
+  int b = blockIdx.x, tid = threadIdx.x;
+  const double* x = raw + (size_t)b * SH_IMG;
+  double lo = 1e300, hi = -1e300;
+  for (int i = tid; i < SH_IMG; i += blockDim.x) { lo = fmin(lo, x[i]); hi = fmax(hi, x[i]); }
+  for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_down(lo, off)); hi = fmax(hi, __shfl_down(hi, off)); }
+  if ((tid & 63) == 0) { smin[tid >> 6] = lo; smax[tid >> 6] = hi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fmin(lo, smin[w]); hi = fmax(hi, smax[w]); }
+    double rng = hi - lo;
+    if (rng == 0.0) rng = 1.0;
+    g_scale = 1.0 / rng;
+    g_min = 0.0 - lo * g_scale;
+  }
+  __syncthreads();
+  double sc = g_scale, mn = g_min;
+  float* o = image + (size_t)b * SH_IMG;
+  for (int i = tid; i < SH_IMG; i += blockDim.x) o[i] = (float)(x[i] * sc + mn);
+}
+
+// one block of 512 lanes per humerus: lane = image row
+__global__ void __launch_bounds__(512)
+k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, const double* __restrict__ shft_theta,
+            const double* __restrict__ prox_zs, double* __restrict__ pts_obb, int* __restrict__ counts, int* __restrict__ err) {
+  __shared__ int cnt[SH_ANP_ROWS];
+  __shared__ int tot_mask[8];
+  int b = blockIdx.x, i = threadIdx.x;
+  const int M = SH_MPROX;
+  const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
+  int ne = 0, nm = 0, prev = 0;
+  for (int j = 0; j < M; ++j) {
+    int m = lg[j] > 0.0f ? 1 : 0;
+    ne += (m != prev);
+    nm += m;
+    prev = m;
+  }
+  cnt[i] = ne;
+  for (int off = 32; off > 0; off >>= 1) nm += __shfl_down(nm, off);
+  if ((i & 63) == 0) tot_mask[i >> 6] = nm;
+  __syncthreads();
+  // exclusive scan of the per-row edge counts (row-major boolean gather order)
+  __shared__ int offs[SH_ANP_ROWS];
+  if (i == 0) {
+    int acc = 0;
+    for (int r = 0; r < SH_ANP_ROWS; ++r) { offs[r] = acc; acc += cnt[r]; }
+    int tm = 0;
+    for (int w = 0; w < 8; ++w) tm += tot_mask[w];
+    counts[2 * b] = acc;
+    counts[2 * b + 1] = tm;
+    if (acc > SH_ANP_CAP) atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
+    if (acc < 6) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+  }
+  __syncthreads();
+  int o = offs[i];
+  const double* t = shft_theta + ((size_t)b * SH_ANP_ROWS + i) * M;
+  const double* r = raw + ((size_t)b * SH_ANP_ROWS + i) * M;
+  double z = prox_zs[(size_t)b * SH_NPROX + SH_ANP_ROW0 + i];
+  prev = 0;
+  for (int j = 0; j < M; ++j) {
+    int m = lg[j] > 0.0f ? 1 : 0;
+    if (m != prev && o < SH_ANP_CAP) {
+      double* p = pts_obb + ((size_t)b * SH_ANP_CAP + o) * 3;
+      p[0] = r[j] * cos(t[j]);
+      p[1] = r[j] * sin(t[j]);
+      p[2] = z;
+      ++o;
+    }
+    prev = m;
+  }
+}
+
+// deterministic block sum of NV values per thread (fixed tree)
+template <int NV>
+__device__ inline void block_sum(double* v, double* sh /*[NV][blockDim/64]*/, int tid, int nw) {
+  for (int k = 0; k < NV; ++k) {
+    double x = v[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    if ((tid & 63) == 0) sh[k * nw + (tid >> 6)] = x;
+  }
+  __syncthreads();
+  for (int k = 0; k < NV; ++k) {
+    double x = 0.0;
+    for (int w = 0; w < nw; ++w) x += sh[k * nw + w];
+    v[k] = x;
+  }
+  __syncthreads();
+}
+
+// Plane.best_fit + LsqEllipse centre (anatomic_neck.py:123-153); one block of 256 per humerus
+__global__ void __launch_bounds__(256)
+k_anp_plane(const double* __restrict__ pts_obb, const int* __restrict__ counts, double* __restrict__ plane /*[B][6]*/, int* __restrict__ err) {
+  __shared__ double sh[21 * 4];
+  int b = blockIdx.x, tid = threadIdx.x;
+  int K = counts[2 * b];
+  if (K > SH_ANP_CAP) K = SH_ANP_CAP;
+  const double* P = pts_obb + (size_t)b * SH_ANP_CAP * 3;
+  double* out = plane + 6 * b;
+  if (K < 6) { if (tid == 0) for (int k = 0; k < 6; ++k) out[k] = 0.0; return; }
+  double s[3] = {0, 0, 0};
+  for (int i = tid; i < K; i += 256) { s[0] += P[3 * i]; s[1] += P[3 * i + 1]; s[2] += P[3 * i + 2]; }
+  block_sum<3>(s, sh, tid, 4);
+  double c[3] = {s[0] / K, s[1] / K, s[2] / K};
+  double m[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = tid; i < K; i += 256) {
+    double x = P[3 * i] - c[0], y = P[3 * i + 1] - c[1], z = P[3 * i + 2] - c[2];
+    m[0] += x * x; m[1] += x * y; m[2] += x * z; m[3] += y * y; m[4] += y * z; m[5] += z * z;
+  }
+  block_sum<6>(m, sh, tid, 4);
+  double C[9] = {m[0], m[1], m[2], m[1], m[3], m[4], m[2], m[4], m[5]};
+  double w[3], V[9];
+  eig_sym3(C, w, V);
+  double nrm[3] = {V[0], V[3], V[6]};        // smallest eigenvalue = plane normal
+  if (nrm[2] < 0) { nrm[0] = -nrm[0]; nrm[1] = -nrm[1]; nrm[2] = -nrm[2]; }
+  double u[3], v[3];
+  plane_basis(nrm, u, v);
+  // 6x6 scatter of [x^2, xy, y^2, x, y, 1] in plane coordinates about c
+  double S[21];
+  for (int k = 0; k < 21; ++k) S[k] = 0.0;
+  for (int i = tid; i < K; i += 256) {
+    double rel[3] = {P[3 * i] - c[0], P[3 * i + 1] - c[1], P[3 * i + 2] - c[2]};
+    double x = dot3(rel, u), y = dot3(rel, v);
+    double d[6] = {x * x, x * y, y * y, x, y, 1.0};
+    int q = 0;
+    for (int a = 0; a < 6; ++a)
+      for (int e = a; e < 6; ++e) S[q++] += d[a] * d[e];
+  }
+  block_sum<21>(S, sh, tid, 4);
+  if (tid == 0) {
+    double S6[36];
+    int q = 0;
+    for (int a = 0; a < 6; ++a)
+      for (int e = a; e < 6; ++e) { S6[a * 6 + e] = S[q]; S6[e * 6 + a] = S[q]; ++q; }
+    double ex, ey;
+    if (!ellipse_center_from_scatter(S6, &ex, &ey)) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); ex = ey = 0.0; }
+    for (int k = 0; k < 3; ++k) { out[k] = c[k] + ex * u[k] + ey * v[k]; out[3 + k] = nrm[k]; }
+  }
+}
+
+// K23: rays from the plane point: 0 = +normal, 1 = -normal, 2 = +central, 3 = -central
+// (central = normal with z zeroed, renormalised).  One block per (humerus, ray), all triangles,
+// Moller-Trumbore in fp64, nearest forward hit.
+__global__ void __launch_bounds__(256)
+k_rays(const double* __restrict__ vobb, const int* __restrict__ faces, const long long* __restrict__ voff,
+       const long long* __restrict__ foff, const double* __restrict__ plane, double* __restrict__ axes_obb, int* __restrict__ err) {
+  __shared__ double wt[4];
+  int b = blockIdx.x, ray = blockIdx.y, tid = threadIdx.x;
+  const double* pl = plane + 6 * b;
+  double o[3] = {pl[0], pl[1], pl[2]};
+  double d[3] = {pl[3], pl[4], pl[5]};
+  if (d[2] < 0) { d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+  if (ray >= 2) { d[2] = 0.0; double n = norm3(d); d[0] /= n; d[1] /= n; d[2] /= n; }
+  if (ray & 1) { d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+  const double* vb = vobb + 3 * voff[b];
+  const int* fb = faces + 3 * foff[b];
+  long long nf = foff[b + 1] - foff[b];
+  double tbest = 1e300;
+  for (long long f = tid; f < nf; f += 256) {
+    const double* A = vb + 3 * (size_t)fb[3 * f];
+    const double* Bv = vb + 3 * (size_t)fb[3 * f + 1];
+    const double* Cv = vb + 3 * (size_t)fb[3 * f + 2];
+    double e1[3] = {Bv[0] - A[0], Bv[1] - A[1], Bv[2] - A[2]};
+    double e2[3] = {Cv[0] - A[0], Cv[1] - A[1], Cv[2] - A[2]};
+    double pv[3];
+    cross3(d, e2, pv);
+    double det = dot3(e1, pv);
+    if (!(fabs(det) > 1e-12)) continue;
+    double inv = 1.0 / det;
+    double tv[3] = {o[0] - A[0], o[1] - A[1], o[2] - A[2]};
+    double uu = dot3(tv, pv) * inv;
+    double qv[3];
+    cross3(tv, e1, qv);
+    double ww = dot3(d, qv) * inv;
+    double t = dot3(e2, qv) * inv;
+    if (uu >= 0 && ww >= 0 && uu + ww <= 1 && t > 1e-9 && t < tbest) tbest = t;
+  }
+  for (int off = 32; off > 0; off >>= 1) tbest = fmin(tbest, __shfl_down(tbest, off));
+  if ((tid & 63) == 0) wt[tid >> 6] = tbest;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) tbest = fmin(tbest, wt[w]);
+    double* a = axes_obb + ((size_t)b * 4 + ray) * 3;
+    if (tbest > 1e299) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); a[0] = a[1] = a[2] = 0.0; }
+    else for (int k = 0; k < 3; ++k) a[k] = o[k] + d[k] * tbest;
+  }
+}
+
+}  // namespace sh

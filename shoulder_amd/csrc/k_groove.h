@@ -1,0 +1,175 @@
+// k_groove.h -- bicipital groove on the device (reference src/shoulder/humerus/bicipital_groove.py).
+//   k_groove_rows     :102-156  per-row savgol / find_peaks / features   (one lane per slice row)
+//   k_groove_scale    :156      StandardScaler statistics                (one lane per feature)
+//   k_groove_rfc      :174-185  random forest P(class 1) per peak        (one lane per peak)
+//   k_groove_kde      :184-188  linear-kernel KDE argmax -> bg_theta     (one block per humerus)
+//   k_groove_localmin :192-232  per-row local radius minimum -> points   (one lane per slice row)
+//   k_groove_axis     :244-265  line fit (wave covariance + power iteration), B-4 orientation
+// Buffers: groove.xraw [B][330*7][9] f64, groove.ptheta [B][330*7] f64, groove.npk [B][330] i32,
+// groove.r0 [B][330][512] f64, groove.stats [B][18] f64 (mean, scale), groove.proba [B][330*7] f32,
+// groove.bg_theta [B] f64, groove.local_idx [B][330] i32, groove.points_obb [B][330][3] f64.
+#pragma once
+#include "k_stages.h"
+
+namespace sh {
+
+#define SH_GSLOTS (SH_GROOVE_NROWS * SH_MAXPEAK)
+
+__global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][512]*/, const double* __restrict__ prox_zs,
+                              const double* __restrict__ canal_axis_ct, int row0, double* __restrict__ scratch,
+                              double* __restrict__ xraw, double* __restrict__ ptheta, int* __restrict__ npk,
+                              double* __restrict__ r0, int* __restrict__ err, int B) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * SH_GROOVE_NROWS) return;
+  int b = gid / SH_GROOVE_NROWS, i = gid % SH_GROOVE_NROWS;
+  const double* row = itr_cs + ((size_t)b * SH_NPROX + row0 + i) * 2 * SH_MPROX;
+  const double* zs = prox_zs + (size_t)b * SH_NPROX + row0;
+  // MinMaxScaler over the cut zs (bicipital_groove.py:89): X*scale_ + min_, zs descend
+  double zmax = zs[0], zmin = zs[0];
+  for (int k = 1; k < SH_GROOVE_NROWS; ++k) { zmax = fmax(zmax, zs[k]); zmin = fmin(zmin, zs[k]); }
+  double rng = zmax - zmin;
+  if (rng == 0.0) rng = 1.0;
+  double sc = 1.0 / rng;
+  double z_scaled = zs[i] * sc + (0.0 - zmin * sc);
+  const double* ax = canal_axis_ct + 6 * b;
+  double cu[3] = {ax[0] - ax[3], ax[1] - ax[4], ax[2] - ax[5]};
+  double n = norm3(cu);
+  cu[0] /= n; cu[1] /= n; cu[2] /= n;
+  double* sc3 = scratch + (size_t)gid * 3 * SH_MPROX;
+  int pidx[SH_MAXPEAK];
+  int np_ = groove_row_features(row, row + SH_MPROX, SH_MPROX, zs[i], z_scaled, cu, sc3,
+                                xraw + ((size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK) * 9,
+                                ptheta + (size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK, pidx);
+  npk[gid] = np_;
+  double* r0row = r0 + (size_t)gid * SH_MPROX;
+  for (int k = 0; k < SH_MPROX; ++k) r0row[k] = -sc3[k];     // polar_0 radius = r - mean(r)
+  // a NaN feature = the reference's IndexError (all other peaks within 0.005 rad)
+  for (int k = 0; k < np_ * 9; ++k) {
+    double v = xraw[((size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK) * 9 + k];
+    if (v != v) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+  }
+}
+
+// sklearn StandardScaler: mean over rows, population variance, scale = sqrt(var) (1 if ~0)
+__global__ void k_groove_scale(const double* __restrict__ xraw, const int* __restrict__ npk, double* __restrict__ stats, int B) {
+  int b = blockIdx.x, f = threadIdx.x;
+  if (f >= 9) return;
+  const double* X = xraw + (size_t)b * SH_GSLOTS * 9;
+  const int* np_ = npk + (size_t)b * SH_GROOVE_NROWS;
+  double s = 0.0;
+  int P = 0;
+  for (int i = 0; i < SH_GROOVE_NROWS; ++i)
+    for (int k = 0; k < np_[i]; ++k) { s += X[((size_t)i * SH_MAXPEAK + k) * 9 + f]; ++P; }
+  double mean = P ? s / (double)P : 0.0;
+  double v = 0.0;
+  for (int i = 0; i < SH_GROOVE_NROWS; ++i)
+    for (int k = 0; k < np_[i]; ++k) { double d = X[((size_t)i * SH_MAXPEAK + k) * 9 + f] - mean; v += d * d; }
+  double var = P ? v / (double)P : 0.0;
+  double scale = sqrt(var);
+  if (scale < 10.0 * 2.220446049250313e-16) scale = 1.0;
+  stats[(size_t)b * 18 + f] = mean;
+  stats[(size_t)b * 18 + 9 + f] = scale;
+}
+
+__global__ void k_groove_rfc(const double* __restrict__ xraw, const int* __restrict__ npk, const double* __restrict__ stats,
+                             const int* __restrict__ feat, const float* __restrict__ thr, const int* __restrict__ ti,
+                             const int* __restrict__ fi, const float* __restrict__ lw, const int* __restrict__ roots, int n_trees,
+                             double* __restrict__ xs /*[B][slots][9] scaled*/, float* __restrict__ proba, int B) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * SH_GSLOTS) return;
+  int b = gid / SH_GSLOTS, s = gid % SH_GSLOTS;
+  int i = s / SH_MAXPEAK, k = s % SH_MAXPEAK;
+  if (k >= npk[(size_t)b * SH_GROOVE_NROWS + i]) { proba[gid] = -1.0f; return; }
+  double x[9];
+  for (int f = 0; f < 9; ++f) {
+    x[f] = (xraw[(size_t)gid * 9 + f] - stats[(size_t)b * 18 + f]) / stats[(size_t)b * 18 + 9 + f];
+    xs[(size_t)gid * 9 + f] = x[f];
+  }
+  proba[gid] = rfc_proba1(feat, thr, ti, fi, lw, roots, n_trees, x);
+}
+
+// KernelDensity(kernel="linear", bandwidth=1): rho(t) ~ sum_i max(0, 1 - |t - theta_i|) over the
+// peaks with P > 0.4; bg_theta = first argmax over linspace(-pi, pi, 1024)
+__global__ void k_groove_kde(const double* __restrict__ ptheta, const float* __restrict__ proba, double* __restrict__ bg_theta,
+                             int* __restrict__ err) {
+  __shared__ double sel[SH_GSLOTS];
+  __shared__ int nsel;
+  __shared__ double wv[4];
+  __shared__ int wi[4];
+  int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int n = 0;
+    for (int s = 0; s < SH_GSLOTS; ++s)
+      if (proba[(size_t)b * SH_GSLOTS + s] > 0.4f) sel[n++] = ptheta[(size_t)b * SH_GSLOTS + s];
+    nsel = n;
+  }
+  __syncthreads();
+  const int n = nsel;
+  if (n == 0) { if (tid == 0) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); bg_theta[b] = 0.0; } return; }
+  double best = -1.0;
+  int bi = 0x7fffffff;
+  for (int j = tid; j < 1024; j += blockDim.x) {
+    double t = linspace_at(-1.0 * M_PI, M_PI, 1024, j);
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) {
+      double d = 1.0 - fabs(t - sel[i]);
+      if (d > 0.0) acc += d;
+    }
+    if (acc > best || (acc == best && j < bi)) { best = acc; bi = j; }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    double ob = __shfl_down(best, off);
+    int oi = __shfl_down(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if ((tid & 63) == 0) { wv[tid >> 6] = best; wi[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+      if (wv[w] > best || (wv[w] == best && wi[w] < bi)) { best = wv[w]; bi = wi[w]; }
+    bg_theta[b] = linspace_at(-1.0 * M_PI, M_PI, 1024, bi);
+  }
+}
+
+__global__ void k_groove_localmin(const double* __restrict__ itr_cs, const double* __restrict__ r0, const double* __restrict__ prox_zs,
+                                  const double* __restrict__ prox_centroids, const double* __restrict__ bg_theta, int row0, double deg_window,
+                                  int* __restrict__ local_idx, double* __restrict__ pts_obb, int B) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * SH_GROOVE_NROWS) return;
+  int b = gid / SH_GROOVE_NROWS, i = gid % SH_GROOVE_NROWS;
+  const double* row = itr_cs + ((size_t)b * SH_NPROX + row0 + i) * 2 * SH_MPROX;
+  int ivar = (int)rint(deg_window / (360.0 / (double)SH_MPROX));
+  if (ivar < 1) ivar = 1;
+  int loc = groove_local_min(row, r0 + (size_t)gid * SH_MPROX, SH_MPROX, bg_theta[b], ivar);
+  local_idx[gid] = loc;
+  int k = loc < 0 ? loc + SH_MPROX : loc;      // python negative index
+  double t = row[k], r = row[SH_MPROX + k];
+  const double* c = prox_centroids + 2 * ((size_t)b * SH_NPROX + row0 + i);
+  double* p = pts_obb + (size_t)gid * 3;
+  p[0] = r * cos(t) + c[0];
+  p[1] = r * sin(t) + c[1];
+  p[2] = prox_zs[(size_t)b * SH_NPROX + row0 + i] + 0.0;
+}
+
+__global__ void k_groove_axis(const double* __restrict__ pts_obb, const double* __restrict__ T_obb, double* __restrict__ axis_ct,
+                              double* __restrict__ pts_ct) {
+  int b = blockIdx.x, lane = threadIdx.x;
+  const double* P = pts_obb + (size_t)b * SH_GROOVE_NROWS * 3;
+  double mean[3], d[3];
+  wave_line_fit(P, SH_GROOVE_NROWS, 3, mean, d);
+  double zmin = 1e300, zmax = -1e300;
+  for (int i = lane; i < SH_GROOVE_NROWS; i += 64) { zmin = fmin(zmin, P[3 * i + 2]); zmax = fmax(zmax, P[3 * i + 2]); }
+  for (int off = 32; off > 0; off >>= 1) { zmin = fmin(zmin, __shfl_down(zmin, off)); zmax = fmax(zmax, __shfl_down(zmax, off)); }
+  zmin = __shfl(zmin, 0); zmax = __shfl(zmax, 0);
+  double Ti[16];
+  inv_transform(T_obb + 16 * b, Ti);
+  for (int i = lane; i < SH_GROOVE_NROWS; i += 64) xform_pt(Ti, P[3 * i], P[3 * i + 1], P[3 * i + 2], pts_ct + ((size_t)b * SH_GROOVE_NROWS + i) * 3);
+  if (lane == 0) {
+    if (d[2] < 0) { d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }      // B-4
+    double h = (zmax - zmin) / 2.0;
+    xform_pt(Ti, mean[0] + d[0] * h, mean[1] + d[1] * h, mean[2] + d[2] * h, axis_ct + 6 * b);
+    xform_pt(Ti, mean[0] - d[0] * h, mean[1] - d[1] * h, mean[2] - d[2] * h, axis_ct + 6 * b + 3);
+  }
+}
+
+}  // namespace sh

@@ -1,0 +1,140 @@
+// k_te.h -- trans-epicondylar axis, coordinate system and the landmark record
+// (reference src/shoulder/humerus/epicondyle.py:29-101, src/shoulder/bone.py:146-157).
+//   k_te_rows   :33-40  min-area rectangle of every distal slice in the cut (one lane per slice)
+//   k_te_final  :39-96  widest slice -> end slivers -> centroids -> farthest pair -> medial first
+//   k_pack      bone.py:146-157 construct_csys(canal, TE) + fill sh_landmarks (CT coordinates)
+#pragma once
+#include "../../include/shoulder_hip.h"
+#include "k_unet.h"
+
+namespace sh {
+
+#define SH_TE_ROW0 2
+#define SH_TE_NROWS 37          // int((1-.99)*200)=2 .. int((1-.8)*200)=39 (slice.py:157-164)
+#define SH_TE_ISCR (3 * SH_MAXSEG + 8)
+
+__global__ void k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, int* __restrict__ iscratch,
+                          double* __restrict__ rects /*[B][37][7]*/, int B) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * SH_TE_NROWS) return;
+  int b = gid / SH_TE_NROWS, j = gid % SH_TE_NROWS;
+  size_t pl = (size_t)b * SH_NDIST + SH_TE_ROW0 + j;
+  const double* xy = ring + pl * (SH_MAXSEG + 1) * 2;
+  int n = ring_n[pl];
+  int* idx = iscratch + (size_t)gid * SH_TE_ISCR;
+  int* hull = idx + SH_MAXSEG;
+  double* o = rects + (size_t)gid * 7;
+  Rect2 r;
+  r.cx = r.cy = r.mx = r.my = r.L = r.W = r.area = 0.0;
+  if (n >= 3) {
+    int nh = convex_hull_2d(xy, n, idx, hull);
+    min_area_rect(xy, hull, nh, &r);
+  }
+  o[0] = r.cx; o[1] = r.cy; o[2] = r.mx; o[3] = r.my; o[4] = r.L; o[5] = r.W; o[6] = r.area;
+}
+
+#define SH_TE_DSCR (6 * SH_MAXSEG + 64 * SH_TE_MAXCH)
+__global__ void k_te_final(const double* __restrict__ ring, const int* __restrict__ ring_n, const double* __restrict__ rects,
+                           const double* __restrict__ distal_zs, const double* __restrict__ T_obb, const double* __restrict__ canal_axis_ct,
+                           const double* __restrict__ axes_obb /*[B][4][3]: +n,-n,+c,-c*/, double* __restrict__ dscratch,
+                           double* __restrict__ te_axis_ct, int* __restrict__ te_row, int* __restrict__ err, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* R = rects + (size_t)b * SH_TE_NROWS * 7;
+  int k = 0;
+  for (int j = 1; j < SH_TE_NROWS; ++j) if (R[j * 7 + 4] > R[k * 7 + 4]) k = j;     // dist.index(max(dist))
+  te_row[b] = SH_TE_ROW0 + k;
+  size_t pl = (size_t)b * SH_NDIST + SH_TE_ROW0 + k;
+  const double* xy = ring + pl * (SH_MAXSEG + 1) * 2;
+  int n = ring_n[pl];
+  const double* r = R + k * 7;
+  double half = 0.5 * 0.999 * r[4];
+  double cents[2 * 16];
+  double* scr = dscratch + (size_t)b * SH_TE_DSCR;
+  int n1 = clip_halfplane_pieces(xy, n, r[0], r[1], r[2], r[3], half, cents, 8, scr);
+  if (n1 < 0) n1 = 0;
+  if (n1 > 8) n1 = 8;
+  int n2 = clip_halfplane_pieces(xy, n, r[0], r[1], -r[2], -r[3], half, cents + 2 * n1, 8, scr);
+  if (n2 < 0) n2 = 0;
+  if (n2 > 8) n2 = 8;
+  int np_ = n1 + n2;
+  double* out = te_axis_ct + 6 * b;
+  if (np_ < 2) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); for (int q = 0; q < 6; ++q) out[q] = 0.0; return; }
+  int bi = 0, bj = 1;
+  double bd = -1.0;
+  for (int i = 0; i < np_; ++i)
+    for (int j = 0; j < np_; ++j) {     // np.argmax over the full (symmetric) distance matrix: first maximum
+      double dx = cents[2 * i] - cents[2 * j], dy = cents[2 * i + 1] - cents[2 * j + 1];
+      double d2 = dx * dx + dy * dy;
+      if (d2 > bd) { bd = d2; bi = i; bj = j; }
+    }
+  int i0 = bi < bj ? bi : bj, i1 = bi < bj ? bj : bi;
+  double z = distal_zs[pl];
+  double Ti[16];
+  inv_transform(T_obb + 16 * b, Ti);
+  double e0[3], e1[3];
+  xform_pt(Ti, cents[2 * i0], cents[2 * i0 + 1], z, e0);
+  xform_pt(Ti, cents[2 * i1], cents[2 * i1 + 1], z, e1);
+  // epicondyle.py:90-96: medial end = smaller x in construct_csys(canal axis, head central axis)
+  double central_ct[6], cs[16];
+  xform_pt(Ti, axes_obb[((size_t)b * 4 + 2) * 3], axes_obb[((size_t)b * 4 + 2) * 3 + 1], axes_obb[((size_t)b * 4 + 2) * 3 + 2], central_ct);
+  xform_pt(Ti, axes_obb[((size_t)b * 4 + 3) * 3], axes_obb[((size_t)b * 4 + 3) * 3 + 1], axes_obb[((size_t)b * 4 + 3) * 3 + 2], central_ct + 3);
+  construct_csys(canal_axis_ct + 6 * b, central_ct, cs);
+  double q0[3], q1[3];
+  xform_pt(cs, e0[0], e0[1], e0[2], q0);
+  xform_pt(cs, e1[0], e1[1], e1[2], q1);
+  bool swap = q1[0] < q0[0];       // np.argmin: first minimum
+  for (int q = 0; q < 3; ++q) { out[q] = swap ? e1[q] : e0[q]; out[3 + q] = swap ? e0[q] : e1[q]; }
+}
+
+__global__ void k_pack(sh_landmarks* __restrict__ lm, const double* __restrict__ T_obb, const double* __restrict__ zb,
+                       const double* __restrict__ neck_z, const int* __restrict__ neck_index, const int* __restrict__ flipped,
+                       const double* __restrict__ canal_axis_ct, const double* __restrict__ te_axis_ct,
+                       const double* __restrict__ groove_axis_ct, const double* __restrict__ bg_theta,
+                       const double* __restrict__ groove_pts_ct, const double* __restrict__ plane, const double* __restrict__ axes_obb,
+                       const double* __restrict__ anp_pts_obb, const int* __restrict__ anp_counts, const int* __restrict__ err,
+                       uint32_t mask, int B) {
+  int b = blockIdx.x;
+  if (b >= B) return;
+  sh_landmarks* L = lm + b;
+  int tid = threadIdx.x;
+  double Ti[16];
+  inv_transform(T_obb + 16 * b, Ti);
+  if (mask & SH_STAGE_GROOVE)
+    for (int i = tid; i < SH_GROOVE_NROWS * 3; i += blockDim.x) L->groove_points[i] = groove_pts_ct[(size_t)b * SH_GROOVE_NROWS * 3 + i];
+  if (mask & SH_STAGE_ANP) {
+    int K = anp_counts[2 * b];
+    if (K > SH_ANP_MAX_PTS) K = SH_ANP_MAX_PTS;
+    for (int i = tid; i < SH_ANP_MAX_PTS; i += blockDim.x) {
+      double o[3] = {0, 0, 0};
+      if (i < K) { const double* p = anp_pts_obb + ((size_t)b * SH_ANP_CAP + i) * 3; xform_pt(Ti, p[0], p[1], p[2], o); }
+      L->anp_points[3 * i] = o[0]; L->anp_points[3 * i + 1] = o[1]; L->anp_points[3 * i + 2] = o[2];
+    }
+  }
+  if (tid != 0) return;
+  for (int i = 0; i < 16; ++i) L->obb_transform[i] = T_obb[16 * b + i];
+  L->z_length = fabs(zb[2 * b]) + fabs(zb[2 * b + 1]);
+  L->neck_z = neck_z[b];
+  L->neck_index = neck_index[b];
+  L->flipped = flipped ? flipped[b] : 0;
+  L->status = err[b];
+  L->pad_ = 0;
+  for (int i = 0; i < 6; ++i) { L->canal_axis[i] = canal_axis_ct[6 * b + i]; }
+  if (mask & SH_STAGE_GROOVE) { for (int i = 0; i < 6; ++i) L->groove_axis[i] = groove_axis_ct[6 * b + i]; L->bg_theta = bg_theta[b]; }
+  if (mask & SH_STAGE_ANP) {
+    const double* pl = plane + 6 * b;
+    xform_pt(Ti, pl[0], pl[1], pl[2], L->anp_plane_point);
+    for (int r = 0; r < 3; ++r) L->anp_plane_normal[r] = (Ti[r * 4] * pl[3] + Ti[r * 4 + 1] * pl[4]) + Ti[r * 4 + 2] * pl[5];
+    for (int ray = 0; ray < 4; ++ray) {
+      const double* a = axes_obb + ((size_t)b * 4 + ray) * 3;
+      double* dst = ray < 2 ? L->anp_axis_normal + 3 * ray : L->anp_axis_central + 3 * (ray - 2);
+      xform_pt(Ti, a[0], a[1], a[2], dst);
+    }
+    L->n_anp = anp_counts[2 * b];
+    L->n_articular = anp_counts[2 * b + 1];
+  }
+  if (mask & SH_STAGE_TE) for (int i = 0; i < 6; ++i) L->te_axis[i] = te_axis_ct[6 * b + i];
+  if (mask & SH_STAGE_CSYS) construct_csys(L->canal_axis, L->te_axis, L->csys);     // bone.py:150
+}
+
+}  // namespace sh

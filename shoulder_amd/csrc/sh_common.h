@@ -169,6 +169,52 @@ SH_HD double interp1(double x, const double* xp, const double* fp, int n, int sx
   return slope * (x - x0) + f0;
 }
 
+// NumPy's np.interp search (compiled_base.c binary_search_with_guess): identical to a plain
+// search on sorted xp, and reproduces NumPy's answer on the not-quite-sorted theta rows of
+// anatomic_neck.py:43-44 because the previous index is carried as the guess.
+SH_HD int np_search_with_guess(double key, const double* arr, int len, int guess) {
+  int imin = 0, imax = len;
+  if (key > arr[len - 1]) return len;
+  else if (key < arr[0]) return -1;
+  if (len <= 4) { int i; for (i = 1; i < len && key >= arr[i]; ++i) {} return i - 1; }
+  if (guess > len - 3) guess = len - 3;
+  if (guess < 1) guess = 1;
+  if (key < arr[guess]) {
+    if (key < arr[guess - 1]) {
+      imax = guess - 1;
+      if (guess > 8 && key >= arr[guess - 8]) imin = guess - 8;
+    } else return guess - 1;
+  } else {
+    if (key < arr[guess + 1]) return guess;
+    else if (key < arr[guess + 2]) return guess + 1;
+    else {
+      imin = guess + 2;
+      if (guess < len - 8 - 1 && key < arr[guess + 8]) imax = guess + 8;
+    }
+  }
+  while (imin < imax) {
+    int imid = imin + ((imax - imin) >> 1);
+    if (key >= arr[imid]) imin = imid + 1; else imax = imid;
+  }
+  return imin - 1;
+}
+
+// One np.interp evaluation with the carried guess *j (arr_interp loop body).
+SH_HD double np_interp_step(double x, const double* xp, const double* fp, int n, int* j) {
+  *j = np_search_with_guess(x, xp, n, *j);
+  if (*j == -1) return fp[0];
+  if (*j == n) return fp[n - 1];
+  if (*j == n - 1) return fp[*j];
+  if (xp[*j] == x) return fp[*j];
+  double slope = (fp[*j + 1] - fp[*j]) / (xp[*j + 1] - xp[*j]);
+  double r = slope * (x - xp[*j]) + fp[*j];
+  if (r != r) {  // NaN: NumPy retries from the right neighbour
+    r = slope * (x - xp[*j + 1]) + fp[*j + 1];
+    if (r != r && fp[*j] == fp[*j + 1]) r = fp[*j];
+  }
+  return r;
+}
+
 // ---- symmetric 3x3 eigen-decomposition (cyclic Jacobi, fp64) ---------------------------
 // w ascending, V columns = eigenvectors (row-major V[r*3+c]).
 SH_HD void eig_sym3(const double* Ain, double* w, double* V) {

@@ -13,6 +13,10 @@
 
 #include "k_slices.h"
 #include "k_stages.h"
+#include "k_groove.h"
+#include "k_anp.h"
+#include "k_unet.h"
+#include "k_te.h"
 
 using namespace sh;
 
@@ -40,6 +44,13 @@ struct sh_ctx {
   std::map<std::string, Buf> bufs;
   bool have_rfc = false, have_unet = false;
   int rfc_nodes = 0, rfc_trees = 0;
+  int unet_base = 0, unet_depth = 0;
+  std::vector<float> h_unet;                 // packed UNet parameters (host copy)
+  std::vector<int32_t> h_feat, h_ti, h_fi, h_roots;
+  std::vector<float> h_thr, h_lw;
+  struct ULayer { size_t w_off, b_off; int cin, cout, taps; };
+  std::map<std::string, ULayer> ulayers;
+  size_t unet_floats = 0;
   bool obb_injected = false;
   // timing
   bool timing = false;
@@ -209,6 +220,38 @@ static int alloc_batch(sh_ctx* c) {
   ENS("prox.ixy", (size_t)B * SH_NPROX * 2 * SH_MPROX * 8, 8);
   ENS("prox.itr_start", (size_t)B * SH_NPROX * 2 * SH_MPROX * 8, 8);
   ENS("prox.itr_centered_start", (size_t)B * SH_NPROX * 2 * SH_MPROX * 8, 8);
+  // groove
+  ENS("groove.scratch", (size_t)B * SH_GROOVE_NROWS * 3 * SH_MPROX * 8, 8);
+  ENS("groove.xraw", (size_t)B * SH_GSLOTS * 9 * 8, 8);
+  ENS("groove.xs", (size_t)B * SH_GSLOTS * 9 * 8, 8);
+  ENS("groove.ptheta", (size_t)B * SH_GSLOTS * 8, 8);
+  ENS("groove.npk", (size_t)B * SH_GROOVE_NROWS * 4, 4);
+  ENS("groove.r0", (size_t)B * SH_GROOVE_NROWS * SH_MPROX * 8, 8);
+  ENS("groove.stats", (size_t)B * 18 * 8, 8);
+  ENS("groove.proba", (size_t)B * SH_GSLOTS * 4, 4);
+  ENS("groove.bg_theta", (size_t)B * 8, 8);
+  ENS("groove.local_idx", (size_t)B * SH_GROOVE_NROWS * 4, 4);
+  ENS("groove.points_obb", (size_t)B * SH_GROOVE_NROWS * 3 * 8, 8);
+  ENS("groove.points_ct", (size_t)B * SH_GROOVE_NROWS * 3 * 8, 8);
+  ENS("groove.axis_ct", (size_t)B * 6 * 8, 8);
+  // anatomic neck
+  ENS("anp.raw", (size_t)B * SH_IMG * 8, 8);
+  ENS("anp.shft_theta", (size_t)B * SH_IMG * 8, 8);
+  ENS("anp.roll", (size_t)B * SH_ANP_ROWS * 4, 4);
+  ENS("anp.image", (size_t)B * SH_IMG * 4, 4);
+  ENS("anp.logits", (size_t)B * SH_IMG * 4, 4);
+  ENS("anp.points_obb", (size_t)B * SH_ANP_CAP * 3 * 8, 8);
+  ENS("anp.counts", (size_t)B * 2 * 4, 4);
+  ENS("anp.plane", (size_t)B * 6 * 8, 8);
+  ENS("anp.axes_obb", (size_t)B * 12 * 8, 8);
+  // trans-epicondylar
+  ENS("te.iscratch", (size_t)B * SH_TE_NROWS * SH_TE_ISCR * 4, 4);
+  ENS("te.dscratch", (size_t)B * SH_TE_DSCR * 8, 8);
+  ENS("te.rects", (size_t)B * SH_TE_NROWS * 7 * 8, 8);
+  ENS("te.axis_ct", (size_t)B * 6 * 8, 8);
+  ENS("te.row", (size_t)B * 4, 4);
+  ENS("flipped", (size_t)B * 4, 4);
+  HIPCHK(c, hipMemsetAsync(buf<int>(c, "flipped"), 0, (size_t)B * 4, c->stream));
 #undef ENS
   c->obb_injected = false;
   return SH_OK;
@@ -361,6 +404,83 @@ int sh_mesh_transformed(sh_ctx* c, int b, const double* T, double* out) {
   return SH_OK;
 }
 
+// ---- UNet forward (f32 MFMA path) ----------------------------------------------------------------------
+static int conv_layer(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const float* src0, const float* src1, int C0, int C1, float* dst,
+                      int H, int W, int nimg, int relu) {
+  if (H % UN_TH || W % UN_TW) return fail(c, SH_ERR_ARG, "unet: feature map is not a multiple of 16");
+  const float* P = buf<float>(c, "params");
+  const float* w = P + L.w_off; const float* b = P + L.b_off;
+  const int tiles = (H / UN_TH) * (W / UN_TW);
+  if (L.taps == 9) {
+    if (L.cout % 64 == 0) {
+      LAUNCH(c, lname, (k_conv_mfma_f32<9, 4>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu);
+    } else {
+      LAUNCH(c, lname, (k_conv_mfma_f32<9, 2>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu);
+    }
+  } else {
+    if (L.cout % 64 == 0) {
+      LAUNCH(c, lname, (k_conv_mfma_f32<1, 4>), dim3(tiles, L.cout / 64, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0);
+    } else {
+      LAUNCH(c, lname, (k_conv_mfma_f32<1, 2>), dim3(tiles, L.cout / 32, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0);
+    }
+  }
+  return SH_OK;
+}
+
+static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
+  const int D = c->unet_depth, base = c->unet_base;
+  if ((H >> D) % 16 || (W >> D) % 16) return fail(c, SH_ERR_ARG, "unet: input size must be a multiple of 16 << depth");
+  int rc;
+  const size_t full = (size_t)nimg * H * W * base * 4;
+  if ((rc = ensure(c, "unet.a", full, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "unet.b", full, 4)) != SH_OK) return rc;
+  std::vector<float*> skip(D);
+  for (int i = 0; i < D; ++i) {
+    std::string nm = "unet.skip" + std::to_string(i);
+    if ((rc = ensure(c, nm.c_str(), full >> i, 4)) != SH_OK) return rc;     // H*W/4^i * base*2^i
+    skip[i] = buf<float>(c, nm.c_str());
+  }
+  float* A = buf<float>(c, "unet.a");
+  float* Bq = buf<float>(c, "unet.b");
+  const float* P = buf<float>(c, "params");
+  auto L = [&](const std::string& n) -> const sh_ctx::ULayer& { return c->ulayers[n]; };
+  int h = H, w = W;
+  {
+    const sh_ctx::ULayer& l = L("enc0a");
+    size_t npx = (size_t)nimg * h * w;
+    LAUNCH(c, "unet.enc0a", k_conv_first, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, A, h, w, l.cout, nimg);
+  }
+  if ((rc = conv_layer(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1)) != SH_OK) return rc;
+  int ch = base;
+  for (int i = 1; i <= D; ++i) {
+    size_t e = (size_t)nimg * (h / 2) * (w / 2) * (ch / 4);
+    LAUNCH(c, "unet.pool", k_maxpool2, dim3((unsigned)std::min<size_t>((e + 255) / 256, 8192)), dim3(256), skip[i - 1], A, h, w, ch, nimg);
+    h /= 2; w /= 2;
+    std::string na = i < D ? "enc" + std::to_string(i) + "a" : "bota", nb = i < D ? "enc" + std::to_string(i) + "b" : "botb";
+    if ((rc = conv_layer(c, ("unet." + na).c_str(), L(na), A, nullptr, ch, 0, Bq, h, w, nimg, 1)) != SH_OK) return rc;
+    ch *= 2;
+    float* dst = i < D ? skip[i] : A;
+    if ((rc = conv_layer(c, ("unet." + nb).c_str(), L(nb), Bq, nullptr, ch, 0, dst, h, w, nimg, 1)) != SH_OK) return rc;
+  }
+  // decoder: x lives in A
+  float* x = A; float* y = Bq;
+  for (int i = D - 1; i >= 0; --i) {
+    std::string nu = "up" + std::to_string(i), na = "dec" + std::to_string(i) + "a", nb = "dec" + std::to_string(i) + "b";
+    if ((rc = conv_layer(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
+    h *= 2; w *= 2; ch /= 2;
+    if ((rc = conv_layer(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;
+    if ((rc = conv_layer(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1)) != SH_OK) return rc;
+    std::swap(x, y);
+  }
+  {
+    const sh_ctx::ULayer& l = L("head");
+    size_t npx = (size_t)nimg * H * W;
+    float hb = c->h_unet[l.b_off];
+    LAUNCH(c, "unet.head", k_head, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, hb, logits, l.cin, npx);
+  }
+  return SH_OK;
+}
+
 // ---- stage runner ----------------------------------------------------------------------------------
 static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample) {
   const int B = c->B;
@@ -422,8 +542,55 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   }
   if (mask & SH_STAGE_PROXIMAL)
     if ((rc = run_slice_set(c, "prox", 1, SH_NPROX, true, true)) != SH_OK) return rc;
-  if (mask & (SH_STAGE_GROOVE | SH_STAGE_ANP | SH_STAGE_TE | SH_STAGE_CSYS))
-    return fail(c, SH_ERR_STATE, "sh_run: groove/ANP/TE/csys stages not available in this build");
+  if (mask & SH_STAGE_GROOVE) {
+    if (!c->have_rfc) return fail(c, SH_ERR_STATE, "sh_run: groove stage needs sh_load_rfc first");
+    int ga, gb;
+    cutoff_range(SH_NPROX, c->params.groove_cutoff[0], c->params.groove_cutoff[1], &ga, &gb);
+    const char* pp = buf<char>(c, "params") + c->unet_floats * 4;
+    const size_t N = c->h_feat.size();
+    const int* feat = (const int*)pp; const float* thr = (const float*)(pp + N * 4); const int* ti = (const int*)(pp + N * 8);
+    const int* fi = (const int*)(pp + N * 12); const float* lw = (const float*)(pp + N * 16); const int* roots = (const int*)(pp + N * 20);
+    const int rows = B * SH_GROOVE_NROWS;
+    LAUNCH(c, "k_groove_rows", k_groove_rows, dim3((rows + 63) / 64), dim3(64), buf<double>(c, "prox.itr_centered_start"),
+           buf<double>(c, "prox.zs"), buf<double>(c, "canal.axis_ct"), ga, buf<double>(c, "groove.scratch"), buf<double>(c, "groove.xraw"),
+           buf<double>(c, "groove.ptheta"), buf<int>(c, "groove.npk"), buf<double>(c, "groove.r0"), buf<int>(c, "err"), B);
+    LAUNCH(c, "k_groove_scale", k_groove_scale, dim3(B), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
+           buf<double>(c, "groove.stats"), B);
+    LAUNCH(c, "k_groove_rfc", k_groove_rfc, dim3((B * SH_GSLOTS + 63) / 64), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
+           buf<double>(c, "groove.stats"), feat, thr, ti, fi, lw, roots, c->rfc_trees, buf<double>(c, "groove.xs"), buf<float>(c, "groove.proba"), B);
+    LAUNCH(c, "k_groove_kde", k_groove_kde, dim3(B), dim3(256), buf<double>(c, "groove.ptheta"), buf<float>(c, "groove.proba"),
+           buf<double>(c, "groove.bg_theta"), buf<int>(c, "err"));
+    LAUNCH(c, "k_groove_localmin", k_groove_localmin, dim3((rows + 63) / 64), dim3(64), buf<double>(c, "prox.itr_centered_start"),
+           buf<double>(c, "groove.r0"), buf<double>(c, "prox.zs"), buf<double>(c, "prox.centroids"), buf<double>(c, "groove.bg_theta"), ga,
+           c->params.groove_deg_window, buf<int>(c, "groove.local_idx"), buf<double>(c, "groove.points_obb"), B);
+    LAUNCH(c, "k_groove_axis", k_groove_axis, dim3(B), dim3(64), buf<double>(c, "groove.points_obb"), buf<double>(c, "obb_transform"),
+           buf<double>(c, "groove.axis_ct"), buf<double>(c, "groove.points_ct"));
+  }
+  if (mask & SH_STAGE_ANP) {
+    if (!c->have_unet) return fail(c, SH_ERR_STATE, "sh_run: anatomic-neck stage needs sh_load_unet first");
+    LAUNCH(c, "k_anp_rows", k_anp_rows, dim3((B * SH_ANP_ROWS + 63) / 64), dim3(64), buf<double>(c, "prox.itr_start"),
+           buf<double>(c, "groove.bg_theta"), buf<double>(c, "anp.raw"), buf<double>(c, "anp.shft_theta"), buf<int>(c, "anp.roll"), B);
+    LAUNCH(c, "k_anp_minmax", k_anp_minmax, dim3(B), dim3(256), buf<double>(c, "anp.raw"), buf<float>(c, "anp.image"));
+    if ((rc = unet_forward(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX)) != SH_OK) return rc;
+    LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(B), dim3(512), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
+           buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"), buf<int>(c, "err"));
+    LAUNCH(c, "k_anp_plane", k_anp_plane, dim3(B), dim3(256), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
+           buf<double>(c, "anp.plane"), buf<int>(c, "err"));
+    LAUNCH(c, "k_rays", k_rays, dim3(B, 4), dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
+           buf<long long>(c, "foff"), buf<double>(c, "anp.plane"), buf<double>(c, "anp.axes_obb"), buf<int>(c, "err"));
+  }
+  if (mask & SH_STAGE_TE) {
+    LAUNCH(c, "k_te_rows", k_te_rows, dim3((B * SH_TE_NROWS + 63) / 64), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
+           buf<int>(c, "te.iscratch"), buf<double>(c, "te.rects"), B);
+    LAUNCH(c, "k_te_final", k_te_final, dim3((B + 63) / 64), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
+           buf<double>(c, "te.rects"), buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
+           buf<double>(c, "anp.axes_obb"), buf<double>(c, "te.dscratch"), buf<double>(c, "te.axis_ct"), buf<int>(c, "te.row"), buf<int>(c, "err"), B);
+  }
+  LAUNCH(c, "k_pack", k_pack, dim3(B), dim3(256), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "obb_transform"), buf<double>(c, "z_bounds"),
+         buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), buf<int>(c, "flipped"), buf<double>(c, "canal.axis_ct"), buf<double>(c, "te.axis_ct"),
+         buf<double>(c, "groove.axis_ct"), buf<double>(c, "groove.bg_theta"), buf<double>(c, "groove.points_ct"), buf<double>(c, "anp.plane"),
+         buf<double>(c, "anp.axes_obb"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"), buf<int>(c, "err"), mask, B);
+  if (out) HIPCHK(c, hipMemcpyAsync(out, buf<sh_landmarks>(c, "landmarks"), (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<int> herr(B);
   HIPCHK(c, hipMemcpy(herr.data(), buf<int>(c, "err"), B * 4, hipMemcpyDeviceToHost));
@@ -444,10 +611,90 @@ int sh_landmarks_device(sh_ctx* c, void** p, size_t* n) {
   return *p ? SH_OK : SH_ERR_STATE;
 }
 
-int sh_load_rfc(sh_ctx* c, const int32_t*, const float*, const int32_t*, const int32_t*, const float*, int, const int32_t*, int) {
-  return fail(c, SH_ERR_STATE, "sh_load_rfc: not available in this build");
+// ---- parameters ------------------------------------------------------------------------------------
+static int upload_params(sh_ctx* c) {
+  const size_t N = c->h_feat.size(), T = c->h_roots.size();
+  const size_t bytes = c->unet_floats * 4 + N * 4 * 5 + T * 4;
+  int rc = ensure(c, "params", bytes ? bytes : 16, 4);
+  if (rc != SH_OK) return rc;
+  char* p = buf<char>(c, "params");
+  size_t o = 0;
+  auto put = [&](const void* src, size_t n) -> hipError_t {
+    hipError_t e = n ? hipMemcpyAsync(p + o, src, n, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    o += n;
+    return e;
+  };
+  HIPCHK(c, put(c->h_unet.data(), c->unet_floats * 4));
+  HIPCHK(c, put(c->h_feat.data(), N * 4));
+  HIPCHK(c, put(c->h_thr.data(), N * 4));
+  HIPCHK(c, put(c->h_ti.data(), N * 4));
+  HIPCHK(c, put(c->h_fi.data(), N * 4));
+  HIPCHK(c, put(c->h_lw.data(), N * 4));
+  HIPCHK(c, put(c->h_roots.data(), T * 4));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
 }
-int sh_load_unet(sh_ctx* c, int, int, const float*, size_t) { return fail(c, SH_ERR_STATE, "sh_load_unet: not available in this build"); }
-int sh_param_block(sh_ctx* c, void**, size_t*) { return fail(c, SH_ERR_STATE, "sh_param_block: not available in this build"); }
+
+int sh_load_rfc(sh_ctx* c, const int32_t* feat, const float* thr, const int32_t* ti, const int32_t* fi, const float* lw, int n_nodes,
+                const int32_t* roots, int n_trees) {
+  if (!c || !feat || !thr || !ti || !fi || !lw || !roots || n_nodes <= 0 || n_trees <= 0) return fail(c, SH_ERR_ARG, "sh_load_rfc: bad argument");
+  for (int i = 0; i < n_nodes; ++i) {
+    if (feat[i] < 0 || feat[i] >= 9) return fail(c, SH_ERR_ARG, "sh_load_rfc: feature id out of range");
+    if ((ti[i] < 0) != (fi[i] < 0) || ti[i] >= n_nodes || fi[i] >= n_nodes) return fail(c, SH_ERR_ARG, "sh_load_rfc: bad child index");
+  }
+  for (int t = 0; t < n_trees; ++t) if (roots[t] < 0 || roots[t] >= n_nodes) return fail(c, SH_ERR_ARG, "sh_load_rfc: bad root");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->h_feat.assign(feat, feat + n_nodes); c->h_thr.assign(thr, thr + n_nodes); c->h_ti.assign(ti, ti + n_nodes);
+  c->h_fi.assign(fi, fi + n_nodes); c->h_lw.assign(lw, lw + n_nodes); c->h_roots.assign(roots, roots + n_trees);
+  c->rfc_nodes = n_nodes; c->rfc_trees = n_trees; c->have_rfc = true;
+  return upload_params(c);
+}
+
+int sh_load_unet(sh_ctx* c, int base, int depth, const float* packed, size_t n_floats) {
+  if (!c || !packed || depth < 1 || depth > 6 || base < 32 || base % 32 != 0) return fail(c, SH_ERR_ARG, "sh_load_unet: bad argument (base must be a multiple of 32)");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->ulayers.clear();
+  size_t o = 0;
+  auto add = [&](const std::string& name, int taps, int cin, int cout) {
+    sh_ctx::ULayer L;
+    L.taps = taps; L.cin = cin; L.cout = cout;
+    L.w_off = o; o += (size_t)taps * cin * cout;
+    L.b_off = o; o += cout;
+    c->ulayers[name] = L;
+  };
+  std::vector<int> ch(depth + 1);
+  for (int i = 0; i <= depth; ++i) ch[i] = base << i;
+  int cin = 1;
+  for (int i = 0; i < depth; ++i) {
+    add("enc" + std::to_string(i) + "a", 9, cin, ch[i]);
+    add("enc" + std::to_string(i) + "b", 9, ch[i], ch[i]);
+    cin = ch[i];
+  }
+  add("bota", 9, ch[depth - 1], ch[depth]);
+  add("botb", 9, ch[depth], ch[depth]);
+  for (int i = depth - 1; i >= 0; --i) {
+    add("up" + std::to_string(i), 4, ch[i + 1], ch[i]);
+    add("dec" + std::to_string(i) + "a", 9, 2 * ch[i], ch[i]);
+    add("dec" + std::to_string(i) + "b", 9, ch[i], ch[i]);
+  }
+  { sh_ctx::ULayer L; L.taps = 1; L.cin = ch[0]; L.cout = 1; L.w_off = o; o += ch[0]; L.b_off = o; o += 1; c->ulayers["head"] = L; }
+  if (o != n_floats) {
+    char m[160];
+    snprintf(m, sizeof m, "sh_load_unet: expected %zu floats for base=%d depth=%d, got %zu", o, base, depth, n_floats);
+    return fail(c, SH_ERR_ARG, m);
+  }
+  c->h_unet.assign(packed, packed + n_floats);
+  c->unet_floats = n_floats; c->unet_base = base; c->unet_depth = depth; c->have_unet = true;
+  return upload_params(c);
+}
+
+int sh_param_block(sh_ctx* c, void** p, size_t* n) {
+  if (!c || !p || !n) return SH_ERR_ARG;
+  auto it = c->bufs.find("params");
+  if (it == c->bufs.end()) return fail(c, SH_ERR_STATE, "sh_param_block: no parameters loaded");
+  *p = it->second.p;
+  *n = c->unet_floats * 4 + c->h_feat.size() * 20 + c->h_roots.size() * 4;
+  return SH_OK;
+}
 
 }  // extern "C"

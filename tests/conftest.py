@@ -26,6 +26,14 @@ def _teacher_weights():
     return unet_spec.make_teacher_weights()
 
 
+def _ensure_chain_lib():
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "_build", "libunet_chain.so")
+    src = os.path.join(ROOT, "oracle", "unet_chain.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+
+
 @pytest.fixture(scope="session")
 def unet_weights():
     return _teacher_weights()
@@ -39,7 +47,8 @@ def oracle_bones(rfc_tables, unet_weights):
 
     def get(name):
         if name not in cache:
-            cache[name] = OracleHumerus.from_stl(os.path.join(BONES, name + ".stl"), rfc_tables, unet_weights)
+            _ensure_chain_lib()
+            cache[name] = OracleHumerus.from_stl(os.path.join(BONES, name + ".stl"), rfc_tables, unet_weights, unet_eval="chain")
         return cache[name]
     return get
 
@@ -48,5 +57,8 @@ def oracle_bones(rfc_tables, unet_weights):
 def engine():
     from shoulder_amd.engine import Engine
     e = Engine(0)
+    from shoulder_amd import unet_spec
+    e.load_rfc()
+    e.load_unet(_teacher_weights(), unet_spec.BASE, unet_spec.DEPTH)
     yield e
     e.close()
