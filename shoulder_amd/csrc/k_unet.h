@@ -2,8 +2,8 @@
 // anatomic_neck.py:62-76).  Activations NHWC float32 in HBM; conv weights [tap][cin][cout].
 //
 // f32 path (parity): every output element is ONE float32 fma chain that starts from the bias and
-// runs over (tap, cin) in order -- v_mfma_f32_16x16x4_f32 accumulates its 4 k-values as a k-ordered
-// fmaf chain, so a K loop of (tap outer, cin inner) with a single accumulator reproduces
+// runs over (16-channel chunk, tap, cin within chunk) in order -- v_mfma_f32_16x16x4_f32 accumulates its 4 k-values as a k-ordered
+// fmaf chain, so this K loop with a single accumulator reproduces
 // oracle/unet_chain.c bit for bit.  No split-K, no re-association.
 //
 // conv3x3 / upconv kernel (implicit GEMM, M = 16 pixels of one image row, N = 16 couts, K = 4 cin):
