@@ -175,7 +175,8 @@ __global__ void k_maxpool2(const float* __restrict__ src, float* __restrict__ ds
 }
 
 // 1x1 head: logit = fma chain over channels from the bias (anatomic_neck.py:76 output)
-__global__ void k_head(const float* __restrict__ src, const float* __restrict__ w, float b, float* __restrict__ logits, int C, size_t npix) {
+__global__ void k_head(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bp, float* __restrict__ logits, int C, size_t npix) {
+  const float b = bp[0];
   for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
     const float* s = src + p * C;
     float a = b;

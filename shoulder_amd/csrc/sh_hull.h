@@ -1,0 +1,193 @@
+// sh_hull.h -- 3-D convex hull (quickhull with conflict lists), host side of SH_STAGE_OBB.
+//
+// The reference reaches the hull through trimesh -> scipy -> qhull inside `Trimesh.apply_obb()`
+// (src/shoulder/humerus/mesh.py:82).  The hull is the one irregular, pointer-chasing step of the
+// path; it runs on the host (one mesh per worker thread) and hands the device a compact record:
+// hull vertices, triangles with unit normals and the edge list used for silhouette tests
+// (k_obb.h).  Points closer than eps = 1e-10 * bbox diagonal to the current hull count as inside.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace shhull {
+
+struct Face {
+  int v[3];
+  int nb[3];          // neighbour across edge v[i] -> v[(i+1)%3]
+  double n[3], d;     // unit normal, plane offset: n.p = d
+  std::vector<int> out;
+  bool alive = true;
+  int mark = 0;
+};
+
+struct Hull {
+  std::vector<int> vert_ids;         // indices into the input points
+  std::vector<int> tris;             // 3 per face, indices into vert_ids
+  std::vector<double> normals;       // 3 per face, outward unit
+  std::vector<int> edges;            // 4 per edge: va, vb (hull vertex ids), face f, face g
+};
+
+struct Builder {
+  const double* P;
+  int n;
+  double eps;
+  std::vector<Face> F;
+
+  double dist(const Face& f, int p) const { return f.n[0] * P[3 * p] + f.n[1] * P[3 * p + 1] + f.n[2] * P[3 * p + 2] - f.d; }
+
+  bool set_plane(Face& f) {
+    const double* a = P + 3 * f.v[0]; const double* b = P + 3 * f.v[1]; const double* c = P + 3 * f.v[2];
+    double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, w[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    double nx = u[1] * w[2] - u[2] * w[1], ny = u[2] * w[0] - u[0] * w[2], nz = u[0] * w[1] - u[1] * w[0];
+    double l = std::sqrt(nx * nx + ny * ny + nz * nz);
+    if (l == 0.0) { f.n[0] = f.n[1] = 0; f.n[2] = 1; f.d = a[2]; return false; }
+    f.n[0] = nx / l; f.n[1] = ny / l; f.n[2] = nz / l;
+    f.d = f.n[0] * a[0] + f.n[1] * a[1] + f.n[2] * a[2];
+    return true;
+  }
+
+  int add_face(int a, int b, int c) {
+    Face f;
+    f.v[0] = a; f.v[1] = b; f.v[2] = c;
+    f.nb[0] = f.nb[1] = f.nb[2] = -1;
+    set_plane(f);
+    F.push_back(std::move(f));
+    return (int)F.size() - 1;
+  }
+};
+
+// pts: n x 3 doubles (any frame).  Returns false for degenerate (flat) input.
+inline bool convex_hull(const double* pts_in, int n, Hull& H) {
+  if (n < 4) return false;
+  // centre the cloud (smaller magnitudes -> smaller plane-distance rounding)
+  std::vector<double> Pc(3 * (size_t)n);
+  double c[3] = {0, 0, 0}, lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) { double v = pts_in[3 * i + k]; c[k] += v; lo[k] = std::min(lo[k], v); hi[k] = std::max(hi[k], v); }
+  for (int k = 0; k < 3; ++k) c[k] /= n;
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) Pc[3 * (size_t)i + k] = pts_in[3 * i + k] - c[k];
+  Builder B;
+  B.P = Pc.data(); B.n = n;
+  double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+  B.eps = 1e-10 * diag;
+  const double* P = B.P;
+  // initial simplex: extreme pair along x, farthest from that line, farthest from that plane
+  int i0 = 0, i1 = 0;
+  for (int i = 1; i < n; ++i) { if (P[3 * i] < P[3 * i0]) i0 = i; if (P[3 * i] > P[3 * i1]) i1 = i; }
+  if (i0 == i1) return false;
+  auto sub = [&](int a, int b, double* o) { for (int k = 0; k < 3; ++k) o[k] = P[3 * a + k] - P[3 * b + k]; };
+  double e[3]; sub(i1, i0, e);
+  int i2 = -1; double best = 0;
+  for (int i = 0; i < n; ++i) {
+    double w[3]; sub(i, i0, w);
+    double cx = e[1] * w[2] - e[2] * w[1], cy = e[2] * w[0] - e[0] * w[2], cz = e[0] * w[1] - e[1] * w[0];
+    double a2 = cx * cx + cy * cy + cz * cz;
+    if (a2 > best) { best = a2; i2 = i; }
+  }
+  if (i2 < 0) return false;
+  Face tmp; tmp.v[0] = i0; tmp.v[1] = i1; tmp.v[2] = i2; B.set_plane(tmp);
+  int i3 = -1; best = 0;
+  for (int i = 0; i < n; ++i) { double d = std::fabs(B.dist(tmp, i)); if (d > best) { best = d; i3 = i; } }
+  if (i3 < 0 || best <= B.eps) return false;
+  if (B.dist(tmp, i3) > 0) std::swap(i1, i2);        // make (i0,i1,i2) face away from i3
+  int f0 = B.add_face(i0, i1, i2), f1 = B.add_face(i0, i3, i1), f2 = B.add_face(i1, i3, i2), f3 = B.add_face(i2, i3, i0);
+  // neighbours: edge v[i]->v[i+1]
+  auto link = [&](int f, int ei, int g) { B.F[f].nb[ei] = g; };
+  // f0: (i0,i1),(i1,i2),(i2,i0) ; f1: (i0,i3),(i3,i1),(i1,i0) ; f2: (i1,i3),(i3,i2),(i2,i1) ; f3: (i2,i3),(i3,i0),(i0,i2)
+  link(f0, 0, f1); link(f0, 1, f2); link(f0, 2, f3);
+  link(f1, 0, f3); link(f1, 1, f2); link(f1, 2, f0);
+  link(f2, 0, f1); link(f2, 1, f3); link(f2, 2, f0);
+  link(f3, 0, f2); link(f3, 1, f1); link(f3, 2, f0);
+  for (int p = 0; p < n; ++p) {
+    if (p == i0 || p == i1 || p == i2 || p == i3) continue;
+    for (int f = 0; f < 4; ++f)
+      if (B.dist(B.F[f], p) > B.eps) { B.F[f].out.push_back(p); break; }
+  }
+  std::vector<int> stack, visible, horizon_f, horizon_e, pending;
+  for (int f = 0; f < 4; ++f) if (!B.F[f].out.empty()) pending.push_back(f);
+  int stamp = 0;
+  std::vector<int> newf_by_start;       // map: horizon start vertex -> new face (linear search lists)
+  while (!pending.empty()) {
+    int f = pending.back(); pending.pop_back();
+    if (!B.F[f].alive || B.F[f].out.empty()) continue;
+    // farthest point of this face
+    int p = -1; double bd = -1;
+    for (int q : B.F[f].out) { double d = B.dist(B.F[f], q); if (d > bd) { bd = d; p = q; } }
+    // visible set by flood fill
+    ++stamp;
+    visible.clear(); horizon_f.clear(); horizon_e.clear();
+    stack.clear(); stack.push_back(f); B.F[f].mark = stamp;
+    while (!stack.empty()) {
+      int g = stack.back(); stack.pop_back();
+      visible.push_back(g);
+      for (int ei = 0; ei < 3; ++ei) {
+        int h = B.F[g].nb[ei];
+        if (B.F[h].mark == stamp) continue;
+        if (B.dist(B.F[h], p) > B.eps) { B.F[h].mark = stamp; stack.push_back(h); }
+        else { horizon_f.push_back(g); horizon_e.push_back(ei); }
+      }
+    }
+    // new faces, one per horizon edge (a -> b as oriented in the visible face)
+    size_t first_new = B.F.size();
+    std::vector<int> starts, ends, outer, outer_e;
+    for (size_t k = 0; k < horizon_f.size(); ++k) {
+      int g = horizon_f[k], ei = horizon_e[k];
+      int a = B.F[g].v[ei], b = B.F[g].v[(ei + 1) % 3];
+      int h = B.F[g].nb[ei];
+      int nf = B.add_face(a, b, p);
+      starts.push_back(a); ends.push_back(b); outer.push_back(h);
+      // neighbour across (a,b) is the non-visible face h; fix h's back pointer
+      B.F[nf].nb[0] = h;
+      for (int q = 0; q < 3; ++q)
+        if (B.F[h].nb[q] == g && B.F[h].v[q] == b && B.F[h].v[(q + 1) % 3] == a) B.F[h].nb[q] = nf;
+    }
+    size_t nn = B.F.size() - first_new;
+    for (size_t k = 0; k < nn; ++k) {
+      // edge 1: b -> p  neighbours the new face whose start == b ; edge 2: p -> a neighbours the one whose end == a
+      int b = ends[k], a = starts[k];
+      for (size_t m = 0; m < nn; ++m) {
+        if (starts[m] == b) B.F[first_new + k].nb[1] = (int)(first_new + m);
+        if (ends[m] == a) B.F[first_new + k].nb[2] = (int)(first_new + m);
+      }
+    }
+    // redistribute the conflict points of the visible faces
+    for (int g : visible) {
+      for (int q : B.F[g].out) {
+        if (q == p) continue;
+        for (size_t k = 0; k < nn; ++k)
+          if (B.dist(B.F[first_new + k], q) > B.eps) { B.F[first_new + k].out.push_back(q); break; }
+      }
+      B.F[g].out.clear(); B.F[g].out.shrink_to_fit();
+      B.F[g].alive = false;
+    }
+    for (size_t k = 0; k < nn; ++k) if (!B.F[first_new + k].out.empty()) pending.push_back((int)(first_new + k));
+  }
+  // compact
+  std::vector<int> vmap(n, -1), fmap(B.F.size(), -1);
+  H.vert_ids.clear(); H.tris.clear(); H.normals.clear(); H.edges.clear();
+  int nf = 0;
+  for (size_t f = 0; f < B.F.size(); ++f) {
+    if (!B.F[f].alive) continue;
+    fmap[f] = nf++;
+    for (int k = 0; k < 3; ++k) {
+      int v = B.F[f].v[k];
+      if (vmap[v] < 0) { vmap[v] = (int)H.vert_ids.size(); H.vert_ids.push_back(v); }
+      H.tris.push_back(vmap[v]);
+    }
+    for (int k = 0; k < 3; ++k) H.normals.push_back(B.F[f].n[k]);
+  }
+  for (size_t f = 0; f < B.F.size(); ++f) {
+    if (!B.F[f].alive) continue;
+    for (int k = 0; k < 3; ++k) {
+      int g = B.F[f].nb[k];
+      if (g < 0 || !B.F[g].alive) return false;       // broken adjacency
+      if ((int)f < g) { H.edges.push_back(vmap[B.F[f].v[k]]); H.edges.push_back(vmap[B.F[f].v[(k + 1) % 3]]); H.edges.push_back(fmap[f]); H.edges.push_back(fmap[g]); }
+    }
+  }
+  return true;
+}
+
+}  // namespace shhull

@@ -17,6 +17,11 @@
 #include "k_anp.h"
 #include "k_unet.h"
 #include "k_te.h"
+#include "k_obb.h"
+#include "sh_hull.h"
+
+#include <atomic>
+#include <thread>
 
 using namespace sh;
 
@@ -52,6 +57,8 @@ struct sh_ctx {
   std::map<std::string, ULayer> ulayers;
   size_t unet_floats = 0;
   bool obb_injected = false;
+  std::vector<float> h_verts;                // host copy of the vertices (hull stage)
+  bool h_verts_valid = false;
   // timing
   bool timing = false;
   std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t>> pending;
@@ -252,6 +259,18 @@ static int alloc_batch(sh_ctx* c) {
   ENS("te.row", (size_t)B * 4, 4);
   ENS("flipped", (size_t)B * 4, 4);
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "flipped"), 0, (size_t)B * 4, c->stream));
+  // oriented bounding box
+  ENS("hull.hv", (size_t)B * SH_HV * 3 * 8, 8);
+  ENS("hull.normals", (size_t)B * SH_HF * 3 * 8, 8);
+  ENS("hull.edges", (size_t)B * SH_HE * 4 * 4, 4);
+  ENS("hull.counts", (size_t)B * 3 * 4, 4);          // nv[B], nf[B], ne[B]
+  ENS("obb.cand_vol", (size_t)B * SH_HF * 8, 8);
+  ENS("obb.cand_edge", (size_t)B * SH_HF * 4, 4);
+  ENS("obb.T_pre", (size_t)B * 16 * 8, 8);
+  ENS("obb.zb_pre", (size_t)B * 2 * 8, 8);
+  ENS("obb.endpts", (size_t)B * 2 * SH_ENDCAP * 2 * 8, 8);
+  ENS("obb.endcnt", (size_t)B * 2 * 4, 4);
+  ENS("obb.resid", (size_t)B * 2 * 8, 8);
 #undef ENS
   c->obb_injected = false;
   return SH_OK;
@@ -272,6 +291,8 @@ int sh_upload_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const 
       if (faces[i] < 0 || faces[i] >= nv) return fail(c, SH_ERR_ARG, "sh_upload_meshes: face index out of range");
   }
   c->B = B;
+  c->h_verts.assign(verts, verts + 3 * c->sumV);
+  c->h_verts_valid = true;
   int rc;
   if ((rc = ensure(c, "verts", c->sumV * 3 * 4, 4)) != SH_OK) return rc;
   if ((rc = ensure(c, "faces", c->sumF * 3 * 4, 4)) != SH_OK) return rc;
@@ -298,6 +319,7 @@ int sh_synth_batch(sh_ctx* c, const double* T, int B) {
   HIPCHK(c, hipMemcpyAsync(buf<int>(c, "tmpl_faces"), buf<int>(c, "faces") + 3 * c->h_foff[0], F * 3 * 4, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->B = B;
+  c->h_verts_valid = false;
   c->sumV = V * B; c->sumF = F * B; c->maxV = V; c->maxF = F;
   c->h_voff.resize(B + 1); c->h_foff.resize(B + 1);
   for (int b = 0; b <= B; ++b) { c->h_voff[b] = V * b; c->h_foff[b] = F * b; }
@@ -475,8 +497,7 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
   {
     const sh_ctx::ULayer& l = L("head");
     size_t npx = (size_t)nimg * H * W;
-    float hb = c->h_unet[l.b_off];
-    LAUNCH(c, "unet.head", k_head, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, hb, logits, l.cin, npx);
+    LAUNCH(c, "unet.head", k_head, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx);
   }
   return SH_OK;
 }
@@ -505,6 +526,76 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   return SH_OK;
 }
 
+// mesh.py:63-125.  Host: one quickhull per humerus on worker threads (sh_hull.h).  Device: candidate
+// boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
+static int run_obb(sh_ctx* c) {
+  const int B = c->B;
+  if (!c->h_verts_valid) {    // device-generated batch: fetch the vertices for the host hull (every run: a new batch is new data)
+    c->h_verts.resize(3 * (size_t)c->sumV);
+    HIPCHK(c, hipMemcpyAsync(c->h_verts.data(), buf<float>(c, "verts"), c->sumV * 3 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  std::vector<double> hv((size_t)B * SH_HV * 3, 0.0), nr((size_t)B * SH_HF * 3, 0.0);
+  std::vector<int> ed((size_t)B * SH_HE * 4, 0), counts(3 * (size_t)B, 0), status(B, 0);
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    std::vector<double> P;
+    shhull::Hull H;
+    for (;;) {
+      int b = next.fetch_add(1);
+      if (b >= B) break;
+      long long v0 = c->h_voff[b], nv = c->h_voff[b + 1] - v0;
+      P.resize(3 * (size_t)nv);
+      for (long long i = 0; i < 3 * nv; ++i) P[i] = (double)c->h_verts[3 * v0 + i];
+      if (!shhull::convex_hull(P.data(), (int)nv, H)) { status[b] = SH_ERR_GEOMETRY; continue; }
+      int hn = (int)H.vert_ids.size(), fn = (int)H.tris.size() / 3, en = (int)H.edges.size() / 4;
+      if (hn > SH_HV || fn > SH_HF || en > SH_HE) { status[b] = SH_ERR_CAPACITY; continue; }
+      for (int i = 0; i < hn; ++i)
+        for (int k = 0; k < 3; ++k) hv[((size_t)b * SH_HV + i) * 3 + k] = P[3 * (size_t)H.vert_ids[i] + k];
+      std::copy(H.normals.begin(), H.normals.end(), nr.begin() + (size_t)b * SH_HF * 3);
+      std::copy(H.edges.begin(), H.edges.end(), ed.begin() + (size_t)b * SH_HE * 4);
+      counts[b] = hn; counts[B + b] = fn; counts[2 * B + b] = en;
+    }
+  };
+  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  nt = std::min<unsigned>(nt, (unsigned)B);
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+  int nvmax = 0, nfmax = 0;
+  for (int b = 0; b < B; ++b) {
+    if (status[b] != 0) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", b, status[b]); return fail(c, status[b], m); }
+    nvmax = std::max(nvmax, counts[b]); nfmax = std::max(nfmax, counts[B + b]);
+  }
+  HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.hv"), hv.data(), hv.size() * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.normals"), nr.data(), nr.size() * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.edges"), ed.data(), ed.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.counts"), counts.data(), counts.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging vectors above are function-local
+  const int* cnt = buf<int>(c, "hull.counts");
+  size_t shm = 2 * (size_t)nvmax * 8;
+  {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
+    hipLaunchKernelGGL(k_obb_candidates, dim3(nfmax, B), dim3(256), shm, c->stream, buf<double>(c, "hull.hv"), cnt, buf<double>(c, "hull.normals"),
+                       cnt + B, buf<int>(c, "hull.edges"), cnt + 2 * B, buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), nvmax);
+    if (c->timing) { (void)hipEventRecord(e1, c->stream); c->pending.emplace_back("k_obb_candidates", e0, e1); }
+    HIPCHK(c, hipGetLastError());
+  }
+  LAUNCH(c, "k_obb_pick", k_obb_pick, dim3(B), dim3(256), buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), cnt + B, buf<int>(c, "hull.edges"),
+         buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<float>(c, "verts"), buf<long long>(c, "voff"), buf<double>(c, "obb.T_pre"),
+         buf<double>(c, "obb.zb_pre"), buf<int>(c, "err"));
+  HIPCHK(c, hipMemsetAsync(buf<int>(c, "obb.endcnt"), 0, (size_t)B * 2 * 4, c->stream));
+  dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 1024), (unsigned)B);
+  LAUNCH(c, "k_obb_end_points", k_obb_end_points, g, dim3(256), buf<float>(c, "verts"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
+         buf<long long>(c, "foff"), buf<double>(c, "obb.T_pre"), buf<double>(c, "obb.zb_pre"), buf<double>(c, "obb.endpts"), buf<int>(c, "obb.endcnt"));
+  LAUNCH(c, "k_obb_ends", k_obb_ends, dim3((2 * B + 63) / 64), dim3(64), buf<double>(c, "obb.endpts"), buf<int>(c, "obb.endcnt"),
+         buf<double>(c, "obb.T_pre"), buf<double>(c, "obb.resid"), buf<double>(c, "obb_transform"), buf<int>(c, "flipped"), buf<int>(c, "err"), B);
+  c->obb_injected = true;
+  return SH_OK;
+}
+
 int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   if (!c) return SH_ERR_ARG;
   if (c->B < 1) return fail(c, SH_ERR_STATE, "sh_run: no meshes uploaded");
@@ -513,7 +604,7 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   int rc;
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "err"), 0, B * 4, c->stream));
   if (mask & SH_STAGE_OBB) {
-    return fail(c, SH_ERR_STATE, "sh_run: SH_STAGE_OBB not available in this build");
+    if ((rc = run_obb(c)) != SH_OK) return rc;
   } else if (!c->obb_injected) {
     return fail(c, SH_ERR_STATE, "sh_run: no OBB transform (run SH_STAGE_OBB or sh_store(\"obb_transform\"))");
   }

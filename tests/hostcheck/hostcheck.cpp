@@ -41,3 +41,15 @@ void hc_dominant(const double* C, double* v) { dominant_eigvec3(C, v); }
 double hc_interp(double x, const double* xp, const double* fp, int n) { return interp1(x, xp, fp, n); }
 double hc_linspace(double a, double b, int n, int k) { return linspace_at(a, b, n, k); }
 }
+
+#include "../../shoulder_amd/csrc/sh_hull.h"
+extern "C" int hc_hull(const double* pts, int n, int* vert_ids, int cap_v, int* tris, int cap_f, int* n_edges) {
+  shhull::Hull H;
+  if (!shhull::convex_hull(pts, n, H)) return -1;
+  int nv = (int)H.vert_ids.size(), nf = (int)H.tris.size() / 3;
+  if (nv > cap_v || nf > cap_f) return -2;
+  for (int i = 0; i < nv; ++i) vert_ids[i] = H.vert_ids[i];
+  for (int i = 0; i < 3 * nf; ++i) tris[i] = H.tris[i];
+  *n_edges = (int)H.edges.size() / 4;
+  return nv * 100000 + nf;
+}

@@ -1,0 +1,80 @@
+"""GPU parity, the whole hot path (SH_STAGE_ALL incl. the OBB stage) through the C-ABI vs the oracle:
+the reference's four STL fixtures, and BASELINE config 3 (synthetic similarity copies) through the
+equivariance property landmarks(T mesh) = T landmarks(mesh)."""
+import numpy as np
+import pytest
+
+from oracle.stl import load_stl
+from shoulder_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+NAMES = ["humerus_left", "humerus_left_flipped", "humerus_left_trab", "humerus_right"]
+MM = 1e-4      # north-star tolerance, mm
+
+
+@pytest.fixture(scope="module")
+def ran(engine, oracle_bones):
+    hs = [oracle_bones(n) for n in NAMES]
+    engine.upload([(h.verts, h.faces) for h in hs])
+    lm = engine.run(_lib.STAGE_ALL)
+    return hs, lm
+
+
+def test_obb_frame(engine, ran):
+    hs, lm = ran
+    for b, h in enumerate(hs):
+        assert lm["status"][b] == 0
+        assert bool(lm["flipped"][b]) == h.obb["flipped"]                    # head-end decision: exact
+        np.testing.assert_allclose(lm["obb_transform"][b][:3, :3], h.T_obb[:3, :3], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(lm["obb_transform"][b][:3, 3], h.T_obb[:3, 3], rtol=0, atol=1e-6)
+        assert abs(lm["z_length"][b] - h.obb["z_length"]) < 1e-7
+
+
+def test_all_landmarks(engine, ran):
+    hs, lm = ran
+    for b, h in enumerate(hs):
+        L = h.landmarks()
+        assert lm["neck_index"][b] == h.neck["bkp"]
+        assert lm["bg_theta"][b] == L["bg_theta"]
+        assert lm["n_anp"][b] == len(L["anp_points"])
+        for key, ref in (("canal_axis", L["canal_axis"]), ("te_axis", L["te_axis"]), ("groove_axis", L["groove_axis"]),
+                         ("groove_points", L["groove_points"]), ("anp_plane_point", L["anp_plane_point"]),
+                         ("anp_axis_normal", L["anp_axis_normal"]), ("anp_axis_central", L["anp_axis_central"])):
+            np.testing.assert_allclose(lm[key][b], ref, rtol=0, atol=MM, err_msg=f"{NAMES[b]}:{key}")
+        K = min(len(L["anp_points"]), 4096)
+        np.testing.assert_allclose(lm["anp_points"][b][:K], L["anp_points"][:K], rtol=0, atol=MM)
+        np.testing.assert_allclose(lm["csys"][b], L["csys"], rtol=0, atol=1e-6)
+
+
+def test_left_vs_flipped_file(ran):
+    """humerus_left_flipped.stl is humerus_left.stl rotated pi about y (x -> -x, z -> -z)."""
+    _, lm = ran
+    S = np.diag([-1.0, 1.0, -1.0])
+    for key in ("canal_axis", "te_axis", "groove_axis"):
+        np.testing.assert_allclose(lm[key][0] @ S, lm[key][1], rtol=0, atol=1e-6)
+
+
+def test_synthetic_batch_equivariance(engine, oracle_bones):
+    """BASELINE config 3: device-side similarity copies of the template; landmarks must follow."""
+    h = oracle_bones("humerus_left")
+    B = 6
+    T = synth.similarity_transforms(B, h.verts)
+    T[0] = np.identity(4)
+    engine.upload([(h.verts, h.faces)])
+    engine.synth_batch(T)
+    lm = engine.run(_lib.STAGE_ALL)
+    assert (lm["status"] == 0).all()
+    base = lm[0]
+    ref = h.landmarks()
+    np.testing.assert_allclose(base["canal_axis"], ref["canal_axis"], rtol=0, atol=MM)
+    # synthetic vertices are re-rounded to float32 after the transform (|coord| up to ~1500 mm ->
+    # 6e-5 mm per vertex), so copies are compared at 5e-3 mm / exact integer decisions
+    for b in range(1, B):
+        tf = lambda p: p @ T[b][:3, :3].T + T[b][:3, 3]
+        assert lm["neck_index"][b] == base["neck_index"]
+        for key in ("canal_axis", "te_axis", "groove_axis"):
+            np.testing.assert_allclose(lm[key][b], tf(base[key]), rtol=0, atol=5e-3 * 3, err_msg=key)
+    # the device-generated vertices themselves: float64 arithmetic, float32 storage
+    v = engine.fetch("verts", np.float32).reshape(B, -1, 3)
+    for b in range(B):
+        np.testing.assert_array_equal(v[b], synth.apply_similarity(T[b], h.verts))

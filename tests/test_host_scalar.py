@@ -212,3 +212,30 @@ def test_csys_eig_interp(hc):
         assert hc.hc_interp(ctypes.c_double(x), dp(xp), dp(fp_), 40) == np.interp(x, xp, fp_)
     for k in range(200):
         assert hc.hc_linspace(ctypes.c_double(171.3), ctypes.c_double(-169.2), 200, k) == np.linspace(171.3, -169.2, 200)[k]
+
+
+def test_hull_vs_qhull(hc):
+    import scipy.spatial
+    from oracle.stl import load_stl
+    from conftest import BONES
+    rng = np.random.default_rng(8)
+    clouds = [rng.standard_normal((500, 3)) * [30, 10, 5], rng.uniform(-1, 1, (2000, 3))]
+    for name in ("humerus_left", "humerus_right"):
+        clouds.append(load_stl(os.path.join(BONES, name + ".stl"))[0].astype(np.float64))
+    for P in clouds:
+        P = np.ascontiguousarray(P)
+        vid = np.zeros(8192, dtype=np.int32)
+        tri = np.zeros(3 * 16384, dtype=np.int32)
+        ne = ctypes.c_int()
+        rc = hc.hc_hull(dp(P), len(P), vid.ctypes.data_as(I), 8192, tri.ctypes.data_as(I), 16384, ctypes.byref(ne))
+        assert rc > 0
+        nv, nf = rc // 100000, rc % 100000
+        ref = scipy.spatial.ConvexHull(P)
+        assert set(vid[:nv]) == set(ref.vertices)              # same extreme points
+        assert nf == 2 * nv - 4 and ne.value == 3 * nv - 6      # closed triangulated sphere (Euler)
+        t = vid[tri[:3 * nf].reshape(-1, 3)]
+        vol = np.abs(np.einsum("ij,ij->i", P[t[:, 0]], np.cross(P[t[:, 1]], P[t[:, 2]])).sum()) / 6
+        c = P.mean(axis=0)
+        Q = P - c
+        vol = np.einsum("ij,ij->i", Q[t[:, 0]], np.cross(Q[t[:, 1]], Q[t[:, 2]])).sum() / 6   # outward orientation -> positive
+        assert abs(vol - ref.volume) <= 1e-9 * ref.volume
