@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- humerus meshes/s end-to-end (all four landmarks) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A step = one pass of the whole hot path (SH_STAGE_ALL: OBB -> slices -> neck ->
+canal -> groove -> anatomic neck incl. UNet -> trans-epicondylar -> csys -> landmark records) over
+one batch of --batch synthetic humeri per GPU (BASELINE config 3 at N=1, config 4 at N=8: similarity
+copies of tests/golden/bones/humerus_left.stl, seed 1234, contiguous shards), with the batch already
+resident in HBM, followed by the gather of the landmark records to rank 0.  Parameters (UNet + random
+forest) are loaded on rank 0 and broadcast over RCCL before the timed region.  No data-path
+collective: meshes are independent (weak scaling).
+
+The JSON line also carries
+  roofline      for the kernel with the largest share of device time (HIP events on the engine's
+                stream around every launch of the timed steps), algorithmic flops/bytes per launch
+                (DESIGN.md "Kernels") / average launch duration vs the gfx950 peak;
+  cpu_baseline  the oracle (NumPy/SciPy restatement of the reference, oracle/) on the same synthetic
+                meshes, one thread, rank 0, N=1 only, a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+PEAK_MFMA_F32_TF = 157.3       # dense f32 MFMA (= vector rate)
+PEAK_MFMA_BF16_TF = 2500.0
+
+GEOM_KERNELS = ["k_obb_candidates", "k_obb_pick", "k_obb_end_points", "k_obb_ends", "k_transform_verts", "k_make_planes",
+                "k_slice_emit", "k_slice_link", "k_resample_polar", "k_neck", "k_canal", "k_groove_rows", "k_groove_scale",
+                "k_groove_rfc", "k_groove_kde", "k_groove_localmin", "k_groove_axis", "k_anp_rows", "k_anp_minmax", "k_anp_edges",
+                "k_anp_plane", "k_rays", "k_te_rows", "k_te_final", "k_pack"]
+
+
+def unet_layers(base, depth, H, W):
+    """name -> (flops per image, bytes per image: activations in+out + weights), f32."""
+    ch = [base << i for i in range(depth + 1)]
+    out = {}
+    h, w = H, W
+
+    def conv(name, cin, cout, h, w, taps=9, up=False):
+        oh, ow = (2 * h, 2 * w) if up else (h, w)
+        fl = 2 * (4 if up else taps) * h * w * cin * cout
+        by = 4 * (h * w * cin + oh * ow * cout + (4 if up else taps) * cin * cout)
+        out["unet." + name] = (fl, by)
+
+    cin = 1
+    for i in range(depth):
+        conv(f"enc{i}a", cin, ch[i], h, w)
+        conv(f"enc{i}b", ch[i], ch[i], h, w)
+        cin = ch[i]
+        h, w = h // 2, w // 2
+    conv("bota", ch[depth - 1], ch[depth], h, w)
+    conv("botb", ch[depth], ch[depth], h, w)
+    for i in reversed(range(depth)):
+        conv(f"up{i}", ch[i + 1], ch[i], h, w, up=True)
+        h, w = 2 * h, 2 * w
+        conv(f"dec{i}a", 2 * ch[i], ch[i], h, w)
+        conv(f"dec{i}b", ch[i], ch[i], h, w)
+    out["unet.head"] = (2 * H * W * ch[0], 4 * H * W * (ch[0] + 1))
+    return out
+
+
+def geom_bytes(B, V, F):
+    """Algorithmic HBM bytes per launch of the geometry kernels (one launch = whole batch)."""
+    seg = 32
+    n_planes = {"full": 200, "distal": 200, "prox": 600}
+    s_per_plane = 145.0     # mean crossing triangles per plane
+    return {
+        "k_transform_verts": B * V * (12 + 24),
+        "k_slice_emit": B * (24 * V + 12 * F) ,          # + segments, accounted on the link side
+        "k_slice_link": B * 600 * s_per_plane * seg + B * 600 * (s_per_plane * 16),
+        "k_resample_polar": B * 600 * (s_per_plane * 16 + 3 * 2 * 512 * 8),
+        "k_groove_rows": B * 330 * (2 * 512 * 8 + 512 * 8),
+        "k_anp_rows": B * 512 * (2 * 512 * 8 + 2 * 512 * 8),
+        "k_anp_minmax": B * 512 * 512 * (8 + 4),
+        "k_anp_edges": B * 512 * 512 * 4,
+        "k_rays": B * 4 * (24 * V + 12 * F),
+        "k_obb_candidates": B * 2732 * (1368 * 24 + 4100 * 16),
+    }
+
+
+class DevMem:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="humeri per GPU per step")
+    ap.add_argument("--unet", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-meshes", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from shoulder_amd import _lib, synth, unet_spec
+    from shoulder_amd.engine import Engine
+    from shoulder_amd.stl import load_stl
+    verts, faces = load_stl(os.path.join(ROOT, "tests", "golden", "bones", "humerus_left.stl"))   # host I/O, outside the timed region
+    V, F, B = len(verts), len(faces), args.batch
+
+    eng = Engine(local)
+    weights = unet_spec.make_teacher_weights()
+    if rank == 0:
+        eng.load_rfc()
+        eng.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
+    else:   # allocate the parameter block with the right shapes, contents arrive by broadcast
+        z = np.load(os.path.join(ROOT, "shoulder_amd", "models", "rfc_bg3.npz"))
+        eng.load_rfc()       # tree topology is needed host-side for validation; values are overwritten below
+        eng.load_unet({k: np.zeros_like(v) for k, v in weights.items()}, unet_spec.BASE, unet_spec.DEPTH)
+    if world > 1:
+        ptr, nbytes = eng.param_block()
+        t = torch.as_tensor(DevMem(ptr, nbytes), device=f"cuda:{local}")
+        dist.broadcast(t, src=0)                       # RCCL broadcast of UNet + forest parameters
+        torch.cuda.synchronize()
+    eng.set_params(unet_dtype=_lib.UNET_BF16 if args.unet == "bf16" else _lib.UNET_F32)
+
+    T = synth.similarity_transforms(B, verts, seed=1234, start=rank * B)
+    eng.upload([(verts, faces)])
+    eng.synth_batch(T)                                 # batch resident in HBM before the timed region
+
+    lm_ptr, lm_bytes = eng.landmarks_device()
+    lm_t = torch.as_tensor(DevMem(lm_ptr, lm_bytes), device=f"cuda:{local}") if world > 1 else None
+    gather_list = [torch.empty_like(lm_t) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        eng.run(_lib.STAGE_ALL, fetch=(world == 1))
+        if world > 1:
+            dist.gather(lm_t, gather_list, dst=0)      # landmark records to rank 0
+
+    for _ in range(args.warmup):
+        step()
+    eng.enable_timing(True)
+    eng.reset_timers()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    eng.enable_timing(False)
+
+    lm = eng.run(_lib.STAGE_ALL) if world > 1 else eng.run(_lib.STAGE_ALL)
+    n_bad = int((lm["status"] != 0).sum())
+
+    if rank == 0:
+        ul = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512)
+        gb = geom_bytes(B, V, F)
+        times = {}
+        for name in GEOM_KERNELS + list(ul) + ["unet.pool", "k_synth_batch"]:
+            ms, n = eng.kernel_time_ms(name)
+            if n:
+                times[name] = (ms, n)
+        total_dev = sum(ms * n for ms, n in times.values())
+        dom = max(times, key=lambda k: times[k][0] * times[k][1]) if times else None
+        roof = None
+        if dom:
+            ms, n = times[dom]
+            if dom in ul:
+                fl = ul[dom][0] * B
+                peak = PEAK_MFMA_BF16_TF if args.unet == "bf16" else PEAK_MFMA_F32_TF
+                ach = fl / (ms * 1e-3) / 1e12
+                roof = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                            traffic=None, avg_ms=round(ms, 4), launches=n, share_of_device_time=round(ms * n / total_dev, 3))
+            else:
+                by = gb.get(dom, 0)
+                ach = by / (ms * 1e-3) / 1e9
+                roof = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
+                            traffic=None, avg_ms=round(ms, 4), launches=n, share_of_device_time=round(ms * n / total_dev, 3))
+        unet_ms = sum(times[k][0] for k in times if k.startswith("unet."))
+        unet_tf = sum(v[0] for v in ul.values()) * B / (unet_ms * 1e-3) / 1e12 if unet_ms else None
+        top = sorted(((k, round(v[0] * v[1] / args.steps, 3)) for k, v in times.items()), key=lambda kv: -kv[1])[:8]
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(verts, faces, T, weights, args.cpu_meshes)
+
+        value = world * B * args.steps / el
+        out = {"metric": "humerus meshes/s end-to-end (all 4 landmarks)", "value": round(value, 3), "unit": "meshes/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry + " + ("bf16" if args.unet == "bf16" else "f32") + " UNet",
+               "data": "synthetic (similarity copies of humerus_left.stl, seed 1234; seeded teacher UNet weights)",
+               "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: batch {B} synthetic humeri per GPU, all stages (SH_STAGE_ALL)",
+                          "batch_per_gpu": B, "global_batch": B * world, "vertices": V, "triangles": F, "unet": f"base{unet_spec.BASE} depth{unet_spec.DEPTH} 512x512",
+                          "parallelism": f"dp{world}", "meshes_with_error_status": n_bad},
+               "roofline": roof, "cpu_baseline": cpu,
+               "unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top}
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(verts, faces, T, weights, n_meshes):
+    """The oracle (port of the reference's CPU path) on the first n_meshes synthetic humeri, 1 thread."""
+    from threadpoolctl import threadpool_limits
+    from oracle import rfc
+    from oracle.humerus import OracleHumerus
+    from shoulder_amd import synth
+    tab = rfc.load_tables(os.path.join(ROOT, "shoulder_amd", "models", "rfc_bg3.npz"))
+    t0 = time.perf_counter()
+    with threadpool_limits(limits=1):
+        for i in range(n_meshes):
+            h = OracleHumerus(synth.apply_similarity(T[i], verts), faces, tab, weights, unet_eval="f64")
+            h.landmarks()
+    el = time.perf_counter() - t0
+    return {"value": round(n_meshes / el, 4), "unit": "meshes/s", "cores": 1, "kind": "port",
+            "sample": f"{n_meshes} of the batch's synthetic humeri, all stages, NumPy/SciPy oracle, BLAS limited to 1 thread, {el:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -129,6 +129,9 @@ int  sh_affine_apply(sh_ctx*, const double* T /* host, B x 16 */, const void* de
                      const int64_t* off /* host, B+1 */, int B);
 /* Trimesh.apply_transform of mesh b (bone.py:155): transformed float64 vertices -> host. */
 int  sh_mesh_transformed(sh_ctx*, int b, const double* T /* 16 */, double* out_verts /* V x 3 */);
+/* utils.transform_pts for one host point set (every Landmark.transform_landmark, e.g. canal.py:84,
+ * anatomic_neck.py:120): upload n xyz float64, transform on the device, download. */
+int  sh_transform_points(sh_ctx*, const double* T /* 16 */, const double* in_pts /* host, n x 3 */, int n, double* out_pts /* host */);
 
 /* ---- stage-level access for parity tests: named intermediate device buffers ----------
  * names: "verts_obb" "obb_transform" "full.zs" "full.centroids" "full.areas" "full.nloops"

@@ -410,6 +410,26 @@ int sh_affine_apply(sh_ctx* c, const double* T, const void* dev_in, void* dev_ou
   return SH_OK;
 }
 
+int sh_transform_points(sh_ctx* c, const double* T, const double* in, int n, double* out) {
+  if (!c || !T || !in || !out || n < 0) return fail(c, SH_ERR_ARG, "sh_transform_points: bad argument");
+  if (n == 0) return SH_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, "tp_T", 16 * 8, 8)) != SH_OK) return rc;
+  if ((rc = ensure(c, "tp_io", (size_t)n * 3 * 8 * 2, 8)) != SH_OK) return rc;
+  if ((rc = ensure(c, "tp_off", 2 * 8, 8)) != SH_OK) return rc;
+  long long off[2] = {0, n};
+  double* io = buf<double>(c, "tp_io");
+  HIPCHK(c, hipMemcpyAsync(buf<double>(c, "tp_T"), T, 16 * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "tp_off"), off, 16, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(io, in, (size_t)n * 3 * 8, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "k_affine_f64", k_affine_f64, dim3((unsigned)std::min(1024, (n + 255) / 256), 1), dim3(256), buf<double>(c, "tp_T"), io, io + (size_t)n * 3,
+         buf<long long>(c, "tp_off"));
+  HIPCHK(c, hipMemcpyAsync(out, io + (size_t)n * 3, (size_t)n * 3 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+
 int sh_mesh_transformed(sh_ctx* c, int b, const double* T, double* out) {
   if (!c || !T || !out || b < 0 || b >= c->B) return fail(c, SH_ERR_ARG, "sh_mesh_transformed: bad argument");
   HIPCHK(c, hipSetDevice(c->device));

@@ -131,6 +131,14 @@ class Engine:
         self._chk(self.L.sh_mesh_transformed(self.h, int(b), _ptr(T), _ptr(out)))
         return out
 
+    def transform_points(self, pts, T):
+        """utils.transform_pts on the device: (n,3) float64 host points -> (n,3)."""
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        out = np.empty_like(pts)
+        self._chk(self.L.sh_transform_points(self.h, _ptr(T), _ptr(pts), len(pts), _ptr(out)))
+        return out
+
     # ---- named buffers -----------------------------------------------------------------------------
     def fetch(self, name, dtype, shape=None):
         n, e = ctypes.c_size_t(), ctypes.c_int()
