@@ -69,11 +69,18 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     double l = sqrt(ex * ex + ey * ey);
     if (l == 0.0) continue;
     ex /= l; ey /= l;
+    // the end points of the silhouette edges are exactly the vertices of the projection's 2-D hull,
+    // so the rectangle extents over them equal the extents over every projected hull vertex
     double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
-    for (int i = 0; i < nv; ++i) {
-      double x = pu[i], y = pv[i];
-      double pa = x * ex + y * ey, pb = y * ex - x * ey;
-      amin = fmin(amin, pa); amax = fmax(amax, pa); bmin = fmin(bmin, pb); bmax = fmax(bmax, pb);
+    for (int s2 = 0; s2 < ns; ++s2) {
+      const int e2 = sil[s2];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        int i = E[4 * e2 + w];
+        double x = pu[i], y = pv[i];
+        double pa = x * ex + y * ey, pb = y * ex - x * ey;
+        amin = fmin(amin, pa); amax = fmax(amax, pa); bmin = fmin(bmin, pb); bmax = fmax(bmax, pb);
+      }
     }
     double area = (amax - amin) * (bmax - bmin);
     if (area < best || (area == best && e < be)) { best = area; be = e; }

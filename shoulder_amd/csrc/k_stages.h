@@ -50,15 +50,40 @@ __global__ void k_init_bounds(unsigned long long* zb_enc, int B) {
 }
 
 // surgical_neck.py:22-34: KernelCPD on areas1((0.70,0.99)) -> neck_z = zs_cut[bkp]
-__global__ void k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* __restrict__ scratch,
-                       double* __restrict__ neck_z, int* __restrict__ neck_index, int B) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// One workgroup (64 lanes) per humerus: lane 0 finds gamma (median of the pairwise squared
+// distances), all lanes fill the Gram matrix, each lane evaluates the cost of some breakpoints with
+// the same arithmetic as sh::cpd_one_bkp, first minimum wins.
+__global__ void __launch_bounds__(64)
+k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* __restrict__ scratch,
+       double* __restrict__ neck_z, int* __restrict__ neck_index, int B) {
+  __shared__ double K[SH_CPD_MAXN * SH_CPD_MAXN];
+  __shared__ double gamma_s;
+  int b = blockIdx.x, lane = threadIdx.x;
   int a, e;
   cutoff_range(SH_NFULL, 0.70, 0.99, &a, &e);
-  int t = cpd_one_bkp(areas + (size_t)b * SH_NFULL + a, e - a, scratch + (size_t)b * 6144);
-  neck_index[b] = t;
-  neck_z[b] = zs[(size_t)b * SH_NFULL + a + t];
+  int n = e - a;
+  if (n > SH_CPD_MAXN) n = SH_CPD_MAXN;
+  const double* x = areas + (size_t)b * SH_NFULL + a;
+  if (lane == 0) gamma_s = cpd_gamma(x, n, scratch + (size_t)b * 6144);
+  __syncthreads();
+  double gamma = gamma_s;
+  for (int q = lane; q < n * n; q += 64) K[q] = cpd_kernel(x[q / n], x[q % n], gamma);
+  __syncthreads();
+  double best = 1e300;
+  int bt = 0x7fffffff;
+  for (int t = 2 + lane; t <= n - 2; t += 64) {
+    double cst = cpd_cost(K, n, t);
+    if (cst < best) { best = cst; bt = t; }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    double ob = __shfl_down(best, off);
+    int ot = __shfl_down(bt, off);
+    if (ob < best || (ob == best && ot < bt)) { best = ob; bt = ot; }
+  }
+  if (lane == 0) {
+    neck_index[b] = bt;
+    neck_z[b] = zs[(size_t)b * SH_NFULL + a + bt];
+  }
 }
 
 __device__ inline double wave_sum(double v) {

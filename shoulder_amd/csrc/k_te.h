@@ -11,7 +11,7 @@ namespace sh {
 
 #define SH_TE_ROW0 2
 #define SH_TE_NROWS 37          // int((1-.99)*200)=2 .. int((1-.8)*200)=39 (slice.py:157-164)
-#define SH_TE_ISCR (3 * SH_MAXSEG + 8)
+#define SH_TE_ISCR (5 * SH_MAXSEG + 16)
 
 __global__ void k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, int* __restrict__ iscratch,
                           double* __restrict__ rects /*[B][37][7]*/, int B) {
@@ -22,12 +22,12 @@ __global__ void k_te_rows(const double* __restrict__ ring, const int* __restrict
   const double* xy = ring + pl * (SH_MAXSEG + 1) * 2;
   int n = ring_n[pl];
   int* idx = iscratch + (size_t)gid * SH_TE_ISCR;
-  int* hull = idx + SH_MAXSEG;
+  int* hull = idx + 2 * SH_MAXSEG + 8;
   double* o = rects + (size_t)gid * 7;
   Rect2 r;
   r.cx = r.cy = r.mx = r.my = r.L = r.W = r.area = 0.0;
   if (n >= 3) {
-    int nh = convex_hull_2d(xy, n, idx, hull);
+    int nh = convex_hull_simple_polygon(xy, n, idx, hull);   // rings are simple polygons in boundary order
     min_area_rect(xy, hull, nh, &r);
   }
   o[0] = r.cx; o[1] = r.cy; o[2] = r.mx; o[3] = r.my; o[4] = r.L; o[5] = r.W; o[6] = r.area;

@@ -175,13 +175,32 @@ __global__ void k_maxpool2(const float* __restrict__ src, float* __restrict__ ds
 }
 
 // 1x1 head: logit = fma chain over channels from the bias (anatomic_neck.py:76 output)
-__global__ void k_head(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bp, float* __restrict__ logits, int C, size_t npix) {
+// 256 pixels per workgroup pass: coalesced 16-byte loads into LDS (row stride C+1 floats, so the
+// per-pixel channel walk below is bank-conflict free), then one sequential chain per lane.
+__global__ void __launch_bounds__(256)
+k_head(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bp, float* __restrict__ logits, int C, size_t npix) {
+  __shared__ float tile[256 * 65];
+  __shared__ float sw[64];
+  const int tid = threadIdx.x;
   const float b = bp[0];
-  for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
-    const float* s = src + p * C;
-    float a = b;
-    for (int c = 0; c < C; ++c) a = __builtin_fmaf(s[c], w[c], a);
-    logits[p] = a;
+  if (tid < C) sw[tid] = w[tid];
+  const int C4 = C / 4, ld = C + 1;
+  for (size_t p0 = (size_t)blockIdx.x * 256; p0 < npix; p0 += (size_t)gridDim.x * 256) {
+    __syncthreads();
+    size_t np_ = npix - p0 < 256 ? npix - p0 : 256;
+    for (int e = tid; e < (int)np_ * C4; e += 256) {
+      int px = e / C4, c4 = e % C4;
+      f32x4 v = *(const f32x4*)(src + (p0 + px) * C + c4 * 4);
+      float* t = tile + px * ld + c4 * 4;
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+    __syncthreads();
+    if ((size_t)tid < np_) {
+      const float* s = tile + tid * ld;
+      float a = b;
+      for (int c = 0; c < C; ++c) a = __builtin_fmaf(s[c], sw[c], a);
+      logits[p0 + tid] = a;
+    }
   }
 }
 

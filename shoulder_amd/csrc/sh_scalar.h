@@ -28,33 +28,41 @@ SH_HD double kth_smallest(double* a, int n, int k) {  // quickselect, destroys a
   return a[k];
 }
 
-// scratch: >= n*(n-1)/2 + n*n doubles
-SH_HD int cpd_one_bkp(const double* x, int n, double* scratch) {
-  const int min_size = 2;
+// gamma by the median heuristic; pd: scratch >= n*(n-1)/2 doubles
+SH_HD double cpd_gamma(const double* x, int n, double* pd) {
   int np_ = n * (n - 1) / 2;
-  double* pd = scratch;
-  double* K = scratch + np_;
   int c = 0;
   for (int i = 0; i < n; ++i)
     for (int j = i + 1; j < n; ++j) { double d = x[i] - x[j]; pd[c++] = d * d; }
   double med;
   if (np_ & 1) med = kth_smallest(pd, np_, np_ / 2);
   else { double a = kth_smallest(pd, np_, np_ / 2 - 1); double b = kth_smallest(pd, np_, np_ / 2); med = (a + b) / 2.0; }
-  double gamma = (med == 0.0) ? 1.0 : 1.0 / med;
+  return (med == 0.0) ? 1.0 : 1.0 / med;
+}
+SH_HD double cpd_kernel(double xi, double xj, double gamma) {
+  double d = xi - xj;
+  double v = d * d * gamma;
+  v = v < 1e-2 ? 1e-2 : (v > 1e2 ? 1e2 : v);
+  return exp(-v);
+}
+// c(0,t) + c(t,n) for the Gram matrix K (n x n)
+SH_HD double cpd_cost(const double* K, int n, int t) {
+  double d0 = 0, s0 = 0, d1 = 0, s1 = 0;
+  for (int i = 0; i < t; ++i) { d0 += K[i * n + i]; for (int j = 0; j < t; ++j) s0 += K[i * n + j]; }
+  for (int i = t; i < n; ++i) { d1 += K[i * n + i]; for (int j = t; j < n; ++j) s1 += K[i * n + j]; }
+  return (d0 - s0 / (double)t) + (d1 - s1 / (double)(n - t));
+}
+// scratch: >= n*(n-1)/2 + n*n doubles
+SH_HD int cpd_one_bkp(const double* x, int n, double* scratch) {
+  const int min_size = 2;
+  double* K = scratch + n * (n - 1) / 2;
+  double gamma = cpd_gamma(x, n, scratch);
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) {
-      double d = x[i] - x[j];
-      double v = d * d * gamma;
-      v = v < 1e-2 ? 1e-2 : (v > 1e2 ? 1e2 : v);
-      K[i * n + j] = exp(-v);
-    }
+    for (int j = 0; j < n; ++j) K[i * n + j] = cpd_kernel(x[i], x[j], gamma);
   int best_t = -1;
   double best = 1e300;
   for (int t = min_size; t <= n - min_size; ++t) {
-    double d0 = 0, s0 = 0, d1 = 0, s1 = 0;
-    for (int i = 0; i < t; ++i) { d0 += K[i * n + i]; for (int j = 0; j < t; ++j) s0 += K[i * n + j]; }
-    for (int i = t; i < n; ++i) { d1 += K[i * n + i]; for (int j = t; j < n; ++j) s1 += K[i * n + j]; }
-    double cst = (d0 - s0 / (double)t) + (d1 - s1 / (double)(n - t));
+    double cst = cpd_cost(K, n, t);
     if (cst < best) { best = cst; best_t = t; }
   }
   return best_t;
@@ -474,6 +482,30 @@ SH_HD int convex_hull_2d(const double* xy, int n, int* idx, int* hull) {
     hull[k++] = idx[i];
   }
   return k - 1;
+}
+
+// Convex hull of a SIMPLE polygon given as an open vertex list in boundary order (Melkman's
+// O(n) deque algorithm; collinear points are dropped like the monotone chain above does).
+// dq: scratch 2n+2 ints; returns the hull size, hull vertices (CCW) in hull[0..).  Falls back to
+// the sort-based hull when the first three vertices are collinear.
+SH_HD int convex_hull_simple_polygon(const double* xy, int n, int* dq, int* hull) {
+  if (n < 3) { for (int i = 0; i < n; ++i) hull[i] = i; return n; }
+  double o = orient2(xy, xy + 2, xy + 4);
+  if (o == 0.0) return convex_hull_2d(xy, n, dq, hull);
+  int bot = n - 2, top = bot + 3;
+  dq[bot] = dq[top] = 2;
+  if (o > 0) { dq[bot + 1] = 0; dq[bot + 2] = 1; } else { dq[bot + 1] = 1; dq[bot + 2] = 0; }
+  for (int i = 3; i < n; ++i) {
+    const double* v = xy + 2 * i;
+    if (orient2(xy + 2 * dq[bot], xy + 2 * dq[bot + 1], v) > 0 && orient2(xy + 2 * dq[top - 1], xy + 2 * dq[top], v) > 0) continue;
+    while (top - bot >= 2 && orient2(xy + 2 * dq[bot], xy + 2 * dq[bot + 1], v) <= 0) ++bot;
+    dq[--bot] = i;
+    while (top - bot >= 2 && orient2(xy + 2 * dq[top - 1], xy + 2 * dq[top], v) <= 0) --top;
+    dq[++top] = i;
+  }
+  int nh = top - bot;
+  for (int k = 0; k < nh; ++k) hull[k] = dq[bot + k];
+  return nh;
 }
 
 struct Rect2 {

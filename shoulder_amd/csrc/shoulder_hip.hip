@@ -643,7 +643,7 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   if (mask & SH_STAGE_DISTAL)
     if ((rc = run_slice_set(c, "distal", 2, SH_NDIST, true, false)) != SH_OK) return rc;
   if (mask & SH_STAGE_NECK) {
-    LAUNCH(c, "k_neck", k_neck, dim3((B + 63) / 64), dim3(64), buf<double>(c, "full.areas"), buf<double>(c, "full.zs"),
+    LAUNCH(c, "k_neck", k_neck, dim3(B), dim3(64), buf<double>(c, "full.areas"), buf<double>(c, "full.zs"),
            buf<double>(c, "cpd_scratch"), buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), B);
   }
   if (mask & SH_STAGE_CANAL) {

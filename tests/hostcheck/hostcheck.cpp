@@ -30,6 +30,14 @@ int hc_mrr(const double* xy, int n, double* out7) {
   out7[0] = r.cx; out7[1] = r.cy; out7[2] = r.mx; out7[3] = r.my; out7[4] = r.L; out7[5] = r.W; out7[6] = r.area;
   return nh;
 }
+int hc_mrr_ring(const double* xy, int n, double* out7) {
+  std::vector<int> dq(2 * n + 8), hull(2 * n + 8);
+  int nh = convex_hull_simple_polygon(xy, n, dq.data(), hull.data());
+  Rect2 r;
+  if (!min_area_rect(xy, hull.data(), nh, &r)) return -1;
+  out7[0] = r.cx; out7[1] = r.cy; out7[2] = r.mx; out7[3] = r.my; out7[4] = r.L; out7[5] = r.W; out7[6] = r.area;
+  return nh;
+}
 int hc_clip(const double* pts, int n, double cx, double cy, double mx, double my, double w0, double* cents, int cap) {
   std::vector<double> s(4 * n + 64 * SH_TE_MAXCH);
   return clip_halfplane_pieces(pts, n, cx, cy, mx, my, w0, cents, cap, s.data());

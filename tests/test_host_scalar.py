@@ -172,6 +172,9 @@ def test_mrr_and_clip(hc):
         np.testing.assert_allclose(out[4:7], [ref["L"], ref["W"], ref["area"]], rtol=1e-13)
         np.testing.assert_allclose(out[0:2], ref["center"], atol=1e-10)
         assert abs(abs(out[2] * ref["major"][0] + out[3] * ref["major"][1]) - 1) < 1e-12
+        out2 = np.zeros(7)
+        assert hc.hc_mrr_ring(dp(xy), n, dp(out2)) == nh        # Melkman (simple polygon) == monotone chain
+        np.testing.assert_array_equal(out2[4:7], out[4:7])
         ring = np.r_[xy, xy[:1]]
         for sgn in (1, -1):
             m = ref["major"] * sgn
