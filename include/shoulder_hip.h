@@ -133,6 +133,11 @@ int  sh_mesh_transformed(sh_ctx*, int b, const double* T /* 16 */, double* out_v
  * anatomic_neck.py:120): upload n xyz float64, transform on the device, download. */
 int  sh_transform_points(sh_ctx*, const double* T /* 16 */, const double* in_pts /* host, n x 3 */, int n, double* out_pts /* host */);
 
+/* `mesh_ct.section(plane_origin, plane_normal).vertices` for mesh b (AnatomicNeck.plane_points,
+ * anatomic_neck.py:155-172): unique crossing points of one general plane, CT coordinates, unordered. */
+int  sh_section_plane(sh_ctx*, int b, const double* origin /* 3 */, const double* normal /* 3 */, double* out_pts /* cap x 3 */,
+                      int cap, int* n_out);
+
 /* ---- stage-level access for parity tests: named intermediate device buffers ----------
  * names: "verts_obb" "obb_transform" "full.zs" "full.centroids" "full.areas" "full.nloops"
  * "distal.*" "prox.*" "prox.ixy" "prox.itr_start" "prox.itr_centered_start" "canal.points"

@@ -92,6 +92,10 @@ __global__ void k_make_planes(int kind, int N, const double* __restrict__ zb /*[
                               double* __restrict__ zs, double* __restrict__ zeff, int B) {
   int b = blockIdx.x;
   if (b >= B) return;
+  if (kind == 3) {   // one plane at neck_z: `mesh.section(plane_origin=[0,0,neck_z])` (surgical_neck.py:37-39)
+    if (threadIdx.x == 0) { zs[b] = neck_z[b]; zeff[b] = neck_z[b]; }
+    return;
+  }
   double zmin = zb[2 * b], zmax = zb[2 * b + 1];
   double a, e;
   if (kind == 0) { a = 0.99 * zmax; e = 0.99 * zmin; }
@@ -131,6 +135,7 @@ __global__ void k_slice_emit(const double* __restrict__ vobb, const int* __restr
     int lo = (int)floor(fmax(klo, 0.0)) - 1, hi = (int)ceil(fmin(khi, (double)(N - 1))) + 1;
     lo = lo < 0 ? 0 : lo;
     hi = hi > N - 1 ? N - 1 : hi;
+    if (N == 1) { lo = 0; hi = 0; }
     for (int k = lo; k <= hi; ++k) {
       double z = zp[k];
       double d[3];

@@ -44,6 +44,34 @@ __global__ void k_affine_f32in(const double* __restrict__ T, const float* __rest
   }
 }
 
+// One general plane section of one mesh: unique crossing points in CT coordinates
+// (`mesh_ct.section(plane_origin, plane_normal).vertices`, anatomic_neck.py:161-165).
+// d = n.(v - o); sign rule and edge orientation as in k_slice_emit; one point per crossed edge.
+__global__ void k_section_points(const float* __restrict__ verts, const int* __restrict__ faces, long long nf,
+                                 const double* __restrict__ plane /*origin xyz, unit normal xyz*/, double* __restrict__ out, int cap,
+                                 int* __restrict__ count) {
+  const double ox = plane[0], oy = plane[1], oz = plane[2], nx = plane[3], ny = plane[4], nz = plane[5];
+  for (long long fi = blockIdx.x * (long long)blockDim.x + threadIdx.x; fi < nf; fi += (long long)gridDim.x * blockDim.x) {
+    int id[3] = {faces[3 * fi], faces[3 * fi + 1], faces[3 * fi + 2]};
+    double P[3][3], d[3];
+    int s[3];
+    for (int k = 0; k < 3; ++k) {
+      for (int q = 0; q < 3; ++q) P[k][q] = (double)verts[3 * (size_t)id[k] + q];
+      d[k] = ((P[k][0] - ox) * nx + (P[k][1] - oy) * ny) + (P[k][2] - oz) * nz;
+      s[k] = d[k] < -SH_SECTION_TOL ? -1 : 1;
+    }
+    if (s[0] == s[1] && s[1] == s[2]) continue;
+    int dn = 0;
+    for (int j = 0; j < 3; ++j) if (s[j] == 1 && s[(j + 1) % 3] == -1) dn = j;
+    int a = dn, c = (dn + 1) % 3;
+    int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
+    double t = d[l] / (d[l] - d[h]);
+    int slot = atomicAdd(count, 1);
+    if (slot < cap)
+      for (int q = 0; q < 3; ++q) out[3 * (size_t)slot + q] = P[l][q] + t * (P[h][q] - P[l][q]);
+  }
+}
+
 __global__ void k_init_bounds(unsigned long long* zb_enc, int B) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 2 * B) zb_enc[i] = (i & 1) ? 0ull : ~0ull;

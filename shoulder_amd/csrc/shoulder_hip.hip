@@ -211,7 +211,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("canal.axis_ct", B * 6 * 8, 8);
   ENS("landmarks", (size_t)B * sizeof(sh_landmarks), 1);
   struct S { const char* p; int N; bool ring; };
-  const S sets[3] = {{"full", SH_NFULL, false}, {"distal", SH_NDIST, true}, {"prox", SH_NPROX, true}};
+  const S sets[4] = {{"full", SH_NFULL, false}, {"distal", SH_NDIST, true}, {"prox", SH_NPROX, true}, {"neckc", 1, true}};
   for (const S& s : sets) {
     std::string p = s.p;
     ENS((p + ".zs").c_str(), (size_t)B * s.N * 8, 8);
@@ -430,6 +430,32 @@ int sh_transform_points(sh_ctx* c, const double* T, const double* in, int n, dou
   return SH_OK;
 }
 
+int sh_section_plane(sh_ctx* c, int b, const double* origin, const double* normal, double* out_pts, int cap, int* n_out) {
+  if (!c || !origin || !normal || !out_pts || !n_out || cap <= 0 || b < 0 || b >= c->B) return fail(c, SH_ERR_ARG, "sh_section_plane: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  double pl[6] = {origin[0], origin[1], origin[2], normal[0], normal[1], normal[2]};
+  double nn = std::sqrt(pl[3] * pl[3] + pl[4] * pl[4] + pl[5] * pl[5]);
+  if (!(nn > 0)) return fail(c, SH_ERR_ARG, "sh_section_plane: zero normal");
+  for (int k = 3; k < 6; ++k) pl[k] /= nn;
+  int rc;
+  if ((rc = ensure(c, "sp_plane", 6 * 8, 8)) != SH_OK) return rc;
+  if ((rc = ensure(c, "sp_out", (size_t)cap * 3 * 8, 8)) != SH_OK) return rc;
+  if ((rc = ensure(c, "sp_cnt", 4, 4)) != SH_OK) return rc;
+  HIPCHK(c, hipMemcpyAsync(buf<double>(c, "sp_plane"), pl, 48, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(buf<int>(c, "sp_cnt"), 0, 4, c->stream));
+  long long nf = c->h_foff[b + 1] - c->h_foff[b];
+  LAUNCH(c, "k_section_points", k_section_points, dim3((unsigned)std::min<long long>((nf + 255) / 256, 1024)), dim3(256),
+         buf<float>(c, "verts") + 3 * c->h_voff[b], buf<int>(c, "faces") + 3 * c->h_foff[b], nf, buf<double>(c, "sp_plane"), buf<double>(c, "sp_out"), cap,
+         buf<int>(c, "sp_cnt"));
+  int n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, buf<int>(c, "sp_cnt"), 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_out = n;
+  if (n > cap) return fail(c, SH_ERR_CAPACITY, "sh_section_plane: more crossing points than capacity");
+  HIPCHK(c, hipMemcpy(out_pts, buf<double>(c, "sp_out"), (size_t)n * 3 * 8, hipMemcpyDeviceToHost));
+  return SH_OK;
+}
+
 int sh_mesh_transformed(sh_ctx* c, int b, const double* T, double* out) {
   if (!c || !T || !out || b < 0 || b >= c->B) return fail(c, SH_ERR_ARG, "sh_mesh_transformed: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
@@ -523,7 +549,7 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
 }
 
 // ---- stage runner ----------------------------------------------------------------------------------
-static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample) {
+static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0) {
   const int B = c->B;
   std::string p = pfx;
   double* zs = buf<double>(c, (p + ".zs").c_str());
@@ -537,7 +563,7 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
          buf<long long>(c, "foff"), zeff, N, cnt, segs, buf<int>(c, "err"));
   LAUNCH(c, "k_slice_link", k_slice_link, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), buf<int>(c, (p + ".ring_n").c_str()),
-         ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr, 0, buf<int>(c, "err"));
+         ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr, select, buf<int>(c, "err"));
   if (resample) {
     LAUNCH(c, "k_resample_polar", k_resample_polar, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, buf<int>(c, (p + ".ring_n").c_str()),
            buf<double>(c, (p + ".ring").c_str()), buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"),
@@ -645,6 +671,8 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   if (mask & SH_STAGE_NECK) {
     LAUNCH(c, "k_neck", k_neck, dim3(B), dim3(64), buf<double>(c, "full.areas"), buf<double>(c, "full.zs"),
            buf<double>(c, "cpd_scratch"), buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), B);
+    // surgical_neck.py:37-54: the contour at neck_z (loop whose vertex mean is nearest the origin)
+    if ((rc = run_slice_set(c, "neckc", 3, 1, true, false, 1)) != SH_OK) return rc;
   }
   if (mask & SH_STAGE_CANAL) {
     LAUNCH(c, "k_canal", k_canal, dim3(B), dim3(64), buf<double>(c, "full.centroids"), buf<double>(c, "full.zs"),

@@ -139,6 +139,15 @@ class Engine:
         self._chk(self.L.sh_transform_points(self.h, _ptr(T), _ptr(pts), len(pts), _ptr(out)))
         return out
 
+    def section_plane(self, b, origin, normal, cap=8192):
+        """Unique crossing points (CT) of mesh b with one plane: `mesh_ct.section(...).vertices`."""
+        o = np.ascontiguousarray(origin, dtype=np.float64)
+        n = np.ascontiguousarray(normal, dtype=np.float64)
+        out = np.empty((cap, 3), dtype=np.float64)
+        k = ctypes.c_int()
+        self._chk(self.L.sh_section_plane(self.h, int(b), _ptr(o), _ptr(n), _ptr(out), cap, ctypes.byref(k)))
+        return out[:k.value].copy()
+
     # ---- named buffers -----------------------------------------------------------------------------
     def fetch(self, name, dtype, shape=None):
         n, e = ctypes.c_size_t(), ctypes.c_int()

@@ -1,0 +1,86 @@
+"""The drop-in facade (shoulder_amd.Humerus) on the GPU: README flow of the reference
+(README.md:22-41), accessor shapes / caching / csys semantics of SURVEY 8(b), checked against the
+oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import BONES
+from oracle import xform
+
+pytestmark = pytest.mark.gpu
+MM = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hum(engine):
+    import shoulder_amd as shoulder
+    return shoulder.Humerus(os.path.join(BONES, "humerus_left.stl"), engine=engine)
+
+
+def test_constructor_state(hum, oracle_bones):
+    h = oracle_bones("humerus_left")
+    assert hum.stl_file.name == "humerus_left.stl"
+    np.testing.assert_array_equal(hum.transform, np.identity(4))
+    assert hum.mesh.vertices.shape == (16222, 3) and hum.mesh.faces.shape == (32440, 3)
+    assert hum.surgical_neck.neck_z == pytest.approx(h.neck["neck_z"], abs=1e-7)
+    np.testing.assert_allclose(hum.surgical_neck.points, h.neck["points_ct"], rtol=0, atol=MM)
+
+
+def test_accessors_in_ct(hum, oracle_bones):
+    h = oracle_bones("humerus_left")
+    L = h.landmarks()
+    np.testing.assert_allclose(hum.canal.axis(), L["canal_axis"], rtol=0, atol=MM)
+    np.testing.assert_allclose(hum.canal.points(), L["canal_points"], rtol=0, atol=MM)
+    assert hum.canal.points().shape == (80, 3)
+    np.testing.assert_allclose(hum.bicipital_groove.points(), L["groove_points"], rtol=0, atol=MM)
+    assert hum.bicipital_groove.bg_theta == L["bg_theta"]
+    np.testing.assert_allclose(hum.bicipital_groove.axis(), L["groove_axis"], rtol=0, atol=MM)
+    np.testing.assert_allclose(hum.anatomic_neck.points(), L["anp_points"], rtol=0, atol=MM)
+    p = hum.anatomic_neck.plane()
+    np.testing.assert_allclose(p.point, L["anp_plane_point"], rtol=0, atol=MM)
+    np.testing.assert_allclose(p.normal, L["anp_plane_normal"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(hum.anatomic_neck.axis_normal(), L["anp_axis_normal"], rtol=0, atol=MM)
+    np.testing.assert_allclose(hum.anatomic_neck.axis_central(), L["anp_axis_central"], rtol=0, atol=MM)
+    np.testing.assert_allclose(hum.trans_epiconylar.axis(), L["te_axis"], rtol=0, atol=MM)
+    # plane_points: every returned point lies on the plane and on the mesh surface section
+    pp = hum.anatomic_neck.plane_points()
+    assert len(pp) > 50
+    assert np.abs((pp - p.point) @ p.normal).max() < 1e-9
+
+
+def test_apply_csys_roundtrip(hum, oracle_bones):
+    h = oracle_bones("humerus_left")
+    L = h.landmarks()
+    T = hum.apply_csys_canal_transepiconylar()
+    np.testing.assert_allclose(T, L["csys"], rtol=0, atol=1e-6)
+    assert hum.transform is hum._tfrm.matrix
+    # in the canal/TE frame: canal axis along +z through the origin, TE axis in the xz... (y = 0 plane normal)
+    ax = hum.canal.axis()
+    np.testing.assert_allclose(ax, xform.transform_pts(L["canal_axis"], L["csys"]), rtol=0, atol=MM)
+    assert abs(ax[:, 0]).max() < 1e-6 and abs(ax[:, 1]).max() < 1e-6 and ax[0, 2] > 0 > ax[1, 2]
+    np.testing.assert_allclose(hum.anatomic_neck.points(), xform.transform_pts(L["anp_points"], L["csys"]), rtol=0, atol=MM)
+    np.testing.assert_allclose(hum.mesh.vertices, xform.transform_pts(h.verts.astype(np.float64), L["csys"]), rtol=0, atol=MM)
+    T2 = hum.apply_csys_obb()
+    np.testing.assert_allclose(T2, h.T_obb, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(hum.canal.axis(), h.canal["axis_obb"], rtol=0, atol=MM)
+    hum.apply_csys_ct()
+    np.testing.assert_array_equal(hum.transform, np.identity(4))
+    np.testing.assert_allclose(hum.canal.axis(), L["canal_axis"], rtol=0, atol=MM)
+    t = np.array([1.0, -2.0, 3.0])
+    hum.apply_translation(t)
+    np.testing.assert_allclose(hum.canal.axis(), L["canal_axis"] + t, rtol=0, atol=MM)
+    hum.apply_csys_ct()
+
+
+def test_errors(hum):
+    with pytest.raises(ValueError, match="Invalid transformation matrix shape"):
+        hum.apply_csys_custom(np.identity(3))
+    with pytest.raises(NotImplementedError):
+        hum.side()
+    import shoulder_amd as shoulder
+    with pytest.raises(NotImplementedError):
+        shoulder.ProximalHumerus("x.stl")
+    with pytest.raises((FileNotFoundError, ValueError)):
+        shoulder.Humerus("does_not_exist.stl", engine=hum._engine)
