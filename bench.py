@@ -70,6 +70,15 @@ def unet_layers(base, depth, H, W):
     return out
 
 
+def unet_couts(base, depth):
+    ch = [base << i for i in range(depth + 1)]
+    out = {}
+    for i in range(depth):
+        out[f"unet.enc{i}a"] = out[f"unet.enc{i}b"] = out[f"unet.up{i}"] = out[f"unet.dec{i}a"] = out[f"unet.dec{i}b"] = ch[i]
+    out["unet.bota"] = out["unet.botb"] = ch[depth]
+    return out
+
+
 def geom_bytes(B, V, F):
     """Algorithmic HBM bytes per launch of the geometry kernels (one launch = whole batch)."""
     seg = 32
@@ -178,6 +187,7 @@ def main():
 
     if rank == 0:
         ul = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512)
+        ul_cout = unet_couts(unet_spec.BASE, unet_spec.DEPTH)
         gb = geom_bytes(B, V, F)
         times = {}
         for name in GEOM_KERNELS + list(ul) + ["unet.pool", "k_synth_batch"]:
@@ -185,24 +195,39 @@ def main():
             if n:
                 times[name] = (ms, n)
         total_dev = sum(ms * n for ms, n in times.values())
-        dom = max(times, key=lambda k: times[k][0] * times[k][1]) if times else None
+        # group the launches by kernel symbol (what rocprofv3 --stats reports): the UNet layers run one of
+        # four instantiations of k_conv_mfma_f32<TAPS, NT>
+        sym = {}
+        for name, (ms, n) in times.items():
+            if name in ul and name not in ("unet.head", "unet.enc0a"):
+                cout = ul_cout[name]
+                key = "k_conv_mfma_%s<%d,%d>" % (args.unet, 1 if name.startswith("unet.up") else 9, 4 if cout % 64 == 0 else 2)
+            else:
+                key = name
+            g = sym.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
+            g["ms"] += ms * n
+            g["n"] += n
+            if name in ul:
+                g["flops"] += ul[name][0] * B * n
+                g["bytes"] += ul[name][1] * B * n
+            else:
+                g["bytes"] += gb.get(name, 0) * n
+        dom = max(sym, key=lambda k: sym[k]["ms"]) if sym else None
         roof = None
         if dom:
-            ms, n = times[dom]
-            if dom in ul:
-                fl = ul[dom][0] * B
+            g = sym[dom]
+            common = dict(kernel=dom, avg_ms=round(g["ms"] / g["n"], 4), launches=g["n"], share_of_device_time=round(g["ms"] / total_dev, 3), traffic=None)
+            if g["flops"] > 0:
                 peak = PEAK_MFMA_BF16_TF if args.unet == "bf16" else PEAK_MFMA_F32_TF
-                ach = fl / (ms * 1e-3) / 1e12
-                roof = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                            traffic=None, avg_ms=round(ms, 4), launches=n, share_of_device_time=round(ms * n / total_dev, 3))
+                ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+                roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                            algorithmic_gbytes_per_launch=round(g["bytes"] / g["n"] / 1e9, 4), **common)
             else:
-                by = gb.get(dom, 0)
-                ach = by / (ms * 1e-3) / 1e9
-                roof = dict(kernel=dom, bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
-                            traffic=None, avg_ms=round(ms, 4), launches=n, share_of_device_time=round(ms * n / total_dev, 3))
+                ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
+                roof = dict(bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), **common)
         unet_ms = sum(times[k][0] for k in times if k.startswith("unet."))
         unet_tf = sum(v[0] for v in ul.values()) * B / (unet_ms * 1e-3) / 1e12 if unet_ms else None
-        top = sorted(((k, round(v[0] * v[1] / args.steps, 3)) for k, v in times.items()), key=lambda kv: -kv[1])[:8]
+        top = sorted(((k, round(v["ms"] / args.steps, 3)) for k, v in sym.items()), key=lambda kv: -kv[1])[:10]
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

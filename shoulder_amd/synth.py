@@ -6,11 +6,13 @@ import numpy as np
 
 def similarity_transforms(n, template_verts, seed=1234, start=0):
     """-> (n,4,4) float64 for meshes start..start+n-1 of the seeded sequence."""
-    rng = np.random.default_rng(seed)
+    # three child streams of the seed (rotation, translation, scale): mesh i is the same whatever the
+    # batch size or shard, so contiguous per-rank shards tile the global sequence exactly
+    sq, st, ss = np.random.SeedSequence(seed).spawn(3)
     total = start + n
-    q = rng.standard_normal((total, 4))
-    t = rng.uniform(-500.0, 500.0, (total, 3))
-    s = rng.uniform(0.85, 1.15, total)
+    q = np.random.default_rng(sq).standard_normal((total, 4))
+    t = np.random.default_rng(st).uniform(-500.0, 500.0, (total, 3))
+    s = np.random.default_rng(ss).uniform(0.85, 1.15, total)
     q /= np.linalg.norm(q, axis=1, keepdims=True)
     c = np.asarray(template_verts, dtype=np.float64).mean(axis=0)
     T = np.zeros((total, 4, 4))
