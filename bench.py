@@ -98,11 +98,6 @@ def geom_bytes(B, V, F):
     }
 
 
-class DevMem:
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,15 +114,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     import torch
-    if world > 1:
+    # SH_BENCH_FORCE_DIST=1 exercises the collective code path with a single rank (1-GPU rehearsal)
+    use_dist = world > 1 or os.environ.get("SH_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from shoulder_amd import _lib, synth, unet_spec
+    from shoulder_amd import dist as shd
     from shoulder_amd.engine import Engine
     from shoulder_amd.stl import load_stl
     verts, faces = load_stl(os.path.join(ROOT, "tests", "golden", "bones", "humerus_left.stl"))   # host I/O, outside the timed region
@@ -142,10 +141,8 @@ def main():
         z = np.load(os.path.join(ROOT, "shoulder_amd", "models", "rfc_bg3.npz"))
         eng.load_rfc()       # tree topology is needed host-side for validation; values are overwritten below
         eng.load_unet({k: np.zeros_like(v) for k, v in weights.items()}, unet_spec.BASE, unet_spec.DEPTH)
-    if world > 1:
-        ptr, nbytes = eng.param_block()
-        t = torch.as_tensor(DevMem(ptr, nbytes), device=f"cuda:{local}")
-        dist.broadcast(t, src=0)                       # RCCL broadcast of UNet + forest parameters
+    if use_dist:
+        shd.broadcast_params(eng.param_block(), src=0, device=f"cuda:{local}")   # RCCL broadcast of UNet + forest parameters
         torch.cuda.synchronize()
     eng.set_params(unet_dtype=_lib.UNET_BF16 if args.unet == "bf16" else _lib.UNET_F32)
 
@@ -153,36 +150,39 @@ def main():
     eng.upload([(verts, faces)])
     eng.synth_batch(T)                                 # batch resident in HBM before the timed region
 
-    lm_ptr, lm_bytes = eng.landmarks_device()
-    lm_t = torch.as_tensor(DevMem(lm_ptr, lm_bytes), device=f"cuda:{local}") if world > 1 else None
-    gather_list = [torch.empty_like(lm_t) for _ in range(world)] if (world > 1 and rank == 0) else None
+    lm_t = shd.as_byte_tensor(eng.landmarks_device(), device=f"cuda:{local}") if use_dist else None
+    gather_list = [torch.empty_like(lm_t) for _ in range(world)] if (use_dist and rank == 0) else None
 
     def step():
-        eng.run(_lib.STAGE_ALL, fetch=(world == 1))
-        if world > 1:
-            dist.gather(lm_t, gather_list, dst=0)      # landmark records to rank 0
+        eng.run(_lib.STAGE_ALL, fetch=not use_dist)
+        if use_dist:
+            dist.gather(lm_t, gather_list, dst=0)      # landmark records of every rank to rank 0 (device to device)
 
     for _ in range(args.warmup):
         step()
     eng.enable_timing(True)
     eng.reset_timers()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     eng.enable_timing(False)
 
-    lm = eng.run(_lib.STAGE_ALL) if world > 1 else eng.run(_lib.STAGE_ALL)
+    if use_dist and rank == 0:      # what rank 0 holds after the last gather: every rank's records, in rank order
+        lm = torch.cat(gather_list).cpu().numpy().view(_lib.LANDMARKS_DTYPE)
+        assert len(lm) == world * B
+    else:
+        lm = eng.run(_lib.STAGE_ALL)
     n_bad = int((lm["status"] != 0).sum())
 
     if rank == 0:
@@ -245,7 +245,7 @@ def main():
                "unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top}
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

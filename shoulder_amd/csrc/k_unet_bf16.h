@@ -1,0 +1,196 @@
+// k_unet_bf16.h -- UNet forward in bf16 on v_mfma_f32_16x16x32_bf16 (throughput path, BASELINE
+// config 3 "UNet bf16"); f32 accumulate, bias f32, activations NHWC bf16 in HBM.
+//
+// Transposed implicit GEMM: A = weights (rows = 16 couts), B = activations (cols = 16 pixels of one
+// image row), K = 32 input channels of one tap.  D then has the pixel on the lane and 4 consecutive
+// couts in the 4 accumulator registers, so the epilogue stores 8 contiguous bytes per lane
+// (4 bf16) instead of 2-byte scattered stores.
+//   lane l: A frag = W[cout l&15][k = 8(l>>4) .. +7]   B frag = X[k = 8(l>>4) .. +7][pixel l&15]
+//   D[row = 4(l>>4)+r (cout)][col = l&15 (pixel)]
+// LDS: pixel-major halo tile and cout-major weight tile, both with 32 channels per row padded to
+// 40 bf16 (80 B = 5 x 16 B): every fragment is one aligned ds_read_b128 and the 16 lanes of a
+// k-group hit distinct 16-B slots.
+// Weights are re-packed once per load to [phase][tap][Cin/32][Cout][32] bf16 (k_pack_w_bf16) so the
+// staging loads are 16-byte and coalesced.
+#pragma once
+#include "k_unet.h"
+
+namespace sh {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define UB_PSTR 40      // bf16 elements per LDS row (32 + 8 pad)
+
+// src f32 [T][Cin][Cout]  ->  dst bf16 [T][Cin/32][Cout][32]
+__global__ void k_pack_w_bf16(const float* __restrict__ src, __bf16* __restrict__ dst, int T, int Cin, int Cout) {
+  size_t total = (size_t)T * Cin * Cout;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    int k = (int)(e % 32);
+    size_t r = e / 32;
+    int co = (int)(r % Cout);
+    r /= Cout;
+    int cc = (int)(r % (Cin / 32));
+    int t = (int)(r / (Cin / 32));
+    dst[e] = (__bf16)src[((size_t)t * Cin + cc * 32 + k) * Cout + co];
+  }
+}
+
+template <int TAPS, int NT>
+__global__ void __launch_bounds__(UN_THREADS)
+k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src1, int C0, int C1,
+                 const __bf16* __restrict__ wgt, const float* __restrict__ bias, __bf16* __restrict__ dst, int H, int W, int Cout, int relu) {
+  constexpr int HALO = TAPS == 9 ? 1 : 0;
+  constexpr int PW = UN_TW + 2 * HALO, PH = UN_TH + 2 * HALO;
+  constexpr int NC = 16 * NT;
+  __shared__ __attribute__((aligned(16))) __bf16 s_in[PH * PW * UB_PSTR];
+  __shared__ __attribute__((aligned(16))) __bf16 s_w[TAPS * NC * UB_PSTR];
+  const int Cin = C0 + C1;
+  const int tiles_x = W / UN_TW;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int n0 = blockIdx.y * NC;
+  const int img = TAPS == 9 ? blockIdx.z : blockIdx.z / 4;
+  const int phase = TAPS == 9 ? 0 : blockIdx.z % 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int x0 = tx * UN_TW, y0 = ty * UN_TH;
+  const __bf16* in0 = src0 + (size_t)img * H * W * C0;
+  const __bf16* in1 = src1 ? src1 + (size_t)img * H * W * C1 : nullptr;
+  const int nchunk = Cin / 32;
+  const __bf16* wp = wgt + (size_t)phase * TAPS * nchunk * Cout * 32;
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    f32x4 bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias[n0 + n * 16 + lk * 4 + r];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m][n] = bv;
+  }
+
+  for (int cc = 0; cc < nchunk; ++cc) {
+    const int c0 = cc * 32;
+    __syncthreads();
+    for (int e = tid; e < PH * PW * 4; e += UN_THREADS) {
+      int q = e & 3, p = e >> 2;
+      int px = p % PW, py = p / PW;
+      int gx = x0 + px - HALO, gy = y0 + py - HALO;
+      int c = c0 + q * 8;
+      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+      if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+        const __bf16* s = (c < C0) ? in0 + ((size_t)gy * W + gx) * C0 + c : in1 + ((size_t)gy * W + gx) * C1 + (c - C0);
+        v = *(const u32x4*)s;
+      }
+      *(u32x4*)(s_in + p * UB_PSTR + q * 8) = v;
+    }
+    for (int e = tid; e < TAPS * NC * 4; e += UN_THREADS) {
+      int q = e & 3, r = e >> 2;                 // r = tap*NC + j
+      int tap = r / NC, j = r % NC;
+      u32x4 v = *(const u32x4*)(wp + (((size_t)tap * nchunk + cc) * Cout + n0 + j) * 32 + q * 8);
+      *(u32x4*)(s_w + r * UB_PSTR + q * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
+      bf16x8 xf[4], wf[NT];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) xf[m] = *(const bf16x8*)(s_in + ((wave * 4 + m + dy) * PW + li + dx) * UB_PSTR + lk * 8);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wf[n] = *(const bf16x8*)(s_w + (tap * NC + n * 16 + li) * UB_PSTR + lk * 8);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[m][n], 0, 0, 0);
+    }
+  }
+  const int OW = TAPS == 9 ? W : 2 * W, OH = TAPS == 9 ? H : 2 * H;
+  __bf16* out = dst + (size_t)img * OH * OW * Cout;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    int gy = y0 + wave * 4 + m, gx = x0 + li;
+    int oy = TAPS == 9 ? gy : 2 * gy + (phase >> 1), ox = TAPS == 9 ? gx : 2 * gx + (phase & 1);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[m][n][r];
+        if (relu) v = fmaxf(v, 0.0f);
+        o[r] = (__bf16)v;
+      }
+      *(bf16x4*)(out + ((size_t)oy * OW + ox) * Cout + n0 + n * 16 + lk * 4) = o;
+    }
+  }
+}
+
+__global__ void k_conv_first_bf16(const float* __restrict__ img, const float* __restrict__ wgt, const float* __restrict__ bias,
+                                  __bf16* __restrict__ dst, int H, int W, int C, int nimg) {
+  __shared__ float sw[9 * 64 + 64];
+  for (int e = threadIdx.x; e < 9 * C; e += blockDim.x) sw[e] = wgt[e];
+  for (int e = threadIdx.x; e < C; e += blockDim.x) sw[9 * 64 + e] = bias[e];
+  __syncthreads();
+  size_t total = (size_t)nimg * H * W;
+  for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+    int x = (int)(p % W), y = (int)((p / W) % H);
+    size_t im = p / ((size_t)H * W);
+    const float* src = img + im * H * W;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      int gy = y + t / 3 - 1, gx = x + t % 3 - 1;
+      v[t] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
+    }
+    __bf16* o = dst + p * C;
+    for (int c8 = 0; c8 < C; c8 += 8) {
+      bf16x8 ov;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float a = sw[9 * 64 + c8 + k];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a = __builtin_fmaf(v[t], sw[t * C + c8 + k], a);
+        ov[k] = (__bf16)fmaxf(a, 0.0f);
+      }
+      *(bf16x8*)(o + c8) = ov;
+    }
+  }
+}
+
+__global__ void k_maxpool2_bf16(const __bf16* __restrict__ src, __bf16* __restrict__ dst, int H, int W, int C, int nimg) {
+  const int OH = H / 2, OW = W / 2, C8 = C / 8;
+  size_t total = (size_t)nimg * OH * OW * C8;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    int c8 = (int)(e % C8);
+    size_t p = e / C8;
+    int ox = (int)(p % OW), oy = (int)((p / OW) % OH);
+    size_t im = p / ((size_t)OH * OW);
+    const __bf16* s = src + ((im * H + 2 * oy) * W + 2 * ox) * C + c8 * 8;
+    bf16x8 a = *(const bf16x8*)s, b = *(const bf16x8*)(s + C), c = *(const bf16x8*)(s + (size_t)W * C), d = *(const bf16x8*)(s + (size_t)W * C + C);
+    bf16x8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (__bf16)fmaxf(fmaxf((float)a[k], (float)b[k]), fmaxf((float)c[k], (float)d[k]));
+    *(bf16x8*)(dst + ((im * OH + oy) * OW + ox) * C + c8 * 8) = r;
+  }
+}
+
+__global__ void k_head_bf16(const __bf16* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bp,
+                            float* __restrict__ logits, int C, size_t npix) {
+  __shared__ float sw[64];
+  if (threadIdx.x < C) sw[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  const float b = bp[0];
+  for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+    const __bf16* s = src + p * C;
+    float a = b;
+    for (int c8 = 0; c8 < C; c8 += 8) {
+      bf16x8 v = *(const bf16x8*)(s + c8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a = __builtin_fmaf((float)v[k], sw[c8 + k], a);
+    }
+    logits[p] = a;
+  }
+}
+
+}  // namespace sh

@@ -16,6 +16,7 @@
 #include "k_groove.h"
 #include "k_anp.h"
 #include "k_unet.h"
+#include "k_unet_bf16.h"
 #include "k_te.h"
 #include "k_obb.h"
 #include "sh_hull.h"
@@ -548,6 +549,89 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
   return SH_OK;
 }
 
+// ---- UNet forward (bf16 MFMA path) ---------------------------------------------------------------------
+static int conv_layer_bf16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const __bf16* src0, const __bf16* src1, int C0, int C1,
+                           __bf16* dst, int H, int W, int nimg, int relu) {
+  if (H % UN_TH || W % UN_TW) return fail(c, SH_ERR_ARG, "unet: feature map is not a multiple of 16");
+  const __bf16* w = buf<__bf16>(c, "params_bf16") + L.w_off;
+  const float* b = buf<float>(c, "params") + L.b_off;
+  const int tiles = (H / UN_TH) * (W / UN_TW);
+  if (L.taps == 9) {
+    if (L.cout % 64 == 0) {
+      LAUNCH(c, lname, (k_conv_mfma_bf16<9, 4>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu);
+    } else {
+      LAUNCH(c, lname, (k_conv_mfma_bf16<9, 2>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu);
+    }
+  } else {
+    if (L.cout % 64 == 0) {
+      LAUNCH(c, lname, (k_conv_mfma_bf16<1, 4>), dim3(tiles, L.cout / 64, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0);
+    } else {
+      LAUNCH(c, lname, (k_conv_mfma_bf16<1, 2>), dim3(tiles, L.cout / 32, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0);
+    }
+  }
+  return SH_OK;
+}
+
+static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
+  const int D = c->unet_depth, base = c->unet_base;
+  if ((H >> D) % 16 || (W >> D) % 16) return fail(c, SH_ERR_ARG, "unet: input size must be a multiple of 16 << depth");
+  int rc;
+  if ((rc = ensure(c, "params_bf16", c->unet_floats * 2, 2)) != SH_OK) return rc;
+  const float* P = buf<float>(c, "params");
+  __bf16* PW = buf<__bf16>(c, "params_bf16");
+  for (auto& kv : c->ulayers) {     // repack the MFMA layers' weights (cheap; stays correct after a parameter broadcast)
+    const sh_ctx::ULayer& l = kv.second;
+    if (l.cin < 32 || l.cout < 32) continue;
+    size_t tot = (size_t)l.taps * l.cin * l.cout;
+    LAUNCH(c, "k_pack_w_bf16", k_pack_w_bf16, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), P + l.w_off, PW + l.w_off, l.taps, l.cin, l.cout);
+  }
+  const size_t full = (size_t)nimg * H * W * base * 2;
+  if ((rc = ensure(c, "unet16.a", full, 2)) != SH_OK) return rc;
+  if ((rc = ensure(c, "unet16.b", full, 2)) != SH_OK) return rc;
+  std::vector<__bf16*> skip(D);
+  for (int i = 0; i < D; ++i) {
+    std::string nm = "unet16.skip" + std::to_string(i);
+    if ((rc = ensure(c, nm.c_str(), full >> i, 2)) != SH_OK) return rc;
+    skip[i] = buf<__bf16>(c, nm.c_str());
+  }
+  __bf16* A = buf<__bf16>(c, "unet16.a");
+  __bf16* Bq = buf<__bf16>(c, "unet16.b");
+  auto L = [&](const std::string& n) -> const sh_ctx::ULayer& { return c->ulayers[n]; };
+  int h = H, w = W;
+  {
+    const sh_ctx::ULayer& l = L("enc0a");
+    size_t npx = (size_t)nimg * h * w;
+    LAUNCH(c, "unet.enc0a", k_conv_first_bf16, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, A, h, w, l.cout, nimg);
+  }
+  if ((rc = conv_layer_bf16(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1)) != SH_OK) return rc;
+  int ch = base;
+  for (int i = 1; i <= D; ++i) {
+    size_t e = (size_t)nimg * (h / 2) * (w / 2) * (ch / 8);
+    LAUNCH(c, "unet.pool", k_maxpool2_bf16, dim3((unsigned)std::min<size_t>((e + 255) / 256, 8192)), dim3(256), skip[i - 1], A, h, w, ch, nimg);
+    h /= 2; w /= 2;
+    std::string na = i < D ? "enc" + std::to_string(i) + "a" : "bota", nb = i < D ? "enc" + std::to_string(i) + "b" : "botb";
+    if ((rc = conv_layer_bf16(c, ("unet." + na).c_str(), L(na), A, nullptr, ch, 0, Bq, h, w, nimg, 1)) != SH_OK) return rc;
+    ch *= 2;
+    __bf16* dst = i < D ? skip[i] : A;
+    if ((rc = conv_layer_bf16(c, ("unet." + nb).c_str(), L(nb), Bq, nullptr, ch, 0, dst, h, w, nimg, 1)) != SH_OK) return rc;
+  }
+  __bf16* x = A; __bf16* y = Bq;
+  for (int i = D - 1; i >= 0; --i) {
+    std::string nu = "up" + std::to_string(i), na = "dec" + std::to_string(i) + "a", nb = "dec" + std::to_string(i) + "b";
+    if ((rc = conv_layer_bf16(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
+    h *= 2; w *= 2; ch /= 2;
+    if ((rc = conv_layer_bf16(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;
+    if ((rc = conv_layer_bf16(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1)) != SH_OK) return rc;
+    std::swap(x, y);
+  }
+  {
+    const sh_ctx::ULayer& l = L("head");
+    size_t npx = (size_t)nimg * H * W;
+    LAUNCH(c, "unet.head", k_head_bf16, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx);
+  }
+  return SH_OK;
+}
+
 // ---- stage runner ----------------------------------------------------------------------------------
 static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0) {
   const int B = c->B;
@@ -710,7 +794,9 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     LAUNCH(c, "k_anp_rows", k_anp_rows, dim3((B * SH_ANP_ROWS + 63) / 64), dim3(64), buf<double>(c, "prox.itr_start"),
            buf<double>(c, "groove.bg_theta"), buf<double>(c, "anp.raw"), buf<double>(c, "anp.shft_theta"), buf<int>(c, "anp.roll"), B);
     LAUNCH(c, "k_anp_minmax", k_anp_minmax, dim3(B), dim3(256), buf<double>(c, "anp.raw"), buf<float>(c, "anp.image"));
-    if ((rc = unet_forward(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX)) != SH_OK) return rc;
+    if (c->params.unet_dtype == SH_UNET_BF16) rc = unet_forward_bf16(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
+    else rc = unet_forward(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
+    if (rc != SH_OK) return rc;
     LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(B), dim3(512), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
            buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"), buf<int>(c, "err"));
     LAUNCH(c, "k_anp_plane", k_anp_plane, dim3(B), dim3(256), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),

@@ -1,0 +1,41 @@
+"""bf16 UNet (throughput path): logits against the float64 evaluation of the same network on the same
+image, within the tolerance stated here; mask identical wherever the logit is not within the bf16
+error band of zero; downstream landmarks stay close to the f32-path result."""
+import numpy as np
+import pytest
+
+from oracle import unet as o_unet
+from shoulder_amd import _lib
+
+pytestmark = pytest.mark.gpu
+LOGIT_ABS_TOL = 0.08      # bf16 activations/weights (8-bit mantissa) through 23 layers; measured max ~0.03
+BAND = 0.10               # pixels with |logit_f64| > BAND must get the same mask value
+
+
+def test_bf16_logits_and_mask(engine, oracle_bones, unet_weights):
+    h = oracle_bones("humerus_left")
+    engine.upload([(h.verts, h.faces)])
+    engine.store("obb_transform", h.T_obb[None])
+    stages = _lib.STAGE_ALL & ~_lib.STAGE_OBB
+    engine.set_params(unet_dtype=_lib.UNET_F32)
+    lm32 = engine.run(stages)[0].copy()
+    try:
+        engine.set_params(unet_dtype=_lib.UNET_BF16)
+        lm16 = engine.run(stages)[0].copy()
+        img = engine.fetch("anp.image", np.float32, (1, 512, 512))[0]
+        lg = engine.fetch("anp.logits", np.float32, (1, 512, 512))[0]
+    finally:
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+    ref = o_unet.forward_f64(unet_weights, img)
+    err = np.abs(lg - ref)
+    print("bf16 logits: max abs err %.4f, mean %.5f" % (err.max(), err.mean()))
+    assert err.max() < LOGIT_ABS_TOL
+    sure = np.abs(ref) > BAND
+    assert ((lg > 0) == (ref > 0))[sure].all()
+    assert lm16["status"] == 0
+    # groove / canal do not depend on the network
+    np.testing.assert_array_equal(lm16["groove_axis"], lm32["groove_axis"])
+    # the neck plane moves by far less than a pixel of the 512x512 image (~0.3 mm)
+    assert np.abs(lm16["anp_plane_point"] - lm32["anp_plane_point"]).max() < 0.3
+    assert np.abs(lm16["anp_axis_central"] - lm32["anp_axis_central"]).max() < 1.0
+    assert abs(int(lm16["n_anp"]) - int(lm32["n_anp"])) < 0.1 * int(lm32["n_anp"])
