@@ -190,7 +190,8 @@ def main():
         ul_cout = unet_couts(unet_spec.BASE, unet_spec.DEPTH)
         gb = geom_bytes(B, V, F)
         times = {}
-        for name in GEOM_KERNELS + list(ul) + ["unet.pool", "k_synth_batch"]:
+        host_ms = {k: eng.kernel_time_ms(k)[0] for k in ("host.verts_d2h", "host.hull")}
+        for name in GEOM_KERNELS + list(ul) + ["unet.pool", "k_synth_batch", "k_pack_w_bf16"]:
             ms, n = eng.kernel_time_ms(name)
             if n:
                 times[name] = (ms, n)
@@ -242,7 +243,8 @@ def main():
                           "batch_per_gpu": B, "global_batch": B * world, "vertices": V, "triangles": F, "unet": f"base{unet_spec.BASE} depth{unet_spec.DEPTH} 512x512",
                           "parallelism": f"dp{world}", "meshes_with_error_status": n_bad},
                "roofline": roof, "cpu_baseline": cpu,
-               "unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top}
+               "unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top,
+               "device_ms_per_step_total": round(total_dev / args.steps, 3), "host_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()}}
         print(json.dumps(out))
     eng.close()
     if use_dist:

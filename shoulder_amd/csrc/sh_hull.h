@@ -17,7 +17,9 @@ struct Face {
   int v[3];
   int nb[3];          // neighbour across edge v[i] -> v[(i+1)%3]
   double n[3], d;     // unit normal, plane offset: n.p = d
-  std::vector<int> out;
+  int head = -1;      // conflict list (points outside this face), linked through Builder::next
+  int far_pt = -1;    // farthest point of the list and its distance
+  double far_d = 0.0;
   bool alive = true;
   int mark = 0;
 };
@@ -34,8 +36,16 @@ struct Builder {
   int n;
   double eps;
   std::vector<Face> F;
+  std::vector<int> next;             // intrusive conflict lists: no per-face allocations
 
   double dist(const Face& f, int p) const { return f.n[0] * P[3 * p] + f.n[1] * P[3 * p + 1] + f.n[2] * P[3 * p + 2] - f.d; }
+
+  void push(int f, int p, double d) {
+    Face& fc = F[f];
+    next[p] = fc.head;
+    fc.head = p;
+    if (fc.far_pt < 0 || d > fc.far_d) { fc.far_pt = p; fc.far_d = d; }
+  }
 
   bool set_plane(Face& f) {
     const double* a = P + 3 * f.v[0]; const double* b = P + 3 * f.v[1]; const double* c = P + 3 * f.v[2];
@@ -53,7 +63,7 @@ struct Builder {
     f.v[0] = a; f.v[1] = b; f.v[2] = c;
     f.nb[0] = f.nb[1] = f.nb[2] = -1;
     set_plane(f);
-    F.push_back(std::move(f));
+    F.push_back(f);
     return (int)F.size() - 1;
   }
 };
@@ -71,6 +81,8 @@ inline bool convex_hull(const double* pts_in, int n, Hull& H) {
     for (int k = 0; k < 3; ++k) Pc[3 * (size_t)i + k] = pts_in[3 * i + k] - c[k];
   Builder B;
   B.P = Pc.data(); B.n = n;
+  B.next.assign(n, -1);
+  B.F.reserve(8192);
   double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
   B.eps = 1e-10 * diag;
   const double* P = B.P;
@@ -94,7 +106,6 @@ inline bool convex_hull(const double* pts_in, int n, Hull& H) {
   if (i3 < 0 || best <= B.eps) return false;
   if (B.dist(tmp, i3) > 0) std::swap(i1, i2);        // make (i0,i1,i2) face away from i3
   int f0 = B.add_face(i0, i1, i2), f1 = B.add_face(i0, i3, i1), f2 = B.add_face(i1, i3, i2), f3 = B.add_face(i2, i3, i0);
-  // neighbours: edge v[i]->v[i+1]
   auto link = [&](int f, int ei, int g) { B.F[f].nb[ei] = g; };
   // f0: (i0,i1),(i1,i2),(i2,i0) ; f1: (i0,i3),(i3,i1),(i1,i0) ; f2: (i1,i3),(i3,i2),(i2,i1) ; f3: (i2,i3),(i3,i0),(i0,i2)
   link(f0, 0, f1); link(f0, 1, f2); link(f0, 2, f3);
@@ -103,19 +114,18 @@ inline bool convex_hull(const double* pts_in, int n, Hull& H) {
   link(f3, 0, f2); link(f3, 1, f1); link(f3, 2, f0);
   for (int p = 0; p < n; ++p) {
     if (p == i0 || p == i1 || p == i2 || p == i3) continue;
-    for (int f = 0; f < 4; ++f)
-      if (B.dist(B.F[f], p) > B.eps) { B.F[f].out.push_back(p); break; }
+    for (int f = 0; f < 4; ++f) {
+      double d = B.dist(B.F[f], p);
+      if (d > B.eps) { B.push(f, p, d); break; }
+    }
   }
-  std::vector<int> stack, visible, horizon_f, horizon_e, pending;
-  for (int f = 0; f < 4; ++f) if (!B.F[f].out.empty()) pending.push_back(f);
+  std::vector<int> stack, visible, horizon_f, horizon_e, pending, starts, ends;
+  for (int f = 0; f < 4; ++f) if (B.F[f].head >= 0) pending.push_back(f);
   int stamp = 0;
-  std::vector<int> newf_by_start;       // map: horizon start vertex -> new face (linear search lists)
   while (!pending.empty()) {
     int f = pending.back(); pending.pop_back();
-    if (!B.F[f].alive || B.F[f].out.empty()) continue;
-    // farthest point of this face
-    int p = -1; double bd = -1;
-    for (int q : B.F[f].out) { double d = B.dist(B.F[f], q); if (d > bd) { bd = d; p = q; } }
+    if (!B.F[f].alive || B.F[f].head < 0) continue;
+    const int p = B.F[f].far_pt;       // farthest point of this face (tracked while the list was built)
     // visible set by flood fill
     ++stamp;
     visible.clear(); horizon_f.clear(); horizon_e.clear();
@@ -131,22 +141,21 @@ inline bool convex_hull(const double* pts_in, int n, Hull& H) {
       }
     }
     // new faces, one per horizon edge (a -> b as oriented in the visible face)
-    size_t first_new = B.F.size();
-    std::vector<int> starts, ends, outer, outer_e;
+    const size_t first_new = B.F.size();
+    starts.clear(); ends.clear();
     for (size_t k = 0; k < horizon_f.size(); ++k) {
       int g = horizon_f[k], ei = horizon_e[k];
       int a = B.F[g].v[ei], b = B.F[g].v[(ei + 1) % 3];
       int h = B.F[g].nb[ei];
       int nf = B.add_face(a, b, p);
-      starts.push_back(a); ends.push_back(b); outer.push_back(h);
-      // neighbour across (a,b) is the non-visible face h; fix h's back pointer
-      B.F[nf].nb[0] = h;
+      starts.push_back(a); ends.push_back(b);
+      B.F[nf].nb[0] = h;                       // across (a,b): the non-visible face h; fix h's back pointer
       for (int q = 0; q < 3; ++q)
         if (B.F[h].nb[q] == g && B.F[h].v[q] == b && B.F[h].v[(q + 1) % 3] == a) B.F[h].nb[q] = nf;
     }
-    size_t nn = B.F.size() - first_new;
+    const size_t nn = B.F.size() - first_new;
     for (size_t k = 0; k < nn; ++k) {
-      // edge 1: b -> p  neighbours the new face whose start == b ; edge 2: p -> a neighbours the one whose end == a
+      // edge 1: b -> p neighbours the new face whose start == b ; edge 2: p -> a the one whose end == a
       int b = ends[k], a = starts[k];
       for (size_t m = 0; m < nn; ++m) {
         if (starts[m] == b) B.F[first_new + k].nb[1] = (int)(first_new + m);
@@ -155,15 +164,20 @@ inline bool convex_hull(const double* pts_in, int n, Hull& H) {
     }
     // redistribute the conflict points of the visible faces
     for (int g : visible) {
-      for (int q : B.F[g].out) {
-        if (q == p) continue;
-        for (size_t k = 0; k < nn; ++k)
-          if (B.dist(B.F[first_new + k], q) > B.eps) { B.F[first_new + k].out.push_back(q); break; }
+      int q = B.F[g].head;
+      while (q >= 0) {
+        int nx = B.next[q];
+        if (q != p)
+          for (size_t k = 0; k < nn; ++k) {
+            double d = B.dist(B.F[first_new + k], q);
+            if (d > B.eps) { B.push((int)(first_new + k), q, d); break; }
+          }
+        q = nx;
       }
-      B.F[g].out.clear(); B.F[g].out.shrink_to_fit();
+      B.F[g].head = -1;
       B.F[g].alive = false;
     }
-    for (size_t k = 0; k < nn; ++k) if (!B.F[first_new + k].out.empty()) pending.push_back((int)(first_new + k));
+    for (size_t k = 0; k < nn; ++k) if (B.F[first_new + k].head >= 0) pending.push_back((int)(first_new + k));
   }
   // compact
   std::vector<int> vmap(n, -1), fmap(B.F.size(), -1);

@@ -22,6 +22,7 @@
 #include "sh_hull.h"
 
 #include <atomic>
+#include <chrono>
 #include <thread>
 
 using namespace sh;
@@ -660,11 +661,13 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
 // boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
 static int run_obb(sh_ctx* c) {
   const int B = c->B;
+  auto t_start = std::chrono::steady_clock::now();
   if (!c->h_verts_valid) {    // device-generated batch: fetch the vertices for the host hull (every run: a new batch is new data)
     c->h_verts.resize(3 * (size_t)c->sumV);
     HIPCHK(c, hipMemcpyAsync(c->h_verts.data(), buf<float>(c, "verts"), c->sumV * 3 * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  auto t_d2h = std::chrono::steady_clock::now();
   std::vector<double> hv((size_t)B * SH_HV * 3, 0.0), nr((size_t)B * SH_HF * 3, 0.0);
   std::vector<int> ed((size_t)B * SH_HE * 4, 0), counts(3 * (size_t)B, 0), status(B, 0);
   std::atomic<int> next(0);
@@ -693,6 +696,11 @@ static int run_obb(sh_ctx* c) {
   for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
   work();
   for (auto& t : pool) t.join();
+  if (c->timing) {
+    auto t_end = std::chrono::steady_clock::now();
+    KTimer& a = c->timers["host.verts_d2h"]; a.ms += std::chrono::duration<double, std::milli>(t_d2h - t_start).count(); a.n += 1;
+    KTimer& h = c->timers["host.hull"]; h.ms += std::chrono::duration<double, std::milli>(t_end - t_d2h).count(); h.n += 1;
+  }
   int nvmax = 0, nfmax = 0;
   for (int b = 0; b < B; ++b) {
     if (status[b] != 0) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", b, status[b]); return fail(c, status[b], m); }

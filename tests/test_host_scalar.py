@@ -27,7 +27,7 @@ def hc():
     src = os.path.join(HC, "hostcheck.cpp")
     hdrs = [os.path.join(ROOT, "shoulder_amd", "csrc", h) for h in ("sh_scalar.h", "sh_common.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in [src] + hdrs):
-        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
+        subprocess.check_call(["g++", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
     lib = ctypes.CDLL(so)
     lib.hc_circle.restype = ctypes.c_double
     lib.hc_rfc.restype = ctypes.c_float
