@@ -226,6 +226,16 @@ def main():
             else:
                 ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
                 roof = dict(bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), **common)
+        # HBM traffic of the dominant kernel from the committed PMC profile of this same command (rocprofv3 cannot
+        # run inside the bench); null when no profile matches the configuration
+        if roof:
+            pmc_path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{B}_{args.unet}.json")
+            if os.path.exists(pmc_path):
+                pk = json.load(open(pmc_path))["kernels"]
+                key = "sh::" + dom.replace(",", ", ") if dom.startswith("k_conv") else "sh::" + dom
+                if key in pk:
+                    roof["traffic"] = pk[key]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = os.path.relpath(pmc_path, ROOT)
         unet_ms = sum(times[k][0] for k in times if k.startswith("unet."))
         unet_tf = sum(v[0] for v in ul.values()) * B / (unet_ms * 1e-3) / 1e12 if unet_ms else None
         top = sorted(((k, round(v["ms"] / args.steps, 3)) for k, v in sym.items()), key=lambda kv: -kv[1])[:10]
