@@ -19,35 +19,92 @@ __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][51
                               const double* __restrict__ canal_axis_ct, int row0, double* __restrict__ scratch,
                               double* __restrict__ xraw, double* __restrict__ ptheta, int* __restrict__ npk,
                               double* __restrict__ r0, int* __restrict__ err, int B) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= B * SH_GROOVE_NROWS) return;
-  int b = gid / SH_GROOVE_NROWS, i = gid % SH_GROOVE_NROWS;
-  const double* row = itr_cs + ((size_t)b * SH_NPROX + row0 + i) * 2 * SH_MPROX;
+  // One wave per slice row; the row lives in LDS.  Same arithmetic as sh::groove_row_features
+  // (sh_scalar.h, host-tested): NumPy's pairwise mean is reproduced with lanes as the 8 x 4 partial
+  // accumulators, every filter tap sum / plateau walk / prominence scan is the sequential routine
+  // applied per sample or per peak.
+  __shared__ double s_r[SH_MPROX], s_neg[SH_MPROX], s_filt[SH_MPROX], s_roll[SH_MPROX];
+  __shared__ int s_cand[SH_PEAK_CAP];
+  __shared__ Peak s_pk[SH_PEAK_CAP];
+  __shared__ int s_pass[SH_PEAK_CAP];
+  __shared__ int s_ncand;
+  const int M = SH_MPROX;
+  const int gid = blockIdx.x, lane = threadIdx.x;
+  const int b = gid / SH_GROOVE_NROWS, i = gid % SH_GROOVE_NROWS;
+  const double* row = itr_cs + ((size_t)b * SH_NPROX + row0 + i) * 2 * M;
   const double* zs = prox_zs + (size_t)b * SH_NPROX + row0;
-  // MinMaxScaler over the cut zs (bicipital_groove.py:89): X*scale_ + min_, zs descend
-  double zmax = zs[0], zmin = zs[0];
-  for (int k = 1; k < SH_GROOVE_NROWS; ++k) { zmax = fmax(zmax, zs[k]); zmin = fmin(zmin, zs[k]); }
-  double rng = zmax - zmin;
-  if (rng == 0.0) rng = 1.0;
-  double sc = 1.0 / rng;
-  double z_scaled = zs[i] * sc + (0.0 - zmin * sc);
-  const double* ax = canal_axis_ct + 6 * b;
-  double cu[3] = {ax[0] - ax[3], ax[1] - ax[4], ax[2] - ax[5]};
-  double n = norm3(cu);
-  cu[0] /= n; cu[1] /= n; cu[2] /= n;
-  double* sc3 = scratch + (size_t)gid * 3 * SH_MPROX;
-  int pidx[SH_MAXPEAK];
-  int np_ = groove_row_features(row, row + SH_MPROX, SH_MPROX, zs[i], z_scaled, cu, sc3,
-                                xraw + ((size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK) * 9,
-                                ptheta + (size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK, pidx);
-  npk[gid] = np_;
-  double* r0row = r0 + (size_t)gid * SH_MPROX;
-  for (int k = 0; k < SH_MPROX; ++k) r0row[k] = -sc3[k];     // polar_0 radius = r - mean(r)
-  // a NaN feature = the reference's IndexError (all other peaks within 0.005 rad)
-  for (int k = 0; k < np_ * 9; ++k) {
-    double v = xraw[((size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK) * 9 + k];
-    if (v != v) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+  for (int k = lane; k < M; k += 64) s_r[k] = row[M + k];
+  if (lane == 0) s_ncand = 0;
+  __syncthreads();
+  // np.mean(r): pairwise_sum(512) = (leaf0 + leaf1) + (leaf2 + leaf3), leaf = 8 strided accumulators
+  double acc = 0.0;
+  if (lane < 32) {
+    const int leaf = lane >> 3, k = lane & 7;
+    acc = s_r[128 * leaf + k];
+    for (int q = 1; q < 16; ++q) acc += s_r[128 * leaf + 8 * q + k];
   }
+  acc = acc + __shfl_down(acc, 1);      // (r0+r1) at k=0, (r2+r3) at k=2, ...
+  acc = acc + __shfl_down(acc, 2);      // ((r0+r1)+(r2+r3)) at k=0, ((r4+r5)+(r6+r7)) at k=4
+  acc = acc + __shfl_down(acc, 4);      // leaf sum at k=0
+  acc = acc + __shfl_down(acc, 8);      // leaf0+leaf1 at lane 0, leaf2+leaf3 at lane 16
+  acc = acc + __shfl_down(acc, 16);
+  const double mean = __shfl(acc, 0) / (double)M;
+  for (int k = lane; k < M; k += 64) s_neg[k] = -1.0 * (s_r[k] - mean);
+  __syncthreads();
+  for (int k = 5 + lane; k < M - 5; k += 64) s_filt[k] = savgol10_1_at(s_neg, k);
+  if (lane == 0) savgol10_1_edges(s_neg, M, s_filt);
+  __syncthreads();
+  // first argmin of the filtered row
+  double bv = 1e300;
+  int bi = 0x7fffffff;
+  for (int k = lane; k < M; k += 64) if (s_filt[k] < bv) { bv = s_filt[k]; bi = k; }
+  for (int off = 32; off > 0; off >>= 1) {
+    double ov = __shfl_down(bv, off);
+    int oi = __shfl_down(bi, off);
+    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  const int amin = __shfl(bi, 0);
+  for (int k = lane; k < M; k += 64) { int src = k + amin; if (src >= M) src -= M; s_roll[k] = s_filt[src]; }
+  double* r0row = r0 + (size_t)gid * M;
+  for (int k = lane; k < M; k += 64) r0row[k] = -s_neg[k];      // polar_0 radius = r - mean(r)
+  __syncthreads();
+  // local maxima: every rising edge is examined independently (equivalent to the sequential scan)
+  for (int k = 1 + lane; k < M - 1; k += 64)
+    if (s_roll[k - 1] < s_roll[k]) {
+      int resume;
+      int pk = local_maximum_at(s_roll, M, k, &resume);
+      if (pk >= 0) { int s = atomicAdd(&s_ncand, 1); if (s < SH_PEAK_CAP) s_cand[s] = pk; }
+    }
+  __syncthreads();
+  int nc = s_ncand < SH_PEAK_CAP ? s_ncand : SH_PEAK_CAP;
+  if (lane == 0)      // ascending index
+    for (int a = 1; a < nc; ++a) { int v = s_cand[a]; int q = a - 1; while (q >= 0 && s_cand[q] > v) { s_cand[q + 1] = s_cand[q]; --q; } s_cand[q + 1] = v; }
+  __syncthreads();
+  if (lane < nc) s_pass[lane] = peak_eval(s_roll, M, s_cand[lane], -10.0, 0.6, 0.1, &s_pk[lane]) ? 1 : 0;
+  __syncthreads();
+  if (lane == 0) {
+    int np_ = 0;
+    for (int a = 0; a < nc; ++a) if (s_pass[a]) s_pk[np_++] = s_pk[a];
+    // MinMaxScaler over the cut zs (bicipital_groove.py:89): X*scale_ + min_, zs descend
+    double zmax = zs[0], zmin = zs[0];
+    for (int k = 1; k < SH_GROOVE_NROWS; ++k) { zmax = fmax(zmax, zs[k]); zmin = fmin(zmin, zs[k]); }
+    double rng = zmax - zmin;
+    if (rng == 0.0) rng = 1.0;
+    double sc = 1.0 / rng;
+    double z_scaled = zs[i] * sc + (0.0 - zmin * sc);
+    const double* ax = canal_axis_ct + 6 * b;
+    double cu[3] = {ax[0] - ax[3], ax[1] - ax[4], ax[2] - ax[5]};
+    double n = norm3(cu);
+    cu[0] /= n; cu[1] /= n; cu[2] /= n;
+    int pidx[SH_MAXPEAK];
+    double* X = xraw + ((size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK) * 9;
+    np_ = groove_features_from_peaks(row, s_r, M, zs[i], z_scaled, cu, s_pk, np_, amin, X,
+                                     ptheta + (size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK, pidx);
+    npk[gid] = np_;
+    // a NaN feature = the reference's IndexError (all other peaks within 0.005 rad)
+    for (int k = 0; k < np_ * 9; ++k) if (X[k] != X[k]) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+  }
+  (void)scratch; (void)B;
 }
 
 // sklearn StandardScaler: mean over rows, population variance, scale = sqrt(var) (1 if ~0)

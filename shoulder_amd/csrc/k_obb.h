@@ -221,23 +221,74 @@ __global__ void k_obb_end_points(const float* __restrict__ verts, const int* __r
   }
 }
 
-__global__ void k_obb_ends(const double* __restrict__ endpts, const int* __restrict__ endcnt, const double* __restrict__ T_pre,
-                           double* __restrict__ resid /*[B][2]*/, double* __restrict__ T_obb, int* __restrict__ flipped, int* __restrict__ err, int B) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  int b = gid >> 1, e = gid & 1;
-  double r = 0.0;
-  bool ok = b < B;
-  if (ok) {
-    int n = endcnt[2 * b + e];
-    if (n > SH_ENDCAP) { atomicExch(&err[b], SH_ERR_CAPACITY_DEV); n = SH_ENDCAP; }
-    if (n < 3) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); r = 1e300; }
-    else r = circle_fit_residual(endpts + ((size_t)b * 2 + e) * SH_ENDCAP * 2, n);
-    resid[2 * b + e] = r;
+// circle_fit_residual (sh_scalar.h) with every sum over the points done by one wave:
+// lane-strided loads + shuffle reductions; all lanes run the same Levenberg-Marquardt iteration.
+__device__ inline double wave_circle_eval(const double* xy, int n, double cx, double cy, double* g, double* H) {
+  const int lane = threadIdx.x & 63;
+  double sr = 0, sux = 0, suy = 0;
+  for (int i = lane; i < n; i += 64) {
+    double dx = xy[2 * i] - cx, dy = xy[2 * i + 1] - cy;
+    double r = sqrt(dx * dx + dy * dy);
+    sr += r; sux += dx / r; suy += dy / r;
   }
-  double other = __shfl_xor(r, 1);
-  if (ok && e == 0) {
+  sr = wave_sum(sr); sux = wave_sum(sux); suy = wave_sum(suy);
+  const double rm = sr / n, mux = sux / n, muy = suy / n;
+  double f2 = 0, g0 = 0, g1 = 0, h0 = 0, h1 = 0, h2 = 0;
+  for (int i = lane; i < n; i += 64) {
+    double dx = xy[2 * i] - cx, dy = xy[2 * i + 1] - cy;
+    double r = sqrt(dx * dx + dy * dy);
+    double f = r - rm;
+    double jx = -(dx / r - mux), jy = -(dy / r - muy);
+    f2 += f * f; g0 += jx * f; g1 += jy * f; h0 += jx * jx; h1 += jx * jy; h2 += jy * jy;
+  }
+  g[0] = wave_sum(g0); g[1] = wave_sum(g1); H[0] = wave_sum(h0); H[1] = wave_sum(h1); H[2] = wave_sum(h2);
+  return wave_sum(f2);
+}
+
+__device__ inline double wave_circle_fit_residual(const double* xy, int n) {
+  const int lane = threadIdx.x & 63;
+  double sx = 0, sy = 0;
+  for (int i = lane; i < n; i += 64) { sx += xy[2 * i]; sy += xy[2 * i + 1]; }
+  double cx = wave_sum(sx) / n, cy = wave_sum(sy) / n;
+  double lam = 1e-3, g[2], H[3];
+  double f2 = wave_circle_eval(xy, n, cx, cy, g, H);
+  for (int it = 0; it < 200; ++it) {
+    double a = H[0] * (1 + lam), b = H[1], d = H[2] * (1 + lam);
+    double det = a * d - b * b;
+    if (det == 0) break;
+    double stx = -(d * g[0] - b * g[1]) / det, sty = -(-b * g[0] + a * g[1]) / det;
+    double g2[2], H2[3];
+    double f2n = wave_circle_eval(xy, n, cx + stx, cy + sty, g2, H2);
+    if (f2n <= f2) {
+      cx += stx; cy += sty;
+      bool done = (fabs(stx) + fabs(sty)) < 1e-13 * (1.0 + fabs(cx) + fabs(cy));
+      f2 = f2n; g[0] = g2[0]; g[1] = g2[1]; H[0] = H2[0]; H[1] = H2[1]; H[2] = H2[2];
+      lam *= 0.2;
+      if (done) break;
+    } else {
+      lam *= 10.0;
+      if (lam > 1e12) break;
+    }
+  }
+  return f2;
+}
+
+// one workgroup of 128 lanes per humerus: wave 0 = zmin end, wave 1 = zmax end
+__global__ void __launch_bounds__(128)
+k_obb_ends(const double* __restrict__ endpts, const int* __restrict__ endcnt, const double* __restrict__ T_pre,
+           double* __restrict__ resid /*[B][2]*/, double* __restrict__ T_obb, int* __restrict__ flipped, int* __restrict__ err, int B) {
+  __shared__ double res[2];
+  const int b = blockIdx.x, e = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int n = endcnt[2 * b + e];
+  double r;
+  if (n > SH_ENDCAP) { if (lane == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); n = SH_ENDCAP; }
+  if (n < 3) { if (lane == 0) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); r = 1e300; }
+  else r = wave_circle_fit_residual(endpts + ((size_t)b * 2 + e) * SH_ENDCAP * 2, n);
+  if (lane == 0) { res[e] = r; resid[2 * b + e] = r; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     // mesh.py:91-112: zmin end first; the head is at zmax only if its residual is strictly smaller
-    bool flip = !(other < r);
+    bool flip = !(res[1] < res[0]);
     flipped[b] = flip ? 1 : 0;
     const double* Tp = T_pre + 16 * b;
     double* To = T_obb + 16 * b;

@@ -13,24 +13,66 @@ namespace sh {
 #define SH_TE_NROWS 37          // int((1-.99)*200)=2 .. int((1-.8)*200)=39 (slice.py:157-164)
 #define SH_TE_ISCR (5 * SH_MAXSEG + 16)
 
-__global__ void k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, int* __restrict__ iscratch,
-                          double* __restrict__ rects /*[B][37][7]*/, int B) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= B * SH_TE_NROWS) return;
-  int b = gid / SH_TE_NROWS, j = gid % SH_TE_NROWS;
-  size_t pl = (size_t)b * SH_NDIST + SH_TE_ROW0 + j;
+// One wave per (humerus, distal slice): lane 0 builds the hull of the ring (Melkman, O(n), LDS deque),
+// then the lanes share the hull edges of sh::min_area_rect (same arithmetic per edge; first minimum
+// in hull order wins, as in the sequential routine).
+__global__ void __launch_bounds__(64)
+k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, int* __restrict__ iscratch,
+          double* __restrict__ rects /*[B][37][7]*/, int B) {
+  __shared__ int dq[2 * SH_MAXSEG + 8];
+  __shared__ int hull[2 * SH_MAXSEG + 8];
+  __shared__ double hx[SH_MAXSEG], hy[SH_MAXSEG];
+  __shared__ int nh_s;
+  const int gid = blockIdx.x, lane = threadIdx.x;
+  const int b = gid / SH_TE_NROWS, j = gid % SH_TE_NROWS;
+  const size_t pl = (size_t)b * SH_NDIST + SH_TE_ROW0 + j;
   const double* xy = ring + pl * (SH_MAXSEG + 1) * 2;
-  int n = ring_n[pl];
-  int* idx = iscratch + (size_t)gid * SH_TE_ISCR;
-  int* hull = idx + 2 * SH_MAXSEG + 8;
+  const int n = ring_n[pl];
   double* o = rects + (size_t)gid * 7;
+  if (n < 3) { if (lane < 7) o[lane] = 0.0; return; }
+  if (lane == 0) nh_s = convex_hull_simple_polygon(xy, n, dq, hull);   // rings are simple polygons in boundary order
+  __syncthreads();
+  const int nh = nh_s;
+  for (int k = lane; k < nh; k += 64) { hx[k] = xy[2 * hull[k]]; hy[k] = xy[2 * hull[k] + 1]; }
+  __syncthreads();
+  double best = 1e300;
+  int bi = 0x7fffffff;
   Rect2 r;
   r.cx = r.cy = r.mx = r.my = r.L = r.W = r.area = 0.0;
-  if (n >= 3) {
-    int nh = convex_hull_simple_polygon(xy, n, idx, hull);   // rings are simple polygons in boundary order
-    min_area_rect(xy, hull, nh, &r);
+  for (int i = lane; i < nh; i += 64) {
+    int i2 = i + 1 == nh ? 0 : i + 1;
+    double ex = hx[i2] - hx[i], ey = hy[i2] - hy[i];
+    double ln = hypot(ex, ey);
+    if (ln == 0) continue;
+    ex /= ln; ey /= ln;
+    double nx = -ey, ny = ex;
+    double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
+    for (int k = 0; k < nh; ++k) {
+      double a = hx[k] * ex + hy[k] * ey, bb = hx[k] * nx + hy[k] * ny;
+      amin = a < amin ? a : amin; amax = a > amax ? a : amax;
+      bmin = bb < bmin ? bb : bmin; bmax = bb > bmax ? bb : bmax;
+    }
+    double ea = amax - amin, eb = bmax - bmin, area = ea * eb;
+    if (area < best) {     // strided i ascends per lane, so '<' keeps the lane's first minimum
+      best = area; bi = i;
+      double ca = 0.5 * (amax + amin), cb = 0.5 * (bmax + bmin);
+      r.cx = ex * ca + nx * cb; r.cy = ey * ca + ny * cb; r.area = area;
+      if (ea >= eb) { r.mx = ex; r.my = ey; r.L = ea; r.W = eb; }
+      else { r.mx = nx; r.my = ny; r.L = eb; r.W = ea; }
+    }
   }
-  o[0] = r.cx; o[1] = r.cy; o[2] = r.mx; o[3] = r.my; o[4] = r.L; o[5] = r.W; o[6] = r.area;
+  // wave argmin (area, then edge index)
+  double wb = best;
+  int wi = bi;
+  for (int off = 32; off > 0; off >>= 1) {
+    double ob = __shfl_down(wb, off);
+    int oi = __shfl_down(wi, off);
+    if (ob < wb || (ob == wb && oi < wi)) { wb = ob; wi = oi; }
+  }
+  wi = __shfl(wi, 0);
+  if (bi == wi && wi != 0x7fffffff) { o[0] = r.cx; o[1] = r.cy; o[2] = r.mx; o[3] = r.my; o[4] = r.L; o[5] = r.W; o[6] = r.area; }
+  else if (wi == 0x7fffffff && lane < 7) o[lane] = 0.0;
+  (void)iscratch;
 }
 
 #define SH_TE_DSCR (6 * SH_MAXSEG + 64 * SH_TE_MAXCH)

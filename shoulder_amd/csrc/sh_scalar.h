@@ -134,12 +134,17 @@ SH_HD double circle_fit_residual(const double* xy, int n, double* cx_out = nullp
 // LAPACK builds, so the canonical taps here are exactly 0.1: |y - scipy| <= 4e-15*|x|);
 // the first / last 5 samples are a least-squares line through the first / last 10 samples
 // (scipy _fit_edges_polyfit).
+SH_HD double savgol10_1_at(const double* x, int i) {     // interior sample, 5 <= i < n-5
+  double s = 0.0;
+  for (int j = 0; j < 10; ++j) s += 0.1 * x[i - 4 + j];
+  return s;
+}
+SH_HD void savgol10_1_edges(const double* x, int n, double* y);
 SH_HD void savgol10_1(const double* x, int n, double* y) {
-  for (int i = 5; i < n - 5; ++i) {
-    double s = 0.0;
-    for (int j = 0; j < 10; ++j) s += 0.1 * x[i - 4 + j];
-    y[i] = s;
-  }
+  for (int i = 5; i < n - 5; ++i) y[i] = savgol10_1_at(x, i);
+  savgol10_1_edges(x, n, y);
+}
+SH_HD void savgol10_1_edges(const double* x, int n, double* y) {
   // edges: line fit a + b*t over t = 0..9
   for (int side = 0; side < 2; ++side) {
     const double* p = side == 0 ? x : x + (n - 10);
@@ -158,42 +163,57 @@ struct Peak {
   double prominence, width, width_height;
 };
 
+// scipy _local_maxima_1d for one candidate start i (x[i-1] < x[i] is the caller's test): follows the
+// plateau; returns the peak index (plateau midpoint) or -1, and the index the scan resumes from.
+SH_HD int local_maximum_at(const double* x, int n, int i, int* resume) {
+  const int i_max = n - 1;
+  int ia = i + 1;
+  while (ia < i_max && x[ia] == x[i]) ++ia;
+  *resume = i;
+  if (x[ia] < x[i]) { *resume = ia; return (i + (ia - 1)) / 2; }
+  return -1;
+}
+
+// height / prominence (wlen=-1) / width (rel_height 0.5) filters of scipy.signal.find_peaks for one
+// local maximum pk; true if it passes all three.
+SH_HD bool peak_eval(const double* x, int n, int pk, double hmin, double pmin, double wmin, Peak* out) {
+  if (!(x[pk] >= hmin)) return false;
+  double left_min = x[pk], right_min = x[pk];
+  int lb = pk, rb = pk, k = pk;
+  while (0 <= k && x[k] <= x[pk]) { if (x[k] < left_min) { left_min = x[k]; lb = k; } --k; }
+  k = pk;
+  while (k <= n - 1 && x[k] <= x[pk]) { if (x[k] < right_min) { right_min = x[k]; rb = k; } ++k; }
+  double prom = x[pk] - (left_min > right_min ? left_min : right_min);
+  if (!(prom >= pmin)) return false;
+  double h = x[pk] - prom * 0.5;
+  k = pk;
+  while (lb < k && h < x[k]) --k;
+  double lip = (double)k;
+  if (x[k] < h) lip += (h - x[k]) / (x[k + 1] - x[k]);
+  k = pk;
+  while (k < rb && h < x[k]) ++k;
+  double rip = (double)k;
+  if (x[k] < h) rip -= (h - x[k]) / (x[k - 1] - x[k]);
+  double w = rip - lip;
+  if (!(w >= wmin)) return false;
+  out->idx = pk; out->prominence = prom; out->width = w; out->width_height = h;
+  return true;
+}
+
 // Returns number of peaks written (all that pass the filters, ascending index), cap = capacity.
 SH_HD int find_peaks_hpw(const double* x, int n, double hmin, double pmin, double wmin, Peak* out, int cap) {
   int np_ = 0;
   int i = 1, i_max = n - 1;
   while (i < i_max) {
     if (x[i - 1] < x[i]) {
-      int ia = i + 1;
-      while (ia < i_max && x[ia] == x[i]) ++ia;
-      if (x[ia] < x[i]) {
-        int pk = (i + (ia - 1)) / 2;
-        i = ia;
-        // height
-        if (x[pk] >= hmin) {
-          // prominence (wlen = -1)
-          double left_min = x[pk], right_min = x[pk];
-          int lb = pk, rb = pk, k = pk;
-          while (0 <= k && x[k] <= x[pk]) { if (x[k] < left_min) { left_min = x[k]; lb = k; } --k; }
-          k = pk;
-          while (k <= n - 1 && x[k] <= x[pk]) { if (x[k] < right_min) { right_min = x[k]; rb = k; } ++k; }
-          double prom = x[pk] - (left_min > right_min ? left_min : right_min);
-          if (prom >= pmin) {
-            double h = x[pk] - prom * 0.5;
-            k = pk;
-            while (lb < k && h < x[k]) --k;
-            double lip = (double)k;
-            if (x[k] < h) lip += (h - x[k]) / (x[k + 1] - x[k]);
-            k = pk;
-            while (k < rb && h < x[k]) ++k;
-            double rip = (double)k;
-            if (x[k] < h) rip -= (h - x[k]) / (x[k - 1] - x[k]);
-            double w = rip - lip;
-            if (w >= wmin) {
-              if (np_ < cap) { out[np_].idx = pk; out[np_].prominence = prom; out[np_].width = w; out[np_].width_height = h; }
-              ++np_;
-            }
-          }
+      int resume;
+      int pk = local_maximum_at(x, n, i, &resume);
+      i = resume;
+      if (pk >= 0) {
+        Peak p;
+        if (peak_eval(x, n, pk, hmin, pmin, wmin, &p)) {
+          if (np_ < cap) out[np_] = p;
+          ++np_;
         }
       }
     }
@@ -211,6 +231,8 @@ SH_HD int find_peaks_hpw(const double* x, int n, double hmin, double pmin, doubl
 // scratch: 3*M doubles.
 // ======================================================================================
 #define SH_PEAK_CAP 64
+SH_HD int groove_features_from_peaks(const double* theta, const double* r, int M, double z, double z_scaled, const double* canal_u,
+                                     Peak* pk, int np_, int amin, double* Xraw, double* peak_theta, int* peak_idx);
 SH_HD double wrapped_abs_diff(double v, double a) { return fabs(atan2(sin(v - a), cos(v - a))); }
 
 SH_HD int groove_row_features(const double* theta, const double* r, int M, double z, double z_scaled,
@@ -258,6 +280,13 @@ SH_HD int groove_row_features(const double* theta, const double* r, int M, doubl
   Peak pk[SH_PEAK_CAP];
   int np_ = find_peaks_hpw(roll, M, -10.0, 0.6, 0.1, pk, SH_PEAK_CAP);
   if (np_ > SH_PEAK_CAP) np_ = SH_PEAK_CAP;
+  return groove_features_from_peaks(theta, r, M, z, z_scaled, canal_u, pk, np_, amin, Xraw, peak_theta, peak_idx);
+}
+
+// Second half of the per-row work (bicipital_groove.py:121-156): pk = peaks of the rolled, filtered
+// row that passed find_peaks (ascending index, np_ <= SH_PEAK_CAP; modified in place), amin = roll.
+SH_HD int groove_features_from_peaks(const double* theta, const double* r, int M, double z, double z_scaled, const double* canal_u,
+                                     Peak* pk, int np_, int amin, double* Xraw /*7x9*/, double* peak_theta /*7*/, int* peak_idx /*7*/) {
   // keep the 7 most prominent (B-5: ascending index order among the kept)
   if (np_ > SH_MAXPEAK) {
     bool keep[SH_PEAK_CAP];

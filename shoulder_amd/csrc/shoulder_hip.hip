@@ -728,7 +728,7 @@ static int run_obb(sh_ctx* c) {
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 1024), (unsigned)B);
   LAUNCH(c, "k_obb_end_points", k_obb_end_points, g, dim3(256), buf<float>(c, "verts"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
          buf<long long>(c, "foff"), buf<double>(c, "obb.T_pre"), buf<double>(c, "obb.zb_pre"), buf<double>(c, "obb.endpts"), buf<int>(c, "obb.endcnt"));
-  LAUNCH(c, "k_obb_ends", k_obb_ends, dim3((2 * B + 63) / 64), dim3(64), buf<double>(c, "obb.endpts"), buf<int>(c, "obb.endcnt"),
+  LAUNCH(c, "k_obb_ends", k_obb_ends, dim3(B), dim3(128), buf<double>(c, "obb.endpts"), buf<int>(c, "obb.endcnt"),
          buf<double>(c, "obb.T_pre"), buf<double>(c, "obb.resid"), buf<double>(c, "obb_transform"), buf<int>(c, "flipped"), buf<int>(c, "err"), B);
   c->obb_injected = true;
   return SH_OK;
@@ -782,7 +782,7 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     const int* feat = (const int*)pp; const float* thr = (const float*)(pp + N * 4); const int* ti = (const int*)(pp + N * 8);
     const int* fi = (const int*)(pp + N * 12); const float* lw = (const float*)(pp + N * 16); const int* roots = (const int*)(pp + N * 20);
     const int rows = B * SH_GROOVE_NROWS;
-    LAUNCH(c, "k_groove_rows", k_groove_rows, dim3((rows + 63) / 64), dim3(64), buf<double>(c, "prox.itr_centered_start"),
+    LAUNCH(c, "k_groove_rows", k_groove_rows, dim3(rows), dim3(64), buf<double>(c, "prox.itr_centered_start"),
            buf<double>(c, "prox.zs"), buf<double>(c, "canal.axis_ct"), ga, buf<double>(c, "groove.scratch"), buf<double>(c, "groove.xraw"),
            buf<double>(c, "groove.ptheta"), buf<int>(c, "groove.npk"), buf<double>(c, "groove.r0"), buf<int>(c, "err"), B);
     LAUNCH(c, "k_groove_scale", k_groove_scale, dim3(B), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
@@ -813,7 +813,7 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
            buf<long long>(c, "foff"), buf<double>(c, "anp.plane"), buf<double>(c, "anp.axes_obb"), buf<int>(c, "err"));
   }
   if (mask & SH_STAGE_TE) {
-    LAUNCH(c, "k_te_rows", k_te_rows, dim3((B * SH_TE_NROWS + 63) / 64), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
+    LAUNCH(c, "k_te_rows", k_te_rows, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<int>(c, "te.iscratch"), buf<double>(c, "te.rects"), B);
     LAUNCH(c, "k_te_final", k_te_final, dim3((B + 63) / 64), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
