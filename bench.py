@@ -41,8 +41,8 @@ GEOM_KERNELS = ["k_obb_candidates", "k_obb_pick", "k_obb_end_points", "k_obb_end
                 "k_anp_plane", "k_rays", "k_te_rows", "k_te_final", "k_pack"]
 
 
-def unet_layers(base, depth, H, W):
-    """name -> (flops per image, bytes per image: activations in+out + weights), f32."""
+def unet_layers(base, depth, H, W, eb=4):
+    """name -> (flops per image, bytes per image: activations in+out + weights); eb = bytes per activation/weight element."""
     ch = [base << i for i in range(depth + 1)]
     out = {}
     h, w = H, W
@@ -50,7 +50,7 @@ def unet_layers(base, depth, H, W):
     def conv(name, cin, cout, h, w, taps=9, up=False):
         oh, ow = (2 * h, 2 * w) if up else (h, w)
         fl = 2 * (4 if up else taps) * h * w * cin * cout
-        by = 4 * (h * w * cin + oh * ow * cout + (4 if up else taps) * cin * cout)
+        by = eb * (h * w * cin + oh * ow * cout + (4 if up else taps) * cin * cout)
         out["unet." + name] = (fl, by)
 
     cin = 1
@@ -66,7 +66,7 @@ def unet_layers(base, depth, H, W):
         h, w = 2 * h, 2 * w
         conv(f"dec{i}a", 2 * ch[i], ch[i], h, w)
         conv(f"dec{i}b", ch[i], ch[i], h, w)
-    out["unet.head"] = (2 * H * W * ch[0], 4 * H * W * (ch[0] + 1))
+    out["unet.head"] = (2 * H * W * ch[0], H * W * (eb * ch[0] + 4))
     return out
 
 
@@ -186,7 +186,7 @@ def main():
     n_bad = int((lm["status"] != 0).sum())
 
     if rank == 0:
-        ul = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512)
+        ul = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512, eb=2 if args.unet == "bf16" else 4)
         ul_cout = unet_couts(unet_spec.BASE, unet_spec.DEPTH)
         gb = geom_bytes(B, V, F)
         times = {}

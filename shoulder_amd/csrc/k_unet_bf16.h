@@ -10,8 +10,11 @@
 // LDS: pixel-major halo tile and cout-major weight tile, both with 32 channels per row padded to
 // 40 bf16 (80 B = 5 x 16 B): every fragment is one aligned ds_read_b128 and the 16 lanes of a
 // k-group hit distinct 16-B slots.
-// Weights are re-packed once per load to [phase][tap][Cin/32][Cout][32] bf16 (k_pack_w_bf16) so the
-// staging loads are 16-byte and coalesced.
+// Software pipeline over the 32-channel chunks: the global loads of chunk c+1 (16 B per lane, all
+// offsets precomputed once per workgroup) are issued into registers before the MFMAs of chunk c and
+// written to LDS after them, so HBM/L2 latency hides under the matrix work.
+// Weights are re-packed once per forward to [phase][tap][Cin/32][Cout][32] bf16 (k_pack_w_bf16) so
+// the staging loads are 16-byte and coalesced.
 #pragma once
 #include "k_unet.h"
 
@@ -44,6 +47,8 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
   constexpr int HALO = TAPS == 9 ? 1 : 0;
   constexpr int PW = UN_TW + 2 * HALO, PH = UN_TH + 2 * HALO;
   constexpr int NC = 16 * NT;
+  constexpr int IN_PIECES = PH * PW * 4, WT_PIECES = TAPS * NC * 4;
+  constexpr int NIN = (IN_PIECES + UN_THREADS - 1) / UN_THREADS, NWT = (WT_PIECES + UN_THREADS - 1) / UN_THREADS;
   __shared__ __attribute__((aligned(16))) __bf16 s_in[PH * PW * UB_PSTR];
   __shared__ __attribute__((aligned(16))) __bf16 s_w[TAPS * NC * UB_PSTR];
   const int Cin = C0 + C1;
@@ -60,6 +65,49 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
   const int nchunk = Cin / 32;
   const __bf16* wp = wgt + (size_t)phase * TAPS * nchunk * Cout * 32;
 
+  // ---- staging plan, fixed for the whole K loop
+  int in_pix[NIN], in_lds[NIN], wt_off[NWT], wt_lds[NWT];
+#pragma unroll
+  for (int k = 0; k < NIN; ++k) {
+    int e = tid + k * UN_THREADS;
+    int q = e & 3, p = e >> 2;
+    int px = p % PW, py = p / PW;
+    int gx = x0 + px - HALO, gy = y0 + py - HALO;
+    bool ok = e < IN_PIECES && gx >= 0 && gx < W && gy >= 0 && gy < H;
+    in_pix[k] = ok ? (gy * W + gx) : -1;
+    in_lds[k] = e < IN_PIECES ? p * UB_PSTR + q * 8 : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < NWT; ++k) {
+    int e = tid + k * UN_THREADS;
+    int q = e & 3, r = e >> 2;
+    int tap = r / NC, j = r % NC;
+    wt_off[k] = e < WT_PIECES ? ((tap * nchunk) * Cout + n0 + j) * 32 + q * 8 : -1;
+    wt_lds[k] = e < WT_PIECES ? r * UB_PSTR + q * 8 : -1;
+  }
+  u32x4 rin[NIN], rwt[NWT];
+  auto load_chunk = [&](int cc) {
+    const int c0 = cc * 32;
+    const bool first = c0 < C0;
+    const __bf16* src = first ? in0 : in1;
+    const int Cs = first ? C0 : C1, cb = first ? c0 : c0 - C0;
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+      if (in_pix[k] >= 0) v = *(const u32x4*)(src + (size_t)in_pix[k] * Cs + cb + ((tid + k * UN_THREADS) & 3) * 8);
+      rin[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NWT; ++k)
+      if (wt_off[k] >= 0) rwt[k] = *(const u32x4*)(wp + (size_t)wt_off[k] + (size_t)cc * Cout * 32);
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) if (in_lds[k] >= 0) *(u32x4*)(s_in + in_lds[k]) = rin[k];
+#pragma unroll
+    for (int k = 0; k < NWT; ++k) if (wt_lds[k] >= 0) *(u32x4*)(s_w + wt_lds[k]) = rwt[k];
+  };
+
   f32x4 acc[4][NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
@@ -70,28 +118,12 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
     for (int m = 0; m < 4; ++m) acc[m][n] = bv;
   }
 
+  load_chunk(0);
   for (int cc = 0; cc < nchunk; ++cc) {
-    const int c0 = cc * 32;
+    __syncthreads();                  // every wave is done reading the previous chunk
+    store_chunk();
     __syncthreads();
-    for (int e = tid; e < PH * PW * 4; e += UN_THREADS) {
-      int q = e & 3, p = e >> 2;
-      int px = p % PW, py = p / PW;
-      int gx = x0 + px - HALO, gy = y0 + py - HALO;
-      int c = c0 + q * 8;
-      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
-        const __bf16* s = (c < C0) ? in0 + ((size_t)gy * W + gx) * C0 + c : in1 + ((size_t)gy * W + gx) * C1 + (c - C0);
-        v = *(const u32x4*)s;
-      }
-      *(u32x4*)(s_in + p * UB_PSTR + q * 8) = v;
-    }
-    for (int e = tid; e < TAPS * NC * 4; e += UN_THREADS) {
-      int q = e & 3, r = e >> 2;                 // r = tap*NC + j
-      int tap = r / NC, j = r % NC;
-      u32x4 v = *(const u32x4*)(wp + (((size_t)tap * nchunk + cc) * Cout + n0 + j) * 32 + q * 8);
-      *(u32x4*)(s_w + r * UB_PSTR + q * 8) = v;
-    }
-    __syncthreads();
+    if (cc + 1 < nchunk) load_chunk(cc + 1);      // in flight during the MFMAs below
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
