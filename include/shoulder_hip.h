@@ -71,6 +71,9 @@ typedef struct sh_landmarks {
   double anp_axis_normal[6];  /* AnatomicNeck.axis_normal(): [upper, lower] (anatomic_neck.py:174-200) */
   double anp_axis_central[6]; /* AnatomicNeck.axis_central(): [upper, lower] (anatomic_neck.py:202-236) */
   double csys[16];            /* apply_csys_canal_transepiconylar() matrix, CT -> canal/TE (bone.py:146-157) */
+  double neckshaft;           /* NeckShaft.calc(), degrees (bone_props.py:88-112) */
+  double retroversion;        /* RetroVersion.calc() with landmarks in CT, degrees (bone_props.py:50-85) */
+  double radius_curvature;    /* RadiusCurvature.calc(), mm (bone_props.py:115-148) */
   double groove_points[SH_GROOVE_ROWS * 3]; /* DeepGroove.points() (bicipital_groove.py:26-242) */
   double anp_points[SH_ANP_MAX_PTS * 3];    /* AnatomicNeck.points(), first n_anp rows valid (anatomic_neck.py:31-121) */
   int32_t n_anp;              /* number of edge points (K) */
@@ -78,7 +81,7 @@ typedef struct sh_landmarks {
   int32_t neck_index;         /* change-point index into areas1((0.70,0.99)) (surgical_neck.py:33) */
   int32_t flipped;            /* 1 if the head end was at -z of the raw box (mesh.py:112) */
   int32_t status;             /* 0 or a negative sh_status for this mesh */
-  int32_t pad_;
+  int32_t side;               /* Side.calc(): 0 = "left", 1 = "right" (bone_props.py:12-47) */
 } sh_landmarks;
 
 /* Tunables the reference exposes as keyword defaults (SURVEY 5 "config / flags"). */

@@ -150,6 +150,18 @@ class OracleHumerus:
     def csys_canal_transepicondylar(self):
         return construct_csys(self.canal["axis_ct"], self.te["axis_ct"])
 
+    # bone_props.py (bone.py:134-144) -----------------------------------------------------
+    def metrics(self, axis_normal_current=None):
+        """side / retroversion / neckshaft / radius_curvature.  `axis_normal_current` = AnatomicNeck.axis_normal()
+        in whatever coordinate system is applied when retroversion() is called (reference quirk,
+        bone_props.py:72-73); default: CT (identity Transform)."""
+        from . import metrics as m
+        an = self.anp["axis_normal_ct"] if axis_normal_current is None else axis_normal_current
+        side = m.side(self.canal["axis_ct"], self.anp["axis_central_ct"], self.groove["points_ct"])
+        return dict(side=side, retroversion=m.retroversion(self.canal["axis_ct"], self.te["axis_ct"], an, side),
+                    neckshaft=m.neckshaft(self.canal["axis_ct"], self.anp["axis_normal_ct"]),
+                    radius_curvature=m.spherefit(self.anp["articular_obb"])[0])
+
     def landmarks(self, with_unet=True):
         """Everything in CT coordinates + the canal/TE coordinate system."""
         out = dict(T_obb=self.T_obb, z_length=self.obb["z_length"], neck_z=self.neck["neck_z"],

@@ -30,6 +30,9 @@ class Landmarks(ctypes.Structure):
         ("anp_axis_normal", ctypes.c_double * 6),
         ("anp_axis_central", ctypes.c_double * 6),
         ("csys", ctypes.c_double * 16),
+        ("neckshaft", ctypes.c_double),
+        ("retroversion", ctypes.c_double),
+        ("radius_curvature", ctypes.c_double),
         ("groove_points", ctypes.c_double * (GROOVE_ROWS * 3)),
         ("anp_points", ctypes.c_double * (ANP_MAX_PTS * 3)),
         ("n_anp", ctypes.c_int32),
@@ -37,7 +40,7 @@ class Landmarks(ctypes.Structure):
         ("neck_index", ctypes.c_int32),
         ("flipped", ctypes.c_int32),
         ("status", ctypes.c_int32),
-        ("pad_", ctypes.c_int32),
+        ("side", ctypes.c_int32),
     ]
 
 
@@ -45,8 +48,8 @@ LANDMARKS_DTYPE = np.dtype([
     ("obb_transform", "<f8", (4, 4)), ("z_length", "<f8"), ("neck_z", "<f8"), ("canal_axis", "<f8", (2, 3)),
     ("te_axis", "<f8", (2, 3)), ("groove_axis", "<f8", (2, 3)), ("bg_theta", "<f8"), ("anp_plane_point", "<f8", (3,)),
     ("anp_plane_normal", "<f8", (3,)), ("anp_axis_normal", "<f8", (2, 3)), ("anp_axis_central", "<f8", (2, 3)),
-    ("csys", "<f8", (4, 4)), ("groove_points", "<f8", (GROOVE_ROWS, 3)), ("anp_points", "<f8", (ANP_MAX_PTS, 3)),
-    ("n_anp", "<i4"), ("n_articular", "<i4"), ("neck_index", "<i4"), ("flipped", "<i4"), ("status", "<i4"), ("pad_", "<i4")])
+    ("csys", "<f8", (4, 4)), ("neckshaft", "<f8"), ("retroversion", "<f8"), ("radius_curvature", "<f8"), ("groove_points", "<f8", (GROOVE_ROWS, 3)), ("anp_points", "<f8", (ANP_MAX_PTS, 3)),
+    ("n_anp", "<i4"), ("n_articular", "<i4"), ("neck_index", "<i4"), ("flipped", "<i4"), ("status", "<i4"), ("side", "<i4")])
 assert LANDMARKS_DTYPE.itemsize == ctypes.sizeof(Landmarks)
 
 

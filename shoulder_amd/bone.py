@@ -269,10 +269,11 @@ class Humerus(Bone):
         self.bicipital_groove = DeepGroove(self)
         self.anatomic_neck = AnatomicNeck(self)
         self.trans_epiconylar = TransEpicondylar(self)
-        self.side = _next_tier("side")
-        self.retroversion = _next_tier("retroversion")
-        self.neckshaft = _next_tier("neckshaft")
-        self.radius_curvature = _next_tier("radius_curvature")
+        # metrics (bone.py:134-144 -> bone_props.py); values come from the device record (k_metrics)
+        self.side = self._side
+        self.retroversion = self._retroversion
+        self.neckshaft = self._neckshaft
+        self.radius_curvature = self._radius_curvature
 
     def _ensure_loaded(self):
         """The shared engine may have been used for another bone since: bring this one back."""
@@ -297,6 +298,36 @@ class Humerus(Bone):
             if int(self._lm_all["status"]) != 0:
                 raise ValueError(f"landmark stage failed with status {int(self._lm_all['status'])}")
         return self._lm_all
+
+    # -- metrics (bone_props.py) ---------------------------------------------------------------------------
+    def _side(self) -> str:
+        """bone_props.py:23-47"""
+        self.canal.axis(); self.anatomic_neck.axis_central(); self.bicipital_groove.points()
+        return "right" if int(self._all()["side"]) == 1 else "left"
+
+    def _neckshaft(self) -> float:
+        """bone_props.py:93-112"""
+        self.canal.axis(); self.anatomic_neck.axis_normal()
+        return float(self._all()["neckshaft"])
+
+    def _radius_curvature(self) -> float:
+        """bone_props.py:119-125"""
+        self.anatomic_neck.points()
+        return float(self._all()["radius_curvature"])
+
+    def _retroversion(self) -> float:
+        """bone_props.py:64-85.  The reference transforms `axis_normal()` as returned in the CURRENT coordinate
+        system (:72-73); with the identity Transform that is the device value, otherwise the same two-point
+        arithmetic is redone here on the re-expressed axis (2 points, host glue)."""
+        self.canal.axis(); self.trans_epiconylar.axis()
+        an = self.anatomic_neck.axis_normal()
+        lm = self._all()
+        if np.array_equal(self._tfrm.matrix, np.identity(4)):
+            return float(lm["retroversion"])
+        q = self._engine.transform_points(an, np.array(lm["csys"], dtype=np.float64))
+        v = (q[0] - q[1]) / np.linalg.norm(q[0] - q[1])
+        theta = float(np.rad2deg(np.arctan2(v[1], -1 * v[0])))
+        return -theta if int(lm["side"]) == 1 else theta
 
     # -- coordinate systems (bone.py:53-105, :146-157) --------------------------------------------------
     def _mesh_in(self, T):

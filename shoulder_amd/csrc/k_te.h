@@ -160,7 +160,7 @@ __global__ void k_pack(sh_landmarks* __restrict__ lm, const double* __restrict__
   L->neck_index = neck_index[b];
   L->flipped = flipped ? flipped[b] : 0;
   L->status = err[b];
-  L->pad_ = 0;
+  L->side = 0; L->neckshaft = 0.0; L->retroversion = 0.0; L->radius_curvature = 0.0;
   for (int i = 0; i < 6; ++i) { L->canal_axis[i] = canal_axis_ct[6 * b + i]; }
   if (mask & SH_STAGE_GROOVE) { for (int i = 0; i < 6; ++i) L->groove_axis[i] = groove_axis_ct[6 * b + i]; L->bg_theta = bg_theta[b]; }
   if (mask & SH_STAGE_ANP) {
@@ -177,6 +177,100 @@ __global__ void k_pack(sh_landmarks* __restrict__ lm, const double* __restrict__
   }
   if (mask & SH_STAGE_TE) for (int i = 0; i < 6; ++i) L->te_axis[i] = te_axis_ct[6 * b + i];
   if (mask & SH_STAGE_CSYS) construct_csys(L->canal_axis, L->te_axis, L->csys);     // bone.py:150
+}
+
+// utils.unitxyz_to_spherical (utils.py:321-332): theta, phi in degrees
+SH_HD void unitxyz_to_spherical_deg(const double* v, double* theta, double* phi) {
+  double r = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  *theta = atan2(v[1], v[0]) * (180.0 / M_PI);
+  *phi = acos(v[2] / r) * (180.0 / M_PI);
+}
+
+// Metrics of bone_props.py from the packed record + the articular mask; one workgroup per humerus.
+//   side :30-47, retroversion :64-85 (landmarks in CT), neckshaft :97-112 on lane 0;
+//   radius_curvature :115-148: least-squares sphere through every mask pixel's (r cos t, r sin t, z),
+//   solved from the 4x4 normal equations of the mean-centred points (the fit is shift invariant).
+__global__ void __launch_bounds__(256)
+k_metrics(sh_landmarks* __restrict__ lm, const float* __restrict__ logits, const double* __restrict__ raw,
+          const double* __restrict__ shft_theta, const double* __restrict__ prox_zs, int* __restrict__ err) {
+  __shared__ double sh[13 * 4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  sh_landmarks* L = lm + b;
+  const float* lg = logits + (size_t)b * SH_IMG;
+  const double* rr = raw + (size_t)b * SH_IMG;
+  const double* tt = shft_theta + (size_t)b * SH_IMG;
+  const double* zz = prox_zs + (size_t)b * SH_NPROX + SH_ANP_ROW0;
+  // pass 1: count and mean
+  double s[4] = {0, 0, 0, 0};
+  for (int i = tid; i < SH_IMG; i += 256)
+    if (lg[i] > 0.0f) {
+      double r = rr[i], t = tt[i];
+      s[0] += r * cos(t); s[1] += r * sin(t); s[2] += zz[i / SH_MPROX]; s[3] += 1.0;
+    }
+  block_sum<4>(s, sh, tid, 4);
+  const double n = s[3];
+  double radius = 0.0;
+  if (n >= 4.0) {
+    const double m[3] = {s[0] / n, s[1] / n, s[2] / n};
+    // pass 2: sum q q^T (6), sum |q|^2 (1), sum q |q|^2 (3), sum q (3)
+    double a[13];
+    for (int k = 0; k < 13; ++k) a[k] = 0.0;
+    for (int i = tid; i < SH_IMG; i += 256)
+      if (lg[i] > 0.0f) {
+        double r = rr[i], t = tt[i];
+        double q[3] = {r * cos(t) - m[0], r * sin(t) - m[1], zz[i / SH_MPROX] - m[2]};
+        double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+        a[0] += q[0] * q[0]; a[1] += q[0] * q[1]; a[2] += q[0] * q[2]; a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
+        a[6] += q2; a[7] += q[0] * q2; a[8] += q[1] * q2; a[9] += q[2] * q2; a[10] += q[0]; a[11] += q[1]; a[12] += q[2];
+      }
+    block_sum<13>(a, sh, tid, 4);
+    if (tid == 0) {
+      // A = [2q, 1]: N = A^T A, g = A^T f with f = |q|^2
+      double N[16] = {4 * a[0], 4 * a[1], 4 * a[2], 2 * a[10],
+                      4 * a[1], 4 * a[3], 4 * a[4], 2 * a[11],
+                      4 * a[2], 4 * a[4], 4 * a[5], 2 * a[12],
+                      2 * a[10], 2 * a[11], 2 * a[12], n};
+      double g[4] = {2 * a[7], 2 * a[8], 2 * a[9], a[6]};
+      double Ni[16];
+      if (mat4_inv(N, Ni)) {
+        double C[4];
+        for (int r = 0; r < 4; ++r) C[r] = ((Ni[r * 4] * g[0] + Ni[r * 4 + 1] * g[1]) + Ni[r * 4 + 2] * g[2]) + Ni[r * 4 + 3] * g[3];
+        radius = sqrt(((C[0] * C[0] + C[1] * C[1]) + C[2] * C[2]) + C[3]);
+      } else atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+    }
+  }
+  if (tid != 0) return;
+  L->radius_curvature = radius;
+  // Side (bone_props.py:30-47)
+  double T[16], p[3];
+  construct_csys(L->canal_axis, L->anp_axis_central, T);
+  double sy = 0.0;
+  for (int i = 0; i < SH_GROOVE_NROWS; ++i) { xform_pt(T, L->groove_points[3 * i], L->groove_points[3 * i + 1], L->groove_points[3 * i + 2], p); sy += p[1]; }
+  L->side = (sy / SH_GROOVE_NROWS <= 0) ? 0 : 1;
+  // NeckShaft (:97-112)
+  {
+    double a0[3], a1[3], v[3], th, ph;
+    construct_csys(L->canal_axis, L->anp_axis_normal, T);
+    xform_pt(T, L->anp_axis_normal[0], L->anp_axis_normal[1], L->anp_axis_normal[2], a0);
+    xform_pt(T, L->anp_axis_normal[3], L->anp_axis_normal[4], L->anp_axis_normal[5], a1);
+    for (int k = 0; k < 3; ++k) v[k] = a0[k] - a1[k];
+    double nn = norm3(v);
+    for (int k = 0; k < 3; ++k) v[k] /= nn;
+    unitxyz_to_spherical_deg(v, &th, &ph);
+    L->neckshaft = 180.0 - ph;
+  }
+  // RetroVersion (:64-85) with the neck-normal axis in CT (identity Transform)
+  {
+    double a0[3], a1[3], v[3], th, ph;
+    xform_pt(L->csys, L->anp_axis_normal[0], L->anp_axis_normal[1], L->anp_axis_normal[2], a0);
+    xform_pt(L->csys, L->anp_axis_normal[3], L->anp_axis_normal[4], L->anp_axis_normal[5], a1);
+    for (int k = 0; k < 3; ++k) v[k] = a0[k] - a1[k];
+    double nn = norm3(v);
+    for (int k = 0; k < 3; ++k) v[k] /= nn;
+    v[0] = -1.0 * v[0];
+    unitxyz_to_spherical_deg(v, &th, &ph);
+    L->retroversion = L->side == 1 ? -th : th;
+  }
 }
 
 }  // namespace sh

@@ -823,6 +823,12 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
          buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), buf<int>(c, "flipped"), buf<double>(c, "canal.axis_ct"), buf<double>(c, "te.axis_ct"),
          buf<double>(c, "groove.axis_ct"), buf<double>(c, "groove.bg_theta"), buf<double>(c, "groove.points_ct"), buf<double>(c, "anp.plane"),
          buf<double>(c, "anp.axes_obb"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"), buf<int>(c, "err"), mask, B);
+  {
+    const uint32_t need = SH_STAGE_GROOVE | SH_STAGE_ANP | SH_STAGE_TE | SH_STAGE_CSYS;
+    if ((mask & need) == need)      // metrics of bone_props.py (side, retroversion, neck-shaft angle, radius of curvature)
+      LAUNCH(c, "k_metrics", k_metrics, dim3(B), dim3(256), buf<sh_landmarks>(c, "landmarks"), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
+             buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<int>(c, "err"));
+  }
   if (out) HIPCHK(c, hipMemcpyAsync(out, buf<sh_landmarks>(c, "landmarks"), (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<int> herr(B);

@@ -240,8 +240,25 @@ def synthetic_contours(n=600, m=512, seed=99):
     return zs, ixy, cents
 
 
+def golden_metrics():
+    """bone_props.RadiusCurvature._spherefit :126-148 and utils.unitxyz_to_spherical :321-332."""
+    from shoulder.humerus import bone_props
+    rng = np.random.default_rng(31)
+    d = rng.standard_normal((5000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d[d[:, 0] + 0.3 * d[:, 2] > 0.2]                      # a spherical cap
+    pts = np.array([4.0, -13.0, 147.0]) + 23.5 * d + rng.normal(0, 0.15, d.shape)
+    rc = bone_props.RadiusCurvature.__new__(bone_props.RadiusCurvature)
+    radius, center = rc._spherefit(pts)
+    v = rng.standard_normal((6, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    sph = np.array([rutils.unitxyz_to_spherical(x) for x in v])
+    np.savez_compressed(os.path.join(HERE, "metrics_golden.npz"), pts=pts, radius=np.float64(radius), center=center, unit_vecs=v, spherical=sph)
+
+
 if __name__ == "__main__":
     golden_utils()
+    golden_metrics()
     # realistic contours: oracle's proximal slices of humerus_left, rounded to float32
     from oracle.humerus import OracleHumerus
     spec_path = os.path.join(ROOT, "shoulder_amd", "unet_spec.py")

@@ -74,11 +74,35 @@ def test_apply_csys_roundtrip(hum, oracle_bones):
     hum.apply_csys_ct()
 
 
+def test_metrics(hum, oracle_bones):
+    """README.md:33-36: radius_curvature / neckshaft / retroversion (+ side), incl. the reference's quirk that
+    retroversion() uses axis_normal() in the coordinate system applied at call time."""
+    h = oracle_bones("humerus_left")
+    hum.apply_csys_ct()
+    m = h.metrics()
+    assert hum.side() == m["side"] == "left"
+    assert hum.neckshaft() == pytest.approx(m["neckshaft"], abs=1e-6)
+    assert hum.radius_curvature() == pytest.approx(m["radius_curvature"], abs=1e-6)
+    assert hum.retroversion() == pytest.approx(m["retroversion"], abs=1e-6)
+    T = hum.apply_csys_canal_transepiconylar()
+    m2 = h.metrics(axis_normal_current=xform.transform_pts(h.anp["axis_normal_ct"], T))
+    assert hum.retroversion() == pytest.approx(m2["retroversion"], abs=1e-6)
+    assert hum.neckshaft() == pytest.approx(m["neckshaft"], abs=1e-6)       # frame independent
+    hum.apply_csys_ct()
+
+
+def test_metrics_right_side(engine, oracle_bones):
+    import shoulder_amd as shoulder
+    r = shoulder.Humerus(os.path.join(BONES, "humerus_right.stl"), engine=engine)
+    m = oracle_bones("humerus_right").metrics()
+    assert r.side() == m["side"] == "right"
+    assert r.retroversion() == pytest.approx(m["retroversion"], abs=1e-6)
+    assert r.radius_curvature() == pytest.approx(m["radius_curvature"], abs=1e-6)
+
+
 def test_errors(hum):
     with pytest.raises(ValueError, match="Invalid transformation matrix shape"):
         hum.apply_csys_custom(np.identity(3))
-    with pytest.raises(NotImplementedError):
-        hum.side()
     import shoulder_amd as shoulder
     with pytest.raises(NotImplementedError):
         shoulder.ProximalHumerus("x.stl")
