@@ -716,8 +716,10 @@ static int run_obb(sh_ctx* c) {
   {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
-    hipLaunchKernelGGL(k_obb_candidates, dim3(nfmax, B), dim3(256), shm, c->stream, buf<double>(c, "hull.hv"), cnt, buf<double>(c, "hull.normals"),
-                       cnt + B, buf<int>(c, "hull.edges"), cnt + 2 * B, buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), nvmax);
+    (void)shm;
+    hipLaunchKernelGGL(k_obb_candidates4, dim3((nfmax + SH_OBB_G - 1) / SH_OBB_G, B), dim3(256), 0, c->stream, buf<double>(c, "hull.hv"), cnt,
+                       buf<double>(c, "hull.normals"), cnt + B, buf<int>(c, "hull.edges"), cnt + 2 * B, buf<double>(c, "obb.cand_vol"),
+                       buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"));
     if (c->timing) { (void)hipEventRecord(e1, c->stream); c->pending.emplace_back("k_obb_candidates", e0, e1); }
     HIPCHK(c, hipGetLastError());
   }
