@@ -190,7 +190,7 @@ def main():
         ul_cout = unet_couts(unet_spec.BASE, unet_spec.DEPTH)
         gb = geom_bytes(B, V, F)
         times = {}
-        host_ms = {k: eng.kernel_time_ms(k)[0] for k in ("host.verts_d2h", "host.hull")}
+        host_ms = {k: (lambda t: t[0] * t[1] / args.steps)(eng.kernel_time_ms(k)) for k in ("host.verts_d2h", "host.hull")}
         for name in GEOM_KERNELS + list(ul) + ["unet.pool", "k_synth_batch", "k_pack_w_bf16"]:
             ms, n = eng.kernel_time_ms(name)
             if n:

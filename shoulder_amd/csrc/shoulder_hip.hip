@@ -32,6 +32,7 @@ struct Buf {
   void* p = nullptr;
   size_t bytes = 0;
   int elem = 1;
+  size_t per_mesh = 0;     // bytes per humerus for [B][...] buffers (0: shared / ragged / scratch)
 };
 
 struct KTimer {
@@ -61,6 +62,11 @@ struct sh_ctx {
   bool obb_injected = false;
   std::vector<float> h_verts;                // host copy of the vertices (hull stage)
   bool h_verts_valid = false;
+  // Window of the batch the stage runner is working on: sh_run walks the batch in windows so that the
+  // host hull of window k+1 overlaps the device work of window k.  buf<T>() applies the offset.
+  int b0 = 0, Bwin = 0;
+  struct HullStage { double* hv = nullptr; double* nr = nullptr; int* ed = nullptr; int* cnt = nullptr; int cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+  HullStage hstage[2];                       // pinned host staging, double buffered
   // timing
   bool timing = false;
   std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t>> pending;
@@ -102,7 +108,8 @@ static int ensure(sh_ctx* c, const char* name, size_t bytes, int elem, void** ou
 template <typename T>
 static T* buf(sh_ctx* c, const char* name) {
   auto it = c->bufs.find(name);
-  return it == c->bufs.end() ? nullptr : (T*)it->second.p;
+  if (it == c->bufs.end() || !it->second.p) return nullptr;
+  return (T*)((char*)it->second.p + (size_t)c->b0 * it->second.per_mesh);
 }
 
 // kernel launch with optional HIP-event timing on the ctx stream
@@ -175,6 +182,10 @@ void sh_ctx_destroy(sh_ctx* c) {
   drain_timers(c);
   for (auto& kv : c->bufs)
     if (kv.second.p) (void)hipFree(kv.second.p);
+  for (auto& hs : c->hstage) {
+    if (hs.hv) { (void)hipHostFree(hs.hv); (void)hipHostFree(hs.nr); (void)hipHostFree(hs.ed); (void)hipHostFree(hs.cnt); }
+    if (hs.ev) (void)hipEventDestroy(hs.ev);
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -198,8 +209,16 @@ int sh_batch_size(const sh_ctx* c) { return c ? c->B : 0; }
 static int alloc_batch(sh_ctx* c) {
   const int B = c->B;
   int rc;
-#define ENS(name, bytes, elem) if ((rc = ensure(c, name, (size_t)(bytes), elem)) != SH_OK) return rc
+#define ENS(name, bytes, elem)                                              \
+  do {                                                                      \
+    if ((rc = ensure(c, name, (size_t)(bytes), elem)) != SH_OK) return rc;  \
+    c->bufs[name].per_mesh = (size_t)(bytes) / (size_t)B;                   \
+  } while (0)
   ENS("verts_obb", c->sumV * 3 * 8, 8);
+  c->bufs["verts_obb"].per_mesh = 0;        // ragged: indexed through voff
+  c->bufs["voff"].per_mesh = 8;             // a window sees voff[b0 + b] (absolute vertex offsets) as voff[b]
+  c->bufs["foff"].per_mesh = 8;
+  c->b0 = 0; c->Bwin = B;
   ENS("obb_transform", B * 16 * 8, 8);
   ENS("zb_enc", B * 2 * 8, 8);
   ENS("z_bounds", B * 2 * 8, 8);
@@ -265,7 +284,9 @@ static int alloc_batch(sh_ctx* c) {
   ENS("hull.hv", (size_t)B * SH_HV * 3 * 8, 8);
   ENS("hull.normals", (size_t)B * SH_HF * 3 * 8, 8);
   ENS("hull.edges", (size_t)B * SH_HE * 4 * 4, 4);
-  ENS("hull.counts", (size_t)B * 3 * 4, 4);          // nv[B], nf[B], ne[B]
+  ENS("hull.nv", (size_t)B * 4, 4);
+  ENS("hull.nf", (size_t)B * 4, 4);
+  ENS("hull.ne", (size_t)B * 4, 4);
   ENS("obb.cand_vol", (size_t)B * SH_HF * 8, 8);
   ENS("obb.cand_edge", (size_t)B * SH_HF * 4, 4);
   ENS("obb.T_pre", (size_t)B * 16 * 8, 8);
@@ -635,7 +656,7 @@ static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int n
 
 // ---- stage runner ----------------------------------------------------------------------------------
 static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0) {
-  const int B = c->B;
+  const int B = c->Bwin;
   std::string p = pfx;
   double* zs = buf<double>(c, (p + ".zs").c_str());
   double* zeff = buf<double>(c, (p + ".zeff").c_str());
@@ -659,17 +680,24 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
 
 // mesh.py:63-125.  Host: one quickhull per humerus on worker threads (sh_hull.h).  Device: candidate
 // boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
-static int run_obb(sh_ctx* c) {
-  const int B = c->B;
-  auto t_start = std::chrono::steady_clock::now();
-  if (!c->h_verts_valid) {    // device-generated batch: fetch the vertices for the host hull (every run: a new batch is new data)
-    c->h_verts.resize(3 * (size_t)c->sumV);
-    HIPCHK(c, hipMemcpyAsync(c->h_verts.data(), buf<float>(c, "verts"), c->sumV * 3 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
+static int run_obb(sh_ctx* c, int window_index) {
+  const int B = c->Bwin, b0 = c->b0;
   auto t_d2h = std::chrono::steady_clock::now();
-  std::vector<double> hv((size_t)B * SH_HV * 3, 0.0), nr((size_t)B * SH_HF * 3, 0.0);
-  std::vector<int> ed((size_t)B * SH_HE * 4, 0), counts(3 * (size_t)B, 0), status(B, 0);
+  // pinned staging, two slots: the host fills slot k+1 while the copies / kernels of slot k are in flight
+  sh_ctx::HullStage& hs = c->hstage[window_index & 1];
+  if (hs.cap < B) {
+    if (hs.hv) { (void)hipHostFree(hs.hv); (void)hipHostFree(hs.nr); (void)hipHostFree(hs.ed); (void)hipHostFree(hs.cnt); }
+    hs.hv = nullptr; hs.cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&hs.hv, (size_t)B * SH_HV * 3 * 8));
+    HIPCHK(c, hipHostMalloc((void**)&hs.nr, (size_t)B * SH_HF * 3 * 8));
+    HIPCHK(c, hipHostMalloc((void**)&hs.ed, (size_t)B * SH_HE * 4 * 4));
+    HIPCHK(c, hipHostMalloc((void**)&hs.cnt, (size_t)B * 3 * 4));
+    hs.cap = B;
+  }
+  if (!hs.ev) HIPCHK(c, hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
+  if (hs.used) HIPCHK(c, hipEventSynchronize(hs.ev));     // the previous copies out of this slot are done
+  double* hv = hs.hv; double* nr = hs.nr; int* ed = hs.ed; int* counts = hs.cnt;
+  std::vector<int> status(B, 0);
   std::atomic<int> next(0);
   auto work = [&]() {
     std::vector<double> P;
@@ -677,7 +705,8 @@ static int run_obb(sh_ctx* c) {
     for (;;) {
       int b = next.fetch_add(1);
       if (b >= B) break;
-      long long v0 = c->h_voff[b], nv = c->h_voff[b + 1] - v0;
+      counts[b] = counts[B + b] = counts[2 * B + b] = 0;
+      long long v0 = c->h_voff[b0 + b], nv = c->h_voff[b0 + b + 1] - v0;
       P.resize(3 * (size_t)nv);
       for (long long i = 0; i < 3 * nv; ++i) P[i] = (double)c->h_verts[3 * v0 + i];
       if (!shhull::convex_hull(P.data(), (int)nv, H)) { status[b] = SH_ERR_GEOMETRY; continue; }
@@ -685,8 +714,8 @@ static int run_obb(sh_ctx* c) {
       if (hn > SH_HV || fn > SH_HF || en > SH_HE) { status[b] = SH_ERR_CAPACITY; continue; }
       for (int i = 0; i < hn; ++i)
         for (int k = 0; k < 3; ++k) hv[((size_t)b * SH_HV + i) * 3 + k] = P[3 * (size_t)H.vert_ids[i] + k];
-      std::copy(H.normals.begin(), H.normals.end(), nr.begin() + (size_t)b * SH_HF * 3);
-      std::copy(H.edges.begin(), H.edges.end(), ed.begin() + (size_t)b * SH_HE * 4);
+      std::copy(H.normals.begin(), H.normals.end(), nr + (size_t)b * SH_HF * 3);
+      std::copy(H.edges.begin(), H.edges.end(), ed + (size_t)b * SH_HE * 4);
       counts[b] = hn; counts[B + b] = fn; counts[2 * B + b] = en;
     }
   };
@@ -698,32 +727,36 @@ static int run_obb(sh_ctx* c) {
   for (auto& t : pool) t.join();
   if (c->timing) {
     auto t_end = std::chrono::steady_clock::now();
-    KTimer& a = c->timers["host.verts_d2h"]; a.ms += std::chrono::duration<double, std::milli>(t_d2h - t_start).count(); a.n += 1;
     KTimer& h = c->timers["host.hull"]; h.ms += std::chrono::duration<double, std::milli>(t_end - t_d2h).count(); h.n += 1;
   }
   int nvmax = 0, nfmax = 0;
   for (int b = 0; b < B; ++b) {
-    if (status[b] != 0) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", b, status[b]); return fail(c, status[b], m); }
+    if (status[b] != 0) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", b0 + b, status[b]); return fail(c, status[b], m); }
     nvmax = std::max(nvmax, counts[b]); nfmax = std::max(nfmax, counts[B + b]);
   }
-  HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.hv"), hv.data(), hv.size() * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.normals"), nr.data(), nr.size() * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.edges"), ed.data(), ed.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.counts"), counts.data(), counts.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));      // the staging vectors above are function-local
-  const int* cnt = buf<int>(c, "hull.counts");
+  HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.hv"), hv, (size_t)B * SH_HV * 3 * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.normals"), nr, (size_t)B * SH_HF * 3 * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.edges"), ed, (size_t)B * SH_HE * 4 * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.nv"), counts, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.nf"), counts + B, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.ne"), counts + 2 * B, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(hs.ev, c->stream));      // pinned slot is free again once these copies have run
+  hs.used = true;
+  const int* cnt_nv = buf<int>(c, "hull.nv");
+  const int* cnt_nf = buf<int>(c, "hull.nf");
+  const int* cnt_ne = buf<int>(c, "hull.ne");
   size_t shm = 2 * (size_t)nvmax * 8;
   {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
-    (void)shm;
-    hipLaunchKernelGGL(k_obb_candidates4, dim3((nfmax + SH_OBB_G - 1) / SH_OBB_G, B), dim3(256), 0, c->stream, buf<double>(c, "hull.hv"), cnt,
-                       buf<double>(c, "hull.normals"), cnt + B, buf<int>(c, "hull.edges"), cnt + 2 * B, buf<double>(c, "obb.cand_vol"),
-                       buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"));
+    // (k_obb_candidates4, 4 faces per workgroup, measured slower: 5.2 vs 4.0 ms at B=64 -- the kernel is bound by
+    //  the fp64 rectangle scans, not by re-reading the hull record from L2)
+    hipLaunchKernelGGL(k_obb_candidates, dim3(nfmax, B), dim3(256), shm, c->stream, buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"),
+                       cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), nvmax);
     if (c->timing) { (void)hipEventRecord(e1, c->stream); c->pending.emplace_back("k_obb_candidates", e0, e1); }
     HIPCHK(c, hipGetLastError());
   }
-  LAUNCH(c, "k_obb_pick", k_obb_pick, dim3(B), dim3(256), buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), cnt + B, buf<int>(c, "hull.edges"),
+  LAUNCH(c, "k_obb_pick", k_obb_pick, dim3(B), dim3(256), buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"),
          buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<float>(c, "verts"), buf<long long>(c, "voff"), buf<double>(c, "obb.T_pre"),
          buf<double>(c, "obb.zb_pre"), buf<int>(c, "err"));
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "obb.endcnt"), 0, (size_t)B * 2 * 4, c->stream));
@@ -736,18 +769,13 @@ static int run_obb(sh_ctx* c) {
   return SH_OK;
 }
 
-int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
-  if (!c) return SH_ERR_ARG;
-  if (c->B < 1) return fail(c, SH_ERR_STATE, "sh_run: no meshes uploaded");
-  HIPCHK(c, hipSetDevice(c->device));
-  const int B = c->B;
+// All stages for the window [c->b0, c->b0 + c->Bwin) of the batch; everything is enqueued on the stream,
+// nothing here waits for the device.
+static int run_window(sh_ctx* c, uint32_t mask, int window_index) {
+  const int B = c->Bwin;
   int rc;
-  HIPCHK(c, hipMemsetAsync(buf<int>(c, "err"), 0, B * 4, c->stream));
-  if (mask & SH_STAGE_OBB) {
-    if ((rc = run_obb(c)) != SH_OK) return rc;
-  } else if (!c->obb_injected) {
-    return fail(c, SH_ERR_STATE, "sh_run: no OBB transform (run SH_STAGE_OBB or sh_store(\"obb_transform\"))");
-  }
+  if (mask & SH_STAGE_OBB)
+    if ((rc = run_obb(c, window_index)) != SH_OK) return rc;
   if (mask & (SH_STAGE_OBB | SH_STAGE_FULL)) {
     // verts_obb + z bounds (mesh.py:85-86)
     HIPCHK(c, hipMemsetAsync(buf<unsigned long long>(c, "zb_enc"), 0, 0, c->stream));
@@ -831,6 +859,39 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
       LAUNCH(c, "k_metrics", k_metrics, dim3(B), dim3(256), buf<sh_landmarks>(c, "landmarks"), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
              buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<int>(c, "err"));
   }
+  return SH_OK;
+}
+
+#define SH_WINDOW 16      // humeri per window = host hull worker threads
+
+int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
+  if (!c) return SH_ERR_ARG;
+  if (c->B < 1) return fail(c, SH_ERR_STATE, "sh_run: no meshes uploaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int B = c->B;
+  c->b0 = 0; c->Bwin = B;
+  HIPCHK(c, hipMemsetAsync(buf<int>(c, "err"), 0, B * 4, c->stream));
+  if (!(mask & SH_STAGE_OBB) && !c->obb_injected)
+    return fail(c, SH_ERR_STATE, "sh_run: no OBB transform (run SH_STAGE_OBB or sh_store(\"obb_transform\"))");
+  if ((mask & SH_STAGE_OBB) && !c->h_verts_valid) {
+    // device-generated batch: the host hull needs the vertices (every run: a new batch is new data)
+    auto t0 = std::chrono::steady_clock::now();
+    c->h_verts.resize(3 * (size_t)c->sumV);
+    HIPCHK(c, hipMemcpyAsync(c->h_verts.data(), buf<float>(c, "verts"), c->sumV * 3 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->timing) { KTimer& a = c->timers["host.verts_d2h"]; a.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); a.n += 1; }
+  }
+  // Windows: with the host hull in play the batch is walked in windows of SH_WINDOW humeri; all device work of a
+  // window is only enqueued, so the hulls of the next window are computed while it runs.
+  const int win = ((mask & SH_STAGE_OBB) && B > SH_WINDOW) ? SH_WINDOW : B;
+  int rc = SH_OK, widx = 0;
+  for (int b0 = 0; b0 < B && rc == SH_OK; b0 += win, ++widx) {
+    c->b0 = b0; c->Bwin = std::min(win, B - b0);
+    rc = run_window(c, mask, widx);
+  }
+  c->b0 = 0; c->Bwin = B;
+  if (mask & SH_STAGE_OBB) c->obb_injected = true;
+  if (rc != SH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
   if (out) HIPCHK(c, hipMemcpyAsync(out, buf<sh_landmarks>(c, "landmarks"), (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<int> herr(B);
@@ -841,7 +902,6 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
       snprintf(m, sizeof m, "mesh %d: device stage error %d (capacity=-4, geometry=-5)", b, herr[b]);
       return fail(c, herr[b], m);
     }
-  (void)out;
   return SH_OK;
 }
 

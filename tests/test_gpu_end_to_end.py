@@ -54,6 +54,25 @@ def test_left_vs_flipped_file(ran):
         np.testing.assert_allclose(lm[key][0] @ S, lm[key][1], rtol=0, atol=1e-6)
 
 
+def test_windowed_run_matches_single_window(engine, oracle_bones):
+    """sh_run walks batches larger than 16 in windows (host hull of window k+1 overlaps the device work of
+    window k): a mesh must get the same landmarks whichever window it falls in."""
+    h = oracle_bones("humerus_left")
+    T = synth.similarity_transforms(20, h.verts)
+    engine.upload([(h.verts, h.faces)])
+    engine.synth_batch(T)                       # 20 meshes -> windows of 16 + 4
+    big = engine.run(_lib.STAGE_ALL).copy()
+    assert (big["status"] == 0).all()
+    engine.upload([(h.verts, h.faces)])
+    engine.synth_batch(T[12:20])                # the same last 8 meshes in one window
+    small = engine.run(_lib.STAGE_ALL)
+    for key in ("obb_transform", "canal_axis", "te_axis", "groove_axis", "anp_axis_central", "csys", "anp_plane_point"):
+        np.testing.assert_allclose(big[key][12:20], small[key], rtol=0, atol=1e-9, err_msg=key)
+    for key in ("neck_index", "n_anp", "n_articular", "flipped", "side"):
+        np.testing.assert_array_equal(big[key][12:20], small[key])
+    np.testing.assert_array_equal(big["bg_theta"][12:20], small["bg_theta"])
+
+
 def test_synthetic_batch_equivariance(engine, oracle_bones):
     """BASELINE config 3: device-side similarity copies of the template; landmarks must follow."""
     h = oracle_bones("humerus_left")
