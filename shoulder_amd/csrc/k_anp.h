@@ -17,33 +17,82 @@ namespace sh {
 
 __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][512]*/, const double* __restrict__ bg_theta,
                            double* __restrict__ raw, double* __restrict__ shft_theta, int* __restrict__ roll, int B) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= B * SH_ANP_ROWS) return;
-  int b = gid / SH_ANP_ROWS, i = gid % SH_ANP_ROWS;
+  // One wave per image row, the (theta, r) row in LDS.  np.interp's search carries the previous index as a
+  // guess; on a sorted xp the answer does not depend on the guess, so when theta[:-1] is non-decreasing every
+  // lane interpolates its own samples; otherwise lane 0 replays NumPy's sequential loop exactly.
+  __shared__ double s_t[SH_MPROX], s_r[SH_MPROX];
+  __shared__ int s_unsorted;
+  const int gid = blockIdx.x, lane = threadIdx.x;
+  const int b = gid / SH_ANP_ROWS, i = gid % SH_ANP_ROWS;
   const int M = SH_MPROX;
   const double* th = itr_start + ((size_t)b * SH_NPROX + SH_ANP_ROW0 + i) * 2 * M;
-  const double* r = th + M;
-  double t0 = th[0], t1 = th[M - 2];
-  double bg = bg_theta[b];
-  // pass 1: argmin |t_sampling - bg_theta| (first minimum)
-  int kbest = 0;
+  for (int k = lane; k < M; k += 64) { s_t[k] = th[k]; s_r[k] = th[M + k]; }
+  if (lane == 0) s_unsorted = 0;
+  __syncthreads();
+  for (int k = 1 + lane; k < M - 1; k += 64) if (s_t[k] < s_t[k - 1]) s_unsorted = 1;
+  const double t0 = s_t[0], t1 = s_t[M - 2];
+  const double bg = bg_theta[b];
+  // argmin |t_sampling - bg_theta| (first minimum)
   double dbest = 1e300;
-  for (int j = 0; j < M; ++j) {
+  int kb = 0x7fffffff;
+  for (int j = lane; j < M; j += 64) {
     double d = fabs(linspace_at(t0, t1, M, j) - bg);
-    if (d < dbest) { dbest = d; kbest = j; }
+    if (d < dbest) { dbest = d; kb = j; }
   }
-  roll[gid] = kbest;
-  // pass 2: np.interp(t_sampling, theta[:-1], r[:-1]) in sample order (guess carried), rolled on write
+  for (int off = 32; off > 0; off >>= 1) {
+    double od = __shfl_down(dbest, off);
+    int ok = __shfl_down(kb, off);
+    if (od < dbest || (od == dbest && ok < kb)) { dbest = od; kb = ok; }
+  }
+  const int kbest = __shfl(kb, 0);
+  if (lane == 0) roll[gid] = kbest;
+  __syncthreads();
   double* o_r = raw + (size_t)gid * M;
   double* o_t = shft_theta + (size_t)gid * M;
-  int jg = 0;
-  for (int j = 0; j < M; ++j) {
-    double t = linspace_at(t0, t1, M, j);
-    double v = np_interp_step(t, th, r, M - 1, &jg);
-    int dst = j - kbest; if (dst < 0) dst += M;
-    o_r[dst] = v;
-    o_t[dst] = t;
+  if (!s_unsorted) {
+    for (int j = lane; j < M; j += 64) {
+      double t = linspace_at(t0, t1, M, j);
+      int jg = 0;
+      double v = np_interp_step(t, s_t, s_r, M - 1, &jg);
+      int dst = j - kbest; if (dst < 0) dst += M;
+      o_r[dst] = v;
+      o_t[dst] = t;
+    }
+  } else if (lane == 0) {
+    int jg = 0;
+    for (int j = 0; j < M; ++j) {
+      double t = linspace_at(t0, t1, M, j);
+      double v = np_interp_step(t, s_t, s_r, M - 1, &jg);
+      int dst = j - kbest; if (dst < 0) dst += M;
+      o_r[dst] = v;
+      o_t[dst] = t;
+    }
   }
+  (void)B;
+}
+
+// Global min / max of one image with 16 workgroups per humerus (order-preserving encoded atomics), then
+// the sklearn MinMaxScaler arithmetic X * scale_ + min_ in a second pass; keeps small batches busy.
+__global__ void __launch_bounds__(256)
+k_anp_minmax_reduce(const double* __restrict__ raw, unsigned long long* __restrict__ mm_enc /*[B][2]*/) {
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const double* x = raw + (size_t)b * SH_IMG;
+  double lo = 1e300, hi = -1e300;
+  for (int i = blockIdx.x * 256 + tid; i < SH_IMG; i += gridDim.x * 256) { lo = fmin(lo, x[i]); hi = fmax(hi, x[i]); }
+  for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_down(lo, off)); hi = fmax(hi, __shfl_down(hi, off)); }
+  if ((tid & 63) == 0) { atomicMin(&mm_enc[2 * b], enc_f64(lo)); atomicMax(&mm_enc[2 * b + 1], enc_f64(hi)); }
+}
+
+__global__ void __launch_bounds__(256)
+k_anp_scale(const double* __restrict__ raw, const unsigned long long* __restrict__ mm_enc, float* __restrict__ image) {
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const double lo = dec_f64(mm_enc[2 * b]), hi = dec_f64(mm_enc[2 * b + 1]);
+  double rng = hi - lo;
+  if (rng == 0.0) rng = 1.0;
+  const double sc = 1.0 / rng, mn = 0.0 - lo * sc;
+  const double* x = raw + (size_t)b * SH_IMG;
+  float* o = image + (size_t)b * SH_IMG;
+  for (int i = blockIdx.x * 256 + tid; i < SH_IMG; i += gridDim.x * 256) o[i] = (float)(x[i] * sc + mn);
 }
 
 __global__ void k_anp_minmax(const double* __restrict__ raw, float* __restrict__ image) {

@@ -92,7 +92,8 @@ k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* 
   int n = e - a;
   if (n > SH_CPD_MAXN) n = SH_CPD_MAXN;
   const double* x = areas + (size_t)b * SH_NFULL + a;
-  if (lane == 0) gamma_s = cpd_gamma(x, n, scratch + (size_t)b * 6144);
+  if (lane == 0) gamma_s = cpd_gamma(x, n, K);       // median select on the pairwise distances, in LDS (K is free until the Gram fill)
+  (void)scratch;
   __syncthreads();
   double gamma = gamma_s;
   for (int q = lane; q < n * n; q += 64) K[q] = cpd_kernel(x[q / n], x[q % n], gamma);

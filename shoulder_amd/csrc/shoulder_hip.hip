@@ -266,6 +266,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("anp.raw", (size_t)B * SH_IMG * 8, 8);
   ENS("anp.shft_theta", (size_t)B * SH_IMG * 8, 8);
   ENS("anp.roll", (size_t)B * SH_ANP_ROWS * 4, 4);
+  ENS("anp.mm_enc", (size_t)B * 2 * 8, 8);
   ENS("anp.image", (size_t)B * SH_IMG * 4, 4);
   ENS("anp.logits", (size_t)B * SH_IMG * 4, 4);
   ENS("anp.points_obb", (size_t)B * SH_ANP_CAP * 3 * 8, 8);
@@ -829,9 +830,11 @@ static int run_window(sh_ctx* c, uint32_t mask, int window_index) {
   }
   if (mask & SH_STAGE_ANP) {
     if (!c->have_unet) return fail(c, SH_ERR_STATE, "sh_run: anatomic-neck stage needs sh_load_unet first");
-    LAUNCH(c, "k_anp_rows", k_anp_rows, dim3((B * SH_ANP_ROWS + 63) / 64), dim3(64), buf<double>(c, "prox.itr_start"),
+    LAUNCH(c, "k_anp_rows", k_anp_rows, dim3(B * SH_ANP_ROWS), dim3(64), buf<double>(c, "prox.itr_start"),
            buf<double>(c, "groove.bg_theta"), buf<double>(c, "anp.raw"), buf<double>(c, "anp.shft_theta"), buf<int>(c, "anp.roll"), B);
-    LAUNCH(c, "k_anp_minmax", k_anp_minmax, dim3(B), dim3(256), buf<double>(c, "anp.raw"), buf<float>(c, "anp.image"));
+    LAUNCH(c, "k_init_bounds", k_init_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "anp.mm_enc"), B);
+    LAUNCH(c, "k_anp_minmax", k_anp_minmax_reduce, dim3(16, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"));
+    LAUNCH(c, "k_anp_scale", k_anp_scale, dim3(64, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"), buf<float>(c, "anp.image"));
     if (c->params.unet_dtype == SH_UNET_BF16) rc = unet_forward_bf16(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
     else rc = unet_forward(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
     if (rc != SH_OK) return rc;
@@ -862,7 +865,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int window_index) {
   return SH_OK;
 }
 
-#define SH_WINDOW 16      // humeri per window = host hull worker threads
+#define SH_WINDOW 32      // humeri per window (2 hulls per host worker thread)
 
 int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   if (!c) return SH_ERR_ARG;

@@ -94,6 +94,6 @@ def test_synthetic_batch_equivariance(engine, oracle_bones):
         for key in ("canal_axis", "te_axis", "groove_axis"):
             np.testing.assert_allclose(lm[key][b], tf(base[key]), rtol=0, atol=5e-3 * 3, err_msg=key)
     # the device-generated vertices themselves: float64 arithmetic, float32 storage
-    v = engine.fetch("verts", np.float32).reshape(B, -1, 3)
+    v = engine.fetch("verts", np.float32, (B, len(h.verts), 3))
     for b in range(B):
         np.testing.assert_array_equal(v[b], synth.apply_similarity(T[b], h.verts))
