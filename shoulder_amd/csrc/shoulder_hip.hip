@@ -886,7 +886,9 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   }
   // Windows: with the host hull in play the batch is walked in windows of SH_WINDOW humeri; all device work of a
   // window is only enqueued, so the hulls of the next window are computed while it runs.
-  const int win = ((mask & SH_STAGE_OBB) && B > SH_WINDOW) ? SH_WINDOW : B;
+  int wsize = SH_WINDOW;
+  if (const char* e = getenv("SHOULDER_WINDOW")) { int v = atoi(e); if (v > 0) wsize = v; }     // tests exercise small windows
+  const int win = ((mask & SH_STAGE_OBB) && B > wsize) ? wsize : B;
   int rc = SH_OK, widx = 0;
   for (int b0 = 0; b0 < B && rc == SH_OK; b0 += win, ++widx) {
     c->b0 = b0; c->Bwin = std::min(win, B - b0);

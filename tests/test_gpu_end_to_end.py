@@ -60,8 +60,13 @@ def test_windowed_run_matches_single_window(engine, oracle_bones):
     h = oracle_bones("humerus_left")
     T = synth.similarity_transforms(20, h.verts)
     engine.upload([(h.verts, h.faces)])
-    engine.synth_batch(T)                       # 20 meshes -> windows of 16 + 4
-    big = engine.run(_lib.STAGE_ALL).copy()
+    engine.synth_batch(T)
+    import os
+    os.environ["SHOULDER_WINDOW"] = "8"         # 20 meshes -> windows of 8 + 8 + 4 (default window: 64)
+    try:
+        big = engine.run(_lib.STAGE_ALL).copy()
+    finally:
+        del os.environ["SHOULDER_WINDOW"]
     assert (big["status"] == 0).all()
     engine.upload([(h.verts, h.faces)])
     engine.synth_batch(T[12:20])                # the same last 8 meshes in one window
