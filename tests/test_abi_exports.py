@@ -1,0 +1,46 @@
+"""CPU-only ABI checks: libshoulder_hip.so loads without a GPU, exports every entry point that
+include/shoulder_hip.h declares, and the record layout agrees between the C header and the ctypes /
+NumPy mirrors.  No compute call is made."""
+import ctypes
+import os
+import re
+import subprocess
+
+from conftest import ROOT
+from shoulder_amd import _lib
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "shoulder_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sh_[a-z_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported():
+    names = _declared()
+    assert len(names) >= 20
+    L = ctypes.CDLL(_lib.lib_path()) if os.path.exists(_lib.lib_path()) else _lib.load()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) == set(names)
+
+
+def test_record_layout_matches_header(tmp_path):
+    prog = tmp_path / "sz.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "shoulder_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(sh_landmarks),'
+                    ' offsetof(sh_landmarks, csys), offsetof(sh_landmarks, groove_points), offsetof(sh_landmarks, n_anp), sizeof(sh_params));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    size, o_csys, o_gp, o_n, psize = map(int, subprocess.check_output([str(exe)]).split())
+    dt = _lib.LANDMARKS_DTYPE
+    assert size == dt.itemsize == ctypes.sizeof(_lib.Landmarks)
+    assert o_csys == dt.fields["csys"][1] and o_gp == dt.fields["groove_points"][1] and o_n == dt.fields["n_anp"][1]
+    assert psize == ctypes.sizeof(_lib.Params)
+
+
+def test_ctx_create_fails_loudly_without_gpu():
+    """No HIP device here (or a bad index): the call reports an error instead of falling back."""
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    rc = L.sh_ctx_create(9999, None, ctypes.byref(h))
+    assert rc != 0 and not h.value
