@@ -7,9 +7,8 @@
 // (4 bf16) instead of 2-byte scattered stores.
 //   lane l: A frag = W[cout l&15][k = 8(l>>4) .. +7]   B frag = X[k = 8(l>>4) .. +7][pixel l&15]
 //   D[row = 4(l>>4)+r (cout)][col = l&15 (pixel)]
-// LDS: pixel-major halo tile and cout-major weight tile, both with 32 channels per row padded to
-// 40 bf16 (80 B = 5 x 16 B): every fragment is one aligned ds_read_b128 and the 16 lanes of a
-// k-group hit distinct 16-B slots.
+// LDS: pixel-major halo tile and cout-major weight tile, 32 channels (64 B) per row, unpadded, with an XOR
+// swizzle of the 16-B slot (UB_OFF): every fragment is one aligned, bank-conflict-free ds_read_b128.
 // Software pipeline over the 32-channel chunks: the global loads of chunk c+1 (16 B per lane, all
 // offsets precomputed once per workgroup) are issued into registers before the MFMAs of chunk c and
 // written to LDS after them, so HBM/L2 latency hides under the matrix work.
@@ -24,7 +23,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-#define UB_PSTR 40      // bf16 elements per LDS row (32 + 8 pad)
+#define UB_PSTR 32      // bf16 elements per LDS row: 32 channels = 64 B = four 16-B slots, unpadded
+// XOR swizzle of the 16-B slot inside a row: slot' = slot ^ ((row >> 1) & 2).  With it the 16 lanes of every
+// ds_read_b128 lane group (rows p0 + (lane & 15), slot lane >> 4) hit 16 distinct slots of the 256-B bank row for
+// every p0 (checked exhaustively), so fragment reads are bank-conflict free without padding.
+#define UB_OFF(row, slot) ((row) * UB_PSTR + (((slot) ^ (((row) >> 1) & 2)) << 3))
 
 // src f32 [T][Cin][Cout]  ->  dst bf16 [T][Cin/32][Cout][32]
 __global__ void k_pack_w_bf16(const float* __restrict__ src, __bf16* __restrict__ dst, int T, int Cin, int Cout) {
@@ -75,7 +78,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
     int gx = x0 + px - HALO, gy = y0 + py - HALO;
     bool ok = e < IN_PIECES && gx >= 0 && gx < W && gy >= 0 && gy < H;
     in_pix[k] = ok ? (gy * W + gx) : -1;
-    in_lds[k] = e < IN_PIECES ? p * UB_PSTR + q * 8 : -1;
+    in_lds[k] = e < IN_PIECES ? UB_OFF(p, q) : -1;
   }
 #pragma unroll
   for (int k = 0; k < NWT; ++k) {
@@ -83,7 +86,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
     int q = e & 3, r = e >> 2;
     int tap = r / NC, j = r % NC;
     wt_off[k] = e < WT_PIECES ? ((tap * nchunk) * Cout + n0 + j) * 32 + q * 8 : -1;
-    wt_lds[k] = e < WT_PIECES ? r * UB_PSTR + q * 8 : -1;
+    wt_lds[k] = e < WT_PIECES ? UB_OFF(r, q) : -1;
   }
   u32x4 rin[NIN], rwt[NWT];
   auto load_chunk = [&](int cc) {
@@ -129,9 +132,9 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
       const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
       bf16x8 xf[4], wf[NT];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) xf[m] = *(const bf16x8*)(s_in + ((wave * 4 + m + dy) * PW + li + dx) * UB_PSTR + lk * 8);
+      for (int m = 0; m < 4; ++m) { const int row = (wave * 4 + m + dy) * PW + li + dx; xf[m] = *(const bf16x8*)(s_in + UB_OFF(row, lk)); }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) wf[n] = *(const bf16x8*)(s_w + (tap * NC + n * 16 + li) * UB_PSTR + lk * 8);
+      for (int n = 0; n < NT; ++n) { const int row = tap * NC + n * 16 + li; wf[n] = *(const bf16x8*)(s_w + UB_OFF(row, lk)); }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
