@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64, help="humeri per GPU per step")
-    ap.add_argument("--unet", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--unet", choices=["f32", "bf16"], default="bf16",
+                    help="UNet arithmetic: bf16 = BASELINE configs[2]/[3] (throughput), f32 = configs[1] parity path (bit-exact vs the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-meshes", type=int, default=2)
     args = ap.parse_args()

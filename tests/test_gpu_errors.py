@@ -1,0 +1,50 @@
+"""Failure behaviour through the C-ABI: bad input is rejected with an error code and message, degenerate
+geometry is reported per mesh -- nothing aborts, nothing silently falls back."""
+import numpy as np
+import pytest
+
+from shoulder_amd import _lib
+from shoulder_amd.engine import ShoulderHipError
+
+pytestmark = pytest.mark.gpu
+
+
+def test_upload_validation(engine, oracle_bones):
+    h = oracle_bones("humerus_left")
+    bad = h.faces.copy()
+    bad[5, 1] = len(h.verts) + 7
+    with pytest.raises(ShoulderHipError, match="face index out of range") as e:
+        engine.upload([(h.verts, bad)])
+    assert e.value.code == -1
+    with pytest.raises(ShoulderHipError, match="fewer than 4"):
+        engine.upload([(h.verts[:3], h.faces[:1] * 0 + np.array([[0, 1, 2]], dtype=np.int32))])
+
+
+def test_open_mesh_is_a_geometry_error(engine, oracle_bones):
+    """Dropping a band of triangles opens the surface: slices through the hole are not closed loops."""
+    h = oracle_bones("humerus_left")
+    zc = h.verts[:, 2][h.faces].mean(axis=1)
+    keep = ~((zc > np.percentile(zc, 45)) & (zc < np.percentile(zc, 47)) & (h.verts[:, 0][h.faces].mean(axis=1) > np.median(h.verts[:, 0])))
+    engine.upload([(h.verts, h.faces[keep]), (h.verts, h.faces)])
+    with pytest.raises(ShoulderHipError) as e:
+        engine.run(_lib.STAGE_ALL)
+    assert e.value.code == -5 and "mesh 0" in str(e.value)
+
+
+def test_missing_parameters_and_stage_order(oracle_bones):
+    from shoulder_amd.engine import Engine
+    h = oracle_bones("humerus_left")
+    e = Engine(0)
+    try:
+        with pytest.raises(ShoulderHipError, match="no meshes uploaded"):
+            e.run(_lib.STAGE_ALL)
+        e.upload([(h.verts, h.faces)])
+        with pytest.raises(ShoulderHipError, match="no OBB transform"):
+            e.run(_lib.STAGE_FULL)
+        e.run(_lib.STAGE_OBB | _lib.STAGE_FULL | _lib.STAGE_NECK | _lib.STAGE_CANAL | _lib.STAGE_PROXIMAL)
+        with pytest.raises(ShoulderHipError, match="sh_load_rfc"):
+            e.run(_lib.STAGE_GROOVE)
+        with pytest.raises(ShoulderHipError, match="330 proximal rows"):
+            e.set_params(groove_cutoff=(0.1, 0.9))
+    finally:
+        e.close()
