@@ -720,7 +720,12 @@ static int run_obb(sh_ctx* c, int window_index) {
       counts[b] = hn; counts[B + b] = fn; counts[2 * B + b] = en;
     }
   };
-  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  // worker threads: the host's hardware threads shared between the ranks of this node (torchrun exports
+  // LOCAL_WORLD_SIZE), at most 32 per rank; SHOULDER_HULL_THREADS overrides
+  unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+  if (const char* e = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(e); if (v > 1) nt = std::max(1u, nt / (unsigned)v); }
+  nt = std::min(nt, 32u);
+  if (const char* e = getenv("SHOULDER_HULL_THREADS")) { int v = atoi(e); if (v > 0) nt = (unsigned)v; }
   nt = std::min<unsigned>(nt, (unsigned)B);
   std::vector<std::thread> pool;
   for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
