@@ -190,41 +190,49 @@ SH_HD void unitxyz_to_spherical_deg(const double* v, double* theta, double* phi)
 //   side :30-47, retroversion :64-85 (landmarks in CT), neckshaft :97-112 on lane 0;
 //   radius_curvature :115-148: least-squares sphere through every mask pixel's (r cos t, r sin t, z),
 //   solved from the 4x4 normal equations of the mean-centred points (the fit is shift invariant).
+// Sphere-fit partial sums over the articular mask, SH_SPH_PARTS workgroups per humerus.  Points are taken
+// relative to the neck-plane point (any shift near the data keeps the normal equations well conditioned; the
+// fit itself is shift invariant).  partial[b][part][14] = sum q q^T (6), |q|^2, q|q|^2 (3), q (3), count.
+#define SH_SPH_PARTS 16
 __global__ void __launch_bounds__(256)
-k_metrics(sh_landmarks* __restrict__ lm, const float* __restrict__ logits, const double* __restrict__ raw,
-          const double* __restrict__ shft_theta, const double* __restrict__ prox_zs, int* __restrict__ err) {
-  __shared__ double sh[13 * 4];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  sh_landmarks* L = lm + b;
+k_sphere_partial(const float* __restrict__ logits, const double* __restrict__ raw, const double* __restrict__ shft_theta,
+                 const double* __restrict__ prox_zs, const double* __restrict__ plane, double* __restrict__ partial) {
+  __shared__ double sh[14 * 4];
+  const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
   const float* lg = logits + (size_t)b * SH_IMG;
   const double* rr = raw + (size_t)b * SH_IMG;
   const double* tt = shft_theta + (size_t)b * SH_IMG;
   const double* zz = prox_zs + (size_t)b * SH_NPROX + SH_ANP_ROW0;
-  // pass 1: count and mean
-  double s[4] = {0, 0, 0, 0};
-  for (int i = tid; i < SH_IMG; i += 256)
+  const double m[3] = {plane[6 * b], plane[6 * b + 1], plane[6 * b + 2]};
+  double a[14];
+  for (int k = 0; k < 14; ++k) a[k] = 0.0;
+  const int chunk = SH_IMG / SH_SPH_PARTS;
+  for (int i = part * chunk + tid; i < (part + 1) * chunk; i += 256)
     if (lg[i] > 0.0f) {
       double r = rr[i], t = tt[i];
-      s[0] += r * cos(t); s[1] += r * sin(t); s[2] += zz[i / SH_MPROX]; s[3] += 1.0;
+      double q[3] = {r * cos(t) - m[0], r * sin(t) - m[1], zz[i / SH_MPROX] - m[2]};
+      double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+      a[0] += q[0] * q[0]; a[1] += q[0] * q[1]; a[2] += q[0] * q[2]; a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
+      a[6] += q2; a[7] += q[0] * q2; a[8] += q[1] * q2; a[9] += q[2] * q2; a[10] += q[0]; a[11] += q[1]; a[12] += q[2]; a[13] += 1.0;
     }
-  block_sum<4>(s, sh, tid, 4);
-  const double n = s[3];
+  block_sum<14>(a, sh, tid, 4);
+  if (tid < 14) partial[((size_t)b * SH_SPH_PARTS + part) * 14 + tid] = a[tid];
+}
+
+__global__ void __launch_bounds__(64)
+k_metrics(sh_landmarks* __restrict__ lm, const double* __restrict__ partial, int* __restrict__ err) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  sh_landmarks* L = lm + b;
   double radius = 0.0;
-  if (n >= 4.0) {
-    const double m[3] = {s[0] / n, s[1] / n, s[2] / n};
-    // pass 2: sum q q^T (6), sum |q|^2 (1), sum q |q|^2 (3), sum q (3)
-    double a[13];
-    for (int k = 0; k < 13; ++k) a[k] = 0.0;
-    for (int i = tid; i < SH_IMG; i += 256)
-      if (lg[i] > 0.0f) {
-        double r = rr[i], t = tt[i];
-        double q[3] = {r * cos(t) - m[0], r * sin(t) - m[1], zz[i / SH_MPROX] - m[2]};
-        double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
-        a[0] += q[0] * q[0]; a[1] += q[0] * q[1]; a[2] += q[0] * q[2]; a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
-        a[6] += q2; a[7] += q[0] * q2; a[8] += q[1] * q2; a[9] += q[2] * q2; a[10] += q[0]; a[11] += q[1]; a[12] += q[2];
-      }
-    block_sum<13>(a, sh, tid, 4);
-    if (tid == 0) {
+  {
+    double a[14];
+    for (int k = 0; k < 14; ++k) {      // fixed order: deterministic
+      double s = 0.0;
+      for (int p = 0; p < SH_SPH_PARTS; ++p) s += partial[((size_t)b * SH_SPH_PARTS + p) * 14 + k];
+      a[k] = s;
+    }
+    const double n = a[13];
+    if (tid == 0 && n >= 4.0) {
       // A = [2q, 1]: N = A^T A, g = A^T f with f = |q|^2
       double N[16] = {4 * a[0], 4 * a[1], 4 * a[2], 2 * a[10],
                       4 * a[1], 4 * a[3], 4 * a[4], 2 * a[11],

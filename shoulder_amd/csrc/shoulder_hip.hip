@@ -267,6 +267,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("anp.shft_theta", (size_t)B * SH_IMG * 8, 8);
   ENS("anp.roll", (size_t)B * SH_ANP_ROWS * 4, 4);
   ENS("anp.mm_enc", (size_t)B * 2 * 8, 8);
+  ENS("metrics.partial", (size_t)B * SH_SPH_PARTS * 14 * 8, 8);
   ENS("anp.image", (size_t)B * SH_IMG * 4, 4);
   ENS("anp.logits", (size_t)B * SH_IMG * 4, 4);
   ENS("anp.points_obb", (size_t)B * SH_ANP_CAP * 3 * 8, 8);
@@ -864,8 +865,11 @@ static int run_window(sh_ctx* c, uint32_t mask, int window_index) {
   {
     const uint32_t need = SH_STAGE_GROOVE | SH_STAGE_ANP | SH_STAGE_TE | SH_STAGE_CSYS;
     if ((mask & need) == need)      // metrics of bone_props.py (side, retroversion, neck-shaft angle, radius of curvature)
-      LAUNCH(c, "k_metrics", k_metrics, dim3(B), dim3(256), buf<sh_landmarks>(c, "landmarks"), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
-             buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<int>(c, "err"));
+    {
+      LAUNCH(c, "k_sphere_partial", k_sphere_partial, dim3(SH_SPH_PARTS, B), dim3(256), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
+             buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.plane"), buf<double>(c, "metrics.partial"));
+      LAUNCH(c, "k_metrics", k_metrics, dim3(B), dim3(64), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "metrics.partial"), buf<int>(c, "err"));
+    }
   }
   return SH_OK;
 }
