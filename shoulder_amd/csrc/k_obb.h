@@ -27,6 +27,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
                  const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge, int nvmax) {
   extern __shared__ double sm[];          // pu[nvmax], pv[nvmax]
   __shared__ int sil[2048];
+  __shared__ int silv[2048];      // start vertex of the edge directed along its front face's winding
   __shared__ int nsil;
   __shared__ double red[8];
   __shared__ double b_area[4];
@@ -56,7 +57,9 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
   const double* NN = normals + (size_t)b * SH_HF * 3;
   for (int e = tid; e < ne; e += 256) {
     double d1 = dot3(NN + 3 * E[4 * e + 2], n), d2 = dot3(NN + 3 * E[4 * e + 3], n);
-    if ((d1 > 0) != (d2 > 0)) { int s = atomicAdd(&nsil, 1); if (s < 2048) sil[s] = e; }
+    // (edge stored with face f's winding: va -> vb; directed along the FRONT face every silhouette vertex
+    //  is the start of exactly one edge, so the start vertices enumerate the 2-D hull once)
+    if ((d1 > 0) != (d2 > 0)) { int s = atomicAdd(&nsil, 1); if (s < 2048) { sil[s] = e; silv[s] = d1 > 0 ? E[4 * e] : E[4 * e + 1]; } }
   }
   __syncthreads();
   const int ns = nsil < 2048 ? nsil : 2048;
@@ -73,14 +76,10 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     // so the rectangle extents over them equal the extents over every projected hull vertex
     double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
     for (int s2 = 0; s2 < ns; ++s2) {
-      const int e2 = sil[s2];
-#pragma unroll
-      for (int w = 0; w < 2; ++w) {
-        int i = E[4 * e2 + w];
-        double x = pu[i], y = pv[i];
-        double pa = x * ex + y * ey, pb = y * ex - x * ey;
-        amin = fmin(amin, pa); amax = fmax(amax, pa); bmin = fmin(bmin, pb); bmax = fmax(bmax, pb);
-      }
+      const int i = silv[s2];
+      double x = pu[i], y = pv[i];
+      double pa = x * ex + y * ey, pb = y * ex - x * ey;
+      amin = fmin(amin, pa); amax = fmax(amax, pa); bmin = fmin(bmin, pb); bmax = fmax(bmax, pb);
     }
     double area = (amax - amin) * (bmax - bmin);
     if (area < best || (area == best && e < be)) { best = area; be = e; }
