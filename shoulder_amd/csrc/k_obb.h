@@ -28,6 +28,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
   extern __shared__ double sm[];          // pu[nvmax], pv[nvmax]
   __shared__ int sil[2048];
   __shared__ int silv[2048];      // start vertex of the edge directed along its front face's winding
+  __shared__ unsigned char front[SH_HF];
   __shared__ int nsil;
   __shared__ double red[8];
   __shared__ double b_area[4];
@@ -52,14 +53,18 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
   if (tid == 0) nsil = 0;
   if ((tid & 63) == 0) { red[tid >> 6] = hmin; red[4 + (tid >> 6)] = hmax; }
   __syncthreads();
-  // silhouette edges: the two incident faces see the direction n from opposite sides
+  // front/back flag of every hull face for this direction: one coalesced pass over the normals
   const int* E = edges + (size_t)b * SH_HE * 4;
   const double* NN = normals + (size_t)b * SH_HF * 3;
+  for (int f2 = tid; f2 < nf; f2 += 256) front[f2] = dot3(NN + 3 * f2, n) > 0 ? 1 : 0;
+  __syncthreads();
+  // silhouette edges: the two incident faces see the direction n from opposite sides
   for (int e = tid; e < ne; e += 256) {
-    double d1 = dot3(NN + 3 * E[4 * e + 2], n), d2 = dot3(NN + 3 * E[4 * e + 3], n);
+    const int4 ed = *(const int4*)(E + 4 * e);
+    const int f1 = front[ed.z], f2 = front[ed.w];
     // (edge stored with face f's winding: va -> vb; directed along the FRONT face every silhouette vertex
     //  is the start of exactly one edge, so the start vertices enumerate the 2-D hull once)
-    if ((d1 > 0) != (d2 > 0)) { int s = atomicAdd(&nsil, 1); if (s < 2048) { sil[s] = e; silv[s] = d1 > 0 ? E[4 * e] : E[4 * e + 1]; } }
+    if (f1 != f2) { int s = atomicAdd(&nsil, 1); if (s < 2048) { sil[s] = e; silv[s] = f1 ? ed.x : ed.y; } }
   }
   __syncthreads();
   const int ns = nsil < 2048 ? nsil : 2048;
