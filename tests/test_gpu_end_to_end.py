@@ -78,6 +78,30 @@ def test_windowed_run_matches_single_window(engine, oracle_bones):
     np.testing.assert_array_equal(big["bg_theta"][12:20], small["bg_theta"])
 
 
+def test_full_size_batch_equivariance(engine, oracle_bones):
+    """BASELINE configs[2] at full size: 64 synthetic humeri (the bench's batch, same seed).  Size-independent
+    property: every mesh's landmarks are the similarity transform of the template's landmarks."""
+    h = oracle_bones("humerus_left")
+    B = 64
+    T = synth.similarity_transforms(B, h.verts, seed=1234)
+    engine.upload([(h.verts, h.faces)])
+    engine.synth_batch(np.concatenate([np.identity(4)[None], T[1:]]))
+    lm = engine.run(_lib.STAGE_ALL)
+    assert (lm["status"] == 0).all()
+    base = lm[0]
+    worst = {}
+    for key in ("canal_axis", "te_axis", "groove_axis", "anp_plane_point"):
+        dev = []
+        for b in range(1, B):
+            exp = np.atleast_2d(base[key]) @ T[b][:3, :3].T + T[b][:3, 3]
+            dev.append(np.abs(np.atleast_2d(lm[key][b]) - exp).max() / np.cbrt(abs(np.linalg.det(T[b][:3, :3]))))
+        worst[key] = max(dev)
+    print("max deviation from equivariance (mm, scale-normalised):", {k: round(v, 5) for k, v in worst.items()})
+    # vertices are re-rounded to float32 at |coord| up to ~1.5e3 mm (6e-5 mm each) before every stage
+    assert worst["canal_axis"] < 2e-2 and worst["groove_axis"] < 5e-2 and worst["te_axis"] < 5e-2
+    assert (lm["neck_index"] == base["neck_index"]).all() and (lm["flipped"] == base["flipped"]).all()
+
+
 def test_synthetic_batch_equivariance(engine, oracle_bones):
     """BASELINE config 3: device-side similarity copies of the template; landmarks must follow."""
     h = oracle_bones("humerus_left")
