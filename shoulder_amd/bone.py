@@ -239,12 +239,6 @@ class TransEpicondylar(_Lm):
             self.axis()
 
 
-def _next_tier(name):
-    def f(*a, **k):
-        raise NotImplementedError(f"{name}: metrics (bone_props.py) are the next row after the landmark hot path (DESIGN.md)")
-    return f
-
-
 class Humerus(Bone):
     """bone.py:109-157"""
 

@@ -1,6 +1,6 @@
 // k_anp.h -- anatomic neck around the UNet (reference src/shoulder/humerus/anatomic_neck.py).
 //   k_anp_rows    :40-54   even-theta re-interpolation + roll to the groove angle (one lane per row)
-//   k_anp_minmax  :56-58   global min-max (sklearn MinMaxScaler arithmetic) -> float32 image (:73-75)
+//   k_anp_minmax_reduce / k_anp_scale  :56-58  global min-max (sklearn MinMaxScaler arithmetic) -> float32 image (:73-75)
 //   k_anp_edges   :79-118  mask = logit > 0, |diff(mask, prepend=0)| along theta, compaction -> points
 //   k_anp_plane   :123-153 plane fit (covariance, smallest eigenvector) + LSQ-ellipse centre
 //   k_rays        :174-236 4 rays (+-normal, +-central) vs all triangles, nearest hit (B-6)
@@ -93,29 +93,6 @@ k_anp_scale(const double* __restrict__ raw, const unsigned long long* __restrict
   const double* x = raw + (size_t)b * SH_IMG;
   float* o = image + (size_t)b * SH_IMG;
   for (int i = blockIdx.x * 256 + tid; i < SH_IMG; i += gridDim.x * 256) o[i] = (float)(x[i] * sc + mn);
-}
-
-__global__ void k_anp_minmax(const double* __restrict__ raw, float* __restrict__ image) {
-  __shared__ double smin[4], smax[4];
-  __shared__ double g_scale, g_min;
-  int b = blockIdx.x, tid = threadIdx.x;
-  const double* x = raw + (size_t)b * SH_IMG;
-  double lo = 1e300, hi = -1e300;
-  for (int i = tid; i < SH_IMG; i += blockDim.x) { lo = fmin(lo, x[i]); hi = fmax(hi, x[i]); }
-  for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_down(lo, off)); hi = fmax(hi, __shfl_down(hi, off)); }
-  if ((tid & 63) == 0) { smin[tid >> 6] = lo; smax[tid >> 6] = hi; }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fmin(lo, smin[w]); hi = fmax(hi, smax[w]); }
-    double rng = hi - lo;
-    if (rng == 0.0) rng = 1.0;
-    g_scale = 1.0 / rng;
-    g_min = 0.0 - lo * g_scale;
-  }
-  __syncthreads();
-  double sc = g_scale, mn = g_min;
-  float* o = image + (size_t)b * SH_IMG;
-  for (int i = tid; i < SH_IMG; i += blockDim.x) o[i] = (float)(x[i] * sc + mn);
 }
 
 // one block of 512 lanes per humerus: lane = image row

@@ -16,7 +16,7 @@ namespace sh {
 #define SH_GSLOTS (SH_GROOVE_NROWS * SH_MAXPEAK)
 
 __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][512]*/, const double* __restrict__ prox_zs,
-                              const double* __restrict__ canal_axis_ct, int row0, double* __restrict__ scratch,
+                              const double* __restrict__ canal_axis_ct, int row0,
                               double* __restrict__ xraw, double* __restrict__ ptheta, int* __restrict__ npk,
                               double* __restrict__ r0, int* __restrict__ err, int B) {
   // One wave per slice row; the row lives in LDS.  Same arithmetic as sh::groove_row_features
@@ -104,7 +104,7 @@ __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][51
     // a NaN feature = the reference's IndexError (all other peaks within 0.005 rad)
     for (int k = 0; k < np_ * 9; ++k) if (X[k] != X[k]) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
   }
-  (void)scratch; (void)B;
+  (void)B;
 }
 
 // sklearn StandardScaler: mean over rows, population variance, scale = sqrt(var) (1 if ~0)

@@ -104,118 +104,6 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
   }
 }
 
-// Same result as k_obb_candidates, 4 candidate faces per workgroup: the hull vertices, face normals
-// and edge list are streamed from L2 once for the four candidates (the single-candidate kernel is
-// bound by those re-reads: 163 KB per candidate).  Only the projected end points of the silhouette
-// edges are kept in LDS (they are the 2-D hull vertices, so they carry the rectangle extents).
-#define SH_OBB_G 4
-#define SH_OBB_SILCAP 512
-__global__ void __launch_bounds__(256)
-k_obb_candidates4(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
-                  const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge,
-                  int* __restrict__ err) {
-  __shared__ double s_pt[SH_OBB_G][SH_OBB_SILCAP][4];     // (pu,pv) of edge start, (pu,pv) of edge end
-  __shared__ int s_eid[SH_OBB_G][SH_OBB_SILCAP];
-  __shared__ int s_ns[SH_OBB_G];
-  __shared__ double s_n[SH_OBB_G][3], s_u[SH_OBB_G][3], s_v[SH_OBB_G][3];
-  __shared__ double s_h[SH_OBB_G][2][4];
-  __shared__ double b_area[4];
-  __shared__ int b_edge[4];
-  const int b = blockIdx.y, f0 = blockIdx.x * SH_OBB_G, tid = threadIdx.x;
-  const int nv = nv_[b], nf = nf_[b], ne = ne_[b];
-  if (f0 >= nf) return;
-  const int ng = nf - f0 < SH_OBB_G ? nf - f0 : SH_OBB_G;
-  if (tid < SH_OBB_G) {
-    s_ns[tid] = 0;
-    if (tid < ng) {
-      const double* N = normals + ((size_t)b * SH_HF + f0 + tid) * 3;
-      double n[3] = {N[0], N[1], N[2]}, u[3], v[3];
-      obb_basis(n, u, v);
-      for (int k = 0; k < 3; ++k) { s_n[tid][k] = n[k]; s_u[tid][k] = u[k]; s_v[tid][k] = v[k]; }
-    }
-  }
-  __syncthreads();
-  // heights: one pass over the hull vertices for all candidates
-  const double* P = hv + (size_t)b * SH_HV * 3;
-  double hmin[SH_OBB_G], hmax[SH_OBB_G];
-#pragma unroll
-  for (int g = 0; g < SH_OBB_G; ++g) { hmin[g] = 1e300; hmax[g] = -1e300; }
-  for (int i = tid; i < nv; i += 256) {
-    double p[3] = {P[3 * i], P[3 * i + 1], P[3 * i + 2]};
-#pragma unroll
-    for (int g = 0; g < SH_OBB_G; ++g) if (g < ng) { double h = dot3(p, s_n[g]); hmin[g] = fmin(hmin[g], h); hmax[g] = fmax(hmax[g], h); }
-  }
-#pragma unroll
-  for (int g = 0; g < SH_OBB_G; ++g) {
-    for (int off = 32; off > 0; off >>= 1) { hmin[g] = fmin(hmin[g], __shfl_down(hmin[g], off)); hmax[g] = fmax(hmax[g], __shfl_down(hmax[g], off)); }
-    if ((tid & 63) == 0) { s_h[g][0][tid >> 6] = hmin[g]; s_h[g][1][tid >> 6] = hmax[g]; }
-  }
-  // silhouette edges of every candidate in one pass over the edge list
-  const int* E = edges + (size_t)b * SH_HE * 4;
-  const double* NN = normals + (size_t)b * SH_HF * 3;
-  for (int e = tid; e < ne; e += 256) {
-    const int va = E[4 * e], vc = E[4 * e + 1];
-    const double* n1 = NN + 3 * E[4 * e + 2];
-    const double* n2 = NN + 3 * E[4 * e + 3];
-    double a1[3] = {n1[0], n1[1], n1[2]}, a2[3] = {n2[0], n2[1], n2[2]};
-#pragma unroll
-    for (int g = 0; g < SH_OBB_G; ++g) {
-      if (g >= ng) continue;
-      double d1 = dot3(a1, s_n[g]), d2 = dot3(a2, s_n[g]);
-      if ((d1 > 0) != (d2 > 0)) {
-        int s = atomicAdd(&s_ns[g], 1);
-        if (s < SH_OBB_SILCAP) {
-          const double* pa = P + 3 * va;
-          const double* pc = P + 3 * vc;
-          s_pt[g][s][0] = dot3(pa, s_u[g]); s_pt[g][s][1] = dot3(pa, s_v[g]);
-          s_pt[g][s][2] = dot3(pc, s_u[g]); s_pt[g][s][3] = dot3(pc, s_v[g]);
-          s_eid[g][s] = e;
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int g = 0; g < ng; ++g) {
-    if (s_ns[g] > SH_OBB_SILCAP && tid == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
-    const int ns = s_ns[g] < SH_OBB_SILCAP ? s_ns[g] : SH_OBB_SILCAP;
-    double best = 1e300;
-    int be = 0x7fffffff;
-    for (int s = tid; s < ns; s += 256) {
-      double ex = s_pt[g][s][2] - s_pt[g][s][0], ey = s_pt[g][s][3] - s_pt[g][s][1];
-      double l = sqrt(ex * ex + ey * ey);
-      if (l == 0.0) continue;
-      ex /= l; ey /= l;
-      double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
-      for (int s2 = 0; s2 < ns; ++s2) {
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-          double x = s_pt[g][s2][2 * w], y = s_pt[g][s2][2 * w + 1];
-          double pa = x * ex + y * ey, pb = y * ex - x * ey;
-          amin = fmin(amin, pa); amax = fmax(amax, pa); bmin = fmin(bmin, pb); bmax = fmax(bmax, pb);
-        }
-      }
-      double area = (amax - amin) * (bmax - bmin);
-      int e = s_eid[g][s];
-      if (area < best || (area == best && e < be)) { best = area; be = e; }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      double ob = __shfl_down(best, off);
-      int oe = __shfl_down(be, off);
-      if (ob < best || (ob == best && oe < be)) { best = ob; be = oe; }
-    }
-    if ((tid & 63) == 0) { b_area[tid >> 6] = best; b_edge[tid >> 6] = be; }
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < 4; ++w) if (b_area[w] < best || (b_area[w] == best && b_edge[w] < be)) { best = b_area[w]; be = b_edge[w]; }
-      double lo = fmin(fmin(s_h[g][0][0], s_h[g][0][1]), fmin(s_h[g][0][2], s_h[g][0][3]));
-      double hi = fmax(fmax(s_h[g][1][0], s_h[g][1][1]), fmax(s_h[g][1][2], s_h[g][1][3]));
-      cand_vol[(size_t)b * SH_HF + f0 + g] = best * (hi - lo);
-      cand_edge[(size_t)b * SH_HF + f0 + g] = be;
-    }
-    __syncthreads();
-  }
-}
-
 // one workgroup (256) per humerus
 __global__ void __launch_bounds__(256)
 k_obb_pick(const double* __restrict__ hv, const double* __restrict__ normals, const int* __restrict__ nf_, const int* __restrict__ edges,

@@ -82,8 +82,7 @@ __global__ void k_init_bounds(unsigned long long* zb_enc, int B) {
 // distances), all lanes fill the Gram matrix, each lane evaluates the cost of some breakpoints with
 // the same arithmetic as sh::cpd_one_bkp, first minimum wins.
 __global__ void __launch_bounds__(64)
-k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* __restrict__ scratch,
-       double* __restrict__ neck_z, int* __restrict__ neck_index, int B) {
+k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* __restrict__ neck_z, int* __restrict__ neck_index, int B) {
   __shared__ double K[SH_CPD_MAXN * SH_CPD_MAXN];
   __shared__ double gamma_s;
   int b = blockIdx.x, lane = threadIdx.x;
@@ -93,7 +92,6 @@ k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* 
   if (n > SH_CPD_MAXN) n = SH_CPD_MAXN;
   const double* x = areas + (size_t)b * SH_NFULL + a;
   if (lane == 0) gamma_s = cpd_gamma(x, n, K);       // median select on the pairwise distances, in LDS (K is free until the Gram fill)
-  (void)scratch;
   __syncthreads();
   double gamma = gamma_s;
   for (int q = lane; q < n * n; q += 64) K[q] = cpd_kernel(x[q / n], x[q % n], gamma);

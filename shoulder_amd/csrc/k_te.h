@@ -11,14 +11,12 @@ namespace sh {
 
 #define SH_TE_ROW0 2
 #define SH_TE_NROWS 37          // int((1-.99)*200)=2 .. int((1-.8)*200)=39 (slice.py:157-164)
-#define SH_TE_ISCR (5 * SH_MAXSEG + 16)
 
 // One wave per (humerus, distal slice): lane 0 builds the hull of the ring (Melkman, O(n), LDS deque),
 // then the lanes share the hull edges of sh::min_area_rect (same arithmetic per edge; first minimum
 // in hull order wins, as in the sequential routine).
 __global__ void __launch_bounds__(64)
-k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, int* __restrict__ iscratch,
-          double* __restrict__ rects /*[B][37][7]*/, int B) {
+k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, double* __restrict__ rects /*[B][37][7]*/, int B) {
   __shared__ int dq[2 * SH_MAXSEG + 8];
   __shared__ int hull[2 * SH_MAXSEG + 8];
   __shared__ double hx[SH_MAXSEG], hy[SH_MAXSEG];
@@ -72,7 +70,7 @@ k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, int* 
   wi = __shfl(wi, 0);
   if (bi == wi && wi != 0x7fffffff) { o[0] = r.cx; o[1] = r.cy; o[2] = r.mx; o[3] = r.my; o[4] = r.L; o[5] = r.W; o[6] = r.area; }
   else if (wi == 0x7fffffff && lane < 7) o[lane] = 0.0;
-  (void)iscratch;
+  (void)B;
 }
 
 #define SH_TE_DSCR (6 * SH_MAXSEG + 64 * SH_TE_MAXCH)

@@ -226,7 +226,6 @@ static int alloc_batch(sh_ctx* c) {
   ENS("err", B * 4, 4);
   ENS("neck_z", B * 8, 8);
   ENS("neck_index", B * 4, 4);
-  ENS("cpd_scratch", (size_t)B * 6144 * 8, 8);
   ENS("canal.points_obb", B * 80 * 3 * 8, 8);
   ENS("canal.axis_obb", B * 6 * 8, 8);
   ENS("canal.axis_ct", B * 6 * 8, 8);
@@ -249,7 +248,6 @@ static int alloc_batch(sh_ctx* c) {
   ENS("prox.itr_start", (size_t)B * SH_NPROX * 2 * SH_MPROX * 8, 8);
   ENS("prox.itr_centered_start", (size_t)B * SH_NPROX * 2 * SH_MPROX * 8, 8);
   // groove
-  ENS("groove.scratch", (size_t)B * SH_GROOVE_NROWS * 3 * SH_MPROX * 8, 8);
   ENS("groove.xraw", (size_t)B * SH_GSLOTS * 9 * 8, 8);
   ENS("groove.xs", (size_t)B * SH_GSLOTS * 9 * 8, 8);
   ENS("groove.ptheta", (size_t)B * SH_GSLOTS * 8, 8);
@@ -275,7 +273,6 @@ static int alloc_batch(sh_ctx* c) {
   ENS("anp.plane", (size_t)B * 6 * 8, 8);
   ENS("anp.axes_obb", (size_t)B * 12 * 8, 8);
   // trans-epicondylar
-  ENS("te.iscratch", (size_t)B * SH_TE_NROWS * SH_TE_ISCR * 4, 4);
   ENS("te.dscratch", (size_t)B * SH_TE_DSCR * 8, 8);
   ENS("te.rects", (size_t)B * SH_TE_NROWS * 7 * 8, 8);
   ENS("te.axis_ct", (size_t)B * 6 * 8, 8);
@@ -785,7 +782,6 @@ static int run_window(sh_ctx* c, uint32_t mask, int window_index) {
     if ((rc = run_obb(c, window_index)) != SH_OK) return rc;
   if (mask & (SH_STAGE_OBB | SH_STAGE_FULL)) {
     // verts_obb + z bounds (mesh.py:85-86)
-    HIPCHK(c, hipMemsetAsync(buf<unsigned long long>(c, "zb_enc"), 0, 0, c->stream));
     LAUNCH(c, "k_init_bounds", k_init_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "zb_enc"), B);
     dim3 g((unsigned)std::min<long long>((c->maxV + 255) / 256, 1024), (unsigned)B);
     LAUNCH(c, "k_transform_verts", k_transform_verts, g, dim3(256), buf<float>(c, "verts"), buf<long long>(c, "voff"),
@@ -799,7 +795,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int window_index) {
     if ((rc = run_slice_set(c, "distal", 2, SH_NDIST, true, false)) != SH_OK) return rc;
   if (mask & SH_STAGE_NECK) {
     LAUNCH(c, "k_neck", k_neck, dim3(B), dim3(64), buf<double>(c, "full.areas"), buf<double>(c, "full.zs"),
-           buf<double>(c, "cpd_scratch"), buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), B);
+           buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), B);
     // surgical_neck.py:37-54: the contour at neck_z (loop whose vertex mean is nearest the origin)
     if ((rc = run_slice_set(c, "neckc", 3, 1, true, false, 1)) != SH_OK) return rc;
   }
@@ -820,7 +816,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int window_index) {
     const int* fi = (const int*)(pp + N * 12); const float* lw = (const float*)(pp + N * 16); const int* roots = (const int*)(pp + N * 20);
     const int rows = B * SH_GROOVE_NROWS;
     LAUNCH(c, "k_groove_rows", k_groove_rows, dim3(rows), dim3(64), buf<double>(c, "prox.itr_centered_start"),
-           buf<double>(c, "prox.zs"), buf<double>(c, "canal.axis_ct"), ga, buf<double>(c, "groove.scratch"), buf<double>(c, "groove.xraw"),
+           buf<double>(c, "prox.zs"), buf<double>(c, "canal.axis_ct"), ga, buf<double>(c, "groove.xraw"),
            buf<double>(c, "groove.ptheta"), buf<int>(c, "groove.npk"), buf<double>(c, "groove.r0"), buf<int>(c, "err"), B);
     LAUNCH(c, "k_groove_scale", k_groove_scale, dim3(B), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
            buf<double>(c, "groove.stats"), B);
@@ -853,7 +849,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int window_index) {
   }
   if (mask & SH_STAGE_TE) {
     LAUNCH(c, "k_te_rows", k_te_rows, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
-           buf<int>(c, "te.iscratch"), buf<double>(c, "te.rects"), B);
+           buf<double>(c, "te.rects"), B);
     LAUNCH(c, "k_te_final", k_te_final, dim3((B + 63) / 64), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
            buf<double>(c, "anp.axes_obb"), buf<double>(c, "te.dscratch"), buf<double>(c, "te.axis_ct"), buf<int>(c, "te.row"), buf<int>(c, "err"), B);
