@@ -108,7 +108,8 @@ def main():
     ap.add_argument("--unet", choices=["f32", "bf16"], default="bf16",
                     help="UNet arithmetic: bf16 = BASELINE configs[2]/[3] (throughput), f32 = configs[1] parity path (bit-exact vs the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-meshes", type=int, default=2)
+    ap.add_argument("--cpu-meshes", type=int, default=4)
+    ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -149,13 +150,20 @@ def main():
     eng.set_params(unet_dtype=_lib.UNET_BF16 if args.unet == "bf16" else _lib.UNET_F32)
 
     T = synth.similarity_transforms(B, verts, seed=1234, start=rank * B)
-    eng.upload([(verts, faces)])
-    eng.synth_batch(T)                                 # batch resident in HBM before the timed region
+    host_batch = None
+    if args.from_host:      # PCIe-inclusive variant (never the headline `value`): the meshes are handed over as host buffers every step
+        host_batch = [(synth.apply_similarity(T[i], verts), faces) for i in range(B)]
+        eng.upload(host_batch)
+    else:
+        eng.upload([(verts, faces)])
+        eng.synth_batch(T)                             # batch resident in HBM before the timed region
 
     lm_t = shd.as_byte_tensor(eng.landmarks_device(), device=f"cuda:{local}") if use_dist else None
     gather_list = [torch.empty_like(lm_t) for _ in range(world)] if (use_dist and rank == 0) else None
 
     def step():
+        if host_batch is not None:
+            eng.upload(host_batch)
         eng.run(_lib.STAGE_ALL, fetch=not use_dist)
         if use_dist:
             dist.gather(lm_t, gather_list, dst=0)      # landmark records of every rank to rank 0 (device to device)
@@ -253,7 +261,7 @@ def main():
                "data": "synthetic (similarity copies of humerus_left.stl, seed 1234; seeded teacher UNet weights)",
                "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: batch {B} synthetic humeri per GPU, all stages (SH_STAGE_ALL)",
                           "batch_per_gpu": B, "global_batch": B * world, "vertices": V, "triangles": F, "unet": f"base{unet_spec.BASE} depth{unet_spec.DEPTH} 512x512",
-                          "parallelism": f"dp{world}", "meshes_with_error_status": n_bad},
+                          "parallelism": f"dp{world}", "input": "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM", "meshes_with_error_status": n_bad},
                "roofline": roof, "cpu_baseline": cpu,
                "unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top,
                "device_ms_per_step_total": round(total_dev / args.steps, 3), "host_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()}}
