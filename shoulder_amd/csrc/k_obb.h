@@ -1,8 +1,8 @@
 // k_obb.h -- oriented bounding box + head-end detection on the device
 // (reference src/shoulder/humerus/mesh.py:63-125; trimesh `oriented_bounds` semantics restated in
 // oracle/obb.py, canonical rule B-3).
-//   k_obb_candidates  one workgroup per (hull face, humerus): project the hull on the face plane,
-//                     find the silhouette edges (= edges of the 2-D hull of the projection), and
+//   k_obb_candidates  one workgroup per (16 hull faces, humerus): for every face normal find the silhouette
+//                     edges of the hull (= edges of the 2-D hull of its projection on the face plane) and
 //                     for each take the enclosing rectangle -> min area x height = candidate volume
 //   k_obb_pick        argmin volume -> axes ordered by ascending extent, signs fixed by vertex 0,
 //                     box centred at the origin  -> T_pre (CT -> raw OBB)
@@ -22,85 +22,161 @@ namespace sh {
 
 __device__ inline void obb_basis(const double* n, double* u, double* v) { plane_basis(n, u, v); }
 
-__global__ void __launch_bounds__(256)
+#define SH_OBB_THREADS 256
+#define SH_OBB_TILE 16           // hull faces (candidate directions) per workgroup
+#define SH_OBB_GROUP 4           // faces whose rectangle scans run together
+#define SH_SIL_MAX 512           // silhouette edges per direction
+
+// One workgroup per (tile of 16 hull faces, humerus).  The hull record (vertices, normals, edges: ~160 KB) is read
+// from L2 once per tile instead of once per face -- with one face per workgroup the kernel was bound by those
+// re-reads (11 TB/s of L2 traffic), not by arithmetic:
+//   heights   every lane keeps min/max of n_j . p over its vertices for the 16 directions (registers)
+//   fronts    16-bit mask per hull face: which of the 16 directions see it from the front
+//   edges     mask[f] ^ mask[g] = directions for which the edge is on the silhouette -> per-direction lists
+//   scans     four directions at a time: project the silhouette start vertices (LDS), then every silhouette
+//             edge takes the extents of all of them (ns x ns, fp64) -> min-area rectangle
+__global__ void __launch_bounds__(SH_OBB_THREADS)
 k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
-                 const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge, int nvmax) {
-  extern __shared__ double sm[];          // pu[nvmax], pv[nvmax]
-  __shared__ int sil[2048];
-  __shared__ int silv[2048];      // start vertex of the edge directed along its front face's winding
-  __shared__ unsigned char front[SH_HF];
-  __shared__ int nsil;
-  __shared__ double red[8];
-  __shared__ double b_area[4];
-  __shared__ int b_edge[4];
-  const int b = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+                 const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge,
+                 int* __restrict__ err) {
+  constexpr int T = SH_OBB_TILE, G = SH_OBB_GROUP, NW = SH_OBB_THREADS / 64;
+  __shared__ double tn[T][3], tu[T][3], tv[T][3];
+  __shared__ double red[NW][2 * T];
+  __shared__ double hlo[T], hhi[T];
+  __shared__ unsigned short fmask[SH_HF];
+  __shared__ unsigned short lists[T][SH_SIL_MAX];      // edge id | (first face is the front face) << 15
+  __shared__ int cnt[T];
+  __shared__ double2 sxy[G][SH_SIL_MAX];
+  __shared__ unsigned long long g_area[G];
+  __shared__ int g_edge[G];
+  const int b = blockIdx.y, f0 = blockIdx.x * T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = nv_[b], nf = nf_[b], ne = ne_[b];
-  if (f >= nf) return;
-  double* pu = sm;
-  double* pv = sm + nvmax;
-  const double* N = normals + ((size_t)b * SH_HF + f) * 3;
-  double n[3] = {N[0], N[1], N[2]}, u[3], v[3];
-  obb_basis(n, u, v);
+  if (f0 >= nf) return;
+  const int nt = min(T, nf - f0);                      // directions in this tile
   const double* P = hv + (size_t)b * SH_HV * 3;
-  double hmin = 1e300, hmax = -1e300;
-  for (int i = tid; i < nv; i += 256) {
-    const double* p = P + 3 * i;
-    pu[i] = dot3(p, u); pv[i] = dot3(p, v);
-    double h = dot3(p, n);
-    hmin = fmin(hmin, h); hmax = fmax(hmax, h);
-  }
-  for (int off = 32; off > 0; off >>= 1) { hmin = fmin(hmin, __shfl_down(hmin, off)); hmax = fmax(hmax, __shfl_down(hmax, off)); }
-  if (tid == 0) nsil = 0;
-  if ((tid & 63) == 0) { red[tid >> 6] = hmin; red[4 + (tid >> 6)] = hmax; }
-  __syncthreads();
-  // front/back flag of every hull face for this direction: one coalesced pass over the normals
-  const int* E = edges + (size_t)b * SH_HE * 4;
   const double* NN = normals + (size_t)b * SH_HF * 3;
-  for (int f2 = tid; f2 < nf; f2 += 256) front[f2] = dot3(NN + 3 * f2, n) > 0 ? 1 : 0;
-  __syncthreads();
-  // silhouette edges: the two incident faces see the direction n from opposite sides
-  for (int e = tid; e < ne; e += 256) {
-    const int4 ed = *(const int4*)(E + 4 * e);
-    const int f1 = front[ed.z], f2 = front[ed.w];
-    // (edge stored with face f's winding: va -> vb; directed along the FRONT face every silhouette vertex
-    //  is the start of exactly one edge, so the start vertices enumerate the 2-D hull once)
-    if (f1 != f2) { int s = atomicAdd(&nsil, 1); if (s < 2048) { sil[s] = e; silv[s] = f1 ? ed.x : ed.y; } }
+  const int* E = edges + (size_t)b * SH_HE * 4;
+  if (tid < T) {
+    const double* N = NN + 3 * (size_t)(f0 + (tid < nt ? tid : 0));
+    double n[3] = {N[0], N[1], N[2]}, u[3], v[3];
+    obb_basis(n, u, v);
+    for (int k = 0; k < 3; ++k) { tn[tid][k] = n[k]; tu[tid][k] = u[k]; tv[tid][k] = v[k]; }
+    cnt[tid] = 0;
   }
   __syncthreads();
-  const int ns = nsil < 2048 ? nsil : 2048;
-  double best = 1e300;
-  int be = 0x7fffffff;
-  for (int s = tid; s < ns; s += 256) {
-    int e = sil[s];
-    int a = E[4 * e], c = E[4 * e + 1];
-    double ex = pu[c] - pu[a], ey = pv[c] - pv[a];
-    double l = sqrt(ex * ex + ey * ey);
-    if (l == 0.0) continue;
-    ex /= l; ey /= l;
-    // the end points of the silhouette edges are exactly the vertices of the projection's 2-D hull,
-    // so the rectangle extents over them equal the extents over every projected hull vertex
-    double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
-    for (int s2 = 0; s2 < ns; ++s2) {
-      const int i = silv[s2];
-      double x = pu[i], y = pv[i];
-      double pa = x * ex + y * ey, pb = y * ex - x * ey;
-      amin = fmin(amin, pa); amax = fmax(amax, pa); bmin = fmin(bmin, pb); bmax = fmax(bmax, pb);
+  // ---- heights
+  {
+    double mn[T], mx[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) { mn[j] = 1e300; mx[j] = -1e300; }
+    for (int i = tid; i < nv; i += SH_OBB_THREADS) {
+      const double p[3] = {P[3 * i], P[3 * i + 1], P[3 * i + 2]};
+#pragma unroll
+      for (int j = 0; j < T; ++j) { double h = dot3(p, tn[j]); mn[j] = fmin(mn[j], h); mx[j] = fmax(mx[j], h); }
     }
-    double area = (amax - amin) * (bmax - bmin);
-    if (area < best || (area == best && e < be)) { best = area; be = e; }
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      for (int off = 32; off > 0; off >>= 1) { mn[j] = fmin(mn[j], __shfl_down(mn[j], off)); mx[j] = fmax(mx[j], __shfl_down(mx[j], off)); }
+      if (lane == 0) { red[wave][j] = mn[j]; red[wave][T + j] = mx[j]; }
+    }
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    double ob = __shfl_down(best, off);
-    int oe = __shfl_down(be, off);
-    if (ob < best || (ob == best && oe < be)) { best = ob; be = oe; }
+  // ---- front masks
+  for (int f2 = tid; f2 < nf; f2 += SH_OBB_THREADS) {
+    const double q[3] = {NN[3 * f2], NN[3 * f2 + 1], NN[3 * f2 + 2]};
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < T; ++j) m |= (dot3(q, tn[j]) > 0 ? 1u : 0u) << j;
+    fmask[f2] = (unsigned short)m;
   }
-  if ((tid & 63) == 0) { b_area[tid >> 6] = best; b_edge[tid >> 6] = be; }
   __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < 4; ++w) if (b_area[w] < best || (b_area[w] == best && b_edge[w] < be)) { best = b_area[w]; be = b_edge[w]; }
-    double lo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3])), hi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-    cand_vol[(size_t)b * SH_HF + f] = best * (hi - lo);
-    cand_edge[(size_t)b * SH_HF + f] = be;
+  if (tid < T) {
+    double lo = red[0][tid], hi = red[0][T + tid];
+    for (int w = 1; w < NW; ++w) { lo = fmin(lo, red[w][tid]); hi = fmax(hi, red[w][T + tid]); }
+    hlo[tid] = lo; hhi[tid] = hi;
+  }
+  // ---- silhouette edges of every direction: the two incident faces see it from opposite sides
+  for (int e = tid; e < ne; e += SH_OBB_THREADS) {
+    const int4 ed = *(const int4*)(E + 4 * e);
+    const unsigned m1 = fmask[ed.z];
+    unsigned x = (m1 ^ fmask[ed.w]) & ((1u << nt) - 1u);
+    while (x) {
+      const int j = __ffs(x) - 1;
+      x &= x - 1;
+      const int s = atomicAdd(&cnt[j], 1);
+      if (s < SH_SIL_MAX) lists[j][s] = (unsigned short)(e | (((m1 >> j) & 1u) << 15));
+    }
+  }
+  __syncthreads();
+  // ---- rectangle scans, G directions at a time
+  for (int g0 = 0; g0 < nt; g0 += G) {
+    int ns[G], pre[G + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int jj = 0; jj < G; ++jj) {
+      const int j = g0 + jj;
+      int c = j < nt ? cnt[j] : 0;
+      if (c > SH_SIL_MAX) { if (tid == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); c = SH_SIL_MAX; }
+      ns[jj] = c; pre[jj + 1] = pre[jj] + c;
+    }
+    if (tid < G) { g_area[tid] = (unsigned long long)__double_as_longlong(1e300); g_edge[tid] = 0x7fffffff; }
+    // (edge stored with its first face's winding: va -> vb; directed along the FRONT face every silhouette vertex
+    //  is the start of exactly one edge, so the start vertices enumerate the projection's 2-D hull once)
+    for (int it = tid; it < pre[G]; it += SH_OBB_THREADS) {
+      int jj = 0;
+#pragma unroll
+      for (int k = 1; k < G; ++k) jj += it >= pre[k] ? 1 : 0;
+      const int s = it - pre[jj], j = g0 + jj;
+      const unsigned short rec = lists[j][s];
+      const int e = rec & 0x7fff;
+      const double* p = P + 3 * (size_t)((rec >> 15) ? E[4 * e] : E[4 * e + 1]);
+      sxy[jj][s] = make_double2(dot3(p, tu[j]), dot3(p, tv[j]));
+    }
+    __syncthreads();
+    // every lane takes item tid of each pass of 256 (edge s of direction jj) and remembers (area, edge, direction);
+    // lexicographic (area, edge) minimum per direction in two steps: areas are non-negative doubles, so their bit
+    // patterns order like the values
+    constexpr int NP = G * SH_SIL_MAX / SH_OBB_THREADS;
+    double a_[NP];
+    int e_[NP], j_[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      a_[p] = 1e300; e_[p] = 0x7fffffff; j_[p] = -1;
+      const int it = p * SH_OBB_THREADS + tid;
+      if (it < pre[G]) {
+        int jj = 0;
+#pragma unroll
+        for (int k = 1; k < G; ++k) jj += it >= pre[k] ? 1 : 0;
+        const int s = it - pre[jj], j = g0 + jj, n2 = ns[jj];
+        const int e = lists[j][s] & 0x7fff;
+        const double* pa3 = P + 3 * (size_t)E[4 * e]; const double* pc3 = P + 3 * (size_t)E[4 * e + 1];
+        double ex = dot3(pc3, tu[j]) - dot3(pa3, tu[j]), ey = dot3(pc3, tv[j]) - dot3(pa3, tv[j]);
+        const double l = sqrt(ex * ex + ey * ey);
+        if (l != 0.0) {
+          ex /= l; ey /= l;
+          double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
+          const double2* sq = sxy[jj];
+#pragma unroll 4
+          for (int s2 = 0; s2 < n2; ++s2) {
+            const double2 q = sq[s2];
+            const double pa = q.x * ex + q.y * ey, pb = q.y * ex - q.x * ey;
+            amin = fmin(amin, pa); amax = fmax(amax, pa); bmin = fmin(bmin, pb); bmax = fmax(bmax, pb);
+          }
+          a_[p] = (amax - amin) * (bmax - bmin); e_[p] = e; j_[p] = jj;
+          atomicMin(&g_area[jj], (unsigned long long)__double_as_longlong(a_[p]));
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if (j_[p] >= 0 && (unsigned long long)__double_as_longlong(a_[p]) == g_area[j_[p]]) atomicMin(&g_edge[j_[p]], e_[p]);
+    __syncthreads();
+    if (tid < G && g0 + tid < nt) {
+      const int j = g0 + tid;
+      cand_vol[(size_t)b * SH_HF + f0 + j] = __longlong_as_double((long long)g_area[tid]) * (hhi[j] - hlo[j]);
+      cand_edge[(size_t)b * SH_HF + f0 + j] = g_edge[tid];
+    }
+    __syncthreads();
   }
 }
 

@@ -749,14 +749,11 @@ static int run_obb(sh_ctx* c, int window_index) {
   const int* cnt_nv = buf<int>(c, "hull.nv");
   const int* cnt_nf = buf<int>(c, "hull.nf");
   const int* cnt_ne = buf<int>(c, "hull.ne");
-  size_t shm = 2 * (size_t)nvmax * 8;
   {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
-    // (k_obb_candidates4, 4 faces per workgroup, measured slower: 5.2 vs 4.0 ms at B=64 -- the kernel is bound by
-    //  the fp64 rectangle scans, not by re-reading the hull record from L2)
-    hipLaunchKernelGGL(k_obb_candidates, dim3(nfmax, B), dim3(256), shm, c->stream, buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"),
-                       cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), nvmax);
+    hipLaunchKernelGGL(k_obb_candidates, dim3((nfmax + SH_OBB_TILE - 1) / SH_OBB_TILE, B), dim3(SH_OBB_THREADS), 0, c->stream, buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"),
+                       cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"));
     if (c->timing) { (void)hipEventRecord(e1, c->stream); c->pending.emplace_back("k_obb_candidates", e0, e1); }
     HIPCHK(c, hipGetLastError());
   }
