@@ -109,6 +109,7 @@ def main():
                     help="UNet arithmetic: bf16 = BASELINE configs[2]/[3] (throughput), f32 = configs[1] parity path (bit-exact vs the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-meshes", type=int, default=4)
+    ap.add_argument("--no-overlap", action="store_true", help="do not compute the host hulls of step k+1 during the device work of step k")
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     args = ap.parse_args()
 
@@ -168,15 +169,23 @@ def main():
         if use_dist:
             dist.gather(lm_t, gather_list, dst=0)      # landmark records of every rank to rank 0 (device to device)
 
+    overlap = not args.no_overlap and host_batch is None
     for _ in range(args.warmup):
         step()
     eng.enable_timing(True)
     eng.reset_timers()
+    # Streaming schedule: inside the timed region the hulls of step k+1 are computed by host threads while the device
+    # works on step k.  Nothing is carried in from the warmup (discard) and nothing is prepared for a step K+1 (overlap
+    # off before the last step): K hull passes and K device passes lie between t0 and t1.
+    eng.discard_prepared()
+    eng.set_overlap(overlap)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for s_ in range(args.steps):
+        if s_ == args.steps - 1:
+            eng.set_overlap(False)
         step()
     torch.cuda.synchronize()
     if use_dist:
@@ -261,7 +270,9 @@ def main():
                "data": "synthetic (similarity copies of humerus_left.stl, seed 1234; seeded teacher UNet weights)",
                "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: batch {B} synthetic humeri per GPU, all stages (SH_STAGE_ALL)",
                           "batch_per_gpu": B, "global_batch": B * world, "vertices": V, "triangles": F, "unet": f"base{unet_spec.BASE} depth{unet_spec.DEPTH} 512x512",
-                          "parallelism": f"dp{world}", "input": "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM", "meshes_with_error_status": n_bad},
+                          "parallelism": f"dp{world}", "input": "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM",
+                          "schedule": "host hulls of step k+1 overlap the device work of step k (pipeline filled and drained inside the timed region)" if overlap else "serial",
+                          "meshes_with_error_status": n_bad},
                "roofline": roof, "cpu_baseline": cpu,
                "unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top,
                "device_ms_per_step_total": round(total_dev / args.steps, 3), "host_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()}}

@@ -154,6 +154,16 @@ int  sh_store(sh_ctx*, const char* name, const void* host, size_t nbytes);
 int  sh_kernel_time_ms(sh_ctx*, const char* kernel, double* avg_ms, int* launches);
 int  sh_enable_timing(sh_ctx*, int on);
 
+/* Streaming use (one sh_run after another on the resident batch): with overlap on, sh_run starts a
+ * background thread, once all its device work is enqueued, that computes the convex hulls the NEXT
+ * sh_run(SH_STAGE_OBB) needs (the host part of mesh.py:82 `apply_obb`), so the host hulls of run
+ * k+1 overlap the device work of run k.  Prepared hulls are used only if the batch is unchanged
+ * (any sh_upload_meshes / sh_synth_batch / sh_store("verts") voids them); sh_discard_prepared
+ * drops them explicitly (the next run then does its host phase inline).  Results are identical
+ * either way.  Off by default. */
+int  sh_set_overlap(sh_ctx*, int on);
+int  sh_discard_prepared(sh_ctx*);
+
 #ifdef __cplusplus
 }
 #endif

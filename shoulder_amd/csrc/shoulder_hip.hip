@@ -67,6 +67,16 @@ struct sh_ctx {
   int b0 = 0, Bwin = 0;
   struct HullStage { double* hv = nullptr; double* nr = nullptr; int* ed = nullptr; int* cnt = nullptr; int cap = 0; hipEvent_t ev = nullptr; bool used = false; };
   HullStage hstage[2];                       // pinned host staging, double buffered
+  int hslot = 0;                             // slot the next hull goes to
+  // Overlap (sh_set_overlap): while the device works on run k, a background thread computes the hulls run k+1 will
+  // need (same resident batch -- invalidated by any upload) into the other pinned slot.
+  struct Prepared {
+    std::thread th; bool active = false; int slot = 0, B = 0, rc = SH_OK, bad_mesh = -1; unsigned long long gen = 0;
+    double d2h_ms = 0, hull_ms = 0; std::string err;
+  } prep;
+  bool overlap = false;
+  unsigned long long batch_gen = 0;
+  hipStream_t copy_stream = nullptr;
   // timing
   bool timing = false;
   std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t>> pending;
@@ -178,8 +188,10 @@ int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
 void sh_ctx_destroy(sh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->prep.active && c->prep.th.joinable()) c->prep.th.join();
   (void)hipStreamSynchronize(c->stream);
   drain_timers(c);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   for (auto& kv : c->bufs)
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto& hs : c->hstage) {
@@ -189,6 +201,8 @@ void sh_ctx_destroy(sh_ctx* c) {
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
+
+static int join_prepared(sh_ctx* c);
 
 const char* sh_last_error(const sh_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
@@ -301,6 +315,7 @@ static int alloc_batch(sh_ctx* c) {
 int sh_upload_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const int64_t* v_off, const int64_t* f_off, int B) {
   if (!c || !verts || !faces || !v_off || !f_off || B <= 0) return fail(c, SH_ERR_ARG, "sh_upload_meshes: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
+  (void)join_prepared(c); ++c->batch_gen;      // hulls prepared for the previous batch are void
   c->h_voff.assign(v_off, v_off + B + 1);
   c->h_foff.assign(f_off, f_off + B + 1);
   c->sumV = v_off[B]; c->sumF = f_off[B];
@@ -332,6 +347,7 @@ int sh_synth_batch(sh_ctx* c, const double* T, int B) {
   if (!c || !T || B <= 0) return fail(c, SH_ERR_ARG, "sh_synth_batch: bad argument");
   if (c->B < 1) return fail(c, SH_ERR_STATE, "sh_synth_batch: upload a template mesh first");
   HIPCHK(c, hipSetDevice(c->device));
+  (void)join_prepared(c); ++c->batch_gen;
   const long long V = c->h_voff[1] - c->h_voff[0], F = c->h_foff[1] - c->h_foff[0];
   // keep the template aside
   int rc;
@@ -387,6 +403,7 @@ int sh_store(sh_ctx* c, const char* name, const void* host, size_t nbytes) {
   if (it == c->bufs.end()) return fail(c, SH_ERR_ARG, std::string("no buffer named ") + name);
   if (nbytes > it->second.bytes) return fail(c, SH_ERR_ARG, std::string("sh_store: size exceeds buffer ") + name);
   HIPCHK(c, hipSetDevice(c->device));
+  if (std::string(name) == "verts") { (void)join_prepared(c); ++c->batch_gen; c->h_verts_valid = false; }
   HIPCHK(c, hipMemcpyAsync(it->second.p, host, nbytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (std::string(name) == "obb_transform") c->obb_injected = true;
@@ -679,22 +696,24 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
 
 // mesh.py:63-125.  Host: one quickhull per humerus on worker threads (sh_hull.h).  Device: candidate
 // boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
-static int run_obb(sh_ctx* c, int window_index) {
-  const int B = c->Bwin, b0 = c->b0;
-  auto t_d2h = std::chrono::steady_clock::now();
-  // pinned staging, two slots: the host fills slot k+1 while the copies / kernels of slot k are in flight
-  sh_ctx::HullStage& hs = c->hstage[window_index & 1];
+// Host phase of the OBB stage for meshes [b0, b0 + B): one quickhull per humerus on worker threads into pinned slot
+// `slot`.  Callable from the background thread: touches no error string, no timers; HIP errors come back as text.
+static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, double* ms, std::string* errtxt) {
+  auto t0 = std::chrono::steady_clock::now();
+  sh_ctx::HullStage& hs = c->hstage[slot];
+#define HULLCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *errtxt = std::string(#call) + ": " + hipGetErrorString(e_); return SH_ERR_HIP; } } while (0)
   if (hs.cap < B) {
     if (hs.hv) { (void)hipHostFree(hs.hv); (void)hipHostFree(hs.nr); (void)hipHostFree(hs.ed); (void)hipHostFree(hs.cnt); }
     hs.hv = nullptr; hs.cap = 0;
-    HIPCHK(c, hipHostMalloc((void**)&hs.hv, (size_t)B * SH_HV * 3 * 8));
-    HIPCHK(c, hipHostMalloc((void**)&hs.nr, (size_t)B * SH_HF * 3 * 8));
-    HIPCHK(c, hipHostMalloc((void**)&hs.ed, (size_t)B * SH_HE * 4 * 4));
-    HIPCHK(c, hipHostMalloc((void**)&hs.cnt, (size_t)B * 3 * 4));
+    HULLCHK(hipHostMalloc((void**)&hs.hv, (size_t)B * SH_HV * 3 * 8));
+    HULLCHK(hipHostMalloc((void**)&hs.nr, (size_t)B * SH_HF * 3 * 8));
+    HULLCHK(hipHostMalloc((void**)&hs.ed, (size_t)B * SH_HE * 4 * 4));
+    HULLCHK(hipHostMalloc((void**)&hs.cnt, (size_t)B * 3 * 4));
     hs.cap = B;
   }
-  if (!hs.ev) HIPCHK(c, hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
-  if (hs.used) HIPCHK(c, hipEventSynchronize(hs.ev));     // the previous copies out of this slot are done
+  if (!hs.ev) HULLCHK(hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
+  if (hs.used) HULLCHK(hipEventSynchronize(hs.ev));     // the previous copies out of this slot are done
+#undef HULLCHK
   double* hv = hs.hv; double* nr = hs.nr; int* ed = hs.ed; int* counts = hs.cnt;
   std::vector<int> status(B, 0);
   std::atomic<int> next(0);
@@ -729,18 +748,33 @@ static int run_obb(sh_ctx* c, int window_index) {
   for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
   work();
   for (auto& t : pool) t.join();
-  if (c->timing) {
-    auto t_end = std::chrono::steady_clock::now();
-    KTimer& h = c->timers["host.hull"]; h.ms += std::chrono::duration<double, std::milli>(t_end - t_d2h).count(); h.n += 1;
+  *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (int b = 0; b < B; ++b)
+    if (status[b] != 0) { *bad_mesh = b0 + b; return status[b]; }
+  return SH_OK;
+}
+
+// mesh.py:63-125.  Host: convex hulls (hull_host_phase; already done by the background thread when `prepared_slot`
+// >= 0).  Device: candidate boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
+static int run_obb(sh_ctx* c, int prepared_slot) {
+  const int B = c->Bwin, b0 = c->b0;
+  int slot = prepared_slot;
+  if (slot < 0) {
+    slot = c->hslot; c->hslot ^= 1;
+    int bad = -1; double ms = 0; std::string et;
+    int hrc = hull_host_phase(c, slot, b0, B, &bad, &ms, &et);
+    if (c->timing) { KTimer& h = c->timers["host.hull"]; h.ms += ms; h.n += 1; }
+    if (hrc == SH_ERR_HIP) { c->err = et; return hrc; }
+    if (hrc != SH_OK) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", bad, hrc); return fail(c, hrc, m); }
   }
-  int nvmax = 0, nfmax = 0;
-  for (int b = 0; b < B; ++b) {
-    if (status[b] != 0) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", b0 + b, status[b]); return fail(c, status[b], m); }
-    nvmax = std::max(nvmax, counts[b]); nfmax = std::max(nfmax, counts[B + b]);
-  }
-  HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.hv"), hv, (size_t)B * SH_HV * 3 * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.normals"), nr, (size_t)B * SH_HF * 3 * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.edges"), ed, (size_t)B * SH_HE * 4 * 4, hipMemcpyHostToDevice, c->stream));
+  sh_ctx::HullStage& hs = c->hstage[slot];
+  double* hv = hs.hv; double* nr = hs.nr; int* ed = hs.ed; int* counts = hs.cnt;
+  int nvmax = 1, nfmax = 1, nemax = 1;
+  for (int b = 0; b < B; ++b) { nvmax = std::max(nvmax, counts[b]); nfmax = std::max(nfmax, counts[B + b]); nemax = std::max(nemax, counts[2 * B + b]); }
+  // only the used head of every fixed-capacity record crosses PCIe (one strided copy per array)
+  HIPCHK(c, hipMemcpy2DAsync(buf<double>(c, "hull.hv"), (size_t)SH_HV * 24, hv, (size_t)SH_HV * 24, (size_t)nvmax * 24, B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(buf<double>(c, "hull.normals"), (size_t)SH_HF * 24, nr, (size_t)SH_HF * 24, (size_t)nfmax * 24, B, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(buf<int>(c, "hull.edges"), (size_t)SH_HE * 16, ed, (size_t)SH_HE * 16, (size_t)nemax * 16, B, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.nv"), counts, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.nf"), counts + B, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.ne"), counts + 2 * B, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
@@ -772,11 +806,11 @@ static int run_obb(sh_ctx* c, int window_index) {
 
 // All stages for the window [c->b0, c->b0 + c->Bwin) of the batch; everything is enqueued on the stream,
 // nothing here waits for the device.
-static int run_window(sh_ctx* c, uint32_t mask, int window_index) {
+static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   const int B = c->Bwin;
   int rc;
   if (mask & SH_STAGE_OBB)
-    if ((rc = run_obb(c, window_index)) != SH_OK) return rc;
+    if ((rc = run_obb(c, prepared_slot)) != SH_OK) return rc;
   if (mask & (SH_STAGE_OBB | SH_STAGE_FULL)) {
     // verts_obb + z bounds (mesh.py:85-86)
     LAUNCH(c, "k_init_bounds", k_init_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "zb_enc"), B);
@@ -872,6 +906,50 @@ static int run_window(sh_ctx* c, uint32_t mask, int window_index) {
 // than the hidden host hull (13 % of the step) buys back.  SHOULDER_WINDOW=<n> enables windows of n.
 #define SH_WINDOW (1 << 30)
 
+// ---- overlap of the host hulls with the device work of the previous run ----------------------------------
+static int join_prepared(sh_ctx* c) {
+  if (!c->prep.active) return SH_OK;
+  if (c->prep.th.joinable()) c->prep.th.join();
+  c->prep.active = false;
+  if (c->timing) {
+    KTimer& h = c->timers["host.hull"]; h.ms += c->prep.hull_ms; h.n += 1;
+    if (c->prep.d2h_ms > 0) { KTimer& a = c->timers["host.verts_d2h"]; a.ms += c->prep.d2h_ms; a.n += 1; }
+  }
+  return c->prep.rc;      // a failed preparation is simply not used: the run repeats the host phase and reports the error itself
+}
+
+static void start_prepare(sh_ctx* c) {
+  sh_ctx::Prepared& p = c->prep;
+  p.active = true; p.slot = c->hslot; p.B = c->B; p.gen = c->batch_gen; p.rc = SH_OK; p.bad_mesh = -1; p.d2h_ms = p.hull_ms = 0; p.err.clear();
+  const bool need_d2h = !c->h_verts_valid;
+  p.th = std::thread([c, need_d2h]() {
+    sh_ctx::Prepared& q = c->prep;
+    if (hipSetDevice(c->device) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
+    if (need_d2h) {      // a device-generated batch is downloaded again for every run, on the copy stream, beside the kernels
+      auto t0 = std::chrono::steady_clock::now();
+      if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
+      c->h_verts.resize(3 * (size_t)c->sumV);
+      if (hipMemcpyAsync(c->h_verts.data(), buf<float>(c, "verts"), c->sumV * 3 * 4, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
+          hipStreamSynchronize(c->copy_stream) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
+      q.d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    q.rc = hull_host_phase(c, q.slot, 0, q.B, &q.bad_mesh, &q.hull_ms, &q.err);
+  });
+}
+
+int sh_set_overlap(sh_ctx* c, int on) {
+  if (!c) return SH_ERR_ARG;
+  c->overlap = on != 0;      // hulls already in preparation stay usable by the next run
+  return SH_OK;
+}
+
+int sh_discard_prepared(sh_ctx* c) {
+  if (!c) return SH_ERR_ARG;
+  (void)join_prepared(c);
+  c->prep.gen = ~0ull;
+  return SH_OK;
+}
+
 int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   if (!c) return SH_ERR_ARG;
   if (c->B < 1) return fail(c, SH_ERR_STATE, "sh_run: no meshes uploaded");
@@ -881,7 +959,18 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "err"), 0, B * 4, c->stream));
   if (!(mask & SH_STAGE_OBB) && !c->obb_injected)
     return fail(c, SH_ERR_STATE, "sh_run: no OBB transform (run SH_STAGE_OBB or sh_store(\"obb_transform\"))");
-  if ((mask & SH_STAGE_OBB) && !c->h_verts_valid) {
+  // Windows: with the host hull in play the batch can be walked in windows of SHOULDER_WINDOW humeri; all device work of
+  // a window is only enqueued, so the hulls of the next window are computed while it runs (off by default).
+  int wsize = SH_WINDOW;
+  if (const char* e = getenv("SHOULDER_WINDOW")) { int v = atoi(e); if (v > 0) wsize = v; }     // tests exercise small windows
+  const int win = ((mask & SH_STAGE_OBB) && B > wsize) ? wsize : B;
+  // hulls prepared by the background thread during the previous run (sh_set_overlap)?
+  int prepared = -1;
+  if (c->prep.active) {
+    int prc = join_prepared(c);
+    if ((mask & SH_STAGE_OBB) && win == B && prc == SH_OK && c->prep.gen == c->batch_gen && c->prep.B == B) { prepared = c->prep.slot; c->hslot = prepared ^ 1; }
+  }
+  if ((mask & SH_STAGE_OBB) && prepared < 0 && !c->h_verts_valid) {
     // device-generated batch: the host hull needs the vertices (every run: a new batch is new data)
     auto t0 = std::chrono::steady_clock::now();
     c->h_verts.resize(3 * (size_t)c->sumV);
@@ -889,16 +978,13 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->timing) { KTimer& a = c->timers["host.verts_d2h"]; a.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); a.n += 1; }
   }
-  // Windows: with the host hull in play the batch is walked in windows of SH_WINDOW humeri; all device work of a
-  // window is only enqueued, so the hulls of the next window are computed while it runs.
-  int wsize = SH_WINDOW;
-  if (const char* e = getenv("SHOULDER_WINDOW")) { int v = atoi(e); if (v > 0) wsize = v; }     // tests exercise small windows
-  const int win = ((mask & SH_STAGE_OBB) && B > wsize) ? wsize : B;
   int rc = SH_OK, widx = 0;
   for (int b0 = 0; b0 < B && rc == SH_OK; b0 += win, ++widx) {
     c->b0 = b0; c->Bwin = std::min(win, B - b0);
-    rc = run_window(c, mask, widx);
+    rc = run_window(c, mask, widx == 0 ? prepared : -1);
   }
+  // everything of this run is enqueued: the host is free until the device is done -> hulls of the next run
+  if (rc == SH_OK && c->overlap && (mask & SH_STAGE_OBB) && win == B) start_prepare(c);
   c->b0 = 0; c->Bwin = B;
   if (mask & SH_STAGE_OBB) c->obb_injected = true;
   if (rc != SH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }

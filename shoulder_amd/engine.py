@@ -166,6 +166,13 @@ class Engine:
     def enable_timing(self, on=True):
         self._chk(self.L.sh_enable_timing(self.h, 1 if on else 0))
 
+    def set_overlap(self, on=True):
+        """Streaming runs on the resident batch: compute the host hulls of the next run while the device works on this one."""
+        self._chk(self.L.sh_set_overlap(self.h, 1 if on else 0))
+
+    def discard_prepared(self):
+        self._chk(self.L.sh_discard_prepared(self.h))
+
     def reset_timers(self):
         self._chk(self.L.sh_kernel_time_ms(self.h, None, None, None))
 

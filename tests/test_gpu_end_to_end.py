@@ -126,3 +126,36 @@ def test_synthetic_batch_equivariance(engine, oracle_bones):
     v = engine.fetch("verts", np.float32, (B, len(h.verts), 3))
     for b in range(B):
         np.testing.assert_array_equal(v[b], synth.apply_similarity(T[b], h.verts))
+
+
+def test_overlapped_hulls_identical_and_invalidated(engine, oracle_bones):
+    """sh_set_overlap: hulls prepared in the background during run k give run k+1 bit-identical records, and a new
+    batch (other transforms) voids them."""
+    h = oracle_bones("humerus_left")
+    verts, faces = h.verts, h.faces
+    B = 6
+    T1 = synth.similarity_transforms(B, verts, seed=7)
+    T2 = synth.similarity_transforms(B, verts, seed=8)
+    def batch(T):      # sh_synth_batch copies mesh 0 of the CURRENT batch: start from the template every time
+        engine.upload([(verts, faces)])
+        engine.synth_batch(T)
+    batch(T1)
+    ref1 = engine.run(_lib.STAGE_ALL).copy()
+    batch(T2)
+    ref2 = engine.run(_lib.STAGE_ALL).copy()
+    batch(T1)
+    engine.set_overlap(True)
+    try:
+        a = engine.run(_lib.STAGE_ALL).copy()       # inline hulls, prepares the next run
+        b = engine.run(_lib.STAGE_ALL).copy()       # uses the prepared hulls
+        c = engine.run(_lib.STAGE_ALL).copy()
+        batch(T2)                                   # prepared hulls belong to the old batch
+        d = engine.run(_lib.STAGE_ALL).copy()
+        e = engine.run(_lib.STAGE_ALL).copy()
+    finally:
+        engine.set_overlap(False)
+        engine.discard_prepared()
+    for r in (a, b, c):
+        assert r.tobytes() == ref1.tobytes()
+    for r in (d, e):
+        assert r.tobytes() == ref2.tobytes()
