@@ -77,23 +77,65 @@ __global__ void k_init_bounds(unsigned long long* zb_enc, int B) {
   if (i < 2 * B) zb_enc[i] = (i & 1) ? 0ull : ~0ull;
 }
 
+// k-th smallest (0-based) of n NON-NEGATIVE doubles by one 64-lane workgroup: radix select on the bit patterns (which order
+// like the values), one byte per pass -- the same value any selection algorithm returns (sh::kth_smallest on the host).
+// hist: 256 counters + 2 words in LDS.
+__device__ inline double wave_kth_smallest_nonneg(const double* v, int n, int k, unsigned* hist) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long prefix = 0, mask = 0;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    for (int i = lane; i < 256; i += 64) hist[i] = 0;
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+      const unsigned long long u = (unsigned long long)__double_as_longlong(v[i]);
+      if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    const unsigned c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+    const unsigned tot = c0 + c1 + c2 + c3;
+    unsigned incl = tot;
+    for (int off = 1; off < 64; off <<= 1) { unsigned o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+    const unsigned excl = incl - tot;
+    if ((unsigned)k >= excl && (unsigned)k < incl) {      // exactly one lane owns the bin that holds rank k
+      unsigned r = (unsigned)k - excl, bin = 4 * lane;
+      if (r >= c0) { r -= c0; ++bin; if (r >= c1) { r -= c1; ++bin; if (r >= c2) { r -= c2; ++bin; } } }
+      hist[256] = bin; hist[257] = r;
+    }
+    __syncthreads();
+    prefix |= (unsigned long long)hist[256] << shift;
+    mask |= 0xffull << shift;
+    k = (int)hist[257];
+    __syncthreads();
+  }
+  return __longlong_as_double((long long)prefix);
+}
+
 // surgical_neck.py:22-34: KernelCPD on areas1((0.70,0.99)) -> neck_z = zs_cut[bkp]
-// One workgroup (64 lanes) per humerus: lane 0 finds gamma (median of the pairwise squared
-// distances), all lanes fill the Gram matrix, each lane evaluates the cost of some breakpoints with
+// One workgroup (64 lanes) per humerus: gamma = 1 / median of the pairwise squared distances (sh::cpd_gamma) by a
+// radix select over all lanes, all lanes fill the Gram matrix, each lane evaluates the cost of some breakpoints with
 // the same arithmetic as sh::cpd_one_bkp, first minimum wins.
 __global__ void __launch_bounds__(64)
 k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* __restrict__ neck_z, int* __restrict__ neck_index, int B) {
   __shared__ double K[SH_CPD_MAXN * SH_CPD_MAXN];
-  __shared__ double gamma_s;
+  __shared__ unsigned hist[258];
   int b = blockIdx.x, lane = threadIdx.x;
   int a, e;
   cutoff_range(SH_NFULL, 0.70, 0.99, &a, &e);
   int n = e - a;
   if (n > SH_CPD_MAXN) n = SH_CPD_MAXN;
   const double* x = areas + (size_t)b * SH_NFULL + a;
-  if (lane == 0) gamma_s = cpd_gamma(x, n, K);       // median select on the pairwise distances, in LDS (K is free until the Gram fill)
+  // pairwise squared distances in K (free until the Gram fill): row i holds j > i
+  for (int i = 0; i < n; ++i) {
+    const int base = i * n - i * (i + 1) / 2 - (i + 1);      // index of (i, j) = base + j
+    for (int j = i + 1 + lane; j < n; j += 64) { double d = x[i] - x[j]; K[base + j] = d * d; }
+  }
   __syncthreads();
-  double gamma = gamma_s;
+  const int np_ = n * (n - 1) / 2;
+  double med;
+  if (np_ & 1) med = wave_kth_smallest_nonneg(K, np_, np_ / 2, hist);
+  else { double lo = wave_kth_smallest_nonneg(K, np_, np_ / 2 - 1, hist); double hi = wave_kth_smallest_nonneg(K, np_, np_ / 2, hist); med = (lo + hi) / 2.0; }
+  const double gamma = (med == 0.0) ? 1.0 : 1.0 / med;
+  __syncthreads();
   for (int q = lane; q < n * n; q += 64) K[q] = cpd_kernel(x[q / n], x[q % n], gamma);
   __syncthreads();
   double best = 1e300;

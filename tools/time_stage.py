@@ -20,5 +20,5 @@ for _ in range(5): run()
 import bench
 names = list(bench.GEOM_KERNELS) + ["host.hull", "host.verts_d2h", "unet.pool", "unet.enc0a", "unet.head"] + list(bench.unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512, eb=2))
 rows = [(k,) + eng.kernel_time_ms(k) for k in names]
-for k, ms, n in sorted(rows, key=lambda r: -r[1] * r[2])[:14]:
+for k, ms, n in sorted(rows, key=lambda r: -r[1] * r[2])[:int(os.environ.get("TOPN", "14"))]:
     if n: print("%-28s %8.3f ms x %.1f per run" % (k, ms, n / 5))
