@@ -108,7 +108,8 @@ def main():
     ap.add_argument("--unet", choices=["f32", "bf16"], default="bf16",
                     help="UNet arithmetic: bf16 = BASELINE configs[2]/[3] (throughput), f32 = configs[1] parity path (bit-exact vs the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-meshes", type=int, default=4)
+    ap.add_argument("--cpu-meshes", type=int, default=4, help="humeri of the batch the single-core oracle leg processes")
+    ap.add_argument("--cpu-pool", type=int, default=-1, help="worker processes of the pooled oracle leg (one humerus each); -1 = host cores of this process, at most 16; 0 = skip")
     ap.add_argument("--no-overlap", action="store_true", help="do not compute the host hulls of step k+1 during the device work of step k")
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     args = ap.parse_args()
@@ -136,8 +137,12 @@ def main():
     verts, faces = load_stl(os.path.join(ROOT, "tests", "golden", "bones", "humerus_left.stl"))   # host I/O, outside the timed region
     V, F, B = len(verts), len(faces), args.batch
 
-    eng = Engine(local)
     weights = unet_spec.make_teacher_weights()
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        # before anything touches the GPU: the pooled leg starts worker processes
+        cpu = cpu_baseline(verts, faces, synth.similarity_transforms(B, verts, seed=1234), weights, args.cpu_meshes, args.cpu_pool)
+    eng = Engine(local)
     if rank == 0:
         eng.load_rfc()
         eng.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
@@ -259,10 +264,6 @@ def main():
         unet_tf = sum(v[0] for v in ul.values()) * B / (unet_ms * 1e-3) / 1e12 if unet_ms else None
         top = sorted(((k, round(v["ms"] / args.steps, 3)) for k, v in sym.items()), key=lambda kv: -kv[1])[:10]
 
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(verts, faces, T, weights, args.cpu_meshes)
-
         value = world * B * args.steps / el
         out = {"metric": "humerus meshes/s end-to-end (all 4 landmarks)", "value": round(value, 3), "unit": "meshes/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True,
@@ -282,8 +283,26 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(verts, faces, T, weights, n_meshes):
-    """The oracle (port of the reference's CPU path) on the first n_meshes synthetic humeri, 1 thread."""
+def _oracle_one(i):
+    """Worker of the pooled CPU leg: humerus i of the synthetic batch through the oracle; returns its wall time."""
+    from threadpoolctl import threadpool_limits
+    from oracle import rfc
+    from oracle.humerus import OracleHumerus
+    from shoulder_amd import synth, unet_spec
+    from shoulder_amd.stl import load_stl
+    verts, faces = load_stl(os.path.join(ROOT, "tests", "golden", "bones", "humerus_left.stl"))
+    tab = rfc.load_tables(os.path.join(ROOT, "shoulder_amd", "models", "rfc_bg3.npz"))
+    weights = unet_spec.make_teacher_weights()
+    T = synth.similarity_transforms(i + 1, verts, seed=1234)      # prefix-stable: row i is humerus i of any batch
+    t0 = time.perf_counter()
+    with threadpool_limits(limits=1):
+        OracleHumerus(synth.apply_similarity(T[i], verts), faces, tab, weights, unet_eval="f64").landmarks()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(verts, faces, T, weights, n_meshes, pool):
+    """The oracle (port of the reference's CPU path) on the first n_meshes synthetic humeri with 1 thread, and -- SURVEY
+    8(d)(ii) -- one humerus per worker process on the host cores this process may use."""
     from threadpoolctl import threadpool_limits
     from oracle import rfc
     from oracle.humerus import OracleHumerus
@@ -295,8 +314,21 @@ def cpu_baseline(verts, faces, T, weights, n_meshes):
             h = OracleHumerus(synth.apply_similarity(T[i], verts), faces, tab, weights, unet_eval="f64")
             h.landmarks()
     el = time.perf_counter() - t0
-    return {"value": round(n_meshes / el, 4), "unit": "meshes/s", "cores": 1, "kind": "port",
-            "sample": f"{n_meshes} of the batch's synthetic humeri, all stages, NumPy/SciPy oracle, BLAS limited to 1 thread, {el:.1f} s"}
+    out = {"value": round(n_meshes / el, 4), "unit": "meshes/s", "cores": 1, "kind": "port",
+           "sample": f"{n_meshes} of the batch's synthetic humeri, all stages, NumPy/SciPy oracle, BLAS limited to 1 thread, {el:.1f} s"}
+    if pool < 0:
+        pool = min(16, len(os.sched_getaffinity(0)))
+    pool = min(pool, len(T))
+    if pool > 1:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        t0 = time.perf_counter()
+        with ProcessPoolExecutor(max_workers=pool, mp_context=mp.get_context("spawn")) as ex:
+            list(ex.map(_oracle_one, range(pool)))
+        elp = time.perf_counter() - t0
+        out["pool"] = {"value": round(pool / elp, 4), "unit": "meshes/s", "cores": pool,
+                       "sample": f"{pool} humeri, one per worker process (spawn, start-up and imports included), {elp:.1f} s"}
+    return out
 
 
 if __name__ == "__main__":

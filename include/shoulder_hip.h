@@ -149,6 +149,11 @@ int  sh_buffer_info(sh_ctx*, const char* name, size_t* nbytes, int* elem_size);
 int  sh_fetch(sh_ctx*, const char* name, void* host, size_t nbytes);
 int  sh_store(sh_ctx*, const char* name, const void* host, size_t nbytes);
 
+/* The anatomic-neck network alone (replaces the `onnxruntime.InferenceSession.run` call of
+ * humerus/anatomic_neck.py:67-76): n images [n][H][W] float32 (host) -> logits [n][H][W] float32
+ * (host), computed in sh_params.unet_dtype.  H and W must be multiples of 16 << depth. */
+int  sh_unet_infer(sh_ctx*, const float* images, int n, int H, int W, float* logits);
+
 /* Average duration (ms) of the named kernel over the launches since the last reset, measured
  * with HIP events on the ctx stream (bench.py roofline); name NULL resets all timers. */
 int  sh_kernel_time_ms(sh_ctx*, const char* kernel, double* avg_ms, int* launches);

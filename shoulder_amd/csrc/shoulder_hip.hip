@@ -670,6 +670,27 @@ static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int n
   return SH_OK;
 }
 
+// The network alone (the `ort.InferenceSession.run` call of anatomic_neck.py:67-76): n images
+// [n][H][W] float32 on the host -> logits [n][H][W] float32 on the host, in the precision sh_params.unet_dtype selects.
+int sh_unet_infer(sh_ctx* c, const float* images, int n, int H, int W, float* logits) {
+  if (!c || !images || !logits || n <= 0 || H <= 0 || W <= 0) return fail(c, SH_ERR_ARG, "sh_unet_infer: bad argument");
+  if (c->ulayers.empty()) return fail(c, SH_ERR_STATE, "sh_unet_infer: no UNet weights loaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t bytes = (size_t)n * H * W * 4;
+  int rc;
+  if ((rc = ensure(c, "infer.image", bytes, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "infer.logits", bytes, 4)) != SH_OK) return rc;
+  const int b0 = c->b0; c->b0 = 0;      // named buffers below are whole-batch
+  HIPCHK(c, hipMemcpyAsync(buf<float>(c, "infer.image"), images, bytes, hipMemcpyHostToDevice, c->stream));
+  rc = c->params.unet_dtype == SH_UNET_BF16 ? unet_forward_bf16(c, buf<float>(c, "infer.image"), buf<float>(c, "infer.logits"), n, H, W)
+                                            : unet_forward(c, buf<float>(c, "infer.image"), buf<float>(c, "infer.logits"), n, H, W);
+  c->b0 = b0;
+  if (rc != SH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+  HIPCHK(c, hipMemcpyAsync(logits, buf<float>(c, "infer.logits"), bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+
 // ---- stage runner ----------------------------------------------------------------------------------
 static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0) {
   const int B = c->Bwin;

@@ -162,6 +162,15 @@ class Engine:
         arr = np.ascontiguousarray(arr)
         self._chk(self.L.sh_store(self.h, name.encode(), _ptr(arr), arr.nbytes))
 
+    def unet_infer(self, images):
+        """The anatomic-neck network alone: images (n, H, W) float32 -> logits (n, H, W) float32 (anatomic_neck.py:67-76)."""
+        x = np.ascontiguousarray(images, dtype=np.float32)
+        if x.ndim != 3:
+            raise ValueError("images must have shape (n, H, W)")
+        out = np.empty_like(x)
+        self._chk(self.L.sh_unet_infer(self.h, _ptr(x), x.shape[0], x.shape[1], x.shape[2], _ptr(out)))
+        return out
+
     # ---- timing --------------------------------------------------------------------------------------
     def enable_timing(self, on=True):
         self._chk(self.L.sh_enable_timing(self.h, 1 if on else 0))

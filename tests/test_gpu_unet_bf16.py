@@ -39,3 +39,28 @@ def test_bf16_logits_and_mask(engine, oracle_bones, unet_weights):
     assert np.abs(lm16["anp_plane_point"] - lm32["anp_plane_point"]).max() < 0.3
     assert np.abs(lm16["anp_axis_central"] - lm32["anp_axis_central"]).max() < 1.0
     assert abs(int(lm16["n_anp"]) - int(lm32["n_anp"])) < 0.1 * int(lm32["n_anp"])
+
+
+def test_unet_alone_256x512(engine, unet_weights):
+    """the network alone on [B,1,256,512] inputs U(0,1), seed 1234 (bf16 here instead of fp16: the
+    product's throughput dtype), through sh_unet_infer; f32 path bit-exact against the C fma-chain restatement."""
+    rng = np.random.default_rng(1234)
+    img = rng.random((2, 256, 512), dtype=np.float32)
+    engine.set_params(unet_dtype=_lib.UNET_F32)
+    try:
+        lo32 = engine.unet_infer(img)
+        engine.set_params(unet_dtype=_lib.UNET_BF16)
+        lo16 = engine.unet_infer(img)
+    finally:
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+    ref = np.stack([o_unet.forward_chain(unet_weights, img[i]) for i in range(2)])
+    assert lo32.dtype == np.float32 and lo32.shape == img.shape
+    assert np.array_equal(lo32, ref)                      # one fma chain per output: bit for bit
+    assert float(np.abs(lo16 - ref).max()) < 0.08
+
+
+def test_unet_infer_rejects_bad_shapes(engine):
+    with pytest.raises(Exception):
+        engine.unet_infer(np.zeros((1, 250, 512), np.float32))      # not a multiple of 16 << depth
+    with pytest.raises(ValueError):
+        engine.unet_infer(np.zeros((512, 512), np.float32))
