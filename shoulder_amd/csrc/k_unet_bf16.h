@@ -43,10 +43,27 @@ __global__ void k_pack_w_bf16(const float* __restrict__ src, __bf16* __restrict_
   }
 }
 
-template <int TAPS, int NT>
+// Fusions at the memory-bound ends of the network (the 32-channel level moves 1.07 GB per tensor at B = 64):
+//   UF_FIRST  the layer's input is the 1-channel image: the 32-channel activations of the first conv (enc0a, VALU,
+//             same fmaf chain as k_conv_first_bf16) are computed into the halo tile instead of being read from HBM
+//   UF_HEAD   the 1x1 head is applied to the f32 accumulators in the epilogue; only the logits are written
+//   UF_POOL   the epilogue also writes the 2x2 max-pooled tensor (input of the next encoder level)
+enum { UF_FIRST = 1, UF_HEAD = 2, UF_POOL = 4 };
+struct ConvFuse {
+  const float* image;      // UF_FIRST: [nimg][H][W] f32
+  const float* w0;         // UF_FIRST: first conv weights [9][32] f32
+  const float* b0;         // UF_FIRST: first conv bias [32]
+  const float* head_w;     // UF_HEAD:  [Cout] f32
+  const float* head_b;     // UF_HEAD:  [1]
+  float* logits;           // UF_HEAD:  [nimg][H][W] f32
+  __bf16* pooled;          // UF_POOL:  [nimg][H/2][W/2][Cout] bf16
+};
+
+template <int TAPS, int NT, int FUSE = 0>
 __global__ void __launch_bounds__(UN_THREADS)
 k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src1, int C0, int C1,
-                 const __bf16* __restrict__ wgt, const float* __restrict__ bias, __bf16* __restrict__ dst, int H, int W, int Cout, int relu) {
+                 const __bf16* __restrict__ wgt, const float* __restrict__ bias, __bf16* __restrict__ dst, int H, int W, int Cout, int relu,
+                 ConvFuse fz) {
   constexpr int HALO = TAPS == 9 ? 1 : 0;
   constexpr int PW = UN_TW + 2 * HALO, PH = UN_TH + 2 * HALO;
   constexpr int NC = 16 * NT;
@@ -54,6 +71,12 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
   constexpr int NIN = (IN_PIECES + UN_THREADS - 1) / UN_THREADS, NWT = (WT_PIECES + UN_THREADS - 1) / UN_THREADS;
   __shared__ __attribute__((aligned(16))) __bf16 s_in[PH * PW * UB_PSTR];
   __shared__ __attribute__((aligned(16))) __bf16 s_w[TAPS * NC * UB_PSTR];
+  __shared__ float s_w0[(FUSE & UF_FIRST) ? 9 * 32 + 32 : 1];
+  if (FUSE & UF_FIRST) {
+    for (int e = threadIdx.x; e < 9 * 32; e += UN_THREADS) s_w0[e] = fz.w0[e];
+    if (threadIdx.x < 32) s_w0[9 * 32 + threadIdx.x] = fz.b0[threadIdx.x];
+    __syncthreads();
+  }
   const int Cin = C0 + C1;
   const int tiles_x = W / UN_TW;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -97,7 +120,29 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (in_pix[k] >= 0) v = *(const u32x4*)(src + (size_t)in_pix[k] * Cs + cb + ((tid + k * UN_THREADS) & 3) * 8);
+      if (FUSE & UF_FIRST) {
+        if (in_pix[k] >= 0) {      // enc0a at this halo pixel, channels 8q..8q+7: relu(b + sum_t img[t] * w[t][c]), one fmaf chain
+          const int gy = in_pix[k] / W, gx = in_pix[k] - gy * W, q8 = ((tid + k * UN_THREADS) & 3) * 8;
+          const float* im = fz.image + (size_t)img * H * W;
+          float t9[9];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
+            t9[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? im[(size_t)yy * W + xx] : 0.0f;
+          }
+          bf16x8 ov;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            float a = s_w0[9 * 32 + q8 + c];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = __builtin_fmaf(t9[t], s_w0[t * 32 + q8 + c], a);
+            ov[c] = (__bf16)fmaxf(a, 0.0f);
+          }
+          v = __builtin_bit_cast(u32x4, ov);
+        }
+      } else {
+        if (in_pix[k] >= 0) v = *(const u32x4*)(src + (size_t)in_pix[k] * Cs + cb + ((tid + k * UN_THREADS) & 3) * 8);
+      }
       rin[k] = v;
     }
 #pragma unroll
@@ -142,6 +187,29 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
     }
   }
   const int OW = TAPS == 9 ? W : 2 * W, OH = TAPS == 9 ? H : 2 * H;
+  if (FUSE & UF_HEAD) {
+    // logits = head_b + sum_c head_w[c] * relu(acc[c]): this lane holds 4 NT of the Cout values of its pixels, the other
+    // three quarters sit in lanes li + 16, + 32, + 48
+    float hw[NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hw[n][r] = fz.head_w[n0 + n * 16 + lk * 4 + r];
+    const float hb = fz.head_b[0];
+    float* lg = fz.logits + (size_t)img * H * W;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float p = 0.0f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p = __builtin_fmaf(fmaxf(acc[m][n][r], 0.0f), hw[n][r], p);
+      p += __shfl_xor(p, 16);
+      p += __shfl_xor(p, 32);
+      if (lk == 0) lg[(size_t)(y0 + wave * 4 + m) * W + x0 + li] = hb + p;
+    }
+    return;
+  }
   __bf16* out = dst + (size_t)img * OH * OW * Cout;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -158,6 +226,26 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
       }
       *(bf16x4*)(out + ((size_t)oy * OW + ox) * Cout + n0 + n * 16 + lk * 4) = o;
     }
+  }
+  if (FUSE & UF_POOL) {
+    // 2x2 max pool of this wave's 4 rows x 16 pixels: rows pair inside the lane, columns pair with lane li ^ 1
+    // (max commutes with the monotone bf16 rounding, so this equals pooling the stored tensor)
+    __bf16* po = fz.pooled + (size_t)img * (H / 2) * (W / 2) * Cout;
+#pragma unroll
+    for (int mp = 0; mp < 2; ++mp)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaxf(acc[2 * mp][n][r], acc[2 * mp + 1][n][r]);
+          v = fmaxf(v, __shfl_xor(v, 1));
+          if (relu) v = fmaxf(v, 0.0f);
+          o[r] = (__bf16)v;
+        }
+        if ((li & 1) == 0)
+          *(bf16x4*)(po + ((size_t)((y0 + wave * 4) / 2 + mp) * (W / 2) + (x0 + li) / 2) * Cout + n0 + n * 16 + lk * 4) = o;
+      }
   }
 }
 

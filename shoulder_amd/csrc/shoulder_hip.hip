@@ -589,27 +589,35 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
 
 // ---- UNet forward (bf16 MFMA path) ---------------------------------------------------------------------
 static int conv_layer_bf16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const __bf16* src0, const __bf16* src1, int C0, int C1,
-                           __bf16* dst, int H, int W, int nimg, int relu) {
+                           __bf16* dst, int H, int W, int nimg, int relu, int fuse = 0, ConvFuse fz = ConvFuse{}) {
   if (H % UN_TH || W % UN_TW) return fail(c, SH_ERR_ARG, "unet: feature map is not a multiple of 16");
   const __bf16* w = buf<__bf16>(c, "params_bf16") + L.w_off;
   const float* b = buf<float>(c, "params") + L.b_off;
   const int tiles = (H / UN_TH) * (W / UN_TW);
-  if (L.taps == 9) {
-    if (L.cout % 64 == 0) {
-      LAUNCH(c, lname, (k_conv_mfma_bf16<9, 4>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu);
-    } else {
-      LAUNCH(c, lname, (k_conv_mfma_bf16<9, 2>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu);
-    }
+  const dim3 blk(UN_THREADS);
+  if (L.taps == 9 && L.cout % 64 == 0) {
+    const dim3 g(tiles, L.cout / 64, nimg);
+    if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 4, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 4, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
+  } else if (L.taps == 9) {
+    const dim3 g(tiles, L.cout / 32, nimg);
+    if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 2, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == (UF_FIRST | UF_POOL)) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 2, UF_FIRST | UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 2, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 2, UF_HEAD>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
+  } else if (L.cout % 64 == 0) {
+    LAUNCH(c, lname, (k_conv_mfma_bf16<1, 4, 0>), dim3(tiles, L.cout / 64, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
   } else {
-    if (L.cout % 64 == 0) {
-      LAUNCH(c, lname, (k_conv_mfma_bf16<1, 4>), dim3(tiles, L.cout / 64, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0);
-    } else {
-      LAUNCH(c, lname, (k_conv_mfma_bf16<1, 2>), dim3(tiles, L.cout / 32, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0);
-    }
+    LAUNCH(c, lname, (k_conv_mfma_bf16<1, 2, 0>), dim3(tiles, L.cout / 32, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
   }
   return SH_OK;
 }
 
+// 4-level double-conv UNet, bf16.  With 32 base channels the memory-bound ends are fused (k_unet_bf16.h): the first
+// conv into the staging of enc0b, every 2x2 max pool into the epilogue of the conv before it, the 1x1 head into the
+// epilogue of dec0b.  SHOULDER_UNET_UNFUSED=1 (or another base width) runs the layer-by-layer form.
 static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
   const int D = c->unet_depth, base = c->unet_base;
   if ((H >> D) % 16 || (W >> D) % 16) return fail(c, SH_ERR_ARG, "unet: input size must be a multiple of 16 << depth");
@@ -623,6 +631,8 @@ static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int n
     size_t tot = (size_t)l.taps * l.cin * l.cout;
     LAUNCH(c, "k_pack_w_bf16", k_pack_w_bf16, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), P + l.w_off, PW + l.w_off, l.taps, l.cin, l.cout);
   }
+  const char* unf = getenv("SHOULDER_UNET_UNFUSED");
+  const bool fused = base == 32 && !(unf && unf[0] == '1');
   const size_t full = (size_t)nimg * H * W * base * 2;
   if ((rc = ensure(c, "unet16.a", full, 2)) != SH_OK) return rc;
   if ((rc = ensure(c, "unet16.b", full, 2)) != SH_OK) return rc;
@@ -636,22 +646,39 @@ static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int n
   __bf16* Bq = buf<__bf16>(c, "unet16.b");
   auto L = [&](const std::string& n) -> const sh_ctx::ULayer& { return c->ulayers[n]; };
   int h = H, w = W;
-  {
+  const char* ff = getenv("SHOULDER_UNET_FUSE_FIRST");
+  if (fused && ff && ff[0] == '1') {
+    const sh_ctx::ULayer& l = L("enc0a");
+    ConvFuse fz{};
+    fz.image = image; fz.w0 = P + l.w_off; fz.b0 = P + l.b_off; fz.pooled = A;
+    if ((rc = conv_layer_bf16(c, "unet.enc0b", L("enc0b"), nullptr, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_FIRST | UF_POOL, fz)) != SH_OK) return rc;
+  } else if (fused) {
+    const sh_ctx::ULayer& l = L("enc0a");
+    size_t npx = (size_t)nimg * h * w;
+    LAUNCH(c, "unet.enc0a", k_conv_first_bf16, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, Bq, h, w, l.cout, nimg);
+    ConvFuse fz{};
+    fz.pooled = A;
+    if ((rc = conv_layer_bf16(c, "unet.enc0b", L("enc0b"), Bq, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_POOL, fz)) != SH_OK) return rc;
+  } else {
     const sh_ctx::ULayer& l = L("enc0a");
     size_t npx = (size_t)nimg * h * w;
     LAUNCH(c, "unet.enc0a", k_conv_first_bf16, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, A, h, w, l.cout, nimg);
+    if ((rc = conv_layer_bf16(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1)) != SH_OK) return rc;
   }
-  if ((rc = conv_layer_bf16(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1)) != SH_OK) return rc;
   int ch = base;
   for (int i = 1; i <= D; ++i) {
-    size_t e = (size_t)nimg * (h / 2) * (w / 2) * (ch / 8);
-    LAUNCH(c, "unet.pool", k_maxpool2_bf16, dim3((unsigned)std::min<size_t>((e + 255) / 256, 8192)), dim3(256), skip[i - 1], A, h, w, ch, nimg);
+    if (!fused) {
+      size_t e = (size_t)nimg * (h / 2) * (w / 2) * (ch / 8);
+      LAUNCH(c, "unet.pool", k_maxpool2_bf16, dim3((unsigned)std::min<size_t>((e + 255) / 256, 8192)), dim3(256), skip[i - 1], A, h, w, ch, nimg);
+    }
     h /= 2; w /= 2;
     std::string na = i < D ? "enc" + std::to_string(i) + "a" : "bota", nb = i < D ? "enc" + std::to_string(i) + "b" : "botb";
     if ((rc = conv_layer_bf16(c, ("unet." + na).c_str(), L(na), A, nullptr, ch, 0, Bq, h, w, nimg, 1)) != SH_OK) return rc;
     ch *= 2;
     __bf16* dst = i < D ? skip[i] : A;
-    if ((rc = conv_layer_bf16(c, ("unet." + nb).c_str(), L(nb), Bq, nullptr, ch, 0, dst, h, w, nimg, 1)) != SH_OK) return rc;
+    ConvFuse fz{};
+    fz.pooled = A;      // (A was consumed by the conv above; the next level reads it)
+    if ((rc = conv_layer_bf16(c, ("unet." + nb).c_str(), L(nb), Bq, nullptr, ch, 0, dst, h, w, nimg, 1, (fused && i < D) ? UF_POOL : 0, fz)) != SH_OK) return rc;
   }
   __bf16* x = A; __bf16* y = Bq;
   for (int i = D - 1; i >= 0; --i) {
@@ -659,6 +686,13 @@ static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int n
     if ((rc = conv_layer_bf16(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
     h *= 2; w *= 2; ch /= 2;
     if ((rc = conv_layer_bf16(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;
+    if (fused && i == 0) {
+      const sh_ctx::ULayer& l = L("head");
+      ConvFuse fz{};
+      fz.head_w = P + l.w_off; fz.head_b = P + l.b_off; fz.logits = logits;
+      if ((rc = conv_layer_bf16(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1, UF_HEAD, fz)) != SH_OK) return rc;
+      return SH_OK;
+    }
     if ((rc = conv_layer_bf16(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1)) != SH_OK) return rc;
     std::swap(x, y);
   }

@@ -64,3 +64,26 @@ def test_unet_infer_rejects_bad_shapes(engine):
         engine.unet_infer(np.zeros((1, 250, 512), np.float32))      # not a multiple of 16 << depth
     with pytest.raises(ValueError):
         engine.unet_infer(np.zeros((512, 512), np.float32))
+
+
+def test_fused_ends_match_layerwise(engine, monkeypatch):
+    """bf16 path: first conv fused into enc0b's staging and pools fused into epilogues are bit-identical to the layer-by-layer
+    kernels (same fmaf chain; max commutes with the bf16 rounding); the fused head sums the 32 products of a pixel in
+    another order and from unrounded f32 activations, so logits agree to bf16-activation precision only."""
+    rng = np.random.default_rng(99)
+    img = rng.random((2, 256, 256), dtype=np.float32)
+    engine.set_params(unet_dtype=_lib.UNET_BF16)
+    try:
+        fused = engine.unet_infer(img)
+        skip_f = engine.fetch("unet16.skip1", np.uint16)
+        monkeypatch.setenv("SHOULDER_UNET_UNFUSED", "1")
+        plain = engine.unet_infer(img)
+        skip_p = engine.fetch("unet16.skip1", np.uint16)
+    finally:
+        monkeypatch.delenv("SHOULDER_UNET_UNFUSED", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+    n = 2 * 128 * 128 * 64
+    assert np.array_equal(skip_f[:n], skip_p[:n])          # level-1 skip tensor: downstream of fused first conv + fused pool
+    assert float(np.abs(fused - plain).max()) < 0.03
+    band = np.abs(plain) > 0.05
+    assert np.array_equal((fused > 0)[band], (plain > 0)[band])

@@ -88,8 +88,8 @@ int main(int argc, char** argv) {
   auto launch = [&]() {
     const int tiles = (H / 16) * (W / 16);
     if (kern == "base") {
-      if (Cout % 64 == 0) hipLaunchKernelGGL((k_conv_mfma_bf16<9, 4>), dim3(tiles, Cout / 64, nimg), dim3(256), 0, 0, src, (const __bf16*)nullptr, Cin, 0, wpk, bias, dst, H, W, Cout, 1);
-      else hipLaunchKernelGGL((k_conv_mfma_bf16<9, 2>), dim3(tiles, Cout / 32, nimg), dim3(256), 0, 0, src, (const __bf16*)nullptr, Cin, 0, wpk, bias, dst, H, W, Cout, 1);
+      if (Cout % 64 == 0) hipLaunchKernelGGL((k_conv_mfma_bf16<9, 4>), dim3(tiles, Cout / 64, nimg), dim3(256), 0, 0, src, (const __bf16*)nullptr, Cin, 0, wpk, bias, dst, H, W, Cout, 1, ConvFuse{});
+      else hipLaunchKernelGGL((k_conv_mfma_bf16<9, 2>), dim3(tiles, Cout / 32, nimg), dim3(256), 0, 0, src, (const __bf16*)nullptr, Cin, 0, wpk, bias, dst, H, W, Cout, 1, ConvFuse{});
     } else if (kern.rfind("abl", 0) == 0) {
       int a = atoi(kern.c_str() + 3);
       launch_ablate(a, tiles, src, Cin, wpk, bias, dst, H, W, Cout, nimg);
