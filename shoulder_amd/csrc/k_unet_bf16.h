@@ -44,8 +44,10 @@ __global__ void k_pack_w_bf16(const float* __restrict__ src, __bf16* __restrict_
 }
 
 // Fusions at the memory-bound ends of the network (the 32-channel level moves 1.07 GB per tensor at B = 64):
-//   UF_FIRST  the layer's input is the 1-channel image: the 32-channel activations of the first conv (enc0a, VALU,
-//             same fmaf chain as k_conv_first_bf16) are computed into the halo tile instead of being read from HBM
+//   UF_FIRST  the layer's input is the 1-channel image: the 32-channel activations of the first conv (enc0a) are
+//             computed into the halo tile on the matrix cores instead of being read from HBM -- one MFMA per 16
+//             halo pixels x 16 channels with K = 9 taps of the image's bf16 high part + 9 taps of its low part
+//             (image precision ~2^-17) against the bf16-rounded first-layer weights
 //   UF_HEAD   the 1x1 head is applied to the f32 accumulators in the epilogue; only the logits are written
 //   UF_POOL   the epilogue also writes the 2x2 max-pooled tensor (input of the next encoder level)
 enum { UF_FIRST = 1, UF_HEAD = 2, UF_POOL = 4 };
@@ -71,12 +73,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
   constexpr int NIN = (IN_PIECES + UN_THREADS - 1) / UN_THREADS, NWT = (WT_PIECES + UN_THREADS - 1) / UN_THREADS;
   __shared__ __attribute__((aligned(16))) __bf16 s_in[PH * PW * UB_PSTR];
   __shared__ __attribute__((aligned(16))) __bf16 s_w[TAPS * NC * UB_PSTR];
-  __shared__ float s_w0[(FUSE & UF_FIRST) ? 9 * 32 + 32 : 1];
-  if (FUSE & UF_FIRST) {
-    for (int e = threadIdx.x; e < 9 * 32; e += UN_THREADS) s_w0[e] = fz.w0[e];
-    if (threadIdx.x < 32) s_w0[9 * 32 + threadIdx.x] = fz.b0[threadIdx.x];
-    __syncthreads();
-  }
+  __shared__ float s_img[(FUSE & UF_FIRST) ? (UN_TH + 4) * (UN_TW + 4) : 1];
   const int Cin = C0 + C1;
   const int tiles_x = W / UN_TW;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -120,29 +117,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (FUSE & UF_FIRST) {
-        if (in_pix[k] >= 0) {      // enc0a at this halo pixel, channels 8q..8q+7: relu(b + sum_t img[t] * w[t][c]), one fmaf chain
-          const int gy = in_pix[k] / W, gx = in_pix[k] - gy * W, q8 = ((tid + k * UN_THREADS) & 3) * 8;
-          const float* im = fz.image + (size_t)img * H * W;
-          float t9[9];
-#pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
-            t9[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? im[(size_t)yy * W + xx] : 0.0f;
-          }
-          bf16x8 ov;
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            float a = s_w0[9 * 32 + q8 + c];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) a = __builtin_fmaf(t9[t], s_w0[t * 32 + q8 + c], a);
-            ov[c] = (__bf16)fmaxf(a, 0.0f);
-          }
-          v = __builtin_bit_cast(u32x4, ov);
-        }
-      } else {
-        if (in_pix[k] >= 0) v = *(const u32x4*)(src + (size_t)in_pix[k] * Cs + cb + ((tid + k * UN_THREADS) & 3) * 8);
-      }
+      if (!(FUSE & UF_FIRST) && in_pix[k] >= 0) v = *(const u32x4*)(src + (size_t)in_pix[k] * Cs + cb + ((tid + k * UN_THREADS) & 3) * 8);
       rin[k] = v;
     }
 #pragma unroll
@@ -151,10 +126,59 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int k = 0; k < NIN; ++k) if (in_lds[k] >= 0) *(u32x4*)(s_in + in_lds[k]) = rin[k];
+    for (int k = 0; k < NIN; ++k) if (!(FUSE & UF_FIRST) && in_lds[k] >= 0) *(u32x4*)(s_in + in_lds[k]) = rin[k];
 #pragma unroll
     for (int k = 0; k < NWT; ++k) if (wt_lds[k] >= 0) *(u32x4*)(s_w + wt_lds[k]) = rwt[k];
   };
+  if (FUSE & UF_FIRST) {
+    // enc0a on the halo tile.  k = 0..8: tap k of the image's bf16 high part, k = 9..17: tap k - 9 of its low part
+    // (v - hi), k >= 18: zero; the weight fragment repeats w[tap] for both parts.
+    constexpr int IW = UN_TW + 4;
+    const float* im = fz.image + (size_t)img * H * W;
+    for (int e = tid; e < (UN_TH + 4) * IW; e += UN_THREADS) {
+      const int gy = y0 - 2 + e / IW, gx = x0 - 2 + e % IW;
+      s_img[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.0f;
+    }
+    bf16x8 wA[2];
+    f32x4 b0v[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = lk * 8 + j, t = k < 9 ? k : (k < 18 ? k - 9 : 0);
+        const float wv = fz.w0[t * 32 + n * 16 + li];
+        wA[n][j] = k < 18 ? (__bf16)wv : (__bf16)0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b0v[n][r] = fz.b0[n * 16 + lk * 4 + r];
+    }
+    __syncthreads();
+    for (int g = wave; g < (PH * PW + 15) / 16; g += UN_THREADS / 64) {
+      const int p = 16 * g + li, pc = p < PH * PW ? p : PH * PW - 1;
+      const int py = pc / PW, px = pc - py * PW;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const int base = py * IW + px;          // patch index of tap (0,0) of this pixel
+      bf16x8 bf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = lk * 8 + j, t = k < 9 ? k : (k < 18 ? k - 9 : 0);
+        const int t3 = (t * 11) >> 5;         // t / 3 for t <= 8
+        const float v = s_img[base + t + (IW - 3) * t3];
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
+        bf[j] = k < 9 ? hi : (k < 18 ? lo : (__bf16)0.0f);
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[n], bf, b0v[n], 0, 0, 0);
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = inside ? (__bf16)fmaxf(a[r], 0.0f) : (__bf16)0.0f;      // outside the image: enc0b's zero padding
+        if (p < PH * PW) *(bf16x4*)(s_in + UB_OFF(p, n * 2 + (lk >> 1)) + (lk & 1) * 4) = o;
+      }
+    }
+  }
 
   f32x4 acc[4][NT];
 #pragma unroll

@@ -647,7 +647,7 @@ static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int n
   auto L = [&](const std::string& n) -> const sh_ctx::ULayer& { return c->ulayers[n]; };
   int h = H, w = W;
   const char* ff = getenv("SHOULDER_UNET_FUSE_FIRST");
-  if (fused && ff && ff[0] == '1') {
+  if (fused && !(ff && ff[0] == '0')) {
     const sh_ctx::ULayer& l = L("enc0a");
     ConvFuse fz{};
     fz.image = image; fz.w0 = P + l.w_off; fz.b0 = P + l.b_off; fz.pooled = A;

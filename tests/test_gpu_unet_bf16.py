@@ -67,23 +67,32 @@ def test_unet_infer_rejects_bad_shapes(engine):
 
 
 def test_fused_ends_match_layerwise(engine, monkeypatch):
-    """bf16 path: first conv fused into enc0b's staging and pools fused into epilogues are bit-identical to the layer-by-layer
-    kernels (same fmaf chain; max commutes with the bf16 rounding); the fused head sums the 32 products of a pixel in
-    another order and from unrounded f32 activations, so logits agree to bf16-activation precision only."""
+    """bf16 path.  Pools fused into conv epilogues are bit-identical to the layer-by-layer kernels (max commutes with the
+    bf16 rounding).  The fused first conv runs on the matrix cores with bf16 weights and a hi+lo split image, the fused head
+    sums a pixel's 32 products in another order from unrounded activations: both agree with the layer-by-layer network to
+    bf16-activation precision."""
     rng = np.random.default_rng(99)
     img = rng.random((2, 256, 256), dtype=np.float32)
+    n1 = 2 * 128 * 128 * 64
+    bf = lambda u: (u.astype(np.uint32) << 16).view(np.float32)
     engine.set_params(unet_dtype=_lib.UNET_BF16)
     try:
         fused = engine.unet_infer(img)
-        skip_f = engine.fetch("unet16.skip1", np.uint16)
+        skip_f = engine.fetch("unet16.skip1", np.uint16)[:n1].copy()
+        monkeypatch.setenv("SHOULDER_UNET_FUSE_FIRST", "0")
+        pools = engine.unet_infer(img)
+        skip_q = engine.fetch("unet16.skip1", np.uint16)[:n1].copy()
         monkeypatch.setenv("SHOULDER_UNET_UNFUSED", "1")
         plain = engine.unet_infer(img)
-        skip_p = engine.fetch("unet16.skip1", np.uint16)
+        skip_p = engine.fetch("unet16.skip1", np.uint16)[:n1].copy()
     finally:
         monkeypatch.delenv("SHOULDER_UNET_UNFUSED", raising=False)
+        monkeypatch.delenv("SHOULDER_UNET_FUSE_FIRST", raising=False)
         engine.set_params(unet_dtype=_lib.UNET_F32)
-    n = 2 * 128 * 128 * 64
-    assert np.array_equal(skip_f[:n], skip_p[:n])          # level-1 skip tensor: downstream of fused first conv + fused pool
-    assert float(np.abs(fused - plain).max()) < 0.03
-    band = np.abs(plain) > 0.05
-    assert np.array_equal((fused > 0)[band], (plain > 0)[band])
+    assert np.array_equal(skip_q, skip_p)                  # fused pools: exact
+    d1 = np.abs(bf(skip_f) - bf(skip_p))
+    assert float(d1.max()) <= 0.02 * float(np.abs(bf(skip_p)).max()) + 1e-3      # fused first conv: a few bf16 ulps at level 1
+    for a in (fused, pools):
+        assert float(np.abs(a - plain).max()) < 0.06      # logits of this noise image reach +-3
+        band = np.abs(plain) > 0.08
+        assert np.array_equal((a > 0)[band], (plain > 0)[band])
