@@ -174,26 +174,30 @@ __global__ void k_slice_emit(const double* __restrict__ vobb, const int* __restr
 // jumping for (a) the minimum edge key of each loop (canonical start, B-1) and (b) the rank of
 // every segment from that start.
 #define SH_LINK_THREADS 256
-#define SH_HASH 2048
 #define SH_MAXLOOPS 32
+#define SH_SMALLSEG 256      // tier boundary: planes with at most this many segments take the small-LDS instantiation
 
-__device__ inline uint32_t hash_key(unsigned long long k) {
+__device__ inline uint32_t hash_key64(unsigned long long k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33;
-  return (uint32_t)k & (SH_HASH - 1);
+  return (uint32_t)k;
 }
 
 // select: 0 = largest loop (slice.py:53-59), 1 = loop whose closed-ring vertex mean is nearest
 // the origin in L1 (surgical_neck.py:40-48)
+// Two instantiations share the grid: CAP = SH_SMALLSEG (17 KB of LDS, 8 workgroups per CU) takes the planes with up to
+// 256 segments -- all but a few -- and CAP = SH_MAXSEG (70 KB, 2 per CU) the rest; the other tier's planes exit at once.
+template <int CAP>
 __global__ void __launch_bounds__(SH_LINK_THREADS)
 k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops,
              int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err) {
-  __shared__ unsigned long long skey[SH_MAXSEG];
-  __shared__ unsigned long long bufA[SH_MAXSEG];   // ekey, then label ping, then ring x
-  __shared__ unsigned long long bufB[SH_MAXSEG];   // label pong, then ring y
-  __shared__ double px[SH_MAXSEG], py[SH_MAXSEG];
-  __shared__ int nxt[SH_MAXSEG], jmpA[SH_MAXSEG], jmpB[SH_MAXSEG], rnkA[SH_MAXSEG], rnkB[SH_MAXSEG];
-  __shared__ int table[SH_HASH];
+  constexpr int HASH = 2 * CAP;
+  __shared__ unsigned long long skey[CAP];
+  __shared__ unsigned long long bufA[CAP];   // ekey, then label ping, then ring x
+  __shared__ unsigned long long bufB[CAP];   // label pong, then ring y
+  __shared__ double px[CAP], py[CAP];
+  __shared__ int nxt[CAP], jmpA[CAP], jmpB[CAP], rnkA[CAP], rnkB[CAP];
+  __shared__ int table[HASH];
   __shared__ int l_start[SH_MAXLOOPS], l_len[SH_MAXLOOPS], l_off[SH_MAXLOOPS];
   __shared__ double l_area[SH_MAXLOOPS], l_sel[SH_MAXLOOPS];
   __shared__ int n_loops, bad, best_loop;
@@ -203,9 +207,10 @@ k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ s
   const int b = pl / N;
   const int tid = threadIdx.x;
   int cnt = seg_count[pl];
+  if (CAP == SH_SMALLSEG ? cnt > SH_SMALLSEG : cnt <= SH_SMALLSEG) return;      // the other tier's plane
   const int n = cnt > SH_MAXSEG ? SH_MAXSEG : cnt;
   if (tid == 0) { n_loops = 0; bad = 0; best_loop = 0; bb[0] = bb[2] = ~0ull; bb[1] = bb[3] = 0ull; }
-  for (int i = tid; i < SH_HASH; i += SH_LINK_THREADS) table[i] = -1;
+  for (int i = tid; i < HASH; i += SH_LINK_THREADS) table[i] = -1;
   const Seg* sp = segs + (size_t)pl * SH_MAXSEG;
   for (int i = tid; i < n; i += SH_LINK_THREADS) {
     Seg s = sp[i];
@@ -222,17 +227,17 @@ k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ s
     return;
   }
   for (int i = tid; i < n; i += SH_LINK_THREADS) {
-    uint32_t h = hash_key(skey[i]);
-    while (atomicCAS(&table[h], -1, i) != -1) h = (h + 1) & (SH_HASH - 1);
+    uint32_t h = hash_key64(skey[i]) & (HASH - 1);
+    while (atomicCAS(&table[h], -1, i) != -1) h = (h + 1) & (HASH - 1);
   }
   __syncthreads();
   for (int i = tid; i < n; i += SH_LINK_THREADS) {
     unsigned long long k = bufA[i];
-    uint32_t h = hash_key(k);
+    uint32_t h = hash_key64(k) & (HASH - 1);
     int t, found = -1;
     while ((t = table[h]) != -1) {
       if (skey[t] == k) { found = t; break; }
-      h = (h + 1) & (SH_HASH - 1);
+      h = (h + 1) & (HASH - 1);
     }
     if (found < 0) { found = i; bad = 1; }   // open contour: self-loop keeps the walk bounded
     nxt[i] = found;
@@ -301,7 +306,7 @@ k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ s
   // label buffers are dead from here on: reuse them for the ordered ring
   double* rx = (double*)bufA;
   double* ry = (double*)bufB;
-  int my_pos[ (SH_MAXSEG + SH_LINK_THREADS - 1) / SH_LINK_THREADS ];
+  int my_pos[(CAP + SH_LINK_THREADS - 1) / SH_LINK_THREADS];
   {
     int c = 0;
     for (int i = tid; i < n; i += SH_LINK_THREADS, ++c) {
@@ -385,11 +390,12 @@ k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ s
 // One workgroup per (mesh, plane).  cumsum is sequential (np.cumsum order); each sample is one
 // np.interp evaluation; theta = atan2(y,x), r = sqrt(x^2+y^2); rows rolled to argmin(theta).
 #define SH_RS_THREADS 256
+template <int CAP>
 __global__ void __launch_bounds__(SH_RS_THREADS)
 k_resample_polar(int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring,
                  const double* __restrict__ centroids, double* __restrict__ ixy,
                  double* __restrict__ itr_start, double* __restrict__ itr_cs) {
-  __shared__ double rx[SH_MAXSEG + 1], ry[SH_MAXSEG + 1], d[SH_MAXSEG + 1];
+  __shared__ double rx[CAP + 1], ry[CAP + 1], d[CAP + 1];
   __shared__ double sx[SH_MPROX], sy[SH_MPROX], th[SH_MPROX], rr[SH_MPROX];
   __shared__ unsigned long long amin_enc;   // (enc(theta) high bits | index) is not exact; use 2-step
   __shared__ int amin_idx;
@@ -397,17 +403,20 @@ k_resample_polar(int N, int M, const int* __restrict__ ring_n, const double* __r
   __shared__ int widx[SH_RS_THREADS / 64];
   const int pl = blockIdx.x, tid = threadIdx.x;
   const int L = ring_n[pl];
+  if (CAP == SH_SMALLSEG ? L > SH_SMALLSEG : L <= SH_SMALLSEG) return;      // the other tier's plane
   const double* rp = ring + (size_t)pl * (SH_MAXSEG + 1) * 2;
   for (int q = tid; q <= L; q += SH_RS_THREADS) { rx[q] = rp[2 * q]; ry[q] = rp[2 * q + 1]; }
+  __syncthreads();
+  // segment lengths by all lanes, then the running sum in np.cumsum's order by one
+  for (int q = 1 + tid; q <= L; q += SH_RS_THREADS) {
+    double dx = rx[q] - rx[q - 1], dy = ry[q] - ry[q - 1];
+    d[q] = sqrt(dx * dx + dy * dy);
+  }
   __syncthreads();
   if (tid == 0) {
     double acc = 0.0;
     d[0] = 0.0;
-    for (int q = 1; q <= L; ++q) {
-      double dx = rx[q] - rx[q - 1], dy = ry[q] - ry[q - 1];
-      acc += sqrt(dx * dx + dy * dy);
-      d[q] = acc;
-    }
+    for (int q = 1; q <= L; ++q) { acc += d[q]; d[q] = acc; }
   }
   __syncthreads();
   const double dmax = d[L];

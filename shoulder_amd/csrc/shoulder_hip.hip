@@ -738,13 +738,18 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 4096), (unsigned)B);
   LAUNCH(c, "k_slice_emit", k_slice_emit, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
          buf<long long>(c, "foff"), zeff, N, cnt, segs, buf<int>(c, "err"));
-  LAUNCH(c, "k_slice_link", k_slice_link, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
-         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), buf<int>(c, (p + ".ring_n").c_str()),
-         ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr, select, buf<int>(c, "err"));
+  // two capacity tiers share the grid (k_slices.h): the planes of the other tier exit at once
+  int* rn = buf<int>(c, (p + ".ring_n").c_str());
+  double* rg = ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr;
+  LAUNCH(c, "k_slice_link", k_slice_link<SH_SMALLSEG>, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
+         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"));
+  LAUNCH(c, "k_slice_link", k_slice_link<SH_MAXSEG>, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
+         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"));
   if (resample) {
-    LAUNCH(c, "k_resample_polar", k_resample_polar, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, buf<int>(c, (p + ".ring_n").c_str()),
-           buf<double>(c, (p + ".ring").c_str()), buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"),
-           buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
+    LAUNCH(c, "k_resample_polar", k_resample_polar<SH_SMALLSEG>, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
+           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
+    LAUNCH(c, "k_resample_polar", k_resample_polar<SH_MAXSEG>, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
+           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
   }
   return SH_OK;
 }
