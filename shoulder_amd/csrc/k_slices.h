@@ -175,7 +175,7 @@ __global__ void k_slice_emit(const double* __restrict__ vobb, const int* __restr
 // every segment from that start.
 #define SH_LINK_THREADS 256
 #define SH_MAXLOOPS 32
-#define SH_SMALLSEG 256      // tier boundary: planes with at most this many segments take the small-LDS instantiation
+#define SH_SMALLSEG 384      // tier boundary: planes with at most this many segments take the small-LDS instantiation (humerus sections: mean 140-210, max ~330)
 
 __device__ inline uint32_t hash_key64(unsigned long long k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33;
@@ -184,14 +184,14 @@ __device__ inline uint32_t hash_key64(unsigned long long k) {
 
 // select: 0 = largest loop (slice.py:53-59), 1 = loop whose closed-ring vertex mean is nearest
 // the origin in L1 (surgical_neck.py:40-48)
-// Two instantiations share the grid: CAP = SH_SMALLSEG (17 KB of LDS, 8 workgroups per CU) takes the planes with up to
-// 256 segments -- all but a few -- and CAP = SH_MAXSEG (70 KB, 2 per CU) the rest; the other tier's planes exit at once.
+// Two instantiations share the grid: CAP = SH_SMALLSEG (27 KB of LDS, 5 workgroups per CU) takes the planes with up to
+// 384 segments -- every section of a humerus at the fixture resolution -- and CAP = SH_MAXSEG (70 KB, 2 per CU) the rest; the other tier's planes exit at once.
 template <int CAP>
 __global__ void __launch_bounds__(SH_LINK_THREADS)
 k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops,
              int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err) {
-  constexpr int HASH = 2 * CAP;
+  constexpr int HASH = CAP <= 256 ? 512 : (CAP <= 512 ? 1024 : 2048);
   __shared__ unsigned long long skey[CAP];
   __shared__ unsigned long long bufA[CAP];   // ekey, then label ping, then ring x
   __shared__ unsigned long long bufB[CAP];   // label pong, then ring y
