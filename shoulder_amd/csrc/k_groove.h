@@ -82,28 +82,81 @@ __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][51
   __syncthreads();
   if (lane < nc) s_pass[lane] = peak_eval(s_roll, M, s_cand[lane], -10.0, 0.6, 0.1, &s_pk[lane]) ? 1 : 0;
   __syncthreads();
+  // Second half of the row (sh::groove_features_from_peaks, same arithmetic per element) spread over the wave: the
+  // 7 x 7 wrapped angle differences (atan2 / sin / cos each) take one lane per pair instead of 49 serial evaluations.
+  __shared__ int s_np;
+  __shared__ double s_th[SH_MAXPEAK], s_d[SH_MAXPEAK][SH_MAXPEAK];
+  __shared__ int s_pidx[SH_MAXPEAK];
   if (lane == 0) {
     int np_ = 0;
     for (int a = 0; a < nc; ++a) if (s_pass[a]) s_pk[np_++] = s_pk[a];
-    // MinMaxScaler over the cut zs (bicipital_groove.py:89): X*scale_ + min_, zs descend
-    double zmax = zs[0], zmin = zs[0];
-    for (int k = 1; k < SH_GROOVE_NROWS; ++k) { zmax = fmax(zmax, zs[k]); zmin = fmin(zmin, zs[k]); }
+    if (np_ > SH_MAXPEAK) {      // keep the 7 most prominent (B-5: ascending index order among the kept)
+      bool keep[SH_PEAK_CAP];
+      for (int k = 0; k < np_; ++k) keep[k] = false;
+      for (int q = 0; q < SH_MAXPEAK; ++q) {
+        int bq = -1;
+        for (int k = 0; k < np_; ++k)
+          if (!keep[k] && (bq < 0 || s_pk[k].prominence > s_pk[bq].prominence)) bq = k;
+        keep[bq] = true;
+      }
+      int w = 0;
+      for (int k = 0; k < np_; ++k) if (keep[k]) s_pk[w++] = s_pk[k];
+      np_ = SH_MAXPEAK;
+    }
+    s_np = np_;
+  }
+  __syncthreads();
+  const int np_ = s_np;
+  if (lane < np_) {
+    const int idx = (s_pk[lane].idx + amin) % M;     // (peaks - rmin) % interp_num with rmin = -amin
+    s_pidx[lane] = idx;
+    s_th[lane] = row[idx];
+  }
+  // MinMaxScaler over the cut zs (bicipital_groove.py:89): X*scale_ + min_
+  double zmax = -1e300, zmin = 1e300;
+  for (int k = lane; k < SH_GROOVE_NROWS; k += 64) { zmax = fmax(zmax, zs[k]); zmin = fmin(zmin, zs[k]); }
+  for (int off = 32; off > 0; off >>= 1) { zmax = fmax(zmax, __shfl_xor(zmax, off)); zmin = fmin(zmin, __shfl_xor(zmin, off)); }
+  __syncthreads();
+  {
+    const int k = lane >> 3, j = lane & 7;
+    if (k < np_ && j < np_) s_d[k][j] = wrapped_abs_diff(s_th[k], s_th[j]);
+  }
+  __syncthreads();
+  if (lane < np_) {
+    const int k = lane;
+    double near = 0.0, next = 0.0;
+    if (np_ > 1) {
+      // sorted wrapped distances to all peaks, dropping those that round to 0.00 (:46)
+      double a[SH_MAXPEAK];
+      int na = 0;
+      for (int j = 0; j < np_; ++j) {
+        double d = s_d[k][j];
+        if (rint(d * 100.0) / 100.0 != 0.0) a[na++] = d;     // np.round(angs, 2) != 0
+      }
+      for (int p = 1; p < na; ++p) { double v = a[p]; int q = p - 1; while (q >= 0 && a[q] > v) { a[q + 1] = a[q]; --q; } a[q + 1] = v; }
+      near = na > 0 ? a[0] : nan("");
+      if (np_ > 2) next = na > 1 ? a[1] : nan("");
+    }
     double rng = zmax - zmin;
     if (rng == 0.0) rng = 1.0;
-    double sc = 1.0 / rng;
-    double z_scaled = zs[i] * sc + (0.0 - zmin * sc);
+    const double sc = 1.0 / rng;
+    const double z_scaled = zs[i] * sc + (0.0 - zmin * sc);
     const double* ax = canal_axis_ct + 6 * b;
     double cu[3] = {ax[0] - ax[3], ax[1] - ax[4], ax[2] - ax[5]};
-    double n = norm3(cu);
+    const double n = norm3(cu);
     cu[0] /= n; cu[1] /= n; cu[2] /= n;
-    int pidx[SH_MAXPEAK];
-    double* X = xraw + ((size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK) * 9;
-    np_ = groove_features_from_peaks(row, s_r, M, zs[i], z_scaled, cu, s_pk, np_, amin, X,
-                                     ptheta + (size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK, pidx);
-    npk[gid] = np_;
+    const double z = zs[i], th = s_th[k];
+    const double rad = s_r[s_pidx[k]];
+    const double px = rad * cos(th), py = rad * sin(th);
+    const double dx = px - cu[0] * z, dy = py - cu[1] * z;
+    double* X = xraw + ((size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK + k) * 9;
+    X[0] = rad; X[1] = near; X[2] = next; X[3] = z_scaled; X[4] = s_pk[k].prominence; X[5] = s_pk[k].width;
+    X[6] = s_pk[k].width_height; X[7] = sqrt(dx * dx + dy * dy); X[8] = (double)np_ / 7.0;
+    ptheta[(size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK + k] = th;
     // a NaN feature = the reference's IndexError (all other peaks within 0.005 rad)
-    for (int k = 0; k < np_ * 9; ++k) if (X[k] != X[k]) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+    for (int q = 0; q < 9; ++q) if (X[q] != X[q]) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
   }
+  if (lane == 0) npk[gid] = np_;
   (void)B;
 }
 
