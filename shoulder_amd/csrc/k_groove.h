@@ -161,24 +161,44 @@ __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][51
 }
 
 // sklearn StandardScaler: mean over rows, population variance, scale = sqrt(var) (1 if ~0)
-__global__ void k_groove_scale(const double* __restrict__ xraw, const int* __restrict__ npk, double* __restrict__ stats, int B) {
-  int b = blockIdx.x, f = threadIdx.x;
-  if (f >= 9) return;
+__global__ void __launch_bounds__(256)
+k_groove_scale(const double* __restrict__ xraw, const int* __restrict__ npk, double* __restrict__ stats, int B) {
+  // The sums run over the peaks in row order, one after the other (the order the oracle's column reduction uses), so
+  // they stay sequential per feature; what is parallel is the staging: the valid rows are compacted into LDS first
+  // (five, then four feature columns), the nine lanes then add from LDS instead of waiting on one global load per term.
+  __shared__ double col[5][SH_GSLOTS];
+  __shared__ int slot[SH_GSLOTS];
+  __shared__ int P_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
   const double* X = xraw + (size_t)b * SH_GSLOTS * 9;
   const int* np_ = npk + (size_t)b * SH_GROOVE_NROWS;
-  double s = 0.0;
-  int P = 0;
-  for (int i = 0; i < SH_GROOVE_NROWS; ++i)
-    for (int k = 0; k < np_[i]; ++k) { s += X[((size_t)i * SH_MAXPEAK + k) * 9 + f]; ++P; }
-  double mean = P ? s / (double)P : 0.0;
-  double v = 0.0;
-  for (int i = 0; i < SH_GROOVE_NROWS; ++i)
-    for (int k = 0; k < np_[i]; ++k) { double d = X[((size_t)i * SH_MAXPEAK + k) * 9 + f] - mean; v += d * d; }
-  double var = P ? v / (double)P : 0.0;
-  double scale = sqrt(var);
-  if (scale < 10.0 * 2.220446049250313e-16) scale = 1.0;
-  stats[(size_t)b * 18 + f] = mean;
-  stats[(size_t)b * 18 + 9 + f] = scale;
+  if (tid == 0) {
+    int P = 0;
+    for (int i = 0; i < SH_GROOVE_NROWS; ++i)
+      for (int k = 0; k < np_[i]; ++k) slot[P++] = i * SH_MAXPEAK + k;
+    P_s = P;
+  }
+  __syncthreads();
+  const int P = P_s;
+  for (int f0 = 0; f0 < 9; f0 += 5) {
+    const int nf = f0 + 5 <= 9 ? 5 : 9 - f0;
+    for (int q = tid; q < P * nf; q += 256) { const int p = q / nf, f = q - p * nf; col[f][p] = X[(size_t)slot[p] * 9 + f0 + f]; }
+    __syncthreads();
+    if (tid < nf) {
+      const double* c = col[tid];
+      double s = 0.0;
+      for (int p = 0; p < P; ++p) s += c[p];
+      const double mean = P ? s / (double)P : 0.0;
+      double v = 0.0;
+      for (int p = 0; p < P; ++p) { double d = c[p] - mean; v += d * d; }
+      const double var = P ? v / (double)P : 0.0;
+      double scale = sqrt(var);
+      if (scale < 10.0 * 2.220446049250313e-16) scale = 1.0;
+      stats[(size_t)b * 18 + f0 + tid] = mean;
+      stats[(size_t)b * 18 + 9 + f0 + tid] = scale;
+    }
+    __syncthreads();
+  }
 }
 
 __global__ void k_groove_rfc(const double* __restrict__ xraw, const int* __restrict__ npk, const double* __restrict__ stats,

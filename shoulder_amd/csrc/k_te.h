@@ -78,19 +78,35 @@ __global__ void k_te_final(const double* __restrict__ ring, const int* __restric
                            const double* __restrict__ distal_zs, const double* __restrict__ T_obb, const double* __restrict__ canal_axis_ct,
                            const double* __restrict__ axes_obb /*[B][4][3]: +n,-n,+c,-c*/, double* __restrict__ dscratch,
                            double* __restrict__ te_axis_ct, int* __restrict__ te_row, int* __restrict__ err, int B) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  // one 64-lane workgroup per humerus: all lanes stage the chosen ring in LDS, lane 0 runs the (sequential) clipping
+  // on it -- the walk over the ring is latency-bound when every point comes from global memory
+  __shared__ double s_xy[2 * (SH_MAXSEG + 1)];
+  __shared__ double s_scr[2 * SH_MAXSEG + 8 * SH_TE_MAXCH];
+  __shared__ int s_k;
+  const int b = blockIdx.x;
   if (b >= B) return;
   const double* R = rects + (size_t)b * SH_TE_NROWS * 7;
-  int k = 0;
-  for (int j = 1; j < SH_TE_NROWS; ++j) if (R[j * 7 + 4] > R[k * 7 + 4]) k = j;     // dist.index(max(dist))
-  te_row[b] = SH_TE_ROW0 + k;
+  if (threadIdx.x == 0) {
+    int k = 0;
+    for (int j = 1; j < SH_TE_NROWS; ++j) if (R[j * 7 + 4] > R[k * 7 + 4]) k = j;     // dist.index(max(dist))
+    s_k = k;
+  }
+  __syncthreads();
+  const int k = s_k;
   size_t pl = (size_t)b * SH_NDIST + SH_TE_ROW0 + k;
-  const double* xy = ring + pl * (SH_MAXSEG + 1) * 2;
+  const double* gxy = ring + pl * (SH_MAXSEG + 1) * 2;
   int n = ring_n[pl];
+  if (n > SH_MAXSEG) n = SH_MAXSEG;
+  for (int q = threadIdx.x; q < 2 * (n + 1); q += blockDim.x) s_xy[q] = gxy[q];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  te_row[b] = SH_TE_ROW0 + k;
+  const double* xy = s_xy;
   const double* r = R + k * 7;
   double half = 0.5 * 0.999 * r[4];
   double cents[2 * 16];
-  double* scr = dscratch + (size_t)b * SH_TE_DSCR;
+  double* scr = s_scr;
+  (void)dscratch;
   int n1 = clip_halfplane_pieces(xy, n, r[0], r[1], r[2], r[3], half, cents, 8, scr);
   if (n1 < 0) n1 = 0;
   if (n1 > 8) n1 = 8;

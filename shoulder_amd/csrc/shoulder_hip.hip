@@ -909,7 +909,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     LAUNCH(c, "k_groove_rows", k_groove_rows, dim3(rows), dim3(64), buf<double>(c, "prox.itr_centered_start"),
            buf<double>(c, "prox.zs"), buf<double>(c, "canal.axis_ct"), ga, buf<double>(c, "groove.xraw"),
            buf<double>(c, "groove.ptheta"), buf<int>(c, "groove.npk"), buf<double>(c, "groove.r0"), buf<int>(c, "err"), B);
-    LAUNCH(c, "k_groove_scale", k_groove_scale, dim3(B), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
+    LAUNCH(c, "k_groove_scale", k_groove_scale, dim3(B), dim3(256), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
            buf<double>(c, "groove.stats"), B);
     LAUNCH(c, "k_groove_rfc", k_groove_rfc, dim3((B * SH_GSLOTS + 63) / 64), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
            buf<double>(c, "groove.stats"), feat, thr, ti, fi, lw, roots, c->rfc_trees, buf<double>(c, "groove.xs"), buf<float>(c, "groove.proba"), B);
@@ -941,7 +941,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   if (mask & SH_STAGE_TE) {
     LAUNCH(c, "k_te_rows", k_te_rows, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), B);
-    LAUNCH(c, "k_te_final", k_te_final, dim3((B + 63) / 64), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
+    LAUNCH(c, "k_te_final", k_te_final, dim3(B), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
            buf<double>(c, "anp.axes_obb"), buf<double>(c, "te.dscratch"), buf<double>(c, "te.axis_ct"), buf<int>(c, "te.row"), buf<int>(c, "err"), B);
   }
