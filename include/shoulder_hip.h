@@ -52,6 +52,11 @@ enum {
 };
 
 enum { SH_UNET_F32 = 0, SH_UNET_BF16 = 1 };
+/* Which facade class of bone.py the meshes are: `Humerus` (bone.py:110-157) or `ProximalHumerus` (bone.py:24-64: a
+ * humerus cut in the shaft -- ProxObb head-end rule and canal range mesh.py:128-192, neck cut-off (0.2, 0.99)
+ * surgical_neck.py:25-26, canal cut-offs from the box canal.py:33-38, no distal / trans-epicondylar stage,
+ * csys = apply_csys_canal_articular bone.py:53-62). */
+enum { SH_BONE_HUMERUS = 0, SH_BONE_PROXIMAL = 1 };
 
 #define SH_GROOVE_ROWS 330   /* rows 150..479 of 600 proximal slices (slice.py:157-164) */
 #define SH_ANP_MAX_PTS 4096  /* capacity of the padded edge-point list                  */
@@ -70,10 +75,12 @@ typedef struct sh_landmarks {
   double anp_plane_normal[3]; /* AnatomicNeck.plane().normal */
   double anp_axis_normal[6];  /* AnatomicNeck.axis_normal(): [upper, lower] (anatomic_neck.py:174-200) */
   double anp_axis_central[6]; /* AnatomicNeck.axis_central(): [upper, lower] (anatomic_neck.py:202-236) */
-  double csys[16];            /* apply_csys_canal_transepiconylar() matrix, CT -> canal/TE (bone.py:146-157) */
+  double csys[16];            /* apply_csys_canal_transepiconylar() matrix, CT -> canal/TE (bone.py:146-157);
+                                 SH_BONE_PROXIMAL: apply_csys_canal_articular() (bone.py:53-62) */
   double neckshaft;           /* NeckShaft.calc(), degrees (bone_props.py:88-112) */
-  double retroversion;        /* RetroVersion.calc() with landmarks in CT, degrees (bone_props.py:50-85) */
+  double retroversion;        /* RetroVersion.calc() with landmarks in CT, degrees (bone_props.py:50-85); NaN for SH_BONE_PROXIMAL */
   double radius_curvature;    /* RadiusCurvature.calc(), mm (bone_props.py:115-148) */
+  double canal_cutoff[2];     /* cut-off fractions the canal used: sh_params.canal_cutoff, or ProxObb.cutoff_pcts (mesh.py:190) */
   double groove_points[SH_GROOVE_ROWS * 3]; /* DeepGroove.points() (bicipital_groove.py:26-242) */
   double anp_points[SH_ANP_MAX_PTS * 3];    /* AnatomicNeck.points(), first n_anp rows valid (anatomic_neck.py:31-121) */
   int32_t n_anp;              /* number of edge points (K) */
@@ -90,7 +97,7 @@ typedef struct sh_params {
   double groove_cutoff[2];    /* bicipital_groove.py:26 default (0.2, 0.75); rows must stay 330 */
   double groove_deg_window;   /* bicipital_groove.py:26 default 7 */
   int32_t unet_dtype;         /* SH_UNET_F32 (parity) or SH_UNET_BF16 (throughput) */
-  int32_t pad_;
+  int32_t bone_kind;          /* SH_BONE_HUMERUS (default) or SH_BONE_PROXIMAL */
 } sh_params;
 
 /* ---- context ------------------------------------------------------------------------ */

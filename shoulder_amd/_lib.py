@@ -14,6 +14,7 @@ STAGE_OBB, STAGE_FULL, STAGE_NECK, STAGE_CANAL, STAGE_PROXIMAL = 1, 2, 4, 8, 16
 STAGE_GROOVE, STAGE_ANP, STAGE_DISTAL, STAGE_TE, STAGE_CSYS = 32, 64, 128, 256, 512
 STAGE_ALL = 0x3FF
 UNET_F32, UNET_BF16 = 0, 1
+BONE_HUMERUS, BONE_PROXIMAL = 0, 1
 
 
 class Landmarks(ctypes.Structure):
@@ -33,6 +34,7 @@ class Landmarks(ctypes.Structure):
         ("neckshaft", ctypes.c_double),
         ("retroversion", ctypes.c_double),
         ("radius_curvature", ctypes.c_double),
+        ("canal_cutoff", ctypes.c_double * 2),
         ("groove_points", ctypes.c_double * (GROOVE_ROWS * 3)),
         ("anp_points", ctypes.c_double * (ANP_MAX_PTS * 3)),
         ("n_anp", ctypes.c_int32),
@@ -48,14 +50,14 @@ LANDMARKS_DTYPE = np.dtype([
     ("obb_transform", "<f8", (4, 4)), ("z_length", "<f8"), ("neck_z", "<f8"), ("canal_axis", "<f8", (2, 3)),
     ("te_axis", "<f8", (2, 3)), ("groove_axis", "<f8", (2, 3)), ("bg_theta", "<f8"), ("anp_plane_point", "<f8", (3,)),
     ("anp_plane_normal", "<f8", (3,)), ("anp_axis_normal", "<f8", (2, 3)), ("anp_axis_central", "<f8", (2, 3)),
-    ("csys", "<f8", (4, 4)), ("neckshaft", "<f8"), ("retroversion", "<f8"), ("radius_curvature", "<f8"), ("groove_points", "<f8", (GROOVE_ROWS, 3)), ("anp_points", "<f8", (ANP_MAX_PTS, 3)),
+    ("csys", "<f8", (4, 4)), ("neckshaft", "<f8"), ("retroversion", "<f8"), ("radius_curvature", "<f8"), ("canal_cutoff", "<f8", (2,)), ("groove_points", "<f8", (GROOVE_ROWS, 3)), ("anp_points", "<f8", (ANP_MAX_PTS, 3)),
     ("n_anp", "<i4"), ("n_articular", "<i4"), ("neck_index", "<i4"), ("flipped", "<i4"), ("status", "<i4"), ("side", "<i4")])
 assert LANDMARKS_DTYPE.itemsize == ctypes.sizeof(Landmarks)
 
 
 class Params(ctypes.Structure):
     _fields_ = [("canal_cutoff", ctypes.c_double * 2), ("groove_cutoff", ctypes.c_double * 2),
-                ("groove_deg_window", ctypes.c_double), ("unet_dtype", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("groove_deg_window", ctypes.c_double), ("unet_dtype", ctypes.c_int32), ("bone_kind", ctypes.c_int32)]
 
 
 EXPORTS = ["sh_ctx_create", "sh_ctx_destroy", "sh_last_error", "sh_default_params", "sh_set_params", "sh_load_rfc",

@@ -65,7 +65,9 @@ class Canal(_Lm):
             # default cutoff is already fixed when user code first gets here (canal.py:60-62)
             e = self._b._engine
             self._b._ensure_loaded()
-            obb = e.fetch("canal.points_obb", np.float64, (1, 80, 3))[0]
+            c0, c1 = self._b._canal_cutoff
+            n = int((1 - c0) * 200) - int((1 - c1) * 200)                 # Slices._cutoff (slice.py:157-164) on the 200 full slices
+            obb = e.fetch("canal.points_obb", np.float64, (1, 200, 3))[0][:n]
             self._points_obb = obb
             self._points_ct = e.transform_points(obb, _inv(self._b._obb_transform))
         self._points = self._t(self._points_ct)
@@ -241,6 +243,9 @@ class TransEpicondylar(_Lm):
 
 class Humerus(Bone):
     """bone.py:109-157"""
+    _BONE_KIND = _lib.BONE_HUMERUS
+    _EARLY = EARLY
+    _LATE = LATE
 
     def __init__(self, stl_file, engine=None):
         self._tfrm = Transform()
@@ -250,10 +255,11 @@ class Humerus(Bone):
         verts, faces = load_stl(self.stl_file)
         self._verts, self._faces = verts, faces
         self._engine.upload([(verts, faces)])
-        self._engine.set_params()
+        self._engine.set_params(bone_kind=self._BONE_KIND)
         self._lm_all = None
         # eager part of the reference constructor: OBB, full slices, surgical neck, canal axis
-        self._early = self._engine.run(EARLY)[0].copy()
+        self._early = self._engine.run(self._EARLY)[0].copy()
+        self._canal_cutoff = tuple(float(x) for x in self._early["canal_cutoff"])
         self._obb_transform = np.array(self._early["obb_transform"], dtype=np.float64)
         self._z_bounds = tuple(self._engine.fetch("z_bounds", np.float64, (1, 2))[0])
         self._mesh_ct = Mesh(verts, faces, self._engine)
@@ -262,6 +268,9 @@ class Humerus(Bone):
         self.canal = Canal(self)
         self.bicipital_groove = DeepGroove(self)
         self.anatomic_neck = AnatomicNeck(self)
+        self._init_kind_specific()
+
+    def _init_kind_specific(self):
         self.trans_epiconylar = TransEpicondylar(self)
         # metrics (bone.py:134-144 -> bone_props.py); values come from the device record (k_metrics)
         self.side = self._side
@@ -274,10 +283,10 @@ class Humerus(Bone):
         e = self._engine
         if e.B != 1 or not np.array_equal(e.fetch("obb_transform", np.float64, (1, 4, 4))[0], self._obb_transform):
             e.upload([(self._verts, self._faces)])
-            e.set_params()
-            e.run(EARLY, fetch=False)
+            e.set_params(bone_kind=self._BONE_KIND)
+            e.run(self._EARLY, fetch=False)
             if self._lm_all is not None:
-                e.run(LATE, fetch=False)
+                e.run(self._LATE, fetch=False)
 
     # -- the late stages, once ------------------------------------------------------------------------
     def _all(self, groove_cutoff=(0.2, 0.75), deg_window=7):
@@ -285,10 +294,10 @@ class Humerus(Bone):
             e = self._engine
             self._ensure_loaded()
             try:
-                e.set_params(groove_cutoff=tuple(groove_cutoff), groove_deg_window=float(deg_window))
+                e.set_params(groove_cutoff=tuple(groove_cutoff), groove_deg_window=float(deg_window), bone_kind=self._BONE_KIND)
             except Exception as ex:
                 raise ValueError(f"bicipital_groove cutoff_pcts {groove_cutoff} is not supported: {ex}") from ex
-            self._lm_all = e.run(LATE)[0].copy()
+            self._lm_all = e.run(self._LATE)[0].copy()
             if int(self._lm_all["status"]) != 0:
                 raise ValueError(f"landmark stage failed with status {int(self._lm_all['status'])}")
         return self._lm_all
@@ -383,8 +392,28 @@ class Humerus(Bone):
         return self.transform
 
 
-class ProximalHumerus:
-    """bone.py:24-105 -- cut humeri (ProxObb).  Next row after the Humerus hot path (SURVEY 8(f) #2)."""
+class ProximalHumerus(Humerus):
+    """bone.py:24-105 -- a humerus whose scan ends in the shaft.  Same landmark classes; the device runs the ProxObb
+    head-end rule and canal range (mesh.py:128-192), the (0.2, 0.99) neck cut-off (surgical_neck.py:25-26) and the canal
+    cut-offs taken from the box (canal.py:33-38); there is no trans-epicondylar axis and no retroversion, and the
+    coordinate system is `apply_csys_canal_articular` (bone.py:53-62)."""
+    _BONE_KIND = _lib.BONE_PROXIMAL
+    _LATE = _lib.STAGE_PROXIMAL | _lib.STAGE_GROOVE | _lib.STAGE_ANP | _lib.STAGE_CSYS
 
-    def __init__(self, stl_file, engine=None):
-        raise NotImplementedError("ProximalHumerus is outside the Humerus hot path built so far (DESIGN.md, 'What comes next')")
+    def _init_kind_specific(self):
+        self.side = self._side
+        self.neckshaft = self._neckshaft
+        self.radius_curvature = self._radius_curvature
+        e = self._engine
+        self.cutoff_pcts = [float(x) for x in self._canal_cutoff]           # ProxObb.cutoff_pcts (mesh.py:190)
+        self.cutoff_bot = int(e.fetch("pobb.cutoff_idx", np.int32, (1, 2))[0][0])      # mesh.py:187
+
+    def apply_csys_canal_transepiconylar(self):
+        raise AttributeError("ProximalHumerus has no trans-epicondylar axis (bone.py:24-64); use apply_csys_canal_articular")
+
+    def apply_csys_canal_articular(self) -> np.ndarray:
+        self.canal.axis()
+        self.anatomic_neck.axis_central()
+        self.anatomic_neck.axis_normal()
+        T = np.array(self._all()["csys"], dtype=np.float64)           # construct_csys(canal, neck-normal axis) on the device (k_pack)
+        return self._apply(T, self._mesh_in(T))

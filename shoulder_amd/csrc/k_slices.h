@@ -87,7 +87,9 @@ __device__ inline double np_pairwise_sum(const double* a, int n) {
 
 // ---- plane heights of one slice set (slice.py:16-19, :219-224, :248-253, :271-276) -----------
 // kind 0: full  linspace(.99 zmax, .99 zmin, N)   kind 1: proximal linspace(.99 zmax, neck_z, N)
-// kind 2: distal linspace(.99 zmin, 0, N)
+// kind 2: distal linspace(.99 zmin, 0, N)             kind 3: the one plane z = neck_z
+// kind 4: ProxObb area scan linspace(.99 zmin, .99 zmax, N) of the raw box bounds, every plane cut at its own z
+//         (`mesh.section(plane_origin=[0,0,z])` in a loop, mesh.py:157-160)
 __global__ void k_make_planes(int kind, int N, const double* __restrict__ zb /*[B][2]*/, const double* __restrict__ neck_z,
                               double* __restrict__ zs, double* __restrict__ zeff, int B) {
   int b = blockIdx.x;
@@ -98,6 +100,10 @@ __global__ void k_make_planes(int kind, int N, const double* __restrict__ zb /*[
   }
   double zmin = zb[2 * b], zmax = zb[2 * b + 1];
   double a, e;
+  if (kind == 4) {
+    for (int k = threadIdx.x; k < N; k += blockDim.x) { double z = linspace_at(zmin * 0.99, zmax * 0.99, N, k); zs[(size_t)b * N + k] = z; zeff[(size_t)b * N + k] = z; }
+    return;
+  }
   if (kind == 0) { a = 0.99 * zmax; e = 0.99 * zmin; }
   else if (kind == 1) { a = 0.99 * zmax; e = neck_z[b]; }
   else { a = 0.99 * zmin; e = 0.0; }
@@ -190,7 +196,8 @@ template <int CAP>
 __global__ void __launch_bounds__(SH_LINK_THREADS)
 k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops,
-             int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err) {
+             int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err,
+             double* __restrict__ areas_total /*nullable: |sum of the signed loop areas| = Path2D.area*/) {
   constexpr int HASH = CAP <= 256 ? 512 : (CAP <= 512 ? 1024 : 2048);
   __shared__ unsigned long long skey[CAP];
   __shared__ unsigned long long bufA[CAP];   // ekey, then label ping, then ring x
@@ -222,7 +229,8 @@ k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ s
   if (n < 3) {
     if (tid == 0) {
       centroids[2 * (size_t)pl] = 0; centroids[2 * (size_t)pl + 1] = 0; areas[pl] = 0; nloops[pl] = 0; ring_n[pl] = 0;
-      atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+      if (areas_total) areas_total[pl] = 0;      // an empty section of the area scan is legal (plane past a ragged cut)
+      else atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
     }
     return;
   }
@@ -368,6 +376,11 @@ k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ s
     int amax = 0;
     for (int l = 1; l < nl; ++l) if (fabs(l_area[l]) > fabs(l_area[amax])) amax = l;
     areas[pl] = fabs(l_area[amax]);
+    if (areas_total) {      // outer loops minus holes (mesh.py:160 `slice.area`), loops in canonical order
+      double tot = 0.0;
+      for (int l = 0; l < nl; ++l) tot += l_area[l];
+      areas_total[pl] = fabs(tot);
+    }
     nloops[pl] = nl;
     ring_n[pl] = l_len[best];
     if (bad) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);

@@ -115,14 +115,15 @@ __device__ inline double wave_kth_smallest_nonneg(const double* v, int n, int k,
 // radix select over all lanes, all lanes fill the Gram matrix, each lane evaluates the cost of some breakpoints with
 // the same arithmetic as sh::cpd_one_bkp, first minimum wins.
 __global__ void __launch_bounds__(64)
-k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* __restrict__ neck_z, int* __restrict__ neck_index, int B) {
-  __shared__ double K[SH_CPD_MAXN * SH_CPD_MAXN];
+k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* __restrict__ neck_z, int* __restrict__ neck_index, int B,
+       double c0, double c1, double* __restrict__ gscratch /*[B][SH_NFULL^2], used when the cut is longer than SH_CPD_MAXN*/) {
+  __shared__ double Ks[SH_CPD_MAXN * SH_CPD_MAXN];
   __shared__ unsigned hist[258];
   int b = blockIdx.x, lane = threadIdx.x;
   int a, e;
-  cutoff_range(SH_NFULL, 0.70, 0.99, &a, &e);
+  cutoff_range(SH_NFULL, c0, c1, &a, &e);      // (0.70, 0.99) for a whole humerus, (0.2, 0.99) for a proximal one (surgical_neck.py:25-28)
   int n = e - a;
-  if (n > SH_CPD_MAXN) n = SH_CPD_MAXN;
+  double* K = n <= SH_CPD_MAXN ? Ks : gscratch + (size_t)b * SH_NFULL * SH_NFULL;
   const double* x = areas + (size_t)b * SH_NFULL + a;
   // pairwise squared distances in K (free until the Gram fill): row i holds j > i
   for (int i = 0; i < n; ++i) {
@@ -132,6 +133,7 @@ k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* 
   __syncthreads();
   const int np_ = n * (n - 1) / 2;
   double med;
+  __threadfence_block();
   if (np_ & 1) med = wave_kth_smallest_nonneg(K, np_, np_ / 2, hist);
   else { double lo = wave_kth_smallest_nonneg(K, np_, np_ / 2 - 1, hist); double hi = wave_kth_smallest_nonneg(K, np_, np_ / 2, hist); med = (lo + hi) / 2.0; }
   const double gamma = (med == 0.0) ? 1.0 : 1.0 / med;
@@ -153,6 +155,31 @@ k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* 
     neck_index[b] = bt;
     neck_z[b] = zs[(size_t)b * SH_NFULL + a + bt];
   }
+}
+
+// mesh.py:163-192 (ProxObb): head = largest section area -> flip so that it is at +z; canal range from the (reversed if
+// flipped) area profile; T_obb = flip * T_pre.  One lane per humerus.
+__global__ void k_prox_obb(const double* __restrict__ area_scan /*[B][SH_NPSCAN]*/, const double* __restrict__ scan_zs, const double* __restrict__ T_pre,
+                           double* __restrict__ T_obb, int* __restrict__ flipped, double* __restrict__ cutoff /*[B][2]*/, int* __restrict__ cutoff_idx /*[B][2]*/,
+                           int* __restrict__ err, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* A = area_scan + (size_t)b * SH_NPSCAN;
+  int k = 0;
+  for (int j = 1; j < SH_NPSCAN; ++j) if (A[j] > A[k]) k = j;      // np.argmax: first maximum
+  const bool flip = scan_zs[(size_t)b * SH_NPSCAN + k] < 0;         // humeral_head_z < 0
+  double ar[SH_NPSCAN], tmp[2 * SH_NPSCAN];
+  for (int j = 0; j < SH_NPSCAN; ++j) ar[j] = flip ? A[SH_NPSCAN - 1 - j] : A[j];      // z_area[::-1]
+  int lo, hi;
+  if (prox_canal_range(ar, SH_NPSCAN, tmp, &lo, &hi) < 1) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+  cutoff_idx[2 * b] = lo; cutoff_idx[2 * b + 1] = hi;
+  cutoff[2 * b] = (double)lo / (double)SH_NPSCAN;
+  cutoff[2 * b + 1] = (double)hi / (double)SH_NPSCAN;
+  flipped[b] = flip ? 1 : 0;
+  const double* Tp = T_pre + 16 * b;
+  double* To = T_obb + 16 * b;
+  for (int q = 0; q < 16; ++q) To[q] = Tp[q];
+  if (flip) for (int q = 0; q < 4; ++q) { To[q] = -Tp[q]; To[8 + q] = -Tp[8 + q]; }     // diag(-1,1,-1,1) * T_pre
 }
 
 __device__ inline double wave_sum(double v) {
@@ -178,15 +205,18 @@ __device__ inline void wave_line_fit(const double* p, int n, int stride, double*
 }
 
 // canal.py:19-85
+#define SH_CANAL_MAXPTS SH_NFULL
 __global__ void k_canal(const double* __restrict__ centroids, const double* __restrict__ zs, const double* __restrict__ zb,
-                        const double* __restrict__ T_obb, double c0, double c1, double* __restrict__ pts_obb,
-                        double* __restrict__ axis_obb, double* __restrict__ axis_ct) {
+                        const double* __restrict__ T_obb, double c0, double c1, const double* __restrict__ cut /*nullable [B][2]: ProxObb.cutoff_pcts (canal.py:33-38)*/,
+                        double* __restrict__ pts_obb, double* __restrict__ axis_obb, double* __restrict__ axis_ct, int* __restrict__ err) {
   int b = blockIdx.x, lane = threadIdx.x;
+  if (cut) { c0 = cut[2 * b]; c1 = cut[2 * b + 1]; }
   int a, e;
   cutoff_range(SH_NFULL, c0, c1, &a, &e);
   int n = e - a;
-  if (n > 80) n = 80;
-  double* P = pts_obb + (size_t)b * 80 * 3;
+  if (n > SH_CANAL_MAXPTS) n = SH_CANAL_MAXPTS;
+  if (n < 2) { if (lane == 0) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); for (int k = 0; k < 6; ++k) { axis_obb[6 * b + k] = 0; axis_ct[6 * b + k] = 0; } } return; }
+  double* P = pts_obb + (size_t)b * SH_CANAL_MAXPTS * 3;
   for (int i = lane; i < n; i += 64) {
     P[3 * i] = centroids[2 * ((size_t)b * SH_NFULL + a + i)];
     P[3 * i + 1] = centroids[2 * ((size_t)b * SH_NFULL + a + i) + 1];

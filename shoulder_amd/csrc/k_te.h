@@ -149,7 +149,7 @@ __global__ void k_pack(sh_landmarks* __restrict__ lm, const double* __restrict__
                        const double* __restrict__ groove_axis_ct, const double* __restrict__ bg_theta,
                        const double* __restrict__ groove_pts_ct, const double* __restrict__ plane, const double* __restrict__ axes_obb,
                        const double* __restrict__ anp_pts_obb, const int* __restrict__ anp_counts, const int* __restrict__ err,
-                       uint32_t mask, int B) {
+                       uint32_t mask, int B, int bone_kind, const double* __restrict__ canal_cut /*[B][2] or null*/, double cc0, double cc1) {
   int b = blockIdx.x;
   if (b >= B) return;
   sh_landmarks* L = lm + b;
@@ -190,7 +190,12 @@ __global__ void k_pack(sh_landmarks* __restrict__ lm, const double* __restrict__
     L->n_articular = anp_counts[2 * b + 1];
   }
   if (mask & SH_STAGE_TE) for (int i = 0; i < 6; ++i) L->te_axis[i] = te_axis_ct[6 * b + i];
-  if (mask & SH_STAGE_CSYS) construct_csys(L->canal_axis, L->te_axis, L->csys);     // bone.py:150
+  L->canal_cutoff[0] = canal_cut ? canal_cut[2 * b] : cc0;
+  L->canal_cutoff[1] = canal_cut ? canal_cut[2 * b + 1] : cc1;
+  if (mask & SH_STAGE_CSYS) {
+    if (bone_kind == SH_BONE_PROXIMAL) construct_csys(L->canal_axis, L->anp_axis_normal, L->csys);     // bone.py:57-59 apply_csys_canal_articular
+    else construct_csys(L->canal_axis, L->te_axis, L->csys);                                          // bone.py:150
+  }
 }
 
 // utils.unitxyz_to_spherical (utils.py:321-332): theta, phi in degrees
@@ -234,7 +239,7 @@ k_sphere_partial(const float* __restrict__ logits, const double* __restrict__ ra
 }
 
 __global__ void __launch_bounds__(64)
-k_metrics(sh_landmarks* __restrict__ lm, const double* __restrict__ partial, int* __restrict__ err) {
+k_metrics(sh_landmarks* __restrict__ lm, const double* __restrict__ partial, int* __restrict__ err, int bone_kind) {
   const int b = blockIdx.x, tid = threadIdx.x;
   sh_landmarks* L = lm + b;
   double radius = 0.0;
@@ -281,8 +286,10 @@ k_metrics(sh_landmarks* __restrict__ lm, const double* __restrict__ partial, int
     unitxyz_to_spherical_deg(v, &th, &ph);
     L->neckshaft = 180.0 - ph;
   }
-  // RetroVersion (:64-85) with the neck-normal axis in CT (identity Transform)
-  {
+  // RetroVersion (:64-85) with the neck-normal axis in CT (identity Transform); a proximal humerus has no
+  // epicondyles, `ProximalHumerus` has no retroversion() (bone.py:45-51)
+  if (bone_kind == SH_BONE_PROXIMAL) L->retroversion = nan("");
+  else {
     double a0[3], a1[3], v[3], th, ph;
     xform_pt(L->csys, L->anp_axis_normal[0], L->anp_axis_normal[1], L->anp_axis_normal[2], a0);
     xform_pt(L->csys, L->anp_axis_normal[3], L->anp_axis_normal[4], L->anp_axis_normal[5], a1);

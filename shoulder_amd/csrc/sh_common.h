@@ -17,6 +17,7 @@
 #define SH_NFULL 200        // slice.py:213
 #define SH_NDIST 200        // slice.py:260
 #define SH_NPROX 600        // slice.py:236 "must not change needed for anp cnn"
+#define SH_NPSCAN 100       // mesh.py:153 ProxObb area scan
 #define SH_MPROX 512        // slice.py:237
 #define SH_ANP_ROWS 512     // rows 88..599 (anatomic_neck.py:34)
 #define SH_ANP_ROW0 88

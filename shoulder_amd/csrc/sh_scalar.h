@@ -69,6 +69,32 @@ SH_HD int cpd_one_bkp(const double* x, int n, double* scratch) {
 }
 
 // ======================================================================================
+// ProxObb canal range   mesh.py:181-190
+// grad = np.gradient(savgol_filter(area, 3, 1)); canal = longest run (first of the longest) of consecutive sections
+// with grad < 10.  savgol(3, 1): interior = mean of 3 (scipy's least-squares taps are 1/3 + 4e-17; tolerance-level),
+// ends = the line fitted to the first / last three samples evaluated at the end ((5 y0 + 2 y1 - y2) / 6).
+// tmp: 2 n doubles.  Returns 0 and lo = hi = 0 when no section qualifies.
+// ======================================================================================
+SH_HD int prox_canal_range(const double* area, int n, double* tmp, int* lo, int* hi) {
+  double* sm = tmp;
+  double* g = tmp + n;
+  for (int i = 1; i + 1 < n; ++i) sm[i] = ((area[i - 1] + area[i]) + area[i + 1]) / 3.0;
+  sm[0] = ((5.0 * area[0] + 2.0 * area[1]) - area[2]) / 6.0;
+  sm[n - 1] = ((5.0 * area[n - 1] + 2.0 * area[n - 2]) - area[n - 3]) / 6.0;
+  g[0] = sm[1] - sm[0];
+  g[n - 1] = sm[n - 1] - sm[n - 2];
+  for (int i = 1; i + 1 < n; ++i) g[i] = (sm[i + 1] - sm[i - 1]) / 2.0;
+  int best_a = 0, best_len = 0, a = -1;
+  for (int i = 0; i <= n; ++i) {
+    const bool in = i < n && g[i] < 10.0;
+    if (in && a < 0) a = i;
+    if (!in && a >= 0) { if (i - a > best_len) { best_len = i - a; best_a = a; } a = -1; }
+  }
+  *lo = best_a; *hi = best_len > 0 ? best_a + best_len - 1 : best_a;
+  return best_len;
+}
+
+// ======================================================================================
 // K4  circle_fit.least_squares_circle residual   mesh.py:102
 // minimise sum (R_i - mean R)^2 over the centre from the barycentre (Levenberg-Marquardt);
 // returns residu = sum (R_i - mean R)^2 at the optimum.

@@ -162,7 +162,7 @@ int sh_default_params(sh_params* p) {
   p->groove_cutoff[0] = 0.2; p->groove_cutoff[1] = 0.75;
   p->groove_deg_window = 7.0;
   p->unet_dtype = SH_UNET_F32;
-  p->pad_ = 0;
+  p->bone_kind = SH_BONE_HUMERUS;
   return SH_OK;
 }
 
@@ -213,6 +213,8 @@ int sh_set_params(sh_ctx* c, const sh_params* p) {
   if (b - a != SH_GROOVE_NROWS) return fail(c, SH_ERR_ARG, "groove_cutoff must select 330 proximal rows");
   cutoff_range(SH_NFULL, p->canal_cutoff[0], p->canal_cutoff[1], &a, &b);
   if (b - a < 2 || a < 0 || b > SH_NFULL) return fail(c, SH_ERR_ARG, "canal_cutoff selects fewer than 2 slices");
+  if (p->bone_kind != SH_BONE_HUMERUS && p->bone_kind != SH_BONE_PROXIMAL) return fail(c, SH_ERR_ARG, "bone_kind must be SH_BONE_HUMERUS or SH_BONE_PROXIMAL");
+  if (c->prep.active && p->bone_kind != c->params.bone_kind) (void)join_prepared(c);
   c->params = *p;
   return SH_OK;
 }
@@ -240,7 +242,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("err", B * 4, 4);
   ENS("neck_z", B * 8, 8);
   ENS("neck_index", B * 4, 4);
-  ENS("canal.points_obb", B * 80 * 3 * 8, 8);
+  ENS("canal.points_obb", B * SH_CANAL_MAXPTS * 3 * 8, 8);
   ENS("canal.axis_obb", B * 6 * 8, 8);
   ENS("canal.axis_ct", B * 6 * 8, 8);
   ENS("landmarks", (size_t)B * sizeof(sh_landmarks), 1);
@@ -309,6 +311,33 @@ static int alloc_batch(sh_ctx* c) {
   ENS("obb.resid", (size_t)B * 2 * 8, 8);
 #undef ENS
   c->obb_injected = false;
+  return SH_OK;
+}
+
+// Extra buffers of the SH_BONE_PROXIMAL path (allocated on first use): the ProxObb area scan and the large Gram matrix
+// of the neck change point.
+static int alloc_prox(sh_ctx* c) {
+  const int B = c->B;
+  int rc;
+#define ENS(name, bytes, elem)                                              \
+  do {                                                                      \
+    if ((rc = ensure(c, name, (size_t)(bytes), elem)) != SH_OK) return rc;  \
+    c->bufs[name].per_mesh = (size_t)(bytes) / (size_t)B;                   \
+  } while (0)
+  const int N = SH_NPSCAN;
+  ENS("pobb.zs", (size_t)B * N * 8, 8);
+  ENS("pobb.zeff", (size_t)B * N * 8, 8);
+  ENS("pobb.seg_count", (size_t)B * N * 4, 4);
+  ENS("pobb.segs", (size_t)B * N * SH_MAXSEG * sizeof(Seg), 1);
+  ENS("pobb.centroids", (size_t)B * N * 2 * 8, 8);
+  ENS("pobb.areas", (size_t)B * N * 8, 8);
+  ENS("pobb.nloops", (size_t)B * N * 4, 4);
+  ENS("pobb.ring_n", (size_t)B * N * 4, 4);
+  ENS("pobb.area_total", (size_t)B * N * 8, 8);
+  ENS("pobb.cutoff", (size_t)B * 2 * 8, 8);
+  ENS("pobb.cutoff_idx", (size_t)B * 2 * 4, 4);
+  ENS("neck.gram", (size_t)B * SH_NFULL * SH_NFULL * 8, 8);
+#undef ENS
   return SH_OK;
 }
 
@@ -726,14 +755,15 @@ int sh_unet_infer(sh_ctx* c, const float* images, int n, int H, int W, float* lo
 }
 
 // ---- stage runner ----------------------------------------------------------------------------------
-static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0) {
+static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0, bool total_area = false) {
   const int B = c->Bwin;
   std::string p = pfx;
   double* zs = buf<double>(c, (p + ".zs").c_str());
   double* zeff = buf<double>(c, (p + ".zeff").c_str());
   int* cnt = buf<int>(c, (p + ".seg_count").c_str());
   Seg* segs = buf<Seg>(c, (p + ".segs").c_str());
-  LAUNCH(c, "k_make_planes", k_make_planes, dim3(B), dim3(256), kind, N, buf<double>(c, "z_bounds"), buf<double>(c, "neck_z"), zs, zeff, B);
+  LAUNCH(c, "k_make_planes", k_make_planes, dim3(B), dim3(256), kind, N, buf<double>(c, kind == 4 ? "obb.zb_pre" : "z_bounds"), buf<double>(c, "neck_z"), zs, zeff, B);
+  double* atot = total_area ? buf<double>(c, (p + ".area_total").c_str()) : (double*)nullptr;
   HIPCHK(c, hipMemsetAsync(cnt, 0, (size_t)B * N * 4, c->stream));
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 4096), (unsigned)B);
   LAUNCH(c, "k_slice_emit", k_slice_emit, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
@@ -742,9 +772,9 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   int* rn = buf<int>(c, (p + ".ring_n").c_str());
   double* rg = ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr;
   LAUNCH(c, "k_slice_link", k_slice_link<SH_SMALLSEG>, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
-         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"));
+         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot);
   LAUNCH(c, "k_slice_link", k_slice_link<SH_MAXSEG>, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
-         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"));
+         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot);
   if (resample) {
     LAUNCH(c, "k_resample_polar", k_resample_polar<SH_SMALLSEG>, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
            buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
@@ -854,6 +884,19 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   LAUNCH(c, "k_obb_pick", k_obb_pick, dim3(B), dim3(256), buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"),
          buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<float>(c, "verts"), buf<long long>(c, "voff"), buf<double>(c, "obb.T_pre"),
          buf<double>(c, "obb.zb_pre"), buf<int>(c, "err"));
+  if (c->params.bone_kind == SH_BONE_PROXIMAL) {
+    // mesh.py:134-192 ProxObb: 100 sections of the mesh in the raw box frame, head = largest area, canal range
+    dim3 gv((unsigned)std::min<long long>((c->maxV + 255) / 256, 1024), (unsigned)B);
+    LAUNCH(c, "k_init_bounds", k_init_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "zb_enc"), B);
+    LAUNCH(c, "k_transform_verts", k_transform_verts, gv, dim3(256), buf<float>(c, "verts"), buf<long long>(c, "voff"),
+           buf<double>(c, "obb.T_pre"), buf<double>(c, "verts_obb"), buf<unsigned long long>(c, "zb_enc"));
+    int rc2;
+    if ((rc2 = run_slice_set(c, "pobb", 4, SH_NPSCAN, false, false, 0, true)) != SH_OK) return rc2;
+    LAUNCH(c, "k_prox_obb", k_prox_obb, dim3((B + 63) / 64), dim3(64), buf<double>(c, "pobb.area_total"), buf<double>(c, "pobb.zs"), buf<double>(c, "obb.T_pre"),
+           buf<double>(c, "obb_transform"), buf<int>(c, "flipped"), buf<double>(c, "pobb.cutoff"), buf<int>(c, "pobb.cutoff_idx"), buf<int>(c, "err"), B);
+    c->obb_injected = true;
+    return SH_OK;
+  }
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "obb.endcnt"), 0, (size_t)B * 2 * 4, c->stream));
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 1024), (unsigned)B);
   LAUNCH(c, "k_obb_end_points", k_obb_end_points, g, dim3(256), buf<float>(c, "verts"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
@@ -885,15 +928,17 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   if (mask & SH_STAGE_DISTAL)
     if ((rc = run_slice_set(c, "distal", 2, SH_NDIST, true, false)) != SH_OK) return rc;
   if (mask & SH_STAGE_NECK) {
+    const bool prox = c->params.bone_kind == SH_BONE_PROXIMAL;      // surgical_neck.py:25-28
     LAUNCH(c, "k_neck", k_neck, dim3(B), dim3(64), buf<double>(c, "full.areas"), buf<double>(c, "full.zs"),
-           buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), B);
+           buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), B, prox ? 0.2 : 0.70, 0.99, prox ? buf<double>(c, "neck.gram") : (double*)nullptr);
     // surgical_neck.py:37-54: the contour at neck_z (loop whose vertex mean is nearest the origin)
     if ((rc = run_slice_set(c, "neckc", 3, 1, true, false, 1)) != SH_OK) return rc;
   }
   if (mask & SH_STAGE_CANAL) {
     LAUNCH(c, "k_canal", k_canal, dim3(B), dim3(64), buf<double>(c, "full.centroids"), buf<double>(c, "full.zs"),
            buf<double>(c, "z_bounds"), buf<double>(c, "obb_transform"), c->params.canal_cutoff[0], c->params.canal_cutoff[1],
-           buf<double>(c, "canal.points_obb"), buf<double>(c, "canal.axis_obb"), buf<double>(c, "canal.axis_ct"));
+           c->params.bone_kind == SH_BONE_PROXIMAL ? buf<double>(c, "pobb.cutoff") : (const double*)nullptr,
+           buf<double>(c, "canal.points_obb"), buf<double>(c, "canal.axis_obb"), buf<double>(c, "canal.axis_ct"), buf<int>(c, "err"));
   }
   if (mask & SH_STAGE_PROXIMAL)
     if ((rc = run_slice_set(c, "prox", 1, SH_NPROX, true, true)) != SH_OK) return rc;
@@ -948,14 +993,16 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   LAUNCH(c, "k_pack", k_pack, dim3(B), dim3(256), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "obb_transform"), buf<double>(c, "z_bounds"),
          buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), buf<int>(c, "flipped"), buf<double>(c, "canal.axis_ct"), buf<double>(c, "te.axis_ct"),
          buf<double>(c, "groove.axis_ct"), buf<double>(c, "groove.bg_theta"), buf<double>(c, "groove.points_ct"), buf<double>(c, "anp.plane"),
-         buf<double>(c, "anp.axes_obb"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"), buf<int>(c, "err"), mask, B);
+         buf<double>(c, "anp.axes_obb"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"), buf<int>(c, "err"), mask, B,
+         (int)c->params.bone_kind, c->params.bone_kind == SH_BONE_PROXIMAL ? buf<double>(c, "pobb.cutoff") : (const double*)nullptr,
+         c->params.canal_cutoff[0], c->params.canal_cutoff[1]);
   {
-    const uint32_t need = SH_STAGE_GROOVE | SH_STAGE_ANP | SH_STAGE_TE | SH_STAGE_CSYS;
+    const uint32_t need = SH_STAGE_GROOVE | SH_STAGE_ANP | SH_STAGE_CSYS | (c->params.bone_kind == SH_BONE_PROXIMAL ? 0u : (uint32_t)SH_STAGE_TE);
     if ((mask & need) == need)      // metrics of bone_props.py (side, retroversion, neck-shaft angle, radius of curvature)
     {
       LAUNCH(c, "k_sphere_partial", k_sphere_partial, dim3(SH_SPH_PARTS, B), dim3(256), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
              buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.plane"), buf<double>(c, "metrics.partial"));
-      LAUNCH(c, "k_metrics", k_metrics, dim3(B), dim3(64), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "metrics.partial"), buf<int>(c, "err"));
+      LAUNCH(c, "k_metrics", k_metrics, dim3(B), dim3(64), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "metrics.partial"), buf<int>(c, "err"), (int)c->params.bone_kind);
     }
   }
   return SH_OK;
@@ -1016,6 +1063,11 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   HIPCHK(c, hipSetDevice(c->device));
   const int B = c->B;
   c->b0 = 0; c->Bwin = B;
+  if (c->params.bone_kind == SH_BONE_PROXIMAL) {
+    if (mask & (SH_STAGE_DISTAL | SH_STAGE_TE)) return fail(c, SH_ERR_ARG, "sh_run: a proximal humerus has no distal / trans-epicondylar stage (bone.py:24-64)");
+    int prc = alloc_prox(c);
+    if (prc != SH_OK) return prc;
+  }
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "err"), 0, B * 4, c->stream));
   if (!(mask & SH_STAGE_OBB) && !c->obb_injected)
     return fail(c, SH_ERR_STATE, "sh_run: no OBB transform (run SH_STAGE_OBB or sh_store(\"obb_transform\"))");

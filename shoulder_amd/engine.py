@@ -77,13 +77,15 @@ class Engine:
         packed = np.ascontiguousarray(packed)
         self._chk(self.L.sh_load_unet(self.h, int(base), int(depth), _ptr(packed), packed.size))
 
-    def set_params(self, canal_cutoff=(0.35, 0.75), groove_cutoff=(0.2, 0.75), groove_deg_window=7.0, unet_dtype=_lib.UNET_F32):
+    def set_params(self, canal_cutoff=(0.35, 0.75), groove_cutoff=(0.2, 0.75), groove_deg_window=7.0, unet_dtype=_lib.UNET_F32,
+                   bone_kind=_lib.BONE_HUMERUS):
         p = _lib.Params()
         self.L.sh_default_params(ctypes.byref(p))
         p.canal_cutoff[0], p.canal_cutoff[1] = canal_cutoff
         p.groove_cutoff[0], p.groove_cutoff[1] = groove_cutoff
         p.groove_deg_window = groove_deg_window
         p.unet_dtype = unet_dtype
+        p.bone_kind = bone_kind
         self._chk(self.L.sh_set_params(self.h, ctypes.byref(p)))
 
     def param_block(self):

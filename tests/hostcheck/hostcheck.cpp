@@ -7,6 +7,7 @@ extern "C" {
 int hc_cpd(const double* x, int n) { std::vector<double> s(n * n + n * n); return cpd_one_bkp(x, n, s.data()); }
 double hc_circle(const double* xy, int n, double* c) { return circle_fit_residual(xy, n, c, c + 1); }
 void hc_savgol(const double* x, int n, double* y) { savgol10_1(x, n, y); }
+int hc_prox_canal_range(const double* a, int n, int* lo, int* hi) { std::vector<double> t(2 * n); return prox_canal_range(a, n, t.data(), lo, hi); }
 int hc_find_peaks(const double* x, int n, double h, double p, double w, int* idx, double* prom, double* wid, double* wh, int cap) {
   std::vector<Peak> pk(cap);
   int k = find_peaks_hpw(x, n, h, p, w, pk.data(), cap);

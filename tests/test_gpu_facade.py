@@ -104,7 +104,7 @@ def test_errors(hum):
     with pytest.raises(ValueError, match="Invalid transformation matrix shape"):
         hum.apply_csys_custom(np.identity(3))
     import shoulder_amd as shoulder
-    with pytest.raises(NotImplementedError):
-        shoulder.ProximalHumerus("x.stl")
+    with pytest.raises((FileNotFoundError, ValueError)):
+        shoulder.ProximalHumerus("x.stl", engine=hum._engine)
     with pytest.raises((FileNotFoundError, ValueError)):
         shoulder.Humerus("does_not_exist.stl", engine=hum._engine)

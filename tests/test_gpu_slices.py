@@ -78,7 +78,7 @@ def test_neck_and_canal(engine, ran):
     nz = engine.fetch("neck_z", np.float64, (B,))
     ni = engine.fetch("neck_index", np.int32, (B,))
     ax = engine.fetch("canal.axis_ct", np.float64, (B, 2, 3))
-    pts = engine.fetch("canal.points_obb", np.float64, (B, 80, 3))
+    pts = engine.fetch("canal.points_obb", np.float64, (B, 200, 3))[:, :80]      # capacity 200 rows per humerus, 80 used with the default cut-offs
     for b, h in enumerate(ran):
         assert ni[b] == h.neck["bkp"]
         assert nz[b] == pytest.approx(h.neck["neck_z"], abs=1e-12)

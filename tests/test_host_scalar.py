@@ -242,3 +242,21 @@ def test_hull_vs_qhull(hc):
         Q = P - c
         vol = np.einsum("ij,ij->i", Q[t[:, 0]], np.cross(Q[t[:, 1]], Q[t[:, 2]])).sum() / 6   # outward orientation -> positive
         assert abs(vol - ref.volume) <= 1e-9 * ref.volume
+
+
+def test_prox_canal_range(hc):
+    """mesh.py:181-190 restated (sh::prox_canal_range) against the oracle's scipy/numpy evaluation on area profiles
+    shaped like a cut humerus (flat shaft, rising head, ragged first samples)."""
+    from oracle import prox
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        n = 100
+        shaft = 350 + rng.normal(0, 3, n).cumsum()
+        head = np.maximum(0, np.arange(n) - rng.integers(55, 80)) ** 2 * rng.uniform(0.5, 3)
+        a = shaft + head
+        a[: rng.integers(0, 4)] *= rng.uniform(0.2, 0.9)
+        a[-rng.integers(1, 6):] *= rng.uniform(0.2, 0.9)
+        lo, hi = ctypes.c_int(), ctypes.c_int()
+        k = hc.hc_prox_canal_range(dp(a), n, ctypes.byref(lo), ctypes.byref(hi))
+        zs, pcts, grad = prox.canal_range(a)
+        assert (lo.value, hi.value) == (int(zs[0]), int(zs[-1])) and k == len(zs)
