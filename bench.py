@@ -227,6 +227,9 @@ def main():
             if name in ul and name not in ("unet.head", "unet.enc0a"):
                 cout = ul_cout[name]
                 key = "k_conv_mfma_%s<%d,%d>" % (args.unet, 1 if name.startswith("unet.up") else 9, 4 if cout % 64 == 0 else 2)
+                if args.unet == "bf16":      # third template argument = fused ends (k_unet_bf16.h): UF_FIRST 1, UF_HEAD 2, UF_POOL 4
+                    fuse = 5 if name == "unet.enc0b" else 2 if name == "unet.dec0b" else 4 if name in ("unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
+                    key = key[:-1] + ",%d>" % fuse
             else:
                 key = name
             g = sym.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
