@@ -73,7 +73,9 @@ struct sh_ctx {
   struct Prepared {
     std::thread th; bool active = false; int slot = 0, B = 0, rc = SH_OK, bad_mesh = -1; unsigned long long gen = 0;
     double d2h_ms = 0, hull_ms = 0; std::string err;
+    bool uploaded = false;      // the hull records are already in the device buffers (copied by the background thread)
   } prep;
+  hipEvent_t obb_done_ev = nullptr;      // recorded after the last kernel of a run that reads the hull.* device buffers
   bool overlap = false;
   unsigned long long batch_gen = 0;
   hipStream_t copy_stream = nullptr;
@@ -192,6 +194,7 @@ void sh_ctx_destroy(sh_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   drain_timers(c);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->obb_done_ev) (void)hipEventDestroy(c->obb_done_ev);
   for (auto& kv : c->bufs)
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto& hs : c->hstage) {
@@ -844,6 +847,25 @@ static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, do
   return SH_OK;
 }
 
+// Hull records of pinned slot `slot` -> device buffers on stream `st`: only the used head of every fixed-capacity record
+// crosses PCIe (one strided copy per array).  `dst` = {hull.hv, hull.normals, hull.edges, hull.nv, hull.nf, hull.ne}.
+static hipError_t hull_upload(sh_ctx* c, int slot, int B, void* const dst[6], hipStream_t st) {
+  sh_ctx::HullStage& hs = c->hstage[slot];
+  const int* counts = hs.cnt;
+  int nvmax = 1, nfmax = 1, nemax = 1;
+  for (int b = 0; b < B; ++b) { nvmax = std::max(nvmax, counts[b]); nfmax = std::max(nfmax, counts[B + b]); nemax = std::max(nemax, counts[2 * B + b]); }
+  hipError_t e;
+  if ((e = hipMemcpy2DAsync(dst[0], (size_t)SH_HV * 24, hs.hv, (size_t)SH_HV * 24, (size_t)nvmax * 24, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpy2DAsync(dst[1], (size_t)SH_HF * 24, hs.nr, (size_t)SH_HF * 24, (size_t)nfmax * 24, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpy2DAsync(dst[2], (size_t)SH_HE * 16, hs.ed, (size_t)SH_HE * 16, (size_t)nemax * 16, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(dst[3], counts, (size_t)B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(dst[4], counts + B, (size_t)B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(dst[5], counts + 2 * B, (size_t)B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipEventRecord(hs.ev, st)) != hipSuccess) return e;      // pinned slot is free again once these copies have run
+  hs.used = true;
+  return hipSuccess;
+}
+
 // mesh.py:63-125.  Host: convex hulls (hull_host_phase; already done by the background thread when `prepared_slot`
 // >= 0).  Device: candidate boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
 static int run_obb(sh_ctx* c, int prepared_slot) {
@@ -857,19 +879,13 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
     if (hrc == SH_ERR_HIP) { c->err = et; return hrc; }
     if (hrc != SH_OK) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", bad, hrc); return fail(c, hrc, m); }
   }
-  sh_ctx::HullStage& hs = c->hstage[slot];
-  double* hv = hs.hv; double* nr = hs.nr; int* ed = hs.ed; int* counts = hs.cnt;
-  int nvmax = 1, nfmax = 1, nemax = 1;
-  for (int b = 0; b < B; ++b) { nvmax = std::max(nvmax, counts[b]); nfmax = std::max(nfmax, counts[B + b]); nemax = std::max(nemax, counts[2 * B + b]); }
-  // only the used head of every fixed-capacity record crosses PCIe (one strided copy per array)
-  HIPCHK(c, hipMemcpy2DAsync(buf<double>(c, "hull.hv"), (size_t)SH_HV * 24, hv, (size_t)SH_HV * 24, (size_t)nvmax * 24, B, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpy2DAsync(buf<double>(c, "hull.normals"), (size_t)SH_HF * 24, nr, (size_t)SH_HF * 24, (size_t)nfmax * 24, B, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpy2DAsync(buf<int>(c, "hull.edges"), (size_t)SH_HE * 16, ed, (size_t)SH_HE * 16, (size_t)nemax * 16, B, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.nv"), counts, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.nf"), counts + B, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.ne"), counts + 2 * B, (size_t)B * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipEventRecord(hs.ev, c->stream));      // pinned slot is free again once these copies have run
-  hs.used = true;
+  const int* counts = c->hstage[slot].cnt;
+  int nfmax = 1;
+  for (int b = 0; b < B; ++b) nfmax = std::max(nfmax, counts[B + b]);
+  if (!(prepared_slot >= 0 && c->prep.uploaded)) {
+    void* const dst[6] = {buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), buf<int>(c, "hull.nv"), buf<int>(c, "hull.nf"), buf<int>(c, "hull.ne")};
+    HIPCHK(c, hull_upload(c, slot, B, dst, c->stream));
+  }
   const int* cnt_nv = buf<int>(c, "hull.nv");
   const int* cnt_nf = buf<int>(c, "hull.nf");
   const int* cnt_ne = buf<int>(c, "hull.ne");
@@ -884,6 +900,8 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   LAUNCH(c, "k_obb_pick", k_obb_pick, dim3(B), dim3(256), buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"),
          buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<float>(c, "verts"), buf<long long>(c, "voff"), buf<double>(c, "obb.T_pre"),
          buf<double>(c, "obb.zb_pre"), buf<int>(c, "err"));
+  if (!c->obb_done_ev) HIPCHK(c, hipEventCreateWithFlags(&c->obb_done_ev, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->obb_done_ev, c->stream));      // hull.* device buffers are free for the next run's records from here
   if (c->params.bone_kind == SH_BONE_PROXIMAL) {
     // mesh.py:134-192 ProxObb: 100 sections of the mesh in the raw box frame, head = largest area, canal range
     dim3 gv((unsigned)std::min<long long>((c->maxV + 255) / 256, 1024), (unsigned)B);
@@ -1028,19 +1046,30 @@ static int join_prepared(sh_ctx* c) {
 static void start_prepare(sh_ctx* c) {
   sh_ctx::Prepared& p = c->prep;
   p.active = true; p.slot = c->hslot; p.B = c->B; p.gen = c->batch_gen; p.rc = SH_OK; p.bad_mesh = -1; p.d2h_ms = p.hull_ms = 0; p.err.clear();
+  p.uploaded = false;
   const bool need_d2h = !c->h_verts_valid;
-  p.th = std::thread([c, need_d2h]() {
+  // device pointers are looked up here: the buffer map belongs to the calling thread
+  const float* d_verts = buf<float>(c, "verts");
+  struct Dst { void* p[6]; } dst = {{buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), buf<int>(c, "hull.nv"), buf<int>(c, "hull.nf"), buf<int>(c, "hull.ne")}};
+  const bool can_upload = c->obb_done_ev != nullptr;
+  p.th = std::thread([c, need_d2h, d_verts, dst, can_upload]() {
     sh_ctx::Prepared& q = c->prep;
     if (hipSetDevice(c->device) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
+    if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
     if (need_d2h) {      // a device-generated batch is downloaded again for every run, on the copy stream, beside the kernels
       auto t0 = std::chrono::steady_clock::now();
-      if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
       c->h_verts.resize(3 * (size_t)c->sumV);
-      if (hipMemcpyAsync(c->h_verts.data(), buf<float>(c, "verts"), c->sumV * 3 * 4, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
+      if (hipMemcpyAsync(c->h_verts.data(), d_verts, c->sumV * 3 * 4, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
           hipStreamSynchronize(c->copy_stream) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
       q.d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     q.rc = hull_host_phase(c, q.slot, 0, q.B, &q.bad_mesh, &q.hull_ms, &q.err);
+    if (q.rc == SH_OK && can_upload) {
+      // the records go to the device as soon as the running step no longer reads the hull.* buffers (after its k_obb_pick)
+      if (hipStreamWaitEvent(c->copy_stream, c->obb_done_ev, 0) == hipSuccess && hull_upload(c, q.slot, q.B, dst.p, c->copy_stream) == hipSuccess &&
+          hipStreamSynchronize(c->copy_stream) == hipSuccess)
+        q.uploaded = true;
+    }
   });
 }
 
