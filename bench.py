@@ -170,14 +170,17 @@ def main():
     def step():
         if host_batch is not None:
             eng.upload(host_batch)
-        eng.run(_lib.STAGE_ALL, fetch=not use_dist)
+        eng.run(_lib.STAGE_ALL, fetch=False if use_dist else "view")      # records land in the engine's page-locked buffer (or are gathered device to device)
         if use_dist:
             dist.gather(lm_t, gather_list, dst=0)      # landmark records of every rank to rank 0 (device to device)
 
     overlap = not args.no_overlap and host_batch is None
     for _ in range(args.warmup):
         step()
-    eng.enable_timing(True)
+    # HIP events around the UNet layers only inside the timed region (level 2): the dominant kernel is one of them, and
+    # events around all ~150 launches of a step stretch the step by ~0.7 ms.  The other kernels are timed in one extra
+    # pass after the region (level 1).
+    eng.enable_timing(2)
     eng.reset_timers()
     # Streaming schedule: inside the timed region the hulls of step k+1 are computed by host threads while the device
     # works on step k.  Nothing is carried in from the warmup (discard) and nothing is prepared for a step K+1 (overlap
@@ -200,7 +203,13 @@ def main():
         tt = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
-    eng.enable_timing(False)
+    ul = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512, eb=2 if args.unet == "bf16" else 4)
+    region_times = {name: eng.kernel_time_ms(name) for name in list(ul) + ["unet.pool", "host.verts_d2h", "host.hull"]}
+    eng.reset_timers()
+    eng.enable_timing(1)
+    eng.run(_lib.STAGE_ALL, fetch=False)      # profiling pass outside the timed region: every kernel between events
+    extra_times = {name: eng.kernel_time_ms(name) for name in GEOM_KERNELS + ["k_synth_batch", "k_pack_w_bf16"]}
+    eng.enable_timing(0)
 
     if use_dist and rank == 0:      # what rank 0 holds after the last gather: every rank's records, in rank order
         lm = torch.cat(gather_list).cpu().numpy().view(_lib.LANDMARKS_DTYPE)
@@ -210,15 +219,17 @@ def main():
     n_bad = int((lm["status"] != 0).sum())
 
     if rank == 0:
-        ul = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512, eb=2 if args.unet == "bf16" else 4)
         ul_cout = unet_couts(unet_spec.BASE, unet_spec.DEPTH)
         gb = geom_bytes(B, V, F)
         times = {}
-        host_ms = {k: (lambda t: t[0] * t[1] / args.steps)(eng.kernel_time_ms(k)) for k in ("host.verts_d2h", "host.hull")}
-        for name in GEOM_KERNELS + list(ul) + ["unet.pool", "k_synth_batch", "k_pack_w_bf16"]:
-            ms, n = eng.kernel_time_ms(name)
+        host_ms = {k: (lambda t: t[0] * t[1] / args.steps)(region_times[k]) for k in ("host.verts_d2h", "host.hull")}
+        for name in list(ul) + ["unet.pool"]:                 # averaged over the launches of the timed steps
+            ms, n = region_times[name]
             if n:
                 times[name] = (ms, n)
+        for name, (ms, n) in extra_times.items():              # one pass: scaled to the same per-step accounting
+            if n:
+                times[name] = (ms, n * args.steps)
         total_dev = sum(ms * n for ms, n in times.values())
         # group the launches by kernel symbol (what rocprofv3 --stats reports): the UNet layers run one of
         # four instantiations of k_conv_mfma_f32<TAPS, NT>

@@ -132,6 +132,10 @@ int  sh_batch_size(const sh_ctx*);
 int  sh_run(sh_ctx*, uint32_t stage_mask, sh_landmarks* out /* B, host, nullable */);
 /* Device address of the B result structs of the last sh_run (for a collective gather). */
 int  sh_landmarks_device(sh_ctx*, void** dev_ptr, size_t* nbytes);
+/* Page-locked host memory for the `out` array of sh_run when it is reused from run to run (the reference returns fresh
+ * NumPy arrays from every accessor; a streaming caller keeps one record buffer): direct D2H, no page faults. */
+int  sh_host_alloc(sh_ctx*, size_t nbytes, void** out);
+int  sh_host_free(sh_ctx*, void* p);
 
 /* utils.transform_pts (utils.py:172-188) for B point sets on the device:
  * out[off[b]..off[b+1]) = T[b] * in[...]; in/out are DEVICE pointers to float64 xyz. */
@@ -164,7 +168,9 @@ int  sh_unet_infer(sh_ctx*, const float* images, int n, int H, int W, float* log
 /* Average duration (ms) of the named kernel over the launches since the last reset, measured
  * with HIP events on the ctx stream (bench.py roofline); name NULL resets all timers. */
 int  sh_kernel_time_ms(sh_ctx*, const char* kernel, double* avg_ms, int* launches);
-int  sh_enable_timing(sh_ctx*, int on);
+/* level 0: off; 1: events around every launch; 2: around the UNet layers only (events around all ~150 launches of a
+ * run stretch it by ~4 % at B = 64, so a measurement inside a timed region uses level 2). */
+int  sh_enable_timing(sh_ctx*, int level);
 
 /* Streaming use (one sh_run after another on the resident batch): with overlap on, sh_run starts a
  * background thread, once all its device work is enqueued, that computes the convex hulls the NEXT

@@ -50,6 +50,7 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            self._free_pinned()
             self.L.sh_ctx_destroy(self.h)
             self.h = None
 
@@ -118,9 +119,30 @@ class Engine:
 
     # ---- run ---------------------------------------------------------------------------------------
     def run(self, stages=_lib.STAGE_ALL, fetch=True):
-        out = np.zeros(self.B, dtype=LANDMARKS_DTYPE) if fetch else None
-        self._chk(self.L.sh_run(self.h, int(stages), _ptr(out) if fetch else None))
+        """One sh_run over the resident batch.  fetch=True: a fresh record array; fetch="view": the engine's page-locked
+        record buffer (no allocation, direct D2H), valid until the next run; fetch=False: records stay on the device."""
+        if fetch == "view":
+            out = self._pinned_records()
+        else:
+            out = np.zeros(self.B, dtype=LANDMARKS_DTYPE) if fetch else None
+        self._chk(self.L.sh_run(self.h, int(stages), _ptr(out) if out is not None else None))
         return out
+
+    def _pinned_records(self):
+        if getattr(self, "_pin_n", 0) < self.B:
+            self._free_pinned()
+            p = ctypes.c_void_p()
+            nbytes = self.B * LANDMARKS_DTYPE.itemsize
+            self._chk(self.L.sh_host_alloc(self.h, nbytes, ctypes.byref(p)))
+            self._pin_ptr, self._pin_n = p, self.B
+            self._pin_arr = np.frombuffer((ctypes.c_char * nbytes).from_address(p.value), dtype=LANDMARKS_DTYPE)
+        return self._pin_arr[: self.B]
+
+    def _free_pinned(self):
+        if getattr(self, "_pin_n", 0):
+            self._pin_arr = None
+            self.L.sh_host_free(self.h, self._pin_ptr)
+            self._pin_n = 0
 
     def landmarks_device(self):
         p, n = ctypes.c_void_p(), ctypes.c_size_t()
@@ -175,7 +197,7 @@ class Engine:
 
     # ---- timing --------------------------------------------------------------------------------------
     def enable_timing(self, on=True):
-        self._chk(self.L.sh_enable_timing(self.h, 1 if on else 0))
+        self._chk(self.L.sh_enable_timing(self.h, int(on)))      # 0 off, 1 every launch, 2 UNet layers only
 
     def set_overlap(self, on=True):
         """Streaming runs on the resident batch: compute the host hulls of the next run while the device works on this one."""
