@@ -1,0 +1,215 @@
+// k_unet_bf16_dma.h -- 3x3 conv, bf16, for the layers with >= 64 output channels: persistent workgroups with
+// LDS-DMA double buffering (the ~900 TFLOP/s ceiling of the two-barriers-per-chunk kernel in k_unet_bf16.h is a property
+// of that structure: every chunk waits for its own staging; here the next chunk streams into the other LDS buffer while
+// this one is multiplied).
+//
+// Workgroup = 512 lanes = 8 waves, one per CU (155 KB of LDS).  Work item = (image, 32x16-pixel tile, 64-cout group); a
+// workgroup walks a contiguous range of items (cout groups of one tile are neighbours: their input tile stays in L2), the
+// (item, 32-channel chunk) steps are flattened and pipelined: while the MFMAs of step i read LDS buffer i & 1, the
+// `global_load_lds_dwordx4` pieces of step i + 1 -- one issued per tap, between the MFMA groups -- fill buffer (i + 1) & 1.
+// One raw s_barrier per step; the DMA is retired by a counted s_waitcnt that leaves the epilogue stores of the previous
+// item in flight (those are inline-asm stores so that their number is exact).
+// LDS image per buffer: 18 x 36 halo-pixel rows (pitch 36: the swizzle bit of a fragment row then depends only on row
+// parity, dx and the lane -> 7 address registers + immediates for all 72 fragment reads of a step), then 576 weight rows
+// ([tap][64 couts]); 32 channels = 64 B per row, XOR slot swizzle as in k_unet_bf16.h, applied on the DMA's SOURCE address
+// (the DMA writes lane-linear) and on the fragment read.  Out-of-image halo pixels read a 64-byte page of zeros.
+#pragma once
+#include "k_unet_bf16.h"
+
+namespace sh {
+
+#define UD_THREADS 512
+#define UD_PW 36
+#define UD_INROWS (18 * UD_PW)              // 648
+#define UD_ROWS (UD_INROWS + 576)           // 1224
+#define UD_BUF (UD_ROWS * 64)               // 78336
+#define UD_SLOTS (UD_ROWS * 4)              // 4896
+#define UD_BIAS_OFF (2 * UD_BUF)
+#define UD_SMEM (2 * UD_BUF + 2048)         // 158720
+
+typedef const __attribute__((address_space(1))) void* ud_gptr;
+typedef __attribute__((address_space(3))) void* ud_lptr;
+
+__device__ inline void ud_store8(__bf16* p, bf16x4 v) {      // exactly one vector-memory instruction (counted by s_waitcnt vmcnt)
+  asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(__builtin_bit_cast(unsigned long long, v)) : "memory");
+}
+
+template <int FUSE>      // 0 or UF_POOL
+__global__ void __launch_bounds__(UD_THREADS)
+k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src1, int C0, int C1,
+                 const __bf16* __restrict__ wgt, const float* __restrict__ bias, __bf16* __restrict__ dst,
+                 int H, int W, int Cout, int relu, int nimg, const __bf16* __restrict__ zero_page, __bf16* __restrict__ pooled) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[UD_SMEM];
+  constexpr int NSTORE = 16 + ((FUSE & UF_POOL) ? 8 : 0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int xh = wave & 1, rg = wave >> 1;
+  const int Cin = C0 + C1, nchunk = Cin >> 5;
+  const int tiles_x = W / 32, tiles_y = H / 16, ngroups = Cout >> 6;
+  const int total = nimg * tiles_x * tiles_y * ngroups;
+  const int per = (total + gridDim.x - 1) / gridDim.x;
+  const int w_begin = blockIdx.x * per, w_end = min(total, w_begin + per);
+  if (w_begin >= w_end) return;
+
+  float* s_bias = (float*)(smem + UD_BIAS_OFF);
+  for (int i = tid; i < Cout; i += UD_THREADS) s_bias[i] = bias[i];
+  __syncthreads();       // every ordinary load is retired before the first LDS-DMA is issued
+
+  // staging plan: slot e_k = tid + 512 k -> row r_k = (tid >> 2) + 128 k; k = 0..4 halo rows, k = 5 mixed, k = 6..9 weight rows.
+  // The swizzle bit (bit 2 of the row) is the same for every k, weight rows advance by two taps per k.
+  const int r0 = tid >> 2;
+  const int q8 = ((tid & 3) ^ ((r0 >> 1) & 2)) * 8;
+  const int rw5 = r0 + 640 - UD_INROWS;
+  const int wstep = 2 * nchunk * Cout * 32;
+  const int wrel5 = ((rw5 >> 6) * nchunk * Cout + (rw5 & 63)) * 32 + q8;
+  const bool in5 = rw5 < 0;
+  const bool w9 = tid + 512 * 9 < UD_SLOTS;
+
+  // fragment read offsets (bytes inside a buffer)
+  int xoff[2][3], woff;
+  {
+    const int rowbase = rg * 4 * UD_PW + xh * 16 + li;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) xoff[sp][dx] = UB_OFF(rowbase + sp * UD_PW + dx, lk) * 2;
+    woff = UB_OFF(UD_INROWS + li, lk) * 2;
+  }
+
+  int i_g, i_tx, i_ty, i_img;      // item being staged
+  {
+    int w = w_begin;
+    i_g = w % ngroups; w /= ngroups;
+    i_tx = w % tiles_x; w /= tiles_x;
+    i_ty = w % tiles_y; i_img = w / tiles_y;
+  }
+  int pixoff[6];
+  auto item_lane_setup = [&]() {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int r = r0 + 128 * k;
+      const int py = r / UD_PW, px = r - py * UD_PW;
+      const int gx = i_tx * 32 + px - 1, gy = i_ty * 16 + py - 1;
+      const bool ok = px < 34 && gx >= 0 && gx < W && gy >= 0 && gy < H;
+      pixoff[k] = ok ? gy * W + gx : -1;
+    }
+  };
+  const __bf16* n_simg; const __bf16* n_wbase; int n_Cs, n_cb; unsigned char* n_lbase;      // step being staged (wave-uniform)
+  auto describe = [&](int cc, int buf) {
+    const int c0 = cc * 32;
+    const bool first = c0 < C0;
+    n_Cs = first ? C0 : C1; n_cb = (first ? c0 : c0 - C0) + q8;
+    n_simg = (first ? src0 : src1) + (size_t)i_img * H * W * n_Cs;
+    n_wbase = wgt + ((size_t)cc * Cout + i_g * 64) * 32;
+    n_lbase = smem + buf * UD_BUF + wave * 1024;
+  };
+  auto piece = [&](int k) {      // k is a compile-time constant at every call site
+    if (k < 5) {
+      const __bf16* p = pixoff[k] >= 0 ? n_simg + (unsigned)(pixoff[k] * n_Cs + n_cb) : zero_page;
+      __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + k * 8192), 16, 0, 0);
+    } else if (k == 5) {
+      const __bf16* pi = pixoff[5] >= 0 ? n_simg + (unsigned)(pixoff[5] * n_Cs + n_cb) : zero_page;
+      const __bf16* p = in5 ? pi : n_wbase + wrel5;
+      __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + 5 * 8192), 16, 0, 0);
+    } else if (k < 9) {
+      __builtin_amdgcn_global_load_lds((ud_gptr)(n_wbase + (wrel5 + (k - 5) * wstep)), (ud_lptr)(n_lbase + k * 8192), 16, 0, 0);
+    } else {
+      if (w9) __builtin_amdgcn_global_load_lds((ud_gptr)(n_wbase + (wrel5 + 4 * wstep)), (ud_lptr)(n_lbase + 9 * 8192), 16, 0, 0);
+    }
+  };
+
+  item_lane_setup();
+  describe(0, 0);
+#pragma unroll
+  for (int k = 0; k < 10; ++k) piece(k);
+  int buf = 0;
+  bool stores_in_flight = false;
+  for (int w = w_begin; w < w_end; ++w) {
+    const int c_x0 = i_tx * 32, c_y0 = i_ty * 16, c_img = i_img, c_n0 = i_g * 64;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const f32x4 bv = *(const f32x4*)(s_bias + c_n0 + n * 16 + lk * 4);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m][n] = bv;
+    }
+    for (int cc = 0; cc < nchunk; ++cc) {
+      // this wave's DMA pieces of the step are older than the NSTORE epilogue stores of the previous item
+      if (stores_in_flight) {
+        if (FUSE & UF_POOL) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stores_in_flight = false;
+      __builtin_amdgcn_s_barrier();      // every wave's pieces have landed; every wave is done reading the other buffer
+      bool has_next = true;
+      if (cc + 1 < nchunk) {
+        describe(cc + 1, buf ^ 1);
+      } else if (w + 1 < w_end) {
+        if (++i_g == ngroups) { i_g = 0; if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; ++i_img; } } }
+        item_lane_setup();
+        describe(0, buf ^ 1);
+      } else has_next = false;
+      const unsigned char* sb = smem + buf * UD_BUF;
+      const unsigned char* xb[2][3];
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) xb[sp][dx] = sb + xoff[sp][dx];
+      const unsigned char* wbp = sb + woff;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap % 3;
+        bf16x8 xf[4], wf[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { const int s = m + dy; xf[m] = *(const bf16x8*)(xb[s & 1][dx] + (s & ~1) * UD_PW * 64); }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) wf[n] = *(const bf16x8*)(wbp + (tap * 64 + n * 16) * 64);
+        if (has_next) { piece(tap); if (tap == 8) piece(9); }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[m][n], 0, 0, 0);
+      }
+      buf ^= 1;
+    }
+    __bf16* out = dst + (size_t)c_img * H * W * Cout;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int gy = c_y0 + rg * 4 + m, gx = c_x0 + xh * 16 + li;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[m][n][r];
+          if (relu) v = fmaxf(v, 0.0f);
+          o[r] = (__bf16)v;
+        }
+        ud_store8(out + ((size_t)gy * W + gx) * Cout + c_n0 + n * 16 + lk * 4, o);
+      }
+    }
+    if (FUSE & UF_POOL) {      // 2x2 max pool of this wave's 4 rows x 16 pixels (rows pair inside the lane, columns with lane li ^ 1)
+      __bf16* po = pooled + (size_t)c_img * (H / 2) * (W / 2) * Cout;
+#pragma unroll
+      for (int mp = 0; mp < 2; ++mp)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = fmaxf(acc[2 * mp][n][r], acc[2 * mp + 1][n][r]);
+            v = fmaxf(v, __shfl_xor(v, 1));
+            if (relu) v = fmaxf(v, 0.0f);
+            o[r] = (__bf16)v;
+          }
+          // odd lanes store too (same value, the pixel of their even neighbour): the store count per wave stays exact
+          ud_store8(po + ((size_t)((c_y0 + rg * 4) / 2 + mp) * (W / 2) + (c_x0 + xh * 16 + li) / 2) * Cout + c_n0 + n * 16 + lk * 4, o);
+        }
+    }
+    (void)NSTORE;
+    stores_in_flight = true;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace sh

@@ -17,6 +17,7 @@
 #include "k_anp.h"
 #include "k_unet.h"
 #include "k_unet_bf16.h"
+#include "k_unet_bf16_dma.h"
 #include "k_te.h"
 #include "k_obb.h"
 #include "sh_hull.h"
@@ -80,6 +81,8 @@ struct sh_ctx {
   unsigned long long batch_gen = 0;
   hipStream_t copy_stream = nullptr;
   // timing
+  bool zero_page_ready = false;
+  int num_cus = 0;
   int timing = 0;      // 0 off, 1 every launch, 2 UNet layers only
   std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t>> pending;
   std::map<std::string, KTimer> timers;
@@ -634,7 +637,20 @@ static int conv_layer_bf16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L
   const float* b = buf<float>(c, "params") + L.b_off;
   const int tiles = (H / UN_TH) * (W / UN_TW);
   const dim3 blk(UN_THREADS);
-  if (L.taps == 9 && L.cout % 64 == 0) {
+  const char* dma_env = getenv("SHOULDER_UNET_DMA");
+  if (L.taps == 9 && L.cout % 64 == 0 && L.cout <= 512 && W % 32 == 0 && H % 16 == 0 && C0 % 32 == 0 && C1 % 32 == 0 && (fuse == 0 || fuse == UF_POOL) &&
+      !(dma_env && dma_env[0] == '0')) {
+    // persistent LDS-DMA form (k_unet_bf16_dma.h): one workgroup per CU walks (image, 32x16 tile, 64-cout group) items
+    int rc0;
+    if ((rc0 = ensure(c, "unet16.zero", 256, 2)) != SH_OK) return rc0;
+    if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
+    if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
+    const int total = nimg * (W / 32) * (H / 16) * (L.cout / 64);
+    const dim3 g((unsigned)std::min(total, c->num_cus));
+    const __bf16* zp = (const __bf16*)c->bufs["unet16.zero"].p;
+    if (fuse == UF_POOL) { LAUNCH(c, lname, k_conv3_dma_bf16<UF_POOL>, g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, fz.pooled); }
+    else { LAUNCH(c, lname, k_conv3_dma_bf16<0>, g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (__bf16*)nullptr); }
+  } else if (L.taps == 9 && L.cout % 64 == 0) {
     const dim3 g(tiles, L.cout / 64, nimg);
     if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 4, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
     else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 4, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
