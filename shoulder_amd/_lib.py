@@ -78,6 +78,11 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     path = lib_path()
+    alt = os.environ.get("SHOULDER_LIB")      # experiments: an alternative build of the same sources (A/B runs on one GPU box)
+    if alt:
+        if not os.path.exists(alt):
+            raise RuntimeError(f"SHOULDER_LIB={alt} does not exist")
+        path, build_if_missing = alt, False
     if build_if_missing and _build.is_stale():
         try:
             _build.build_lib(verbose=False)

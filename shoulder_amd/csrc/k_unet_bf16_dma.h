@@ -165,10 +165,16 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
 #pragma unroll
         for (int n = 0; n < 4; ++n) wf[n] = *(const bf16x8*)(wbp + (tap * 64 + n * 16) * 64);
         if (has_next) { piece(tap); if (tap == 8) piece(9); }
+#ifdef SH_DMA_SETPRIO
+        __builtin_amdgcn_s_setprio(1);      // +4..7 % per layer in tools/conv_lab, -1..3 % inside this library (co-compiled kernels shift the schedule): off
+#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[m][n], 0, 0, 0);
+#ifdef SH_DMA_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
       buf ^= 1;
     }

@@ -111,6 +111,9 @@ int main(int argc, char** argv) {
     } else if (kern == "v4a3") { launch_conv_v4<1, 0, 0, 3>(src, nullptr, Cin, 0, wpk, bias, dst, H, W, Cout, nimg, 1, 0);
     } else if (kern == "v4a4") { launch_conv_v4<1, 0, 0, 4>(src, nullptr, Cin, 0, wpk, bias, dst, H, W, Cout, nimg, 1, 0);
     } else if (kern == "v4a5") { launch_conv_v4<1, 0, 0, 5>(src, nullptr, Cin, 0, wpk, bias, dst, H, W, Cout, nimg, 1, 0);
+    } else if (kern == "v4a6") { launch_conv_v4<1, 0, 0, 6>(src, nullptr, Cin, 0, wpk, bias, dst, H, W, Cout, nimg, 1, 0);
+    } else if (kern == "v4a7") { launch_conv_v4<1, 0, 0, 7>(src, nullptr, Cin, 0, wpk, bias, dst, H, W, Cout, nimg, 1, 0);
+    } else if (kern == "v4a8") { launch_conv_v4<1, 0, 0, 8>(src, nullptr, Cin, 0, wpk, bias, dst, H, W, Cout, nimg, 1, 0);
     } else { fprintf(stderr, "unknown kernel %s\n", kern.c_str()); exit(1); }
   };
   launch();

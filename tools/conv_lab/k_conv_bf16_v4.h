@@ -178,9 +178,12 @@ k_conv3_bf16_v4(const __bf16* __restrict__ src0, const __bf16* __restrict__ src1
         for (int tap = 0; tap < 9; ++tap) {
           bf16x8 xf[4], wf[4];
           if (ABL == 3) rd3(tap, xf, wf); else rd(tap, xf, wf);
-          if (SPREAD && has_next) { piece(tap); if (tap == 8) piece(9); }
+          if (SPREAD && has_next && ABL != 7 && ABL != 8) { piece(tap); if (tap == 8) piece(9); }
           if (PIN) __builtin_amdgcn_sched_barrier(0);
+          if (ABL == 6 || ABL == 8) __builtin_amdgcn_s_setprio(1);
           mm(xf, wf);
+          if (ABL == 6 || ABL == 8) __builtin_amdgcn_s_setprio(0);
+          if (SPREAD && has_next && (ABL == 7 || ABL == 8)) { piece(tap); if (tap == 8) piece(9); }
           if (PIN) __builtin_amdgcn_sched_barrier(0);
         }
       }
