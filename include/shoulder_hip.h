@@ -123,6 +123,11 @@ int  sh_param_block(sh_ctx*, void** dev_ptr, size_t* nbytes);
 /* ---- meshes (replace MeshLoader, mesh.py:14-41; vertices already merged) ------------- */
 int  sh_upload_meshes(sh_ctx*, const float* verts /* sumV x 3 */, const int32_t* faces /* sumF x 3, per-mesh local ids */,
                       const int64_t* v_off /* B+1 */, const int64_t* f_off /* B+1 */, int B);
+/* The same from B binary STL files held in host memory (`trimesh.load_mesh(stl_file)` at mesh.py:22-27 incl. its vertex
+ * merge): records are parsed and merged on the device -- vertices with equal bit patterns (after -0.0 -> +0.0) become
+ * one, numbered by first appearance in the file; triangles that use a vertex twice are dropped.  v_off_out / f_off_out
+ * (B+1 each, nullable) receive the resulting offsets. */
+int  sh_upload_stl(sh_ctx*, const void* const* files, const size_t* nbytes, int B, int64_t* v_off_out, int64_t* f_off_out);
 /* Synthetic batch (BASELINE config 3/4): mesh i = similarity transform T[i] (4x4, float64)
  * of uploaded mesh 0, evaluated on the device in float64 and stored as float32. */
 int  sh_synth_batch(sh_ctx*, const double* T /* B x 16 */, int B);

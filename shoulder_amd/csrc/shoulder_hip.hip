@@ -18,6 +18,7 @@
 #include "k_unet.h"
 #include "k_unet_bf16.h"
 #include "k_unet_bf16_dma.h"
+#include "k_stl.h"
 #include "k_te.h"
 #include "k_obb.h"
 #include "sh_hull.h"
@@ -382,6 +383,78 @@ int sh_upload_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const 
   HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "voff"), c->h_voff.data(), (B + 1) * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "foff"), c->h_foff.data(), (B + 1) * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return alloc_batch(c);
+}
+
+// Binary STL files -> merged meshes, on the device (k_stl.h; replaces `trimesh.load_mesh(stl)` of mesh.py:22-27 incl. the
+// vertex merge).  The host only checks the 84-byte headers and sums sizes.
+int sh_upload_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int B, int64_t* v_off_out, int64_t* f_off_out) {
+  if (!c || !files || !nbytes || B <= 0) return fail(c, SH_ERR_ARG, "sh_upload_stl: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  (void)join_prepared(c); ++c->batch_gen;
+  std::vector<long long> file_off(B + 1, 0), coff(B + 1, 0);
+  long long maxc = 0;
+  for (int b = 0; b < B; ++b) {
+    if (!files[b] || nbytes[b] < 84) return fail(c, SH_ERR_ARG, "sh_upload_stl: a file is too short for a binary STL");
+    uint32_t nt;
+    memcpy(&nt, (const char*)files[b] + 80, 4);
+    if (nbytes[b] != 84 + 50ull * nt) return fail(c, SH_ERR_ARG, "sh_upload_stl: not a binary STL (size does not match the triangle count)");
+    if (nt < 4 || nt > 0x7fffffffu / 3) return fail(c, SH_ERR_ARG, "sh_upload_stl: a mesh has fewer than 4 (or too many) triangles");
+    file_off[b + 1] = file_off[b] + (long long)((nbytes[b] + 3) & ~(size_t)3);
+    coff[b + 1] = coff[b] + 3ll * nt;
+    maxc = std::max(maxc, 3ll * nt);
+  }
+  int tsize = 1024;
+  while (tsize < 2 * maxc) tsize <<= 1;
+  const long long sumC = coff[B];
+  int rc;
+  if ((rc = ensure(c, "stl.raw", (size_t)file_off[B], 1)) != SH_OK) return rc;
+  if ((rc = ensure(c, "stl.file_off", (B + 1) * 8, 8)) != SH_OK) return rc;
+  if ((rc = ensure(c, "stl.coff", (B + 1) * 8, 8)) != SH_OK) return rc;
+  if ((rc = ensure(c, "stl.corners", (size_t)sumC * 12, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "stl.table", (size_t)B * tsize * 8, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "stl.slot", (size_t)sumC * 4, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "stl.vid", (size_t)sumC * 4, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "stl.fpos", (size_t)(sumC / 3) * 4, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "stl.counts", (size_t)B * 8, 4)) != SH_OK) return rc;
+  for (const char* nm : {"stl.raw", "stl.file_off", "stl.coff", "stl.corners", "stl.table", "stl.slot", "stl.vid", "stl.fpos", "stl.counts"}) c->bufs[nm].per_mesh = 0;
+  c->b0 = 0;
+  unsigned char* raw = buf<unsigned char>(c, "stl.raw");
+  for (int b = 0; b < B; ++b) HIPCHK(c, hipMemcpyAsync(raw + file_off[b], files[b], nbytes[b], hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "stl.file_off"), file_off.data(), (B + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "stl.coff"), coff.data(), (B + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  const dim3 gc((unsigned)std::min<long long>((maxc + 255) / 256, 1024), (unsigned)B);
+  LAUNCH(c, "k_stl_corners", k_stl_corners, gc, dim3(256), raw, buf<long long>(c, "stl.file_off"), buf<long long>(c, "stl.coff"), buf<float>(c, "stl.corners"));
+  LAUNCH(c, "k_stl_table_init", k_stl_table_init, dim3(1024), dim3(256), buf<int2>(c, "stl.table"), (size_t)B * tsize);
+  LAUNCH(c, "k_stl_hash", k_stl_hash, gc, dim3(256), buf<float>(c, "stl.corners"), buf<long long>(c, "stl.coff"), buf<int2>(c, "stl.table"), tsize, buf<int>(c, "stl.slot"));
+  LAUNCH(c, "k_stl_rank", k_stl_rank, dim3(B), dim3(SH_STL_SCAN_THREADS), buf<long long>(c, "stl.coff"), buf<int2>(c, "stl.table"), tsize, buf<int>(c, "stl.slot"),
+         buf<int>(c, "stl.vid"), buf<int>(c, "stl.fpos"), buf<int>(c, "stl.counts"));
+  std::vector<int> counts(2 * B);
+  HIPCHK(c, hipMemcpyAsync(counts.data(), buf<int>(c, "stl.counts"), (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->h_voff.assign(B + 1, 0); c->h_foff.assign(B + 1, 0);
+  c->maxV = c->maxF = 0;
+  for (int b = 0; b < B; ++b) {
+    if (counts[2 * b] < 4 || counts[2 * b + 1] < 4) return fail(c, SH_ERR_ARG, "sh_upload_stl: a mesh has fewer than 4 vertices/faces after merging");
+    c->h_voff[b + 1] = c->h_voff[b] + counts[2 * b];
+    c->h_foff[b + 1] = c->h_foff[b] + counts[2 * b + 1];
+    c->maxV = std::max<long long>(c->maxV, counts[2 * b]); c->maxF = std::max<long long>(c->maxF, counts[2 * b + 1]);
+  }
+  c->sumV = c->h_voff[B]; c->sumF = c->h_foff[B];
+  c->B = B;
+  c->h_verts_valid = false;      // the hull stage downloads the merged vertices (as for a device-generated batch)
+  if ((rc = ensure(c, "verts", c->sumV * 3 * 4, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "faces", c->sumF * 3 * 4, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "voff", (B + 1) * 8, 8)) != SH_OK) return rc;
+  if ((rc = ensure(c, "foff", (B + 1) * 8, 8)) != SH_OK) return rc;
+  c->bufs["verts"].per_mesh = 0; c->bufs["faces"].per_mesh = 0;
+  HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "voff"), c->h_voff.data(), (B + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "foff"), c->h_foff.data(), (B + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "k_stl_emit", k_stl_emit, gc, dim3(256), buf<float>(c, "stl.corners"), buf<long long>(c, "stl.coff"), buf<int2>(c, "stl.table"), tsize, buf<int>(c, "stl.slot"),
+         buf<int>(c, "stl.vid"), buf<int>(c, "stl.fpos"), buf<long long>(c, "voff"), buf<long long>(c, "foff"), buf<float>(c, "verts"), buf<int>(c, "faces"));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (v_off_out) for (int b = 0; b <= B; ++b) v_off_out[b] = c->h_voff[b];
+  if (f_off_out) for (int b = 0; b <= B; ++b) f_off_out[b] = c->h_foff[b];
   return alloc_batch(c);
 }
 

@@ -106,6 +106,19 @@ class Engine:
         self._chk(self.L.sh_upload_meshes(self.h, _ptr(verts), _ptr(faces), _ptr(voff), _ptr(foff), len(meshes)))
         self.voff, self.foff = voff, foff
 
+    def upload_stl(self, files):
+        """files: list of paths or bytes objects, each one binary STL; parsed and merged on the device (sh_upload_stl)."""
+        import pathlib
+        blobs = [f if isinstance(f, (bytes, bytearray)) else pathlib.Path(f).read_bytes() for f in files]
+        n = len(blobs)
+        keep = [bytes(b) for b in blobs]      # the buffers must outlive the call
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(k), ctypes.c_void_p) for k in keep])
+        sizes = (ctypes.c_size_t * n)(*[len(k) for k in keep])
+        voff = np.zeros(n + 1, dtype=np.int64)
+        foff = np.zeros(n + 1, dtype=np.int64)
+        self._chk(self.L.sh_upload_stl(self.h, ptrs, sizes, n, _ptr(voff), _ptr(foff)))
+        self.voff, self.foff = voff, foff
+
     def synth_batch(self, T):
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(-1, 16)
         V, F = int(self.voff[1] - self.voff[0]), int(self.foff[1] - self.foff[0])
