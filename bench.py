@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--cpu-pool", type=int, default=-1, help="worker processes of the pooled oracle leg (one humerus each); -1 = host cores of this process, at most 16; 0 = skip")
     ap.add_argument("--no-overlap", action="store_true", help="do not compute the host hulls of step k+1 during the device work of step k")
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
+    ap.add_argument("--from-stl", action="store_true", help="every step starts from the bytes of B binary STL files (device-side parse + vertex merge, sh_upload_stl)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,7 +158,12 @@ def main():
 
     T = synth.similarity_transforms(B, verts, seed=1234, start=rank * B)
     host_batch = None
-    if args.from_host:      # PCIe-inclusive variant (never the headline `value`): the meshes are handed over as host buffers every step
+    stl_blobs = None
+    if args.from_stl:       # STL bytes -> landmarks: the files of the synthetic batch are serialised here, outside the timed region
+        stl_blobs = [stl_bytes(synth.apply_similarity(T[i], verts), faces) for i in range(B)]
+        eng.upload_stl(stl_blobs)
+        host_batch = stl_blobs
+    elif args.from_host:      # PCIe-inclusive variant (never the headline `value`): the meshes are handed over as host buffers every step
         host_batch = [(synth.apply_similarity(T[i], verts), faces) for i in range(B)]
         eng.upload(host_batch)
     else:
@@ -168,7 +174,9 @@ def main():
     gather_list = [torch.empty_like(lm_t) for _ in range(world)] if (use_dist and rank == 0) else None
 
     def step():
-        if host_batch is not None:
+        if stl_blobs is not None:
+            eng.upload_stl(stl_blobs)
+        elif host_batch is not None:
             eng.upload(host_batch)
         eng.run(_lib.STAGE_ALL, fetch=False if use_dist else "view")      # records land in the engine's page-locked buffer (or are gathered device to device)
         if use_dist:
@@ -287,7 +295,7 @@ def main():
                "data": "synthetic (similarity copies of humerus_left.stl, seed 1234; seeded teacher UNet weights)",
                "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: batch {B} synthetic humeri per GPU, all stages (SH_STAGE_ALL)",
                           "batch_per_gpu": B, "global_batch": B * world, "vertices": V, "triangles": F, "unet": f"base{unet_spec.BASE} depth{unet_spec.DEPTH} 512x512",
-                          "parallelism": f"dp{world}", "input": "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM",
+                          "parallelism": f"dp{world}", "input": "binary STL bytes every step (device parse + merge, PCIe inclusive)" if args.from_stl else "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM",
                           "schedule": "host hulls of step k+1 overlap the device work of step k (pipeline filled and drained inside the timed region)" if overlap else "serial",
                           "meshes_with_error_status": n_bad},
                "roofline": roof, "cpu_baseline": cpu,
@@ -297,6 +305,15 @@ def main():
     eng.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def stl_bytes(verts, faces):
+    """Binary STL image of a triangle mesh (float32, zero normals), as a scanner export would hand it over."""
+    import struct
+    tri = np.asarray(verts, dtype="<f4")[np.asarray(faces)]                      # (F, 3, 3)
+    rec = np.zeros(len(tri), dtype=np.dtype([("n", "<f4", (3,)), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+    rec["v"] = tri
+    return b"\0" * 80 + struct.pack("<I", len(tri)) + rec.tobytes()
 
 
 def _oracle_one(i):
