@@ -95,29 +95,38 @@ k_anp_scale(const double* __restrict__ raw, const unsigned long long* __restrict
   for (int i = blockIdx.x * 256 + tid; i < SH_IMG; i += gridDim.x * 256) o[i] = (float)(x[i] * sc + mn);
 }
 
-// one block of 512 lanes per humerus: lane = image row
+// one block of 512 lanes per humerus; a wave takes whole image rows (coalesced 64-pixel reads, edges by ballot)
 __global__ void __launch_bounds__(512)
 k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, const double* __restrict__ shft_theta,
             const double* __restrict__ prox_zs, double* __restrict__ pts_obb, int* __restrict__ counts, int* __restrict__ err) {
   __shared__ int cnt[SH_ANP_ROWS];
+  __shared__ int offs[SH_ANP_ROWS];
   __shared__ int tot_mask[8];
-  int b = blockIdx.x, i = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = SH_MPROX;
-  const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
-  int ne = 0, nm = 0, prev = 0;
-  for (int j = 0; j < M; ++j) {
-    int m = lg[j] > 0.0f ? 1 : 0;
-    ne += (m != prev);
-    nm += m;
-    prev = m;
+  // pass 1: per row, number of mask changes along theta (np.diff(mask, prepend=0) != 0) and mask pixels
+  int nm_w = 0;
+  for (int i = wave; i < SH_ANP_ROWS; i += 8) {
+    const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
+    float v[SH_MPROX / 64];
+#pragma unroll
+    for (int c = 0; c < SH_MPROX / 64; ++c) v[c] = lg[c * 64 + lane];      // the whole row in flight at once
+    int ne = 0, carry = 0;
+#pragma unroll
+    for (int c = 0; c < SH_MPROX / 64; ++c) {
+      const int m = v[c] > 0.0f ? 1 : 0;
+      int prev = __shfl_up(m, 1);
+      if (lane == 0) prev = carry;
+      ne += __popcll(__ballot(m != prev));
+      nm_w += __popcll(__ballot(m));
+      carry = __shfl(m, 63);
+    }
+    if (lane == 0) cnt[i] = ne;
   }
-  cnt[i] = ne;
-  for (int off = 32; off > 0; off >>= 1) nm += __shfl_down(nm, off);
-  if ((i & 63) == 0) tot_mask[i >> 6] = nm;
+  if (lane == 0) tot_mask[wave] = nm_w;
   __syncthreads();
   // exclusive scan of the per-row edge counts (row-major boolean gather order)
-  __shared__ int offs[SH_ANP_ROWS];
-  if (i == 0) {
+  if (tid == 0) {
     int acc = 0;
     for (int r = 0; r < SH_ANP_ROWS; ++r) { offs[r] = acc; acc += cnt[r]; }
     int tm = 0;
@@ -128,21 +137,35 @@ k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, co
     if (acc < 6) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
   }
   __syncthreads();
-  int o = offs[i];
-  const double* t = shft_theta + ((size_t)b * SH_ANP_ROWS + i) * M;
-  const double* r = raw + ((size_t)b * SH_ANP_ROWS + i) * M;
-  double z = prox_zs[(size_t)b * SH_NPROX + SH_ANP_ROW0 + i];
-  prev = 0;
-  for (int j = 0; j < M; ++j) {
-    int m = lg[j] > 0.0f ? 1 : 0;
-    if (m != prev && o < SH_ANP_CAP) {
-      double* p = pts_obb + ((size_t)b * SH_ANP_CAP + o) * 3;
-      p[0] = r[j] * cos(t[j]);
-      p[1] = r[j] * sin(t[j]);
-      p[2] = z;
-      ++o;
+  // pass 2: the edge pixels as points (r cos t, r sin t, z), in row-major order
+  for (int i = wave; i < SH_ANP_ROWS; i += 8) {
+    const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
+    const double* t = shft_theta + ((size_t)b * SH_ANP_ROWS + i) * M;
+    const double* r = raw + ((size_t)b * SH_ANP_ROWS + i) * M;
+    const double z = prox_zs[(size_t)b * SH_NPROX + SH_ANP_ROW0 + i];
+    int o = offs[i], carry = 0;
+    float v[SH_MPROX / 64];
+#pragma unroll
+    for (int c = 0; c < SH_MPROX / 64; ++c) v[c] = lg[c * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < SH_MPROX / 64; ++c) {
+      const int j = c * 64 + lane;
+      const int m = v[c] > 0.0f ? 1 : 0;
+      int prev = __shfl_up(m, 1);
+      if (lane == 0) prev = carry;
+      const unsigned long long eb = __ballot(m != prev);
+      if (m != prev) {
+        const int pos = o + __popcll(eb & ((1ull << lane) - 1ull));
+        if (pos < SH_ANP_CAP) {
+          double* p = pts_obb + ((size_t)b * SH_ANP_CAP + pos) * 3;
+          p[0] = r[j] * cos(t[j]);
+          p[1] = r[j] * sin(t[j]);
+          p[2] = z;
+        }
+      }
+      o += __popcll(eb);
+      carry = __shfl(m, 63);
     }
-    prev = m;
   }
 }
 

@@ -201,21 +201,41 @@ k_groove_scale(const double* __restrict__ xraw, const int* __restrict__ npk, dou
   }
 }
 
-__global__ void k_groove_rfc(const double* __restrict__ xraw, const int* __restrict__ npk, const double* __restrict__ stats,
-                             const int* __restrict__ feat, const float* __restrict__ thr, const int* __restrict__ ti,
-                             const int* __restrict__ fi, const float* __restrict__ lw, const int* __restrict__ roots, int n_trees,
-                             double* __restrict__ xs /*[B][slots][9] scaled*/, float* __restrict__ proba, int B) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+// Forest tables re-packed for the walk: one 16-byte node {feature, threshold bits (leaf: leaf weight bits), true, false} per
+// load instead of four dependent 4-byte loads (done per run: the parameter block may have been re-broadcast)
+__global__ void k_rfc_pack(const int* __restrict__ feat, const float* __restrict__ thr, const int* __restrict__ ti, const int* __restrict__ fi,
+                           const float* __restrict__ lw, int4* __restrict__ nodes, int N) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const bool leaf = ti[i] < 0;
+  nodes[i] = make_int4(feat[i], __float_as_int(leaf ? lw[i] : thr[i]), ti[i], fi[i]);
+}
+
+// sh::rfc_proba1 (onnxruntime TreeEnsembleClassifier walk, bicipital_groove.py:178-181) on the packed nodes; the nine
+// scaled features of a lane sit in LDS so that the per-node feature pick is one ds_read
+__global__ void __launch_bounds__(64)
+k_groove_rfc(const double* __restrict__ xraw, const int* __restrict__ npk, const double* __restrict__ stats,
+             const int4* __restrict__ nodes, const int* __restrict__ roots, int n_trees,
+             double* __restrict__ xs /*[B][slots][9] scaled*/, float* __restrict__ proba, int B) {
+  __shared__ double sx[9][64];
+  const int tid = threadIdx.x;
+  int gid = blockIdx.x * blockDim.x + tid;
   if (gid >= B * SH_GSLOTS) return;
   int b = gid / SH_GSLOTS, s = gid % SH_GSLOTS;
   int i = s / SH_MAXPEAK, k = s % SH_MAXPEAK;
   if (k >= npk[(size_t)b * SH_GROOVE_NROWS + i]) { proba[gid] = -1.0f; return; }
-  double x[9];
   for (int f = 0; f < 9; ++f) {
-    x[f] = (xraw[(size_t)gid * 9 + f] - stats[(size_t)b * 18 + f]) / stats[(size_t)b * 18 + 9 + f];
-    xs[(size_t)gid * 9 + f] = x[f];
+    const double v = (xraw[(size_t)gid * 9 + f] - stats[(size_t)b * 18 + f]) / stats[(size_t)b * 18 + 9 + f];
+    xs[(size_t)gid * 9 + f] = v;
+    sx[f][tid] = v;
   }
-  proba[gid] = rfc_proba1(feat, thr, ti, fi, lw, roots, n_trees, x);
+  double acc = 0.0;
+  for (int t = 0; t < n_trees; ++t) {
+    int4 nd = nodes[roots[t]];
+    while (nd.z >= 0) nd = nodes[(sx[nd.x][tid] <= (double)__int_as_float(nd.y)) ? nd.z : nd.w];
+    acc += (double)__int_as_float(nd.y);
+  }
+  proba[gid] = (float)acc;
 }
 
 // KernelDensity(kernel="linear", bandwidth=1): rho(t) ~ sum_i max(0, 1 - |t - theta_i|) over the

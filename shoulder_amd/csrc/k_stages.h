@@ -114,16 +114,19 @@ __device__ inline double wave_kth_smallest_nonneg(const double* v, int n, int k,
 // One workgroup (64 lanes) per humerus: gamma = 1 / median of the pairwise squared distances (sh::cpd_gamma) by a
 // radix select over all lanes, all lanes fill the Gram matrix, each lane evaluates the cost of some breakpoints with
 // the same arithmetic as sh::cpd_one_bkp, first minimum wins.
+template <bool BIG>      // BIG: the cut is longer than SH_CPD_MAXN samples, the Gram matrix lives in global scratch (proximal humeri)
 __global__ void __launch_bounds__(64)
 k_neck(const double* __restrict__ areas, const double* __restrict__ zs, double* __restrict__ neck_z, int* __restrict__ neck_index, int B,
-       double c0, double c1, double* __restrict__ gscratch /*[B][SH_NFULL^2], used when the cut is longer than SH_CPD_MAXN*/) {
-  __shared__ double Ks[SH_CPD_MAXN * SH_CPD_MAXN];
+       double c0, double c1, double* __restrict__ gscratch /*[B][SH_NFULL^2]*/) {
+  __shared__ double Ks[BIG ? 1 : SH_CPD_MAXN * SH_CPD_MAXN];
   __shared__ unsigned hist[258];
   int b = blockIdx.x, lane = threadIdx.x;
   int a, e;
   cutoff_range(SH_NFULL, c0, c1, &a, &e);      // (0.70, 0.99) for a whole humerus, (0.2, 0.99) for a proximal one (surgical_neck.py:25-28)
   int n = e - a;
-  double* K = n <= SH_CPD_MAXN ? Ks : gscratch + (size_t)b * SH_NFULL * SH_NFULL;
+  if (!BIG && n > SH_CPD_MAXN) n = SH_CPD_MAXN;
+  double* K;
+  if (BIG) K = gscratch + (size_t)b * SH_NFULL * SH_NFULL; else K = Ks;
   const double* x = areas + (size_t)b * SH_NFULL + a;
   // pairwise squared distances in K (free until the Gram fill): row i holds j > i
   for (int i = 0; i < n; ++i) {

@@ -15,19 +15,27 @@ namespace sh {
 // One wave per (humerus, distal slice): lane 0 builds the hull of the ring (Melkman, O(n), LDS deque),
 // then the lanes share the hull edges of sh::min_area_rect (same arithmetic per edge; first minimum
 // in hull order wins, as in the sequential routine).
+// Two capacity tiers share the grid like k_slice_link (CAP = SH_SMALLSEG: 24 KB of LDS; the ring is staged in LDS first --
+// lane 0's hull walk is latency-bound when every point comes from global memory).
+template <int CAP>
 __global__ void __launch_bounds__(64)
 k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, double* __restrict__ rects /*[B][37][7]*/, int B) {
-  __shared__ int dq[2 * SH_MAXSEG + 8];
-  __shared__ int hull[2 * SH_MAXSEG + 8];
-  __shared__ double hx[SH_MAXSEG], hy[SH_MAXSEG];
+  __shared__ int dq[2 * CAP + 8];
+  __shared__ int hull[2 * CAP + 8];
+  __shared__ double hx[CAP], hy[CAP];
+  __shared__ double s_xy[2 * (CAP + 1)];
   __shared__ int nh_s;
   const int gid = blockIdx.x, lane = threadIdx.x;
   const int b = gid / SH_TE_NROWS, j = gid % SH_TE_NROWS;
   const size_t pl = (size_t)b * SH_NDIST + SH_TE_ROW0 + j;
-  const double* xy = ring + pl * (SH_MAXSEG + 1) * 2;
+  const double* gxy = ring + pl * (SH_MAXSEG + 1) * 2;
   const int n = ring_n[pl];
+  if (CAP == SH_SMALLSEG ? n > SH_SMALLSEG : n <= SH_SMALLSEG) return;      // the other tier's slice
   double* o = rects + (size_t)gid * 7;
   if (n < 3) { if (lane < 7) o[lane] = 0.0; return; }
+  for (int q = lane; q < 2 * (n + 1); q += 64) s_xy[q] = gxy[q];
+  __syncthreads();
+  const double* xy = s_xy;
   if (lane == 0) nh_s = convex_hull_simple_polygon(xy, n, dq, hull);   // rings are simple polygons in boundary order
   __syncthreads();
   const int nh = nh_s;

@@ -1043,8 +1043,13 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     if ((rc = run_slice_set(c, "distal", 2, SH_NDIST, true, false)) != SH_OK) return rc;
   if (mask & SH_STAGE_NECK) {
     const bool prox = c->params.bone_kind == SH_BONE_PROXIMAL;      // surgical_neck.py:25-28
-    LAUNCH(c, "k_neck", k_neck, dim3(B), dim3(64), buf<double>(c, "full.areas"), buf<double>(c, "full.zs"),
-           buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), B, prox ? 0.2 : 0.70, 0.99, prox ? buf<double>(c, "neck.gram") : (double*)nullptr);
+    if (prox) {
+      LAUNCH(c, "k_neck", k_neck<true>, dim3(B), dim3(64), buf<double>(c, "full.areas"), buf<double>(c, "full.zs"),
+             buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), B, 0.2, 0.99, buf<double>(c, "neck.gram"));
+    } else {
+      LAUNCH(c, "k_neck", k_neck<false>, dim3(B), dim3(64), buf<double>(c, "full.areas"), buf<double>(c, "full.zs"),
+             buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), B, 0.70, 0.99, (double*)nullptr);
+    }
     // surgical_neck.py:37-54: the contour at neck_z (loop whose vertex mean is nearest the origin)
     if ((rc = run_slice_set(c, "neckc", 3, 1, true, false, 1)) != SH_OK) return rc;
   }
@@ -1070,8 +1075,11 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<double>(c, "groove.ptheta"), buf<int>(c, "groove.npk"), buf<double>(c, "groove.r0"), buf<int>(c, "err"), B);
     LAUNCH(c, "k_groove_scale", k_groove_scale, dim3(B), dim3(256), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
            buf<double>(c, "groove.stats"), B);
+    if ((rc = ensure(c, "rfc.nodes", N * 16, 4)) != SH_OK) return rc;
+    int4* nodes = (int4*)c->bufs["rfc.nodes"].p;
+    LAUNCH(c, "k_rfc_pack", k_rfc_pack, dim3((unsigned)((N + 255) / 256)), dim3(256), feat, thr, ti, fi, lw, nodes, (int)N);
     LAUNCH(c, "k_groove_rfc", k_groove_rfc, dim3((B * SH_GSLOTS + 63) / 64), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
-           buf<double>(c, "groove.stats"), feat, thr, ti, fi, lw, roots, c->rfc_trees, buf<double>(c, "groove.xs"), buf<float>(c, "groove.proba"), B);
+           buf<double>(c, "groove.stats"), nodes, roots, c->rfc_trees, buf<double>(c, "groove.xs"), buf<float>(c, "groove.proba"), B);
     LAUNCH(c, "k_groove_kde", k_groove_kde, dim3(B), dim3(256), buf<double>(c, "groove.ptheta"), buf<float>(c, "groove.proba"),
            buf<double>(c, "groove.bg_theta"), buf<int>(c, "err"));
     LAUNCH(c, "k_groove_localmin", k_groove_localmin, dim3((rows + 63) / 64), dim3(64), buf<double>(c, "prox.itr_centered_start"),
@@ -1098,7 +1106,9 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<long long>(c, "foff"), buf<double>(c, "anp.plane"), buf<double>(c, "anp.axes_obb"), buf<int>(c, "err"));
   }
   if (mask & SH_STAGE_TE) {
-    LAUNCH(c, "k_te_rows", k_te_rows, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
+    LAUNCH(c, "k_te_rows", k_te_rows<SH_SMALLSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
+           buf<double>(c, "te.rects"), B);
+    LAUNCH(c, "k_te_rows", k_te_rows<SH_MAXSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), B);
     LAUNCH(c, "k_te_final", k_te_final, dim3(B), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
