@@ -80,7 +80,67 @@ __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][51
   if (lane == 0)      // ascending index
     for (int a = 1; a < nc; ++a) { int v = s_cand[a]; int q = a - 1; while (q >= 0 && s_cand[q] > v) { s_cand[q + 1] = s_cand[q]; --q; } s_cand[q + 1] = v; }
   __syncthreads();
-  if (lane < nc) s_pass[lane] = peak_eval(s_roll, M, s_cand[lane], -10.0, 0.6, 0.1, &s_pk[lane]) ? 1 : 0;
+  static_assert(SH_MPROX == 512, "8 samples per lane");
+  // sh::peak_eval for every candidate.  Its prominence walks (left and right until a higher sample, up to the whole row
+  // for the highest peak, one dependent LDS read per step) are done by the whole wave per candidate instead: every lane
+  // holds 8 consecutive samples; nearest higher sample, minimum of the stretch up to it and the occurrence of that minimum
+  // closest to the peak are wave reductions -- the same values and indices as the sequential walk.
+  __shared__ int s_lb[SH_PEAK_CAP], s_rb[SH_PEAK_CAP];
+  __shared__ double s_lmin[SH_PEAK_CAP], s_rmin[SH_PEAK_CAP];
+  {
+    double xr[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xr[q] = s_roll[8 * lane + q];
+    for (int cnd = 0; cnd < nc; ++cnd) {
+      const int pk = s_cand[cnd];
+      const double v = s_roll[pk];
+      int L = -1, R = M;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int k = 8 * lane + q; if (k < pk && xr[q] > v) L = k; }
+#pragma unroll
+      for (int q = 7; q >= 0; --q) { const int k = 8 * lane + q; if (k > pk && xr[q] > v) R = k; }
+      for (int off = 32; off > 0; off >>= 1) { L = max(L, __shfl_xor(L, off)); R = min(R, __shfl_xor(R, off)); }
+      double lm = v, rm = v;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = 8 * lane + q;
+        if (k > L && k <= pk) lm = fmin(lm, xr[q]);
+        if (k >= pk && k < R) rm = fmin(rm, xr[q]);
+      }
+      for (int off = 32; off > 0; off >>= 1) { lm = fmin(lm, __shfl_xor(lm, off)); rm = fmin(rm, __shfl_xor(rm, off)); }
+      int lb = -1, rb = M;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int k = 8 * lane + q; if (k > L && k <= pk && xr[q] == lm) lb = k; }
+#pragma unroll
+      for (int q = 7; q >= 0; --q) { const int k = 8 * lane + q; if (k >= pk && k < R && xr[q] == rm) rb = k; }
+      for (int off = 32; off > 0; off >>= 1) { lb = max(lb, __shfl_xor(lb, off)); rb = min(rb, __shfl_xor(rb, off)); }
+      if (lane == 0) { s_lb[cnd] = lb; s_rb[cnd] = rb; s_lmin[cnd] = lm; s_rmin[cnd] = rm; }
+    }
+  }
+  __syncthreads();
+  if (lane < nc) {      // heights, prominence threshold, widths at half prominence (short walks): as in sh::peak_eval
+    const double* x = s_roll;
+    const int pk = s_cand[lane], lb = s_lb[lane], rb = s_rb[lane];
+    const double left_min = s_lmin[lane], right_min = s_rmin[lane];
+    bool ok = x[pk] >= -10.0;
+    const double prom = x[pk] - (left_min > right_min ? left_min : right_min);
+    ok = ok && prom >= 0.6;
+    if (ok) {
+      const double h = x[pk] - prom * 0.5;
+      int k = pk;
+      while (lb < k && h < x[k]) --k;
+      double lip = (double)k;
+      if (x[k] < h) lip += (h - x[k]) / (x[k + 1] - x[k]);
+      k = pk;
+      while (k < rb && h < x[k]) ++k;
+      double rip = (double)k;
+      if (x[k] < h) rip -= (h - x[k]) / (x[k - 1] - x[k]);
+      const double w = rip - lip;
+      ok = w >= 0.1;
+      if (ok) { s_pk[lane].idx = pk; s_pk[lane].prominence = prom; s_pk[lane].width = w; s_pk[lane].width_height = h; }
+    }
+    s_pass[lane] = ok ? 1 : 0;
+  }
   __syncthreads();
   // Second half of the row (sh::groove_features_from_peaks, same arithmetic per element) spread over the wave: the
   // 7 x 7 wrapped angle differences (atan2 / sin / cos each) take one lane per pair instead of 49 serial evaluations.
