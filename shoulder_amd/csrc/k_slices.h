@@ -348,19 +348,26 @@ k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ s
       atomicMin(&bb[2], enc_f64(y0)); atomicMax(&bb[3], enc_f64(y1));
     }
   }
-  // per-loop shoelace area (ring order, one lane per loop) and the selection score
-  if (tid < nl) {
-    int o = l_off[tid], L = l_len[tid];
-    double a2 = 0.0, mx = 0.0, my = 0.0;
-    for (int q = 0; q < L; ++q) {
-      int qn = q + 1 == L ? 0 : q + 1;
-      a2 += rx[o + q] * ry[o + qn] - rx[o + qn] * ry[o + q];
-      mx += rx[o + q]; my += ry[o + q];
+  // per-loop shoelace area and the selection score: one wave per loop, lane-strided terms in ring order, fixed shuffle
+  // tree (deterministic; one lane walking the ring alone cost as much as the whole join)
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int l = wave; l < nl; l += SH_LINK_THREADS / 64) {
+      const int o = l_off[l], L = l_len[l];
+      double a2 = 0.0, mx = 0.0, my = 0.0;
+      for (int q = lane; q < L; q += 64) {
+        const int qn = q + 1 == L ? 0 : q + 1;
+        a2 += rx[o + q] * ry[o + qn] - rx[o + qn] * ry[o + q];
+        mx += rx[o + q]; my += ry[o + q];
+      }
+      for (int off = 32; off > 0; off >>= 1) { a2 += __shfl_down(a2, off); mx += __shfl_down(mx, off); my += __shfl_down(my, off); }
+      if (lane == 0) {
+        l_area[l] = 0.5 * a2;
+        // surgical_neck.py:43-46: mean over the CLOSED ring (first vertex counted twice)
+        mx = (mx + rx[o]) / (double)(L + 1); my = (my + ry[o]) / (double)(L + 1);
+        l_sel[l] = fabs(mx) + fabs(my);
+      }
     }
-    l_area[tid] = 0.5 * a2;
-    // surgical_neck.py:43-46: mean over the CLOSED ring (first vertex counted twice)
-    mx = (mx + rx[o]) / (double)(L + 1); my = (my + ry[o]) / (double)(L + 1);
-    l_sel[tid] = fabs(mx) + fabs(my);
   }
   __syncthreads();
   if (tid == 0) {
