@@ -193,8 +193,7 @@ __device__ inline uint32_t hash_key64(unsigned long long k) {
 // Two instantiations share the grid: CAP = SH_SMALLSEG (27 KB of LDS, 5 workgroups per CU) takes the planes with up to
 // 384 segments -- every section of a humerus at the fixture resolution -- and CAP = SH_MAXSEG (70 KB, 2 per CU) the rest; the other tier's planes exit at once.
 template <int CAP>
-__global__ void __launch_bounds__(SH_LINK_THREADS)
-k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
+__device__ inline void slice_link_plane(const int pl, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops,
              int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err,
              double* __restrict__ areas_total /*nullable: |sum of the signed loop areas| = Path2D.area*/) {
@@ -210,8 +209,7 @@ k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ s
   __shared__ int n_loops, bad, best_loop;
   __shared__ unsigned long long bb[4];
 
-  const int pl = blockIdx.x;           // b*N + k
-  const int b = pl / N;
+  const int b = pl / N;                // pl = b*N + k
   const int tid = threadIdx.x;
   int cnt = seg_count[pl];
   if (CAP == SH_SMALLSEG ? cnt > SH_SMALLSEG : cnt <= SH_SMALLSEG) return;      // the other tier's plane
@@ -406,13 +404,29 @@ k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ s
   }
 }
 
+// small tier: one workgroup per plane.  Large tier: a small grid sweeps all planes and works on the few (usually none)
+// with more than SH_SMALLSEG segments -- a workgroup per plane would pay its 70 KB LDS allocation 40 000 times for nothing.
+__global__ void __launch_bounds__(SH_LINK_THREADS)
+k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs, double* __restrict__ centroids, double* __restrict__ areas,
+             int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total) {
+  slice_link_plane<SH_SMALLSEG>(blockIdx.x, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total);
+}
+__global__ void __launch_bounds__(SH_LINK_THREADS)
+k_slice_link_large(int nplanes, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs, double* __restrict__ centroids, double* __restrict__ areas,
+                   int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total) {
+  for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
+    if (seg_count[pl] <= SH_SMALLSEG) continue;
+    slice_link_plane<SH_MAXSEG>(pl, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total);
+    __syncthreads();
+  }
+}
+
 // ---- K8/K9: arclength resampling + polar images (slice.py:65-147, :166-206) -------------------
 // One workgroup per (mesh, plane).  cumsum is sequential (np.cumsum order); each sample is one
 // np.interp evaluation; theta = atan2(y,x), r = sqrt(x^2+y^2); rows rolled to argmin(theta).
 #define SH_RS_THREADS 256
 template <int CAP>
-__global__ void __launch_bounds__(SH_RS_THREADS)
-k_resample_polar(int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring,
+__device__ inline void resample_polar_plane(const int pl, int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring,
                  const double* __restrict__ centroids, double* __restrict__ ixy,
                  double* __restrict__ itr_start, double* __restrict__ itr_cs) {
   __shared__ double rx[CAP + 1], ry[CAP + 1], d[CAP + 1];
@@ -421,7 +435,7 @@ k_resample_polar(int N, int M, const int* __restrict__ ring_n, const double* __r
   __shared__ int amin_idx;
   __shared__ double wmin[SH_RS_THREADS / 64];
   __shared__ int widx[SH_RS_THREADS / 64];
-  const int pl = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int L = ring_n[pl];
   if (CAP == SH_SMALLSEG ? L > SH_SMALLSEG : L <= SH_SMALLSEG) return;      // the other tier's plane
   const double* rp = ring + (size_t)pl * (SH_MAXSEG + 1) * 2;
@@ -484,6 +498,21 @@ k_resample_polar(int N, int M, const int* __restrict__ ring_n, const double* __r
     __syncthreads();
   }
   (void)amin_enc;
+}
+
+__global__ void __launch_bounds__(SH_RS_THREADS)
+k_resample_polar(int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring, const double* __restrict__ centroids,
+                 double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs) {
+  resample_polar_plane<SH_SMALLSEG>(blockIdx.x, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs);
+}
+__global__ void __launch_bounds__(SH_RS_THREADS)
+k_resample_polar_large(int nplanes, int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring, const double* __restrict__ centroids,
+                       double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs) {
+  for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
+    if (ring_n[pl] <= SH_SMALLSEG) continue;
+    resample_polar_plane<SH_MAXSEG>(pl, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs);
+    __syncthreads();
+  }
 }
 
 }  // namespace sh

@@ -870,14 +870,14 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   // two capacity tiers share the grid (k_slices.h): the planes of the other tier exit at once
   int* rn = buf<int>(c, (p + ".ring_n").c_str());
   double* rg = ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr;
-  LAUNCH(c, "k_slice_link", k_slice_link<SH_SMALLSEG>, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
+  LAUNCH(c, "k_slice_link", k_slice_link, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot);
-  LAUNCH(c, "k_slice_link", k_slice_link<SH_MAXSEG>, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
+  LAUNCH(c, "k_slice_link", k_slice_link_large, dim3(std::min(B * N, 512)), dim3(SH_LINK_THREADS), B * N, N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot);
   if (resample) {
-    LAUNCH(c, "k_resample_polar", k_resample_polar<SH_SMALLSEG>, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
+    LAUNCH(c, "k_resample_polar", k_resample_polar, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
            buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
-    LAUNCH(c, "k_resample_polar", k_resample_polar<SH_MAXSEG>, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
+    LAUNCH(c, "k_resample_polar", k_resample_polar_large, dim3(std::min(B * N, 512)), dim3(SH_RS_THREADS), B * N, N, SH_MPROX, rn, rg,
            buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
   }
   return SH_OK;
