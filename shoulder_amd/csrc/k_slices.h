@@ -129,25 +129,52 @@ __global__ void k_slice_emit(const double* __restrict__ vobb, const int* __restr
   const double* zp = zeff + (size_t)b * N;
   double z_first = zp[0], z_last = zp[N - 1];
   double inv_step = (double)(N - 1) / (z_last - z_first);
-  for (long long fi = blockIdx.x * (long long)blockDim.x + threadIdx.x; fi < nf; fi += (long long)gridDim.x * blockDim.x) {
-    const int* f = faces + 3 * (f0 + fi);
+  for (long long f_base = blockIdx.x * (long long)blockDim.x; f_base < nf; f_base += (long long)gridDim.x * blockDim.x) {
+    const long long fi = f_base + threadIdx.x;
+    const bool live = fi < nf;
+    const int* f = faces + 3 * (f0 + (live ? fi : 0));
     int id[3] = {f[0], f[1], f[2]};
     double X[3], Y[3], Z[3];
     for (int k = 0; k < 3; ++k) { X[k] = vb[3 * (size_t)id[k]]; Y[k] = vb[3 * (size_t)id[k] + 1]; Z[k] = vb[3 * (size_t)id[k] + 2]; }
     double fzmin = fmin(Z[0], fmin(Z[1], Z[2])), fzmax = fmax(Z[0], fmax(Z[1], Z[2]));
     double ka = (fzmin - z_first) * inv_step, kb = (fzmax - z_first) * inv_step;
     double klo = fmin(ka, kb), khi = fmax(ka, kb);
-    if (khi < -1.0 || klo > (double)N) continue;
-    int lo = (int)floor(fmax(klo, 0.0)) - 1, hi = (int)ceil(fmin(khi, (double)(N - 1))) + 1;
-    lo = lo < 0 ? 0 : lo;
-    hi = hi > N - 1 ? N - 1 : hi;
-    if (N == 1) { lo = 0; hi = 0; }
-    for (int k = lo; k <= hi; ++k) {
-      double z = zp[k];
+    int lo = 1, hi = 0;      // empty range: lanes without a triangle or without planes still take part in the wave-wide slot step
+    if (live && !(khi < -1.0 || klo > (double)N)) {
+      lo = (int)floor(fmax(klo, 0.0)) - 1; hi = (int)ceil(fmin(khi, (double)(N - 1))) + 1;
+      lo = lo < 0 ? 0 : lo;
+      hi = hi > N - 1 ? N - 1 : hi;
+      if (N == 1) { lo = 0; hi = 0; }
+    }
+    // every lane walks its own plane range; the wave stays together (uniform trip count) so that lanes that cross the SAME
+    // plane in a round share one slot atomic: same-address atomics are what bounds this kernel (~150 per counter)
+    int span = hi - lo + 1;
+    for (int off = 32; off > 0; off >>= 1) span = max(span, __shfl_xor(span, off));
+    for (int it = 0; it < span; ++it) {
+      const int k = lo + it;
+      const bool in_range = k <= hi;
+      double z = in_range ? zp[k] : 0.0;
       double d[3];
       int s[3];
       for (int j = 0; j < 3; ++j) { d[j] = Z[j] - z; s[j] = d[j] < -SH_SECTION_TOL ? -1 : 1; }
-      if (s[0] == s[1] && s[1] == s[2]) continue;
+      const bool cross = in_range && !(s[0] == s[1] && s[1] == s[2]);
+      // slot: one atomic per distinct plane among the wave's crossing lanes
+      int slot = 0;
+      {
+        unsigned long long todo = __ballot(cross);
+        const int lane_ = threadIdx.x & 63;
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const int kk = __shfl(k, leader);
+          const unsigned long long grp = __ballot(cross && k == kk);
+          int base = 0;
+          if (lane_ == leader) base = atomicAdd(&seg_count[(size_t)b * N + kk], __popcll(grp));
+          base = __shfl(base, leader);
+          if (cross && k == kk) slot = base + __popcll(grp & ((1ull << lane_) - 1ull));
+          todo &= ~grp;
+        }
+      }
+      if (!cross) continue;
       int up = 0, dn = 0;
       for (int j = 0; j < 3; ++j) {
         int jn = (j + 1) % 3;
@@ -168,7 +195,6 @@ __global__ void k_slice_emit(const double* __restrict__ vobb, const int* __restr
         int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
         sg.e_lo = (uint32_t)id[l]; sg.e_hi = (uint32_t)id[h];
       }
-      int slot = atomicAdd(&seg_count[(size_t)b * N + k], 1);
       if (slot < SH_MAXSEG) segs[((size_t)b * N + k) * SH_MAXSEG + slot] = sg;
       else atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
     }
