@@ -24,7 +24,7 @@ __device__ inline void obb_basis(const double* n, double* u, double* v) { plane_
 
 #define SH_OBB_THREADS 256
 #define SH_OBB_TILE 16           // hull faces (candidate directions) per workgroup
-#define SH_OBB_GROUP 4           // faces whose rectangle scans run together
+#define SH_OBB_GROUP 4           // faces whose rectangle scans run together (2 would fit three workgroups per CU: measured slower)
 #define SH_SIL_MAX 512           // silhouette edges per direction
 
 // One workgroup per (tile of 16 hull faces, humerus).  The hull record (vertices, normals, edges: ~160 KB) is read
@@ -38,7 +38,7 @@ __device__ inline void obb_basis(const double* n, double* u, double* v) { plane_
 __global__ void __launch_bounds__(SH_OBB_THREADS)
 k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
                  const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge,
-                 int* __restrict__ err) {
+                 int* __restrict__ err, unsigned long long* __restrict__ best_enc /*[B]: bits of the smallest candidate volume so far, ~0 = none*/) {
   constexpr int T = SH_OBB_TILE, G = SH_OBB_GROUP, NW = SH_OBB_THREADS / 64;
   __shared__ double tn[T][3], tu[T][3], tv[T][3];
   __shared__ double red[NW][2 * T];
@@ -49,6 +49,8 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
   __shared__ double2 sxy[G][SH_SIL_MAX];
   __shared__ unsigned long long g_area[G];
   __shared__ int g_edge[G];
+  __shared__ double g_hull2[G];      // twice the signed area of the projected hull (shoelace over the directed silhouette edges)
+  __shared__ int g_skip[G];
   const int b = blockIdx.y, f0 = blockIdx.x * T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = nv_[b], nf = nf_[b], ne = ne_[b];
   if (f0 >= nf) return;
@@ -69,10 +71,19 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     double mn[T], mx[T];
 #pragma unroll
     for (int j = 0; j < T; ++j) { mn[j] = 1e300; mx[j] = -1e300; }
-    for (int i = tid; i < nv; i += SH_OBB_THREADS) {
-      const double p[3] = {P[3 * i], P[3 * i + 1], P[3 * i + 2]};
+    // (the three record sweeps below are bound by the latency of their global loads at two workgroups per CU: every
+    //  sweep keeps the loads of several iterations in flight)
+    for (int i0 = tid; i0 < nv; i0 += 4 * SH_OBB_THREADS) {
+      double p[4][3];
 #pragma unroll
-      for (int j = 0; j < T; ++j) { double h = dot3(p, tn[j]); mn[j] = fmin(mn[j], h); mx[j] = fmax(mx[j], h); }
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * SH_OBB_THREADS, ic = i < nv ? i : i0;
+        p[u][0] = P[3 * ic]; p[u][1] = P[3 * ic + 1]; p[u][2] = P[3 * ic + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < T; ++j) { double h = dot3(p[u], tn[j]); mn[j] = fmin(mn[j], h); mx[j] = fmax(mx[j], h); }      // (a repeated vertex changes no min / max)
     }
 #pragma unroll
     for (int j = 0; j < T; ++j) {
@@ -81,12 +92,21 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     }
   }
   // ---- front masks
-  for (int f2 = tid; f2 < nf; f2 += SH_OBB_THREADS) {
-    const double q[3] = {NN[3 * f2], NN[3 * f2 + 1], NN[3 * f2 + 2]};
-    unsigned m = 0;
+  for (int f0_ = tid; f0_ < nf; f0_ += 4 * SH_OBB_THREADS) {
+    double q[4][3];
 #pragma unroll
-    for (int j = 0; j < T; ++j) m |= (dot3(q, tn[j]) > 0 ? 1u : 0u) << j;
-    fmask[f2] = (unsigned short)m;
+    for (int u = 0; u < 4; ++u) {
+      const int f2 = f0_ + u * SH_OBB_THREADS, fc = f2 < nf ? f2 : f0_;
+      q[u][0] = NN[3 * fc]; q[u][1] = NN[3 * fc + 1]; q[u][2] = NN[3 * fc + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f2 = f0_ + u * SH_OBB_THREADS;
+      unsigned m = 0;
+#pragma unroll
+      for (int j = 0; j < T; ++j) m |= (dot3(q[u], tn[j]) > 0 ? 1u : 0u) << j;
+      if (f2 < nf) fmask[f2] = (unsigned short)m;
+    }
   }
   __syncthreads();
   if (tid < T) {
@@ -95,15 +115,23 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     hlo[tid] = lo; hhi[tid] = hi;
   }
   // ---- silhouette edges of every direction: the two incident faces see it from opposite sides
-  for (int e = tid; e < ne; e += SH_OBB_THREADS) {
-    const int4 ed = *(const int4*)(E + 4 * e);
-    const unsigned m1 = fmask[ed.z];
-    unsigned x = (m1 ^ fmask[ed.w]) & ((1u << nt) - 1u);
-    while (x) {
-      const int j = __ffs(x) - 1;
-      x &= x - 1;
-      const int s = atomicAdd(&cnt[j], 1);
-      if (s < SH_SIL_MAX) lists[j][s] = (unsigned short)(e | (((m1 >> j) & 1u) << 15));
+  for (int e0 = tid; e0 < ne; e0 += 4 * SH_OBB_THREADS) {
+    int4 ed4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = e0 + u * SH_OBB_THREADS; ed4[u] = *(const int4*)(E + 4 * (e < ne ? e : e0)); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * SH_OBB_THREADS;
+      if (e >= ne) break;
+      const int4 ed = ed4[u];
+      const unsigned m1 = fmask[ed.z];
+      unsigned x = (m1 ^ fmask[ed.w]) & ((1u << nt) - 1u);
+      while (x) {
+        const int j = __ffs(x) - 1;
+        x &= x - 1;
+        const int s = atomicAdd(&cnt[j], 1);
+        if (s < SH_SIL_MAX) lists[j][s] = (unsigned short)(e | (((m1 >> j) & 1u) << 15));
+      }
     }
   }
   __syncthreads();
@@ -118,7 +146,8 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
       if (c > SH_SIL_MAX) { if (tid == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); c = SH_SIL_MAX; }
       ns[jj] = c; pre[jj + 1] = pre[jj] + c;
     }
-    if (tid < G) { g_area[tid] = (unsigned long long)__double_as_longlong(1e300); g_edge[tid] = 0x7fffffff; }
+    if (tid < G) { g_area[tid] = (unsigned long long)__double_as_longlong(1e300); g_edge[tid] = 0x7fffffff; g_hull2[tid] = 0.0; g_skip[tid] = 0; }
+    __syncthreads();
     // (edge stored with its first face's winding: va -> vb; directed along the FRONT face every silhouette vertex
     //  is the start of exactly one edge, so the start vertices enumerate the projection's 2-D hull once)
     for (int it = tid; it < pre[G]; it += SH_OBB_THREADS) {
@@ -128,8 +157,27 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
       const int s = it - pre[jj], j = g0 + jj;
       const unsigned short rec = lists[j][s];
       const int e = rec & 0x7fff;
-      const double* p = P + 3 * (size_t)((rec >> 15) ? E[4 * e] : E[4 * e + 1]);
-      sxy[jj][s] = make_double2(dot3(p, tu[j]), dot3(p, tv[j]));
+      const bool fwd = (rec >> 15) != 0;
+      const double* p = P + 3 * (size_t)(fwd ? E[4 * e] : E[4 * e + 1]);
+      const double* q = P + 3 * (size_t)(fwd ? E[4 * e + 1] : E[4 * e]);
+      const double2 a = make_double2(dot3(p, tu[j]), dot3(p, tv[j]));
+      sxy[jj][s] = a;
+      atomicAdd(&g_hull2[jj], a.x * dot3(q, tv[j]) - dot3(q, tu[j]) * a.y);      // start x end of the directed edge
+    }
+    __syncthreads();
+    // Lower bound of a direction's box volume: area of the projected hull x height <= min-area rectangle x height.  A direction
+    // whose bound already exceeds the smallest volume any workgroup of this humerus has found cannot win: its ns^2 scan is
+    // skipped (the survivor set depends on scheduling, the minimum does not: an equal or smaller volume is never skipped).
+    if (tid < G && g0 + tid < nt) {
+      const unsigned long long ub = *(volatile unsigned long long*)&best_enc[b];
+      const double lb = 0.5 * fabs(g_hull2[tid]) * (hhi[g0 + tid] - hlo[g0 + tid]);
+      if (ub != ~0ull && lb * (1.0 - 1e-9) > __longlong_as_double((long long)ub)) g_skip[tid] = 1;
+#ifdef SH_OBB_SKIPALL
+      g_skip[tid] = 1;
+#endif
+#ifdef SH_OBB_COUNT
+      if (g_skip[tid]) atomicAdd((unsigned long long*)&best_enc[gridDim.y + b], 1ull);
+#endif
     }
     __syncthreads();
     // every lane takes item tid of each pass of 256 (edge s of direction jj) and remembers (area, edge, direction);
@@ -146,12 +194,12 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
         int jj = 0;
 #pragma unroll
         for (int k = 1; k < G; ++k) jj += it >= pre[k] ? 1 : 0;
-        const int s = it - pre[jj], j = g0 + jj, n2 = ns[jj];
+        const int s = it - pre[jj], j = g0 + jj, n2 = g_skip[jj] ? 0 : ns[jj];
         const int e = lists[j][s] & 0x7fff;
         const double* pa3 = P + 3 * (size_t)E[4 * e]; const double* pc3 = P + 3 * (size_t)E[4 * e + 1];
         double ex = dot3(pc3, tu[j]) - dot3(pa3, tu[j]), ey = dot3(pc3, tv[j]) - dot3(pa3, tv[j]);
         const double l = sqrt(ex * ex + ey * ey);
-        if (l != 0.0) {
+        if (l != 0.0 && n2 > 0) {
           ex /= l; ey /= l;
           double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
           const double2* sq = sxy[jj];
@@ -173,8 +221,10 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     __syncthreads();
     if (tid < G && g0 + tid < nt) {
       const int j = g0 + tid;
-      cand_vol[(size_t)b * SH_HF + f0 + j] = __longlong_as_double((long long)g_area[tid]) * (hhi[j] - hlo[j]);
+      const double vol = g_skip[tid] ? 1e300 : __longlong_as_double((long long)g_area[tid]) * (hhi[j] - hlo[j]);
+      cand_vol[(size_t)b * SH_HF + f0 + j] = vol;
       cand_edge[(size_t)b * SH_HF + f0 + j] = g_edge[tid];
+      if (vol < 1e299) atomicMin(&best_enc[b], (unsigned long long)__double_as_longlong(vol));
     }
     __syncthreads();
   }

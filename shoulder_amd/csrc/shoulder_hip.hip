@@ -318,6 +318,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("hull.ne", (size_t)B * 4, 4);
   ENS("obb.cand_vol", (size_t)B * SH_HF * 8, 8);
   ENS("obb.cand_edge", (size_t)B * SH_HF * 4, 4);
+  ENS("obb.best_enc", (size_t)B * 8, 8);
   ENS("obb.T_pre", (size_t)B * 16 * 8, 8);
   ENS("obb.zb_pre", (size_t)B * 2 * 8, 8);
   ENS("obb.endpts", (size_t)B * 2 * SH_ENDCAP * 2 * 8, 8);
@@ -987,9 +988,11 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   const int* cnt_ne = buf<int>(c, "hull.ne");
   {
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(c, hipMemsetAsync(buf<unsigned long long>(c, "obb.best_enc"), 0xFF, (size_t)B * 8, c->stream));      // "no candidate volume yet"
     if (c->timing == 1) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
     hipLaunchKernelGGL(k_obb_candidates, dim3((nfmax + SH_OBB_TILE - 1) / SH_OBB_TILE, B), dim3(SH_OBB_THREADS), 0, c->stream, buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"),
-                       cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"));
+                       cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"),
+                       buf<unsigned long long>(c, "obb.best_enc"));
     if (c->timing == 1) { (void)hipEventRecord(e1, c->stream); c->pending.emplace_back("k_obb_candidates", e0, e1); }
     HIPCHK(c, hipGetLastError());
   }
