@@ -19,6 +19,12 @@
 
 namespace sh {
 
+// Activation layout: channel-blocked "NC/32HW32" -- per image, 32-channel planes of [H][W][32] bf16 (64 B per pixel and
+// plane).  A 32-channel chunk of a tile row is then one contiguous run (full 128-B lines for the staging loads and the
+// LDS-DMA), where the plain NHWC form made every staging step touch half of each pixel's line and fetched most lines twice
+// (PMC: 1.34 GB per launch against 0.65 GB algorithmic).  A 32-channel tensor is plain NHWC either way.
+__device__ __host__ inline size_t act_off(size_t HW, size_t pix, int c) { return ((size_t)(c >> 5) * HW + pix) * 32 + (size_t)(c & 31); }
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -117,7 +123,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-      if (!(FUSE & UF_FIRST) && in_pix[k] >= 0) v = *(const u32x4*)(src + (size_t)in_pix[k] * Cs + cb + ((tid + k * UN_THREADS) & 3) * 8);
+      if (!(FUSE & UF_FIRST) && in_pix[k] >= 0) v = *(const u32x4*)(src + act_off((size_t)H * W, (size_t)in_pix[k], cb) + ((tid + k * UN_THREADS) & 3) * 8);
       rin[k] = v;
     }
 #pragma unroll
@@ -248,7 +254,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
         if (relu) v = fmaxf(v, 0.0f);
         o[r] = (__bf16)v;
       }
-      *(bf16x4*)(out + ((size_t)oy * OW + ox) * Cout + n0 + n * 16 + lk * 4) = o;
+      *(bf16x4*)(out + act_off((size_t)OH * OW, (size_t)oy * OW + ox, n0 + n * 16 + lk * 4)) = o;
     }
   }
   if (FUSE & UF_POOL) {
@@ -268,7 +274,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
           o[r] = (__bf16)v;
         }
         if ((li & 1) == 0)
-          *(bf16x4*)(po + ((size_t)((y0 + wave * 4) / 2 + mp) * (W / 2) + (x0 + li) / 2) * Cout + n0 + n * 16 + lk * 4) = o;
+          *(bf16x4*)(po + act_off((size_t)(H / 2) * (W / 2), (size_t)((y0 + wave * 4) / 2 + mp) * (W / 2) + (x0 + li) / 2, n0 + n * 16 + lk * 4)) = o;
       }
   }
 }
@@ -290,7 +296,8 @@ __global__ void k_conv_first_bf16(const float* __restrict__ img, const float* __
       int gy = y + t / 3 - 1, gx = x + t % 3 - 1;
       v[t] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
     }
-    __bf16* o = dst + p * C;
+    __bf16* o = dst + im * H * W * C;
+    const size_t pin = p - im * (size_t)H * W;
     for (int c8 = 0; c8 < C; c8 += 8) {
       bf16x8 ov;
 #pragma unroll
@@ -300,7 +307,7 @@ __global__ void k_conv_first_bf16(const float* __restrict__ img, const float* __
         for (int t = 0; t < 9; ++t) a = __builtin_fmaf(v[t], sw[t * C + c8 + k], a);
         ov[k] = (__bf16)fmaxf(a, 0.0f);
       }
-      *(bf16x8*)(o + c8) = ov;
+      *(bf16x8*)(o + act_off((size_t)H * W, pin, c8)) = ov;
     }
   }
 }
@@ -313,26 +320,27 @@ __global__ void k_maxpool2_bf16(const __bf16* __restrict__ src, __bf16* __restri
     size_t p = e / C8;
     int ox = (int)(p % OW), oy = (int)((p / OW) % OH);
     size_t im = p / ((size_t)OH * OW);
-    const __bf16* s = src + ((im * H + 2 * oy) * W + 2 * ox) * C + c8 * 8;
-    bf16x8 a = *(const bf16x8*)s, b = *(const bf16x8*)(s + C), c = *(const bf16x8*)(s + (size_t)W * C), d = *(const bf16x8*)(s + (size_t)W * C + C);
+    const __bf16* s = src + im * H * W * C + act_off((size_t)H * W, (size_t)(2 * oy) * W + 2 * ox, c8 * 8);
+    bf16x8 a = *(const bf16x8*)s, b = *(const bf16x8*)(s + 32), c = *(const bf16x8*)(s + (size_t)W * 32), d = *(const bf16x8*)(s + (size_t)W * 32 + 32);
     bf16x8 r;
 #pragma unroll
     for (int k = 0; k < 8; ++k) r[k] = (__bf16)fmaxf(fmaxf((float)a[k], (float)b[k]), fmaxf((float)c[k], (float)d[k]));
-    *(bf16x8*)(dst + ((im * OH + oy) * OW + ox) * C + c8 * 8) = r;
+    *(bf16x8*)(dst + im * OH * OW * C + act_off((size_t)OH * OW, (size_t)oy * OW + ox, c8 * 8)) = r;
   }
 }
 
 __global__ void k_head_bf16(const __bf16* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bp,
-                            float* __restrict__ logits, int C, size_t npix) {
+                            float* __restrict__ logits, int C, size_t npix, size_t HW) {
   __shared__ float sw[64];
   if (threadIdx.x < C) sw[threadIdx.x] = w[threadIdx.x];
   __syncthreads();
   const float b = bp[0];
   for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
-    const __bf16* s = src + p * C;
+    const size_t im = p / HW, pin = p - im * HW;
+    const __bf16* s = src + im * HW * C;
     float a = b;
     for (int c8 = 0; c8 < C; c8 += 8) {
-      bf16x8 v = *(const bf16x8*)(s + c8);
+      bf16x8 v = *(const bf16x8*)(s + act_off(HW, pin, c8));
 #pragma unroll
       for (int k = 0; k < 8; ++k) a = __builtin_fmaf((float)v[k], sw[c8 + k], a);
     }

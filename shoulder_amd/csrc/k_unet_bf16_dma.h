@@ -98,17 +98,18 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
   auto describe = [&](int cc, int buf) {
     const int c0 = cc * 32;
     const bool first = c0 < C0;
-    n_Cs = first ? C0 : C1; n_cb = (first ? c0 : c0 - C0) + q8;
+    n_Cs = first ? C0 : C1;
+    n_cb = ((first ? c0 : c0 - C0) >> 5) * (H * W);      // pixel offset of this chunk's 32-channel plane (channel-blocked activations)
     n_simg = (first ? src0 : src1) + (size_t)i_img * H * W * n_Cs;
     n_wbase = wgt + ((size_t)cc * Cout + i_g * 64) * 32;
     n_lbase = smem + buf * UD_BUF + wave * 1024;
   };
   auto piece = [&](int k) {      // k is a compile-time constant at every call site
     if (k < 5) {
-      const __bf16* p = pixoff[k] >= 0 ? n_simg + (unsigned)(pixoff[k] * n_Cs + n_cb) : zero_page;
+      const __bf16* p = pixoff[k] >= 0 ? n_simg + (unsigned)((n_cb + pixoff[k]) * 32 + q8) : zero_page;
       __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + k * 8192), 16, 0, 0);
     } else if (k == 5) {
-      const __bf16* pi = pixoff[5] >= 0 ? n_simg + (unsigned)(pixoff[5] * n_Cs + n_cb) : zero_page;
+      const __bf16* pi = pixoff[5] >= 0 ? n_simg + (unsigned)((n_cb + pixoff[5]) * 32 + q8) : zero_page;
       const __bf16* p = in5 ? pi : n_wbase + wrel5;
       __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + 5 * 8192), 16, 0, 0);
     } else if (k < 9) {
@@ -191,7 +192,7 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
           if (relu) v = fmaxf(v, 0.0f);
           o[r] = (__bf16)v;
         }
-        ud_store8(out + ((size_t)gy * W + gx) * Cout + c_n0 + n * 16 + lk * 4, o);
+        ud_store8(out + act_off((size_t)H * W, (size_t)gy * W + gx, c_n0 + n * 16 + lk * 4), o);
       }
     }
     if (FUSE & UF_POOL) {      // 2x2 max pool of this wave's 4 rows x 16 pixels (rows pair inside the lane, columns with lane li ^ 1)
@@ -209,7 +210,7 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
             o[r] = (__bf16)v;
           }
           // odd lanes store too (same value, the pixel of their even neighbour): the store count per wave stays exact
-          ud_store8(po + ((size_t)((c_y0 + rg * 4) / 2 + mp) * (W / 2) + (c_x0 + xh * 16 + li) / 2) * Cout + c_n0 + n * 16 + lk * 4, o);
+          ud_store8(po + act_off((size_t)(H / 2) * (W / 2), (size_t)((c_y0 + rg * 4) / 2 + mp) * (W / 2) + (c_x0 + xh * 16 + li) / 2, c_n0 + n * 16 + lk * 4), o);
         }
     }
     (void)NSTORE;

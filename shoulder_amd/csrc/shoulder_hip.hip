@@ -828,7 +828,7 @@ static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int n
   {
     const sh_ctx::ULayer& l = L("head");
     size_t npx = (size_t)nimg * H * W;
-    LAUNCH(c, "unet.head", k_head_bf16, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx);
+    LAUNCH(c, "unet.head", k_head_bf16, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx, (size_t)H * W);
   }
   return SH_OK;
 }
