@@ -19,8 +19,10 @@
 
 using namespace sh;
 
+// blocked = 1: src is channel-blocked NC/32HW32 (the product kernels' activation layout); the lab variants v2..v4 keep NHWC.
+// The comparison buffer `out` is always [pixel][Cout] f32; k_cmp reads the kernel output through the same layout switch.
 __global__ void k_naive(const __bf16* src, const float* wf /*[9][Cin][Cout] f32 (bf16-rounded values)*/, const float* bias, float* out,
-                        int H, int W, int Cin, int Cout, int nimg, int relu) {
+                        int H, int W, int Cin, int Cout, int nimg, int relu, int blocked) {
   size_t total = (size_t)nimg * H * W * Cout;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     int co = (int)(e % Cout);
@@ -31,9 +33,10 @@ __global__ void k_naive(const __bf16* src, const float* wf /*[9][Cin][Cout] f32 
     for (int t = 0; t < 9; ++t) {
       int gy = y + t / 3 - 1, gx = x + t % 3 - 1;
       if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
-      const __bf16* s = src + ((im * H + gy) * W + gx) * Cin;
+      const __bf16* s = src + im * H * W * Cin;
+      const size_t pix = (size_t)gy * W + gx;
       const float* w = wf + (size_t)t * Cin * Cout + co;
-      for (int c = 0; c < Cin; ++c) a += (float)s[c] * w[(size_t)c * Cout];
+      for (int c = 0; c < Cin; ++c) a += (float)s[blocked ? act_off((size_t)H * W, pix, c) : pix * Cin + c] * w[(size_t)c * Cout];
     }
     if (relu) a = fmaxf(a, 0.0f);
     out[e] = a;
@@ -52,10 +55,13 @@ __global__ void k_round_f32(float* p, size_t n) {
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) p[e] = (float)(__bf16)p[e];
 }
 
-__global__ void k_cmp(const __bf16* a, const float* r, size_t n, float* maxerr, float* maxref) {
+__global__ void k_cmp(const __bf16* a, const float* r, size_t n, float* maxerr, float* maxref, int blocked, size_t HW, int Cout) {
   float me = 0, mr = 0;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-    me = fmaxf(me, fabsf((float)a[e] - r[e]));
+    const size_t p = e / Cout, im = p / HW;
+    const int co = (int)(e % Cout);
+    const size_t ai = blocked ? im * HW * Cout + act_off(HW, p - im * HW, co) : e;
+    me = fmaxf(me, fabsf((float)a[ai] - r[e]));
     mr = fmaxf(mr, fabsf(r[e]));
   }
   atomicMax((int*)maxerr, __float_as_int(me));
@@ -120,9 +126,10 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   if (check) {
     CK(hipMalloc(&ref, nout * 4));
-    k_naive<<<8192, 256>>>(src, wf, bias, ref, H, W, Cin, Cout, nimg, 1);
+    const int blocked = (kern == "base" || kern.rfind("abl", 0) == 0) ? 1 : 0;
+    k_naive<<<8192, 256>>>(src, wf, bias, ref, H, W, Cin, Cout, nimg, 1, blocked);
     CK(hipMemset(stat, 0, 8));
-    k_cmp<<<1024, 256>>>(dst, ref, nout, stat, stat + 1);
+    k_cmp<<<1024, 256>>>(dst, ref, nout, stat, stat + 1, blocked, (size_t)H * W, Cout);
     float hs[2];
     CK(hipMemcpy(hs, stat, 8, hipMemcpyDeviceToHost));
     printf("check: max|err| %.5f  max|ref| %.3f  %s\n", hs[0], hs[1], hs[0] <= 0.02f * fmaxf(hs[1], 1.0f) ? "OK" : "MISMATCH");
