@@ -102,14 +102,15 @@ def geom_bytes(B, V, F):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="humeri per GPU per step")
     ap.add_argument("--unet", choices=["f32", "bf16"], default="bf16",
                     help="UNet arithmetic: bf16 = BASELINE configs[2]/[3] (throughput), f32 = configs[1] parity path (bit-exact vs the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-meshes", type=int, default=4, help="humeri of the batch the single-core oracle leg processes")
     ap.add_argument("--cpu-pool", type=int, default=-1, help="worker processes of the pooled oracle leg (one humerus each); -1 = host cores of this process, at most 16; 0 = skip")
+    ap.add_argument("--no-pipeline", action="store_true", help="wait for every step before enqueueing the next one (sh_run instead of sh_submit / sh_collect)")
     ap.add_argument("--no-overlap", action="store_true", help="do not compute the host hulls of step k+1 during the device work of step k")
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     ap.add_argument("--from-stl", action="store_true", help="every step starts from the bytes of B binary STL files (device-side parse + vertex merge, sh_upload_stl)")
@@ -172,6 +173,9 @@ def main():
 
     lm_t = shd.as_byte_tensor(eng.landmarks_device(), device=f"cuda:{local}") if use_dist else None
     gather_list = [torch.empty_like(lm_t) for _ in range(world)] if (use_dist and rank == 0) else None
+    # pipelined schedule: every run copies its records (device to device, on the engine's stream) into one of two send buffers
+    send = [torch.empty_like(lm_t) for _ in range(2)] if use_dist else None
+    pipelined = host_batch is None and not args.no_pipeline
 
     def step():
         if stl_blobs is not None:
@@ -199,10 +203,30 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s_ in range(args.steps):
-        if s_ == args.steps - 1:
-            eng.set_overlap(False)
-        step()
+    if pipelined:
+        # Two runs in flight: step k+1 is enqueued (sh_submit) while step k still executes, so the device goes from one step to
+        # the next without waiting for the host; the records of step k are collected (and gathered) after that.  All K submits
+        # and all K collects lie inside the timed region.
+        def finish(k):
+            eng.collect()
+            if use_dist:
+                dist.gather(send[k & 1], gather_list, dst=0)
+                torch.cuda.current_stream().synchronize()      # the send buffer is free before the run after next reuses it
+        for s_ in range(args.steps):
+            if s_ == args.steps - 1:
+                eng.set_overlap(False)
+            if use_dist:
+                eng.submit(_lib.STAGE_ALL, fetch=False, out_ptr=send[s_ & 1].data_ptr())
+            else:
+                eng.submit(_lib.STAGE_ALL, fetch="view")
+            if s_ > 0:
+                finish(s_ - 1)
+        finish(args.steps - 1)
+    else:
+        for s_ in range(args.steps):
+            if s_ == args.steps - 1:
+                eng.set_overlap(False)
+            step()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -296,7 +320,7 @@ def main():
                "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: batch {B} synthetic humeri per GPU, all stages (SH_STAGE_ALL)",
                           "batch_per_gpu": B, "global_batch": B * world, "vertices": V, "triangles": F, "unet": f"base{unet_spec.BASE} depth{unet_spec.DEPTH} 512x512",
                           "parallelism": f"dp{world}", "input": "binary STL bytes every step (device parse + merge, PCIe inclusive)" if args.from_stl else "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM",
-                          "schedule": "host hulls of step k+1 overlap the device work of step k (pipeline filled and drained inside the timed region)" if overlap else "serial",
+                          "schedule": ("two steps in flight (sh_submit / sh_collect); " if pipelined else "") + ("host hulls of step k+1 overlap the device work of step k; pipeline filled and drained inside the timed region" if overlap else "serial hulls"),
                           "meshes_with_error_status": n_bad},
                "roofline": roof, "cpu_baseline": cpu,
                "unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top,

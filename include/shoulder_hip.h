@@ -135,6 +135,12 @@ int  sh_batch_size(const sh_ctx*);
 
 /* ---- the hot path -------------------------------------------------------------------- */
 int  sh_run(sh_ctx*, uint32_t stage_mask, sh_landmarks* out /* B, host, nullable */);
+/* The same in two halves, for callers that stream runs: sh_submit enqueues a run (all device work, the copy of the records to
+ * `out` -- page-locked memory, see sh_host_alloc, or the call blocks -- and of the per-mesh status words) and returns;
+ * sh_collect waits for the oldest submitted run and reports its status like sh_run.  At most two runs may be in flight, so
+ * the device goes from one run to the next without waiting for the host.  sh_run = sh_submit + sh_collect. */
+int  sh_submit(sh_ctx*, uint32_t stage_mask, sh_landmarks* out /* B, host, nullable */);
+int  sh_collect(sh_ctx*);
 /* Device address of the B result structs of the last sh_run (for a collective gather). */
 int  sh_landmarks_device(sh_ctx*, void** dev_ptr, size_t* nbytes);
 /* Page-locked host memory for the `out` array of sh_run when it is reused from run to run (the reference returns fresh

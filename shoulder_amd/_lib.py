@@ -63,7 +63,7 @@ class Params(ctypes.Structure):
 EXPORTS = ["sh_ctx_create", "sh_ctx_destroy", "sh_last_error", "sh_default_params", "sh_set_params", "sh_load_rfc",
            "sh_load_unet", "sh_param_block", "sh_upload_meshes", "sh_synth_batch", "sh_batch_size", "sh_run",
            "sh_landmarks_device", "sh_affine_apply", "sh_mesh_transformed", "sh_transform_points", "sh_section_plane", "sh_buffer_info", "sh_fetch", "sh_store",
-           "sh_kernel_time_ms", "sh_enable_timing", "sh_set_overlap", "sh_discard_prepared", "sh_unet_infer", "sh_host_alloc", "sh_host_free", "sh_upload_stl"]
+           "sh_kernel_time_ms", "sh_enable_timing", "sh_set_overlap", "sh_discard_prepared", "sh_unet_infer", "sh_host_alloc", "sh_host_free", "sh_upload_stl", "sh_submit", "sh_collect"]
 
 _lib = None
 
@@ -107,6 +107,8 @@ def load(build_if_missing=True):
     L.sh_synth_batch.argtypes = [vp, vp, ctypes.c_int]
     L.sh_batch_size.argtypes = [vp]
     L.sh_run.argtypes = [vp, ctypes.c_uint32, vp]
+    L.sh_submit.argtypes = [vp, ctypes.c_uint32, vp]
+    L.sh_collect.argtypes = [vp]
     L.sh_landmarks_device.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
     L.sh_affine_apply.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int]
     L.sh_mesh_transformed.argtypes = [vp, ctypes.c_int, vp, vp]

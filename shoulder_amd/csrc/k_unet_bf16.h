@@ -67,6 +67,25 @@ struct ConvFuse {
   __bf16* pooled;          // UF_POOL:  [nimg][H/2][W/2][Cout] bf16
 };
 
+// All MFMA layers in one launch (the forward re-packs every time -- the parameter block may have been re-broadcast -- and
+// 21 separate 5-us launches cost more in launch gaps than in work).  tab[l] = {first element, w_off, T, Cin, Cout}.
+struct PackEntry { long long first; long long w_off; int T, Cin, Cout, pad; };
+__global__ void k_pack_w_bf16_all(const float* __restrict__ P, __bf16* __restrict__ PW, const PackEntry* __restrict__ tab, int nlayers, long long total) {
+  for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    int l = 0;
+    while (l + 1 < nlayers && tab[l + 1].first <= g) ++l;
+    const PackEntry t = tab[l];
+    const long long e = g - t.first;
+    const int k = (int)(e % 32);
+    long long r = e / 32;
+    const int co = (int)(r % t.Cout);
+    r /= t.Cout;
+    const int cc = (int)(r % (t.Cin / 32));
+    const int tp = (int)(r / (t.Cin / 32));
+    PW[t.w_off + e] = (__bf16)P[t.w_off + ((long long)tp * t.Cin + cc * 32 + k) * t.Cout + co];
+  }
+}
+
 template <int TAPS, int NT, int FUSE = 0>
 __global__ void __launch_bounds__(UN_THREADS)
 k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src1, int C0, int C1,

@@ -78,11 +78,17 @@ struct sh_ctx {
     bool uploaded = false;      // the hull records are already in the device buffers (copied by the background thread)
   } prep;
   hipEvent_t obb_done_ev = nullptr;      // recorded after the last kernel of a run that reads the hull.* device buffers
+  // sh_submit / sh_collect: up to two runs in flight (the second one is enqueued while the first still executes)
+  struct Ticket { hipEvent_t ev = nullptr; int* h_err = nullptr; int cap = 0, B = 0; bool pending = false; sh_landmarks* host_out = nullptr; };
+  Ticket tickets[2];
+  int t_head = 0, t_tail = 0, n_pending = 0;
+  hipStream_t out_stream = nullptr;      // sh_collect copies the records / status words of a finished run to the host on this stream
   bool overlap = false;
   unsigned long long batch_gen = 0;
   hipStream_t copy_stream = nullptr;
   // timing
   bool zero_page_ready = false;
+  bool packtab_ready = false;      // layer table of k_pack_w_bf16_all uploaded (reset by sh_load_unet)
   int num_cus = 0;
   int timing = 0;      // 0 off, 1 every launch, 2 UNet layers only
   std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t>> pending;
@@ -206,6 +212,8 @@ void sh_ctx_destroy(sh_ctx* c) {
   drain_timers(c);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->obb_done_ev) (void)hipEventDestroy(c->obb_done_ev);
+  for (auto& tk : c->tickets) { if (tk.ev) (void)hipEventDestroy(tk.ev); if (tk.h_err) (void)hipHostFree(tk.h_err); }
+  if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
   for (auto& kv : c->bufs)
     if (kv.second.p) (void)hipFree(kv.second.p);
   for (auto& hs : c->hstage) {
@@ -754,11 +762,22 @@ static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int n
   if ((rc = ensure(c, "params_bf16", c->unet_floats * 2, 2)) != SH_OK) return rc;
   const float* P = buf<float>(c, "params");
   __bf16* PW = buf<__bf16>(c, "params_bf16");
-  for (auto& kv : c->ulayers) {     // repack the MFMA layers' weights (cheap; stays correct after a parameter broadcast)
-    const sh_ctx::ULayer& l = kv.second;
-    if (l.cin < 32 || l.cout < 32) continue;
-    size_t tot = (size_t)l.taps * l.cin * l.cout;
-    LAUNCH(c, "k_pack_w_bf16", k_pack_w_bf16, dim3((unsigned)std::min<size_t>((tot + 255) / 256, 4096)), dim3(256), P + l.w_off, PW + l.w_off, l.taps, l.cin, l.cout);
+  {     // repack the MFMA layers' weights (cheap; stays correct after a parameter broadcast): one launch for all layers
+    std::vector<PackEntry> tab;
+    long long total = 0;
+    for (auto& kv : c->ulayers) {
+      const sh_ctx::ULayer& l = kv.second;
+      if (l.cin < 32 || l.cout < 32) continue;
+      tab.push_back(PackEntry{total, (long long)l.w_off, l.taps, l.cin, l.cout, 0});
+      total += (long long)l.taps * l.cin * l.cout;
+    }
+    if ((rc = ensure(c, "unet16.packtab", tab.size() * sizeof(PackEntry), 8)) != SH_OK) return rc;
+    if (!c->packtab_ready) {
+      HIPCHK(c, hipMemcpyAsync(c->bufs["unet16.packtab"].p, tab.data(), tab.size() * sizeof(PackEntry), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));      // `tab` is a local
+      c->packtab_ready = true;
+    }
+    LAUNCH(c, "k_pack_w_bf16", k_pack_w_bf16_all, dim3(2048), dim3(256), P, PW, (const PackEntry*)c->bufs["unet16.packtab"].p, (int)tab.size(), total);
   }
   const char* unf = getenv("SHOULDER_UNET_UNFUSED");
   const bool fused = base == 32 && !(unf && unf[0] == '1');
@@ -1195,11 +1214,21 @@ int sh_discard_prepared(sh_ctx* c) {
   return SH_OK;
 }
 
-int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
+int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   if (!c) return SH_ERR_ARG;
   if (c->B < 1) return fail(c, SH_ERR_STATE, "sh_run: no meshes uploaded");
+  if (c->n_pending >= 2) return fail(c, SH_ERR_STATE, "sh_submit: two runs are in flight already (sh_collect first)");
   HIPCHK(c, hipSetDevice(c->device));
   const int B = c->B;
+  sh_ctx::Ticket& tk = c->tickets[c->t_head];
+  if (tk.cap < B) {
+    if (tk.h_err) (void)hipHostFree(tk.h_err);
+    tk.h_err = nullptr; tk.cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&tk.h_err, (size_t)B * 4));
+    tk.cap = B;
+  }
+  if (!tk.ev) HIPCHK(c, hipEventCreateWithFlags(&tk.ev, hipEventDisableTiming));
+  if (!c->out_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
   c->b0 = 0; c->Bwin = B;
   if (c->params.bone_kind == SH_BONE_PROXIMAL) {
     if (mask & (SH_STAGE_DISTAL | SH_STAGE_TE)) return fail(c, SH_ERR_ARG, "sh_run: a proximal humerus has no distal / trans-epicondylar stage (bone.py:24-64)");
@@ -1238,17 +1267,62 @@ int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   c->b0 = 0; c->Bwin = B;
   if (mask & SH_STAGE_OBB) c->obb_injected = true;
   if (rc != SH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
-  if (out) HIPCHK(c, hipMemcpyAsync(out, buf<sh_landmarks>(c, "landmarks"), (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  std::vector<int> herr(B);
-  HIPCHK(c, hipMemcpy(herr.data(), buf<int>(c, "err"), B * 4, hipMemcpyDeviceToHost));
-  for (int b = 0; b < B; ++b)
-    if (herr[b] != 0) {
+  // (`out` may also be device memory, e.g. the send buffer of a gather: hipMemcpyDefault)
+  // Results.  A device-to-host copy enqueued HERE would sit in a DMA queue until the kernels of this run are done and hold
+  // up every later copy behind it - the vertex read-back of the background hull thread above all, which then loses its
+  // overlap with the device (measured: 14.3 -> 19.2 ms per step at B=64).  So the records and status words are parked in a
+  // per-ticket device buffer (a 16 us device-to-device copy at the end of the run) and sh_collect copies them to the host
+  // once the run has finished.  Device `out` (the send buffer of a gather) is written directly.
+  hipPointerAttribute_t at{};
+  const bool out_on_device = out && hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeDevice;
+  (void)hipGetLastError();
+  const std::string tslot = std::to_string(c->t_head);
+  void *lm_stage = nullptr, *err_stage = nullptr;
+  if (int e = ensure(c, ("out.err" + tslot).c_str(), (size_t)B * 4, 4, &err_stage)) return e;
+  tk.host_out = nullptr;
+  if (out_on_device) {
+    HIPCHK(c, hipMemcpyAsync(out, buf<sh_landmarks>(c, "landmarks"), (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToDevice, c->stream));
+  } else if (out) {
+    if (int e = ensure(c, ("out.landmarks" + tslot).c_str(), (size_t)B * sizeof(sh_landmarks), 1, &lm_stage)) return e;
+    HIPCHK(c, hipMemcpyAsync(lm_stage, buf<sh_landmarks>(c, "landmarks"), (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToDevice, c->stream));
+    tk.host_out = out;
+  }
+  HIPCHK(c, hipMemcpyAsync(err_stage, buf<int>(c, "err"), (size_t)B * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(tk.ev, c->stream));
+  tk.B = B; tk.pending = true;
+  c->t_head ^= 1; ++c->n_pending;
+  return SH_OK;
+}
+
+int sh_collect(sh_ctx* c) {
+  if (!c) return SH_ERR_ARG;
+  if (c->n_pending == 0) return fail(c, SH_ERR_STATE, "sh_collect: nothing in flight");
+  HIPCHK(c, hipSetDevice(c->device));
+  sh_ctx::Ticket& tk = c->tickets[c->t_tail];
+  const std::string tslot = std::to_string(c->t_tail);
+  c->t_tail ^= 1; --c->n_pending; tk.pending = false;
+  HIPCHK(c, hipEventSynchronize(tk.ev));
+  if (tk.host_out)
+    HIPCHK(c, hipMemcpyAsync(tk.host_out, buf<char>(c, ("out.landmarks" + tslot).c_str()), (size_t)tk.B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->out_stream));
+  HIPCHK(c, hipMemcpyAsync(tk.h_err, buf<char>(c, ("out.err" + tslot).c_str()), (size_t)tk.B * 4, hipMemcpyDeviceToHost, c->out_stream));
+  HIPCHK(c, hipStreamSynchronize(c->out_stream));
+  for (int b = 0; b < tk.B; ++b)
+    if (tk.h_err[b] != 0) {
       char m[128];
-      snprintf(m, sizeof m, "mesh %d: device stage error %d (capacity=-4, geometry=-5)", b, herr[b]);
-      return fail(c, herr[b], m);
+      snprintf(m, sizeof m, "mesh %d: device stage error %d (capacity=-4, geometry=-5)", b, tk.h_err[b]);
+      return fail(c, tk.h_err[b], m);
     }
   return SH_OK;
+}
+
+int sh_run(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
+  if (!c) return SH_ERR_ARG;
+  if (c->n_pending != 0) return fail(c, SH_ERR_STATE, "sh_run: submitted runs are still in flight (sh_collect them first)");
+  int rc = sh_submit(c, mask, out);
+  if (rc != SH_OK) return rc;
+  rc = sh_collect(c);
+  if (rc == SH_OK) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return rc;
 }
 
 // Page-locked host memory for result buffers the caller reuses from run to run (a fresh pageable buffer per run costs a
@@ -1316,6 +1390,7 @@ int sh_load_unet(sh_ctx* c, int base, int depth, const float* packed, size_t n_f
   if (!c || !packed || depth < 1 || depth > 6 || base < 32 || base % 32 != 0) return fail(c, SH_ERR_ARG, "sh_load_unet: bad argument (base must be a multiple of 32)");
   HIPCHK(c, hipSetDevice(c->device));
   c->ulayers.clear();
+  c->packtab_ready = false;
   size_t o = 0;
   auto add = [&](const std::string& name, int taps, int cin, int cout) {
     sh_ctx::ULayer L;

@@ -141,21 +141,52 @@ class Engine:
         self._chk(self.L.sh_run(self.h, int(stages), _ptr(out) if out is not None else None))
         return out
 
-    def _pinned_records(self):
-        if getattr(self, "_pin_n", 0) < self.B:
-            self._free_pinned()
+    def submit(self, stages=_lib.STAGE_ALL, fetch="view", out_ptr=None):
+        """Enqueue one run and return at once (sh_submit); at most two may be in flight.  `collect()` hands back the records of
+        the oldest one.  fetch="view": records go to one of the engine's two page-locked buffers; False: they stay on the
+        device; out_ptr: raw address of B records of page-locked host or DEVICE memory (e.g. a gather's send buffer)."""
+        if fetch not in ("view", False):
+            raise ValueError('submit(fetch=...) takes "view" or False')
+        if not hasattr(self, "_inflight"):
+            self._inflight, self._pin_slot = [], 0
+        out = None
+        if out_ptr is not None:
+            ptr = ctypes.c_void_p(int(out_ptr))
+        elif fetch == "view":
+            out = self._pinned_records(self._pin_slot)
+            self._pin_slot ^= 1
+            ptr = _ptr(out)
+        else:
+            ptr = None
+        self._inflight.append(out)
+        try:
+            self._chk(self.L.sh_submit(self.h, int(stages), ptr))
+        except Exception:
+            self._inflight.pop()
+            raise
+
+    def collect(self):
+        out = self._inflight.pop(0)
+        self._chk(self.L.sh_collect(self.h))
+        return out
+
+    def _pinned_records(self, slot=0):
+        pins = self.__dict__.setdefault("_pins", {})
+        ent = pins.get(slot)
+        if ent is None or ent[1] < self.B:
+            if ent is not None:
+                self.L.sh_host_free(self.h, ent[0])
             p = ctypes.c_void_p()
             nbytes = self.B * LANDMARKS_DTYPE.itemsize
             self._chk(self.L.sh_host_alloc(self.h, nbytes, ctypes.byref(p)))
-            self._pin_ptr, self._pin_n = p, self.B
-            self._pin_arr = np.frombuffer((ctypes.c_char * nbytes).from_address(p.value), dtype=LANDMARKS_DTYPE)
-        return self._pin_arr[: self.B]
+            arr = np.frombuffer((ctypes.c_char * nbytes).from_address(p.value), dtype=LANDMARKS_DTYPE)
+            ent = pins[slot] = (p, self.B, arr)
+        return ent[2][: self.B]
 
     def _free_pinned(self):
-        if getattr(self, "_pin_n", 0):
-            self._pin_arr = None
-            self.L.sh_host_free(self.h, self._pin_ptr)
-            self._pin_n = 0
+        for p, _, _ in self.__dict__.get("_pins", {}).values():
+            self.L.sh_host_free(self.h, p)
+        self.__dict__["_pins"] = {}
 
     def landmarks_device(self):
         p, n = ctypes.c_void_p(), ctypes.c_size_t()

@@ -159,3 +159,32 @@ def test_overlapped_hulls_identical_and_invalidated(engine, oracle_bones):
         assert r.tobytes() == ref1.tobytes()
     for r in (d, e):
         assert r.tobytes() == ref2.tobytes()
+
+
+def test_submit_collect_pipeline(engine, oracle_bones):
+    """sh_submit / sh_collect: two runs in flight (with and without prepared hulls) return the same records as sh_run;
+    a third submit without a collect and sh_run with runs in flight are refused."""
+    h = oracle_bones("humerus_left")
+    B = 5
+    T = synth.similarity_transforms(B, h.verts, seed=3)
+    engine.upload([(h.verts, h.faces)])
+    engine.synth_batch(T)
+    ref = engine.run(_lib.STAGE_ALL).copy()
+    for overlap in (False, True):
+        engine.set_overlap(overlap)
+        try:
+            engine.submit(_lib.STAGE_ALL)
+            engine.submit(_lib.STAGE_ALL)
+            with pytest.raises(Exception):
+                engine.submit(_lib.STAGE_ALL)
+            with pytest.raises(Exception):
+                engine.run(_lib.STAGE_ALL)
+            a = engine.collect().copy()
+            engine.submit(_lib.STAGE_ALL)
+            b = engine.collect().copy()
+            c = engine.collect().copy()
+        finally:
+            engine.set_overlap(False)
+            engine.discard_prepared()
+        for r in (a, b, c):
+            assert r.tobytes() == ref.tobytes()
