@@ -78,6 +78,14 @@ class Engine:
         packed = np.ascontiguousarray(packed)
         self._chk(self.L.sh_load_unet(self.h, int(base), int(depth), _ptr(packed), packed.size))
 
+    def load_unet_onnx(self, path_or_bytes):
+        """Parameters of the anatomic-neck network from an ONNX file of the supported UNet family (onnx_import.py; the
+        reference opens `humerus/models/unetcrf_anp.onnx` at anatomic_neck.py:62-69).  Returns (base, depth)."""
+        from .onnx_import import unet_from_onnx
+        w, base, depth = unet_from_onnx(path_or_bytes)
+        self.load_unet(w, base, depth)
+        return base, depth
+
     def set_params(self, canal_cutoff=(0.35, 0.75), groove_cutoff=(0.2, 0.75), groove_deg_window=7.0, unet_dtype=_lib.UNET_F32,
                    bone_kind=_lib.BONE_HUMERUS):
         p = _lib.Params()
