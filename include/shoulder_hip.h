@@ -163,6 +163,19 @@ int  sh_transform_points(sh_ctx*, const double* T /* 16 */, const double* in_pts
 int  sh_section_plane(sh_ctx*, int b, const double* origin /* 3 */, const double* normal /* 3 */, double* out_pts /* cap x 3 */,
                       int cap, int* n_out);
 
+/* `mesh.slice_plane(origin, normal)` (HumeralHeadOsteotomy.resect_mesh, arthroplasty.py:80-87; trimesh
+ * slice_faces_plane + the constructor's 8-decimal vertex merge) for ONE mesh given as host arrays in any coordinate
+ * system and P planes at once (a sweep of resection planes is one call): per plane the part on the side the normal
+ * points to -- kept faces, cut faces re-triangulated, unreferenced vertices dropped, vertices merged.  Vertex order is
+ * this library's canonical one (by first use; trimesh's depends on its hash sort), faces keep trimesh's order.
+ * out_edges (nullable): per cut face the edge between its two new vertices = the section polyline of the plane
+ * (HumeralHeadOsteotomy.points, arthroplasty.py:69-78).  counts: P x (n_verts, n_faces, n_edges).
+ * out_verts == NULL: count only; counts then hold capacities that suffice (n_verts is an upper bound). */
+int  sh_slice_mesh_planes(sh_ctx*, const double* verts /* nv x 3 */, int nv, const int32_t* faces /* nf x 3 */, int nf,
+                          const double* origins /* P x 3 */, const double* normals /* P x 3 */, int P,
+                          double* out_verts /* P x cap_v x 3 */, int cap_v, int32_t* out_faces /* P x cap_f x 3 */, int cap_f,
+                          int32_t* out_edges /* P x cap_e x 2 */, int cap_e, int32_t* counts /* P x 3 */);
+
 /* ---- stage-level access for parity tests: named intermediate device buffers ----------
  * names: "verts_obb" "obb_transform" "full.zs" "full.centroids" "full.areas" "full.nloops"
  * "distal.*" "prox.*" "prox.ixy" "prox.itr_start" "prox.itr_centered_start" "canal.points"

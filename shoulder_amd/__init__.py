@@ -10,7 +10,8 @@ include/shoulder_hip.h; see DESIGN.md and INTEGRATION.md.
 """
 __version__ = "0.1.0"
 
-_LAZY = {"Humerus": "bone", "ProximalHumerus": "bone", "default_engine": "bone", "Engine": "engine", "ShoulderHipError": "engine"}
+_LAZY = {"Humerus": "bone", "ProximalHumerus": "bone", "default_engine": "bone", "Engine": "engine", "ShoulderHipError": "engine",
+         "HumeralHeadOsteotomy": "arthroplasty"}
 
 
 def __getattr__(name):

@@ -63,7 +63,8 @@ class Params(ctypes.Structure):
 EXPORTS = ["sh_ctx_create", "sh_ctx_destroy", "sh_last_error", "sh_default_params", "sh_set_params", "sh_load_rfc",
            "sh_load_unet", "sh_param_block", "sh_upload_meshes", "sh_synth_batch", "sh_batch_size", "sh_run",
            "sh_landmarks_device", "sh_affine_apply", "sh_mesh_transformed", "sh_transform_points", "sh_section_plane", "sh_buffer_info", "sh_fetch", "sh_store",
-           "sh_kernel_time_ms", "sh_enable_timing", "sh_set_overlap", "sh_discard_prepared", "sh_unet_infer", "sh_host_alloc", "sh_host_free", "sh_upload_stl", "sh_submit", "sh_collect"]
+           "sh_kernel_time_ms", "sh_enable_timing", "sh_set_overlap", "sh_discard_prepared", "sh_unet_infer", "sh_host_alloc", "sh_host_free", "sh_upload_stl", "sh_submit", "sh_collect",
+           "sh_slice_mesh_planes"]
 
 _lib = None
 
@@ -114,6 +115,7 @@ def load(build_if_missing=True):
     L.sh_mesh_transformed.argtypes = [vp, ctypes.c_int, vp, vp]
     L.sh_transform_points.argtypes = [vp, vp, vp, ctypes.c_int, vp]
     L.sh_section_plane.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.sh_slice_mesh_planes.argtypes = [vp, vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp]
     L.sh_buffer_info.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
     L.sh_fetch.argtypes = [vp, cp, vp, ctypes.c_size_t]
     L.sh_store.argtypes = [vp, cp, vp, ctypes.c_size_t]

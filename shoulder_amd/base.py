@@ -72,6 +72,73 @@ class Mesh:
         self.vertices = self._engine.transform_points(self.vertices, T)     # k_affine_f64 on the device
         return self
 
+    def _need_engine(self, what):
+        if self._engine is None:
+            raise RuntimeError(f"Mesh.{what} needs the HIP engine (no CPU fallback)")
+
+    def slice_plane(self, plane_origin, plane_normal):
+        """The part of the mesh on the side `plane_normal` points to, uncapped (`trimesh.Trimesh.slice_plane` as called at
+        arthroplasty.py:82-85): k_clip_* on the device."""
+        self._need_engine("slice_plane")
+        v, f = self._engine.slice_mesh_planes(self.vertices, self.faces, [plane_origin], [plane_normal])[0]
+        return Mesh(v, f, self._engine)
+
+    def section(self, plane_normal, plane_origin):
+        """Cross-section with one plane (`trimesh.Trimesh.section` as called at arthroplasty.py:71): the cut edges of the
+        same device pass, chained into closed loops."""
+        self._need_engine("section")
+        v, f, e = self._engine.slice_mesh_planes(self.vertices, self.faces, [plane_origin], [plane_normal], edges=True)[0]
+        return Section(v, e, np.asarray(plane_normal, dtype=np.float64))
+
+
+class _Polygon:
+    def __init__(self, area):
+        self.area = area
+
+
+class Section:
+    """Stand-in for the trimesh Path3D a section returns, as far as the reference touches it (arthroplasty.py:71-78):
+    `.entities` (one per closed loop), `.discrete` (list of (k+1, 3) closed point loops), `.polygons_closed[i].area`.
+    The start vertex and direction of a loop are implementation details of trimesh's graph traversal; here every loop
+    starts at its smallest vertex id."""
+
+    def __init__(self, vertices, edges, normal):
+        adj = {}
+        for a, b in np.asarray(edges).tolist():
+            if a != b:
+                adj.setdefault(a, []).append(b)
+                adj.setdefault(b, []).append(a)
+        loops, seen = [], set()
+        for s in sorted(adj):
+            if s in seen or len(adj[s]) != 2:
+                continue
+            loop, prev, cur, closed = [s], None, s, False
+            seen.add(s)
+            while True:
+                cand = [x for x in adj[cur] if x != prev] or adj[cur]
+                nx = cand[0]
+                if nx == s:
+                    closed = True
+                    break
+                if nx in seen or len(adj.get(nx, ())) != 2:
+                    break
+                loop.append(nx)
+                seen.add(nx)
+                prev, cur = cur, nx
+            if closed and len(loop) >= 3:
+                loops.append(loop)
+        n = normal / np.linalg.norm(normal)
+        u = np.cross(n, [1.0, 0.0, 0.0] if abs(n[0]) < 0.9 else [0.0, 1.0, 0.0])
+        u /= np.linalg.norm(u)
+        w = np.cross(n, u)
+        self.entities = loops
+        self.discrete = [np.asarray(vertices)[lp + lp[:1]] for lp in loops]
+        areas = []
+        for d in self.discrete:
+            x, y = d @ u, d @ w
+            areas.append(0.5 * abs(np.sum(x[:-1] * y[1:] - x[1:] * y[:-1])))
+        self.polygons_closed = [_Polygon(a) for a in areas]
+
 
 class Bone(ABC):
     """base.py:24-42"""

@@ -19,6 +19,7 @@
 #include "k_unet_bf16.h"
 #include "k_unet_bf16_dma.h"
 #include "k_stl.h"
+#include "k_clip.h"
 #include "k_te.h"
 #include "k_obb.h"
 #include "sh_hull.h"
@@ -616,6 +617,94 @@ int sh_section_plane(sh_ctx* c, int b, const double* origin, const double* norma
   *n_out = n;
   if (n > cap) return fail(c, SH_ERR_CAPACITY, "sh_section_plane: more crossing points than capacity");
   HIPCHK(c, hipMemcpy(out_pts, buf<double>(c, "sp_out"), (size_t)n * 3 * 8, hipMemcpyDeviceToHost));
+  return SH_OK;
+}
+
+// Cut one mesh (host arrays, any coordinate system) with P planes and keep the side each normal points to
+// (`Trimesh.slice_plane`, arthroplasty.py:80-87).  out_verts == nullptr: count only (counts[].n_verts = upper bound).
+int sh_slice_mesh_planes(sh_ctx* c, const double* verts, int nv, const int32_t* faces, int nf, const double* origins, const double* normals, int P,
+                         double* out_verts, int cap_v, int32_t* out_faces, int cap_f, int32_t* out_edges, int cap_e, int32_t* counts) {
+  if (!c || !verts || !faces || !origins || !normals || !counts || nv < 1 || nf < 1 || P < 1 || P > 4096)
+    return fail(c, SH_ERR_ARG, "sh_slice_mesh_planes: bad argument");
+  if (out_verts && (!out_faces || cap_v < 1 || cap_f < 1 || (out_edges && cap_e < 1))) return fail(c, SH_ERR_ARG, "sh_slice_mesh_planes: bad output arguments");
+  for (int i = 0; i < 3 * nf; ++i)
+    if (faces[i] < 0 || faces[i] >= nv) return fail(c, SH_ERR_ARG, "sh_slice_mesh_planes: face index out of range");
+  if ((long long)P * ((long long)nv + 2LL * nf) > (1LL << 30)) return fail(c, SH_ERR_CAPACITY, "sh_slice_mesh_planes: planes x mesh too large for one call");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<double> pl(6 * (size_t)P);
+  for (int p = 0; p < P; ++p) {
+    const double* n = normals + 3 * p;
+    if (!((n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) > 0)) return fail(c, SH_ERR_ARG, "sh_slice_mesh_planes: zero normal");
+    for (int k = 0; k < 3; ++k) { pl[6 * p + k] = origins[3 * p + k]; pl[6 * p + 3 + k] = n[k]; }      // the normal is used as given (trimesh does not normalise it)
+  }
+  void *d_v, *d_f, *d_pl, *d_sign, *d_cls, *d_fpos, *d_cnt;
+  int rc;
+  if ((rc = ensure(c, "clip.verts", (size_t)nv * 24, 8, &d_v)) || (rc = ensure(c, "clip.faces", (size_t)nf * 12, 4, &d_f)) ||
+      (rc = ensure(c, "clip.planes", (size_t)P * 48, 8, &d_pl)) || (rc = ensure(c, "clip.sign", (size_t)P * nv, 1, &d_sign)) ||
+      (rc = ensure(c, "clip.cls", (size_t)P * nf, 1, &d_cls)) || (rc = ensure(c, "clip.fpos", (size_t)P * nf * 4, 4, &d_fpos)) ||
+      (rc = ensure(c, "clip.counts", (size_t)P * sizeof(ClipCounts), 4, &d_cnt)))
+    return rc;
+  HIPCHK(c, hipMemcpyAsync(d_v, verts, (size_t)nv * 24, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_f, faces, (size_t)nf * 12, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_pl, pl.data(), (size_t)P * 48, hipMemcpyHostToDevice, c->stream));
+  const unsigned gv = (unsigned)std::min(256, (nv + 255) / 256), gf = (unsigned)std::min(256, (nf + 255) / 256);
+  LAUNCH(c, "k_clip_sign", k_clip_sign, dim3(gv, P), dim3(256), (const double*)d_v, nv, (const double*)d_pl, (signed char*)d_sign);
+  LAUNCH(c, "k_clip_class", k_clip_class, dim3(P), dim3(SH_STL_SCAN_THREADS), (const double*)d_v, (const int*)d_f, nf, nv, (const double*)d_pl,
+         (const signed char*)d_sign, (unsigned char*)d_cls, (int*)d_fpos, (ClipCounts*)d_cnt);
+  std::vector<ClipCounts> cn(P);
+  HIPCHK(c, hipMemcpyAsync(cn.data(), d_cnt, (size_t)P * sizeof(ClipCounts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  auto report = [&](bool upper) {
+    for (int p = 0; p < P; ++p) { counts[3 * p] = upper ? cn[p].n_pre : cn[p].n_verts; counts[3 * p + 1] = cn[p].n_faces; counts[3 * p + 2] = cn[p].n_edges; }
+  };
+  if (!out_verts) { report(true); return SH_OK; }
+  // per-plane offsets of the pre-merge arrays
+  std::vector<long long> off(4 * (size_t)(P + 1) + (P + 1), 0);
+  long long *new_off = off.data(), *face_off = new_off + (P + 1), *edge_off = face_off + (P + 1), *pre_off = edge_off + (P + 1), *tab_off = pre_off + (P + 1);
+  for (int p = 0; p < P; ++p) {
+    if (cn[p].n_faces > cap_f || (out_edges && cn[p].n_edges > cap_e)) { report(true); return fail(c, SH_ERR_CAPACITY, "sh_slice_mesh_planes: output capacity too small (counts hold the sizes needed)"); }
+    new_off[p + 1] = new_off[p] + 2LL * (cn[p].n_quad + cn[p].n_tri);
+    face_off[p + 1] = face_off[p] + cn[p].n_faces;
+    edge_off[p + 1] = edge_off[p] + cn[p].n_edges;
+    pre_off[p + 1] = pre_off[p] + cn[p].n_pre;
+    long long ts = 1024;
+    while (ts < 2LL * cn[p].n_pre) ts <<= 1;
+    tab_off[p + 1] = tab_off[p] + ts;
+  }
+  void *d_off, *d_np, *d_pf, *d_pe, *d_ref, *d_keys, *d_tab, *d_slot, *d_vid, *d_ov, *d_of, *d_oe = nullptr;
+  if ((rc = ensure(c, "clip.off", off.size() * 8, 8, &d_off)) || (rc = ensure(c, "clip.new_pts", (size_t)std::max(1LL, new_off[P]) * 24, 8, &d_np)) ||
+      (rc = ensure(c, "clip.pre_faces", (size_t)std::max(1LL, face_off[P]) * 12, 4, &d_pf)) || (rc = ensure(c, "clip.pre_edges", (size_t)std::max(1LL, edge_off[P]) * 8, 4, &d_pe)) ||
+      (rc = ensure(c, "clip.referenced", (size_t)pre_off[P], 1, &d_ref)) || (rc = ensure(c, "clip.keys", (size_t)pre_off[P] * 24, 8, &d_keys)) ||
+      (rc = ensure(c, "clip.table", (size_t)tab_off[P] * 8, 8, &d_tab)) || (rc = ensure(c, "clip.slot", (size_t)pre_off[P] * 4, 4, &d_slot)) ||
+      (rc = ensure(c, "clip.vid", (size_t)pre_off[P] * 4, 4, &d_vid)) || (rc = ensure(c, "clip.out_verts", (size_t)P * cap_v * 24, 8, &d_ov)) ||
+      (rc = ensure(c, "clip.out_faces", (size_t)P * cap_f * 12, 4, &d_of)))
+    return rc;
+  if (out_edges && (rc = ensure(c, "clip.out_edges", (size_t)P * cap_e * 8, 4, &d_oe))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, c->stream));
+  const long long *g_new = (const long long*)d_off, *g_face = g_new + (P + 1), *g_edge = g_face + (P + 1), *g_pre = g_edge + (P + 1), *g_tab = g_pre + (P + 1);
+  HIPCHK(c, hipMemsetAsync(d_ref, 0, (size_t)pre_off[P], c->stream));
+  LAUNCH(c, "k_stl_table_init", k_stl_table_init, dim3(256), dim3(256), (int2*)d_tab, (size_t)tab_off[P]);
+  LAUNCH(c, "k_clip_emit", k_clip_emit, dim3(gf, P), dim3(256), (const double*)d_v, (const int*)d_f, nf, nv, (const double*)d_pl, (const signed char*)d_sign,
+         (const unsigned char*)d_cls, (const int*)d_fpos, (const ClipCounts*)d_cnt, g_new, g_face, g_edge, (double*)d_np, (int*)d_pf, (int*)d_pe);
+  LAUNCH(c, "k_clip_mark", k_clip_mark, dim3(gf, P), dim3(256), (const int*)d_pf, g_face, g_pre, (unsigned char*)d_ref);
+  LAUNCH(c, "k_clip_hash", k_clip_hash, dim3(gv + gf, P), dim3(256), (const double*)d_v, nv, (const double*)d_np, g_new, g_pre, (const unsigned char*)d_ref,
+         (long long*)d_keys, (int2*)d_tab, g_tab, (int*)d_slot);
+  LAUNCH(c, "k_clip_rank", k_clip_rank, dim3(P), dim3(SH_STL_SCAN_THREADS), g_pre, (const unsigned char*)d_ref, (const int2*)d_tab, g_tab, (const int*)d_slot,
+         (int*)d_vid, (ClipCounts*)d_cnt);
+  HIPCHK(c, hipMemcpyAsync(cn.data(), d_cnt, (size_t)P * sizeof(ClipCounts), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  report(false);
+  for (int p = 0; p < P; ++p)
+    if (cn[p].n_verts > cap_v) return fail(c, SH_ERR_CAPACITY, "sh_slice_mesh_planes: vertex capacity too small (counts hold the sizes needed)");
+  LAUNCH(c, "k_clip_out", k_clip_out, dim3(gv + gf, P), dim3(256), (const double*)d_v, nv, (const double*)d_np, g_new, g_pre, (const unsigned char*)d_ref,
+         (const int2*)d_tab, g_tab, (const int*)d_slot, (const int*)d_vid, (const int*)d_pf, g_face, (const int*)d_pe, g_edge, (double*)d_ov, cap_v, (int*)d_of,
+         cap_f, (int*)d_oe, cap_e);
+  for (int p = 0; p < P; ++p) {
+    if (cn[p].n_verts) HIPCHK(c, hipMemcpyAsync(out_verts + 3 * (size_t)p * cap_v, (double*)d_ov + 3 * (size_t)p * cap_v, (size_t)cn[p].n_verts * 24, hipMemcpyDeviceToHost, c->stream));
+    if (cn[p].n_faces) HIPCHK(c, hipMemcpyAsync(out_faces + 3 * (size_t)p * cap_f, (int*)d_of + 3 * (size_t)p * cap_f, (size_t)cn[p].n_faces * 12, hipMemcpyDeviceToHost, c->stream));
+    if (out_edges && cn[p].n_edges) HIPCHK(c, hipMemcpyAsync(out_edges + 2 * (size_t)p * cap_e, (int*)d_oe + 2 * (size_t)p * cap_e, (size_t)cn[p].n_edges * 8, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return SH_OK;
 }
 

@@ -29,3 +29,23 @@ def construct_csys(vec_z, vec_y):
     if np.round(np.linalg.det(T)) == -1:
         T[:, 0] *= -1
     return inv_transform(T)
+
+
+def unitxyz_to_spherical(xyz):
+    """[r, theta (retroversion), phi (neck-shaft)] in mm and degrees (utils.py:321-330)."""
+    xyz = np.asarray(xyz, dtype=np.float64)
+    r = np.sqrt(np.sum(xyz ** 2))
+    return np.array([r, np.rad2deg(np.arctan2(xyz[1], xyz[0])), np.rad2deg(np.arccos(xyz[2] / r))])
+
+
+def spherical_to_unitxyz(sphr):
+    """utils.py:333-339."""
+    theta, phi = np.deg2rad(sphr[1]), np.deg2rad(sphr[2])
+    return np.array([sphr[0] * np.sin(phi) * np.cos(theta), sphr[0] * np.sin(phi) * np.sin(theta), sphr[0] * np.cos(phi)])
+
+
+def transform_plane_pn(point, normal, T):
+    """(point, normal) of a plane under the 4x4 T (utils.py:191-206: the point moves, the normal only rotates)."""
+    T = np.asarray(T, dtype=np.float64)
+    p = T @ np.r_[np.asarray(point, dtype=np.float64).reshape(3), 1.0]
+    return p[:3], T[:3, :3] @ np.asarray(normal, dtype=np.float64).reshape(3)

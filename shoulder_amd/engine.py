@@ -224,6 +224,30 @@ class Engine:
         self._chk(self.L.sh_section_plane(self.h, int(b), _ptr(o), _ptr(n), _ptr(out), cap, ctypes.byref(k)))
         return out[:k.value].copy()
 
+    def slice_mesh_planes(self, verts, faces, origins, normals, edges=False):
+        """`Trimesh.slice_plane(origin, normal)` of one mesh for P planes in one device pass (sh_slice_mesh_planes;
+        arthroplasty.py:80-87).  -> list of (verts (n,3) f64, faces (m,3) i32[, cut edges (k,2) i32]) per plane."""
+        v = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        n = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+        if len(o) != len(n):
+            raise ValueError("one origin per normal")
+        P = len(o)
+        cnt = np.zeros((P, 3), dtype=np.int32)
+        self._chk(self.L.sh_slice_mesh_planes(self.h, _ptr(v), len(v), _ptr(f), len(f), _ptr(o), _ptr(n), P, None, 0, None, 0, None, 0, _ptr(cnt)))
+        cv, cf, ce = (max(1, int(x)) for x in cnt.max(axis=0))
+        ov = np.empty((P, cv, 3), dtype=np.float64)
+        of = np.empty((P, cf, 3), dtype=np.int32)
+        oe = np.empty((P, ce, 2), dtype=np.int32) if edges else None
+        self._chk(self.L.sh_slice_mesh_planes(self.h, _ptr(v), len(v), _ptr(f), len(f), _ptr(o), _ptr(n), P, _ptr(ov), cv, _ptr(of), cf,
+                                              _ptr(oe) if edges else None, ce if edges else 0, _ptr(cnt)))
+        out = []
+        for p in range(P):
+            nv_, nf_, ne_ = (int(x) for x in cnt[p])
+            out.append((ov[p, :nv_].copy(), of[p, :nf_].copy()) + ((oe[p, :ne_].copy(),) if edges else ()))
+        return out
+
     # ---- named buffers -----------------------------------------------------------------------------
     def fetch(self, name, dtype, shape=None):
         n, e = ctypes.c_size_t(), ctypes.c_int()
