@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--cpu-meshes", type=int, default=4, help="humeri of the batch the single-core oracle leg processes")
     ap.add_argument("--cpu-pool", type=int, default=-1, help="worker processes of the pooled oracle leg (one humerus each); -1 = host cores of this process, at most 16; 0 = skip")
     ap.add_argument("--no-pipeline", action="store_true", help="wait for every step before enqueueing the next one (sh_run instead of sh_submit / sh_collect)")
+    ap.add_argument("--lanes", type=int, default=2, help="engine contexts per GPU; steps alternate between them and their streams overlap on the device "
+                    "(the small geometry kernels of one step fill the gaps of the other step's UNet); 1 = a single context")
     ap.add_argument("--no-overlap", action="store_true", help="do not compute the host hulls of step k+1 during the device work of step k")
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     ap.add_argument("--from-stl", action="store_true", help="every step starts from the bytes of B binary STL files (device-side parse + vertex merge, sh_upload_stl)")
@@ -120,15 +122,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); two streams on one queue run in
+    # order.  The lanes below need their streams on different queues next to torch's and RCCL's streams, so: more queues,
+    # and the engine contexts are created before anything else makes streams.  (Must be set before HIP initialises.)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     # SH_BENCH_FORCE_DIST=1 exercises the collective code path with a single rank (1-GPU rehearsal)
     use_dist = world > 1 or os.environ.get("SH_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -144,18 +144,33 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         # before anything touches the GPU: the pooled leg starts worker processes
         cpu = cpu_baseline(verts, faces, synth.similarity_transforms(B, verts, seed=1234), weights, args.cpu_meshes, args.cpu_pool)
-    eng = Engine(local)
-    if rank == 0:
-        eng.load_rfc()
-        eng.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
-    else:   # allocate the parameter block with the right shapes, contents arrive by broadcast
-        z = np.load(os.path.join(ROOT, "shoulder_amd", "models", "rfc_bg3.npz"))
-        eng.load_rfc()       # tree topology is needed host-side for validation; values are overwritten below
-        eng.load_unet({k: np.zeros_like(v) for k, v in weights.items()}, unet_spec.BASE, unet_spec.DEPTH)
+    # Lanes: independent engine contexts (own stream, own scratch) on this GPU.  Step s runs on lane s % lanes, so the launch-
+    # and latency-bound geometry kernels of one step execute beside the chip-filling UNet kernels of the previous step.
+    lanes = max(1, args.lanes) if not (args.from_host or args.from_stl or args.no_pipeline) else 1
+    engs = [Engine(local) for _ in range(lanes)]
+    eng = engs[0]
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    for e in engs:
+        if rank == 0:
+            e.load_rfc()
+            e.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
+        else:   # allocate the parameter block with the right shapes, contents arrive by broadcast
+            e.load_rfc()       # tree topology is needed host-side for validation; values are overwritten below
+            e.load_unet({k: np.zeros_like(v) for k, v in weights.items()}, unet_spec.BASE, unet_spec.DEPTH)
     if use_dist:
         shd.broadcast_params(eng.param_block(), src=0, device=f"cuda:{local}")   # RCCL broadcast of UNet + forest parameters
+        src_blk = shd.as_byte_tensor(eng.param_block(), device=f"cuda:{local}")
+        for e in engs[1:]:                                                          # the other lanes copy the block device to device
+            shd.as_byte_tensor(e.param_block(), device=f"cuda:{local}").copy_(src_blk)
         torch.cuda.synchronize()
-    eng.set_params(unet_dtype=_lib.UNET_BF16 if args.unet == "bf16" else _lib.UNET_F32)
+    for e in engs:
+        e.set_params(unet_dtype=_lib.UNET_BF16 if args.unet == "bf16" else _lib.UNET_F32)
+        e.set_unet_turns(lanes > 1 and os.environ.get("SH_BENCH_NO_TURNS") != "1")
 
     T = synth.similarity_transforms(B, verts, seed=1234, start=rank * B)
     host_batch = None
@@ -168,13 +183,15 @@ def main():
         host_batch = [(synth.apply_similarity(T[i], verts), faces) for i in range(B)]
         eng.upload(host_batch)
     else:
-        eng.upload([(verts, faces)])
-        eng.synth_batch(T)                             # batch resident in HBM before the timed region
+        for e in engs:
+            e.upload([(verts, faces)])
+            e.synth_batch(T)                           # batch resident in HBM (of every lane) before the timed region
 
     lm_t = shd.as_byte_tensor(eng.landmarks_device(), device=f"cuda:{local}") if use_dist else None
     gather_list = [torch.empty_like(lm_t) for _ in range(world)] if (use_dist and rank == 0) else None
-    # pipelined schedule: every run copies its records (device to device, on the engine's stream) into one of two send buffers
-    send = [torch.empty_like(lm_t) for _ in range(2)] if use_dist else None
+    # pipelined schedule: every run copies its records (device to device, on its engine's stream) into one of the send buffers
+    nsend = 2 * lanes
+    send = [torch.empty_like(lm_t) for _ in range(nsend)] if use_dist else None
     pipelined = host_batch is None and not args.no_pipeline
 
     def step():
@@ -189,39 +206,50 @@ def main():
     overlap = not args.no_overlap and host_batch is None
     for _ in range(args.warmup):
         step()
+        for e in engs[1:]:
+            e.run(_lib.STAGE_ALL, fetch=False)
     # HIP events around the UNet layers only inside the timed region (level 2): the dominant kernel is one of them, and
     # events around all ~150 launches of a step stretch the step by ~0.7 ms.  The other kernels are timed in one extra
     # pass after the region (level 1).
-    eng.enable_timing(2)
-    eng.reset_timers()
+    for e in engs:
+        e.enable_timing(2)
+        e.reset_timers()
     # Streaming schedule: inside the timed region the hulls of step k+1 are computed by host threads while the device
     # works on step k.  Nothing is carried in from the warmup (discard) and nothing is prepared for a step K+1 (overlap
     # off before the last step): K hull passes and K device passes lie between t0 and t1.
-    eng.discard_prepared()
-    eng.set_overlap(overlap)
+    for e in engs:
+        e.discard_prepared()
+        e.set_overlap(overlap)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if pipelined:
-        # Two runs in flight: step k+1 is enqueued (sh_submit) while step k still executes, so the device goes from one step to
-        # the next without waiting for the host; the records of step k are collected (and gathered) after that.  All K submits
-        # and all K collects lie inside the timed region.
-        def finish(k):
-            eng.collect()
+        # Steps in flight: step s is enqueued (sh_submit) on lane s % lanes while the steps before it still execute, so the
+        # device goes from one step to the next without waiting for the host and the lanes' streams overlap; the records of a
+        # step are collected (and gathered) once `depth` later steps are enqueued.  All K submits and all K collects lie
+        # inside the timed region.
+        depth = lanes if lanes > 1 else 2
+        pend = []
+
+        def finish(k, e):
+            e.collect()
             if use_dist:
-                dist.gather(send[k & 1], gather_list, dst=0)
-                torch.cuda.current_stream().synchronize()      # the send buffer is free before the run after next reuses it
+                dist.gather(send[k % nsend], gather_list, dst=0)
+                torch.cuda.current_stream().synchronize()      # the send buffer is free before a later step reuses it
         for s_ in range(args.steps):
-            if s_ == args.steps - 1:
-                eng.set_overlap(False)
+            e = engs[s_ % lanes]
+            if args.steps - s_ <= lanes:
+                e.set_overlap(False)                           # the last step of a lane prepares nothing
+            if len(pend) >= depth:
+                finish(*pend.pop(0))
             if use_dist:
-                eng.submit(_lib.STAGE_ALL, fetch=False, out_ptr=send[s_ & 1].data_ptr())
+                e.submit(_lib.STAGE_ALL, fetch=False, out_ptr=send[s_ % nsend].data_ptr())
             else:
-                eng.submit(_lib.STAGE_ALL, fetch="view")
-            if s_ > 0:
-                finish(s_ - 1)
-        finish(args.steps - 1)
+                e.submit(_lib.STAGE_ALL, fetch="view")
+            pend.append((s_, e))
+        for k_e in pend:
+            finish(*k_e)
     else:
         for s_ in range(args.steps):
             if s_ == args.steps - 1:
@@ -236,11 +264,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     ul = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512, eb=2 if args.unet == "bf16" else 4)
-    region_times = {name: eng.kernel_time_ms(name) for name in list(ul) + ["unet.pool", "host.verts_d2h", "host.hull"]}
-    eng.reset_timers()
+    def merged(name):       # (average ms, launches) over all lanes
+        parts = [e.kernel_time_ms(name) for e in engs]
+        n = sum(p[1] for p in parts)
+        return (sum(p[0] * p[1] for p in parts) / n if n else 0.0, n)
+    region_times = {name: merged(name) for name in list(ul) + ["unet.pool", "host.verts_d2h", "host.hull"]}
+    for e in engs:
+        e.reset_timers()
+        e.enable_timing(0)
     eng.enable_timing(1)
-    eng.run(_lib.STAGE_ALL, fetch=False)      # profiling pass outside the timed region: every kernel between events
+    eng.run(_lib.STAGE_ALL, fetch=False)      # profiling pass outside the timed region, one lane alone: every kernel between events
     extra_times = {name: eng.kernel_time_ms(name) for name in GEOM_KERNELS + ["k_synth_batch", "k_pack_w_bf16"]}
+    alone_times = {name: eng.kernel_time_ms(name) for name in ul}
     eng.enable_timing(0)
 
     if use_dist and rank == 0:      # what rank 0 holds after the last gather: every rank's records, in rank order
@@ -265,7 +300,7 @@ def main():
         total_dev = sum(ms * n for ms, n in times.values())
         # group the launches by kernel symbol (what rocprofv3 --stats reports): the UNet layers run one of
         # four instantiations of k_conv_mfma_f32<TAPS, NT>
-        sym = {}
+        sym, sym_of = {}, {}
         for name, (ms, n) in times.items():
             if name in ul and name not in ("unet.head", "unet.enc0a"):
                 cout = ul_cout[name]
@@ -277,6 +312,7 @@ def main():
                         key = "k_conv3_dma_bf16<%d>" % fuse      # persistent LDS-DMA form of the >= 64-channel 3x3 layers (k_unet_bf16_dma.h)
             else:
                 key = name
+            sym_of[name] = key
             g = sym.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
             g["ms"] += ms * n
             g["n"] += n
@@ -295,6 +331,15 @@ def main():
                 ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
                 roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                             algorithmic_gbytes_per_launch=round(g["bytes"] / g["n"] / 1e9, 4), **common)
+                if lanes > 1:
+                    # the same launches with one lane alone on the device (profiling pass after the timed region): what the
+                    # kernel does when no other stream shares the CUs with it
+                    members = [nm for nm in ul if nm in times and sym_of.get(nm) == dom]
+                    a_ms = sum(alone_times[nm][0] * alone_times[nm][1] for nm in members)
+                    a_fl = sum(ul[nm][0] * B * alone_times[nm][1] for nm in members)
+                    if a_ms > 0:
+                        roof["one_lane_alone"] = dict(avg_ms=round(a_ms / sum(alone_times[nm][1] for nm in members), 4),
+                                                      achieved=round(a_fl / (a_ms * 1e-3) / 1e12, 2), frac=round(a_fl / (a_ms * 1e-3) / 1e12 / peak, 4))
             else:
                 ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
                 roof = dict(bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), **common)
@@ -320,13 +365,15 @@ def main():
                "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: batch {B} synthetic humeri per GPU, all stages (SH_STAGE_ALL)",
                           "batch_per_gpu": B, "global_batch": B * world, "vertices": V, "triangles": F, "unet": f"base{unet_spec.BASE} depth{unet_spec.DEPTH} 512x512",
                           "parallelism": f"dp{world}", "input": "binary STL bytes every step (device parse + merge, PCIe inclusive)" if args.from_stl else "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM",
-                          "schedule": ("two steps in flight (sh_submit / sh_collect); " if pipelined else "") + ("host hulls of step k+1 overlap the device work of step k; pipeline filled and drained inside the timed region" if overlap else "serial hulls"),
+                          "lanes": lanes,
+                          "schedule": ((f"{lanes} engine contexts per GPU, step s on lane s % {lanes}, their streams overlap on the device (sh_submit / sh_collect); " if lanes > 1 else "two steps in flight (sh_submit / sh_collect); ") if pipelined else "") + ("host hulls of step k+1 overlap the device work of step k; pipeline filled and drained inside the timed region" if overlap else "serial hulls"),
                           "meshes_with_error_status": n_bad},
                "roofline": roof, "cpu_baseline": cpu,
                "unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top,
                "device_ms_per_step_total": round(total_dev / args.steps, 3), "host_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()}}
         print(json.dumps(out))
-    eng.close()
+    for e in engs:
+        e.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -206,6 +206,17 @@ int  sh_enable_timing(sh_ctx*, int level);
 int  sh_set_overlap(sh_ctx*, int on);
 int  sh_discard_prepared(sh_ctx*);
 
+/* Several contexts on ONE device ("lanes": own stream, own scratch; consecutive batches go to alternating contexts
+ * through sh_submit / sh_collect).  Their streams overlap on the device: the launch- and latency-bound geometry
+ * kernels of one run execute beside the chip-filling UNet kernels of another (measured at B = 64: 14.2 -> 11.5 ms per
+ * batch with two contexts).  Two UNet passes side by side gain nothing, each just takes twice as long; contexts that
+ * turn this on chain their UNet passes with events in the order the host enqueued them, so a UNet pass only ever
+ * shares the device with geometry.  Results are identical either way.  Off by default.
+ * The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on
+ * one queue run in order: a process that also runs torch / RCCL streams should export GPU_MAX_HW_QUEUES=8 before HIP
+ * initialises (bench.py does). */
+int  sh_set_unet_turns(sh_ctx*, int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,7 +64,7 @@ EXPORTS = ["sh_ctx_create", "sh_ctx_destroy", "sh_last_error", "sh_default_param
            "sh_load_unet", "sh_param_block", "sh_upload_meshes", "sh_synth_batch", "sh_batch_size", "sh_run",
            "sh_landmarks_device", "sh_affine_apply", "sh_mesh_transformed", "sh_transform_points", "sh_section_plane", "sh_buffer_info", "sh_fetch", "sh_store",
            "sh_kernel_time_ms", "sh_enable_timing", "sh_set_overlap", "sh_discard_prepared", "sh_unet_infer", "sh_host_alloc", "sh_host_free", "sh_upload_stl", "sh_submit", "sh_collect",
-           "sh_slice_mesh_planes"]
+           "sh_slice_mesh_planes", "sh_set_unet_turns"]
 
 _lib = None
 
@@ -122,6 +122,7 @@ def load(build_if_missing=True):
     L.sh_kernel_time_ms.argtypes = [vp, cp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
     L.sh_enable_timing.argtypes = [vp, ctypes.c_int]
     L.sh_set_overlap.argtypes = [vp, ctypes.c_int]
+    L.sh_set_unet_turns.argtypes = [vp, ctypes.c_int]
     L.sh_discard_prepared.argtypes = [vp]
     L.sh_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.sh_host_free.argtypes = [vp, vp]

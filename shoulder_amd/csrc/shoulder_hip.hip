@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -85,6 +86,8 @@ struct sh_ctx {
   int t_head = 0, t_tail = 0, n_pending = 0;
   hipStream_t out_stream = nullptr;      // sh_collect copies the records / status words of a finished run to the host on this stream
   bool overlap = false;
+  bool unet_turn = false;                // sh_set_unet_turns: UNet passes of the contexts of one device run one after another
+  hipEvent_t unet_done_ev = nullptr;
   unsigned long long batch_gen = 0;
   hipStream_t copy_stream = nullptr;
   // timing
@@ -198,18 +201,22 @@ int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
   sh_default_params(&c->params);
   if (hip_stream) c->stream = (hipStream_t)hip_stream;
   else {
-    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return SH_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SH_ERR_HIP; }
     c->own_stream = true;
   }
   *out = c;
   return SH_OK;
 }
 
+static void unet_turn_forget(sh_ctx* c);
+
 void sh_ctx_destroy(sh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->prep.active && c->prep.th.joinable()) c->prep.th.join();
   (void)hipStreamSynchronize(c->stream);
+  unet_turn_forget(c);
+  if (c->unet_done_ev) (void)hipEventDestroy(c->unet_done_ev);
   drain_timers(c);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->obb_done_ev) (void)hipEventDestroy(c->obb_done_ev);
@@ -747,6 +754,36 @@ static int conv_layer(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, con
   return SH_OK;
 }
 
+// ---- UNet turns ----------------------------------------------------------------------------------------
+// Several contexts on one device overlap well when the launch-bound geometry kernels of one run beside the chip-filling
+// UNet kernels of another -- and badly when two UNet passes share the CUs (each just takes twice as long).  Contexts
+// that opted in (sh_set_unet_turns) therefore chain their UNet passes with events, in the order the host enqueued them.
+static std::mutex g_turn_mu;
+static hipEvent_t g_turn_last[64] = {};      // per device: recorded at the end of the most recently enqueued UNet pass
+static sh_ctx* g_turn_owner[64] = {};
+
+static int unet_turn_enter(sh_ctx* c) {
+  if (!c->unet_turn || c->device < 0 || c->device >= 64) return SH_OK;
+  std::lock_guard<std::mutex> lk(g_turn_mu);
+  if (g_turn_last[c->device] && g_turn_owner[c->device] != c) HIPCHK(c, hipStreamWaitEvent(c->stream, g_turn_last[c->device], 0));
+  return SH_OK;
+}
+
+static int unet_turn_leave(sh_ctx* c) {
+  if (!c->unet_turn || c->device < 0 || c->device >= 64) return SH_OK;
+  std::lock_guard<std::mutex> lk(g_turn_mu);
+  if (!c->unet_done_ev) HIPCHK(c, hipEventCreateWithFlags(&c->unet_done_ev, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->unet_done_ev, c->stream));
+  g_turn_last[c->device] = c->unet_done_ev;
+  g_turn_owner[c->device] = c;
+  return SH_OK;
+}
+
+static void unet_turn_forget(sh_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_turn_mu);
+  if (c->device >= 0 && c->device < 64 && g_turn_owner[c->device] == c) { g_turn_last[c->device] = nullptr; g_turn_owner[c->device] = nullptr; }
+}
+
 static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
   const int D = c->unet_depth, base = c->unet_base;
   if ((H >> D) % 16 || (W >> D) % 16) return fail(c, SH_ERR_ARG, "unet: input size must be a multiple of 16 << depth");
@@ -1206,8 +1243,10 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     LAUNCH(c, "k_init_bounds", k_init_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "anp.mm_enc"), B);
     LAUNCH(c, "k_anp_minmax", k_anp_minmax_reduce, dim3(16, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"));
     LAUNCH(c, "k_anp_scale", k_anp_scale, dim3(64, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"), buf<float>(c, "anp.image"));
+    if ((rc = unet_turn_enter(c)) != SH_OK) return rc;
     if (c->params.unet_dtype == SH_UNET_BF16) rc = unet_forward_bf16(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
     else rc = unet_forward(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
+    (void)unet_turn_leave(c);      // also after a failed pass: whatever was enqueued is what the next context waits for
     if (rc != SH_OK) return rc;
     LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(B), dim3(512), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
            buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"), buf<int>(c, "err"));
@@ -1293,6 +1332,13 @@ static void start_prepare(sh_ctx* c) {
 int sh_set_overlap(sh_ctx* c, int on) {
   if (!c) return SH_ERR_ARG;
   c->overlap = on != 0;      // hulls already in preparation stay usable by the next run
+  return SH_OK;
+}
+
+int sh_set_unet_turns(sh_ctx* c, int on) {
+  if (!c) return SH_ERR_ARG;
+  c->unet_turn = on != 0;
+  if (!c->unet_turn) unet_turn_forget(c);
   return SH_OK;
 }
 

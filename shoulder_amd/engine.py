@@ -279,6 +279,10 @@ class Engine:
         """Streaming runs on the resident batch: compute the host hulls of the next run while the device works on this one."""
         self._chk(self.L.sh_set_overlap(self.h, 1 if on else 0))
 
+    def set_unet_turns(self, on=True):
+        """Several engines on one device: their UNet passes run one after another, geometry overlaps (sh_set_unet_turns)."""
+        self._chk(self.L.sh_set_unet_turns(self.h, 1 if on else 0))
+
     def discard_prepared(self):
         self._chk(self.L.sh_discard_prepared(self.h))
 

@@ -188,3 +188,51 @@ def test_submit_collect_pipeline(engine, oracle_bones):
             engine.discard_prepared()
         for r in (a, b, c):
             assert r.tobytes() == ref.tobytes()
+
+
+def test_two_contexts_on_one_device(engine, oracle_bones):
+    """Lanes (sh_set_unet_turns): two contexts on one device, runs interleaved through sh_submit / sh_collect, UNet passes
+    chained by events; every run returns the records a single context returns, with different batches per lane."""
+    from shoulder_amd import unet_spec
+    from shoulder_amd.engine import Engine
+    from conftest import _teacher_weights
+    h = oracle_bones("humerus_left")
+    B = 4
+    Ts = [synth.similarity_transforms(B, h.verts, seed=s) for s in (5, 6)]
+    refs = []
+    for T in Ts:
+        engine.upload([(h.verts, h.faces)])
+        engine.synth_batch(T)
+        refs.append(engine.run(_lib.STAGE_ALL).copy())
+    assert refs[0].tobytes() != refs[1].tobytes()
+    lanes = []
+    try:
+        for T in Ts:
+            e = Engine(0)
+            e.load_rfc()
+            e.load_unet(_teacher_weights(), unet_spec.BASE, unet_spec.DEPTH)
+            e.upload([(h.verts, h.faces)])
+            e.synth_batch(T)
+            e.set_unet_turns(True)
+            e.set_overlap(True)
+            lanes.append(e)
+        got = [[], []]
+        pend = []
+        for s in range(6):
+            if len(pend) >= 2:
+                k = pend.pop(0)
+                got[k].append(lanes[k].collect().copy())
+            lanes[s % 2].submit(_lib.STAGE_ALL)
+            pend.append(s % 2)
+        for k in pend:
+            got[k].append(lanes[k].collect().copy())
+        for k in range(2):
+            assert len(got[k]) == 3
+            for r in got[k]:
+                assert r.tobytes() == refs[k].tobytes()
+        lanes[0].set_unet_turns(False)                 # leaving the chain is allowed at any time
+        assert lanes[0].run(_lib.STAGE_ALL).tobytes() == refs[0].tobytes()
+        assert lanes[1].run(_lib.STAGE_ALL).tobytes() == refs[1].tobytes()
+    finally:
+        for e in lanes:
+            e.close()
