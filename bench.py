@@ -308,8 +308,9 @@ def main():
                 if args.unet == "bf16":      # third template argument = fused ends (k_unet_bf16.h): UF_FIRST 1, UF_HEAD 2, UF_POOL 4
                     fuse = 5 if name == "unet.enc0b" else 2 if name == "unet.dec0b" else 4 if name in ("unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
                     key = key[:-1] + ",%d>" % fuse
-                    if cout % 64 == 0 and not name.startswith("unet.up") and os.environ.get("SHOULDER_UNET_DMA") != "0":
-                        key = "k_conv3_dma_bf16<%d>" % fuse      # persistent LDS-DMA form of the >= 64-channel 3x3 layers (k_unet_bf16_dma.h)
+                    if not name.startswith("unet.up") and not (fuse & 1) and os.environ.get("SHOULDER_UNET_DMA") != "0" and \
+                            (cout % 64 == 0 or os.environ.get("SHOULDER_UNET_DMA32") != "0"):
+                        key = "k_conv3_dma_bf16<%d,%d>" % (fuse, 4 if cout % 64 == 0 else 2)      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h)
             else:
                 key = name
             sym_of[name] = key

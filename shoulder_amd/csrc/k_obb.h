@@ -172,12 +172,6 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
       const unsigned long long ub = *(volatile unsigned long long*)&best_enc[b];
       const double lb = 0.5 * fabs(g_hull2[tid]) * (hhi[g0 + tid] - hlo[g0 + tid]);
       if (ub != ~0ull && lb * (1.0 - 1e-9) > __longlong_as_double((long long)ub)) g_skip[tid] = 1;
-#ifdef SH_OBB_SKIPALL
-      g_skip[tid] = 1;
-#endif
-#ifdef SH_OBB_COUNT
-      if (g_skip[tid]) atomicAdd((unsigned long long*)&best_enc[gridDim.y + b], 1ull);
-#endif
     }
     __syncthreads();
     // every lane takes item tid of each pass of 256 (edge s of direction jj) and remembers (area, edge, direction);

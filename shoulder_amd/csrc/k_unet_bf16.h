@@ -138,7 +138,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
     const int c0 = cc * 32;
     const bool first = c0 < C0;
     const __bf16* src = first ? in0 : in1;
-    const int Cs = first ? C0 : C1, cb = first ? c0 : c0 - C0;
+    const int cb = first ? c0 : c0 - C0;
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};

@@ -33,19 +33,39 @@ typedef __attribute__((address_space(3))) void* ud_lptr;
 __device__ inline void ud_store8(__bf16* p, bf16x4 v) {      // exactly one vector-memory instruction (counted by s_waitcnt vmcnt)
   asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(__builtin_bit_cast(unsigned long long, v)) : "memory");
 }
+__device__ inline void ud_store4(float* p, float v) {
+  asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+template <int N> __device__ inline void ud_wait_vm() {      // s_waitcnt takes an immediate
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
-template <int FUSE>      // 0 or UF_POOL
+// FUSE: 0, UF_POOL (2x2 max pool written beside the output) or UF_HEAD (1x1 head: only the logits leave the kernel).
+// NN: 16-cout tiles per item: 4 (64-cout groups) or 2 (the 32-channel level: 288 weight rows, 8 DMA pieces per step).
+template <int FUSE, int NN = 4>
 __global__ void __launch_bounds__(UD_THREADS)
 k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src1, int C0, int C1,
                  const __bf16* __restrict__ wgt, const float* __restrict__ bias, __bf16* __restrict__ dst,
-                 int H, int W, int Cout, int relu, int nimg, const __bf16* __restrict__ zero_page, __bf16* __restrict__ pooled) {
+                 int H, int W, int Cout, int relu, int nimg, const __bf16* __restrict__ zero_page, __bf16* __restrict__ pooled,
+                 const float* __restrict__ head_w, const float* __restrict__ head_b, float* __restrict__ logits) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[UD_SMEM];
-  constexpr int NSTORE = 16 + ((FUSE & UF_POOL) ? 8 : 0);
+  static_assert(NN == 4 || NN == 2, "64- or 32-cout items");
+  static_assert(!(FUSE & UF_HEAD) || NN == 2, "the head reads all 32 channels of a pixel from one item");
+  constexpr int WR = 16 * NN;                        // weight rows per tap
+  constexpr int WSH = NN == 4 ? 6 : 5;               // log2(WR)
+  constexpr int SLOTS = (UD_INROWS + 9 * WR) * 4;    // 16-byte slots of a step: 4896 / 3744
+  constexpr int NPIECE = (SLOTS + UD_THREADS - 1) / UD_THREADS;      // 10 / 8
+  constexpr int NSTORE = (FUSE & UF_HEAD) ? 4 : 4 * NN + ((FUSE & UF_POOL) ? 2 * NN : 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int xh = wave & 1, rg = wave >> 1;
   const int Cin = C0 + C1, nchunk = Cin >> 5;
-  const int tiles_x = W / 32, tiles_y = H / 16, ngroups = Cout >> 6;
+  const int tiles_x = W / 32, tiles_y = H / 16, ngroups = Cout / WR;
   const int total = nimg * tiles_x * tiles_y * ngroups;
   const int per = (total + gridDim.x - 1) / gridDim.x;
   const int w_begin = blockIdx.x * per, w_end = min(total, w_begin + per);
@@ -53,6 +73,7 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
 
   float* s_bias = (float*)(smem + UD_BIAS_OFF);
   for (int i = tid; i < Cout; i += UD_THREADS) s_bias[i] = bias[i];
+  if (FUSE & UF_HEAD) for (int i = tid; i < 32; i += UD_THREADS) s_bias[256 + i] = head_w[i];
   __syncthreads();       // every ordinary load is retired before the first LDS-DMA is issued
 
   // staging plan: slot e_k = tid + 512 k -> row r_k = (tid >> 2) + 128 k; k = 0..4 halo rows, k = 5 mixed, k = 6..9 weight rows.
@@ -60,10 +81,10 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
   const int r0 = tid >> 2;
   const int q8 = ((tid & 3) ^ ((r0 >> 1) & 2)) * 8;
   const int rw5 = r0 + 640 - UD_INROWS;
-  const int wstep = 2 * nchunk * Cout * 32;
-  const int wrel5 = ((rw5 >> 6) * nchunk * Cout + (rw5 & 63)) * 32 + q8;
+  const int wstep = (128 / WR) * nchunk * Cout * 32;      // 128 rows per piece = 2 (4) taps
+  const int wrel5 = ((rw5 >> WSH) * nchunk * Cout + (rw5 & (WR - 1))) * 32 + q8;
   const bool in5 = rw5 < 0;
-  const bool w9 = tid + 512 * 9 < UD_SLOTS;
+  const bool wlast = tid + 512 * (NPIECE - 1) < SLOTS;
 
   // fragment read offsets (bytes inside a buffer)
   int xoff[2][3], woff;
@@ -101,7 +122,7 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
     n_Cs = first ? C0 : C1;
     n_cb = ((first ? c0 : c0 - C0) >> 5) * (H * W);      // pixel offset of this chunk's 32-channel plane (channel-blocked activations)
     n_simg = (first ? src0 : src1) + (size_t)i_img * H * W * n_Cs;
-    n_wbase = wgt + ((size_t)cc * Cout + i_g * 64) * 32;
+    n_wbase = wgt + ((size_t)cc * Cout + i_g * WR) * 32;
     n_lbase = smem + buf * UD_BUF + wave * 1024;
   };
   auto piece = [&](int k) {      // k is a compile-time constant at every call site
@@ -112,34 +133,32 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
       const __bf16* pi = pixoff[5] >= 0 ? n_simg + (unsigned)((n_cb + pixoff[5]) * 32 + q8) : zero_page;
       const __bf16* p = in5 ? pi : n_wbase + wrel5;
       __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + 5 * 8192), 16, 0, 0);
-    } else if (k < 9) {
+    } else if (k < NPIECE - 1) {
       __builtin_amdgcn_global_load_lds((ud_gptr)(n_wbase + (wrel5 + (k - 5) * wstep)), (ud_lptr)(n_lbase + k * 8192), 16, 0, 0);
-    } else {
-      if (w9) __builtin_amdgcn_global_load_lds((ud_gptr)(n_wbase + (wrel5 + 4 * wstep)), (ud_lptr)(n_lbase + 9 * 8192), 16, 0, 0);
+    } else if (k == NPIECE - 1) {
+      if (wlast) __builtin_amdgcn_global_load_lds((ud_gptr)(n_wbase + (wrel5 + (NPIECE - 6) * wstep)), (ud_lptr)(n_lbase + (NPIECE - 1) * 8192), 16, 0, 0);
     }
   };
 
   item_lane_setup();
   describe(0, 0);
 #pragma unroll
-  for (int k = 0; k < 10; ++k) piece(k);
+  for (int k = 0; k < NPIECE; ++k) piece(k);
   int buf = 0;
   bool stores_in_flight = false;
   for (int w = w_begin; w < w_end; ++w) {
-    const int c_x0 = i_tx * 32, c_y0 = i_ty * 16, c_img = i_img, c_n0 = i_g * 64;
-    f32x4 acc[4][4];
+    const int c_x0 = i_tx * 32, c_y0 = i_ty * 16, c_img = i_img, c_n0 = i_g * WR;
+    f32x4 acc[4][NN];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+    for (int n = 0; n < NN; ++n) {
       const f32x4 bv = *(const f32x4*)(s_bias + c_n0 + n * 16 + lk * 4);
 #pragma unroll
       for (int m = 0; m < 4; ++m) acc[m][n] = bv;
     }
     for (int cc = 0; cc < nchunk; ++cc) {
       // this wave's DMA pieces of the step are older than the NSTORE epilogue stores of the previous item
-      if (stores_in_flight) {
-        if (FUSE & UF_POOL) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (stores_in_flight) ud_wait_vm<NSTORE>();
+      else ud_wait_vm<0>();
       stores_in_flight = false;
       __builtin_amdgcn_s_barrier();      // every wave's pieces have landed; every wave is done reading the other buffer
       bool has_next = true;
@@ -160,31 +179,47 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
-        bf16x8 xf[4], wf[4];
+        bf16x8 xf[4], wf[NN];
 #pragma unroll
         for (int m = 0; m < 4; ++m) { const int s = m + dy; xf[m] = *(const bf16x8*)(xb[s & 1][dx] + (s & ~1) * UD_PW * 64); }
 #pragma unroll
-        for (int n = 0; n < 4; ++n) wf[n] = *(const bf16x8*)(wbp + (tap * 64 + n * 16) * 64);
-        if (has_next) { piece(tap); if (tap == 8) piece(9); }
+        for (int n = 0; n < NN; ++n) wf[n] = *(const bf16x8*)(wbp + (tap * WR + n * 16) * 64);
+        if (has_next) { if (tap < NPIECE) piece(tap); if (tap == 8 && NPIECE == 10) piece(9); }
 #ifdef SH_DMA_SETPRIO
         __builtin_amdgcn_s_setprio(1);      // +4..7 % per layer in tools/conv_lab, -1..3 % inside this library (co-compiled kernels shift the schedule): off
 #endif
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < NN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[m][n], 0, 0, 0);
 #ifdef SH_DMA_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
       }
       buf ^= 1;
     }
+    if (FUSE & UF_HEAD) {      // logit = head_b + sum over the 32 channels of relu(conv) * head_w: 8 in the lane, the rest in lanes li + 16 k
+      float* lo = logits + (size_t)c_img * H * W;
+      const float hb = head_b[0];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float sacc = 0.0f;      // same operation order as the UF_HEAD epilogue of k_conv_mfma_bf16
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc = __builtin_fmaf(fmaxf(acc[m][n][r], 0.0f), s_bias[256 + n * 16 + lk * 4 + r], sacc);
+        sacc += __shfl_xor(sacc, 16);
+        sacc += __shfl_xor(sacc, 32);
+        // all four lanes of a pixel store the same value: the store count per wave stays exact
+        ud_store4(lo + (size_t)(c_y0 + rg * 4 + m) * W + c_x0 + xh * 16 + li, hb + sacc);
+      }
+    } else {
     __bf16* out = dst + (size_t)c_img * H * W * Cout;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int gy = c_y0 + rg * 4 + m, gx = c_x0 + xh * 16 + li;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < NN; ++n) {
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -195,12 +230,13 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
         ud_store8(out + act_off((size_t)H * W, (size_t)gy * W + gx, c_n0 + n * 16 + lk * 4), o);
       }
     }
+    }
     if (FUSE & UF_POOL) {      // 2x2 max pool of this wave's 4 rows x 16 pixels (rows pair inside the lane, columns with lane li ^ 1)
       __bf16* po = pooled + (size_t)c_img * (H / 2) * (W / 2) * Cout;
 #pragma unroll
       for (int mp = 0; mp < 2; ++mp)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NN; ++n) {
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

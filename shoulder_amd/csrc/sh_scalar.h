@@ -271,7 +271,6 @@ SH_HD int groove_row_features(const double* theta, const double* r, int M, doubl
   double mean;
   {
     double tot = 0.0;
-    int done = 0;
     // pairwise_sum for n = 512: split 256/256 -> 128/128 each; leaf (<=128) uses 8 partial sums
     double leaf[8];
     int nleaf = 0;
@@ -290,7 +289,6 @@ SH_HD int groove_row_features(const double* theta, const double* r, int M, doubl
         for (; k8 < len; ++k8) res += p[k8];
       }
       leaf[nleaf++] = res;
-      done += len;
     }
     // combine leaves pairwise (valid for M = 512: ((l0+l1)+(l2+l3)); generic fallback sequential)
     if (nleaf == 4) tot = (leaf[0] + leaf[1]) + (leaf[2] + leaf[3]);

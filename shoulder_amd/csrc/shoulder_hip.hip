@@ -846,18 +846,27 @@ static int conv_layer_bf16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L
   const int tiles = (H / UN_TH) * (W / UN_TW);
   const dim3 blk(UN_THREADS);
   const char* dma_env = getenv("SHOULDER_UNET_DMA");
-  if (L.taps == 9 && L.cout % 64 == 0 && L.cout <= 512 && W % 32 == 0 && H % 16 == 0 && C0 % 32 == 0 && C1 % 32 == 0 && (fuse == 0 || fuse == UF_POOL) &&
-      !(dma_env && dma_env[0] == '0')) {
-    // persistent LDS-DMA form (k_unet_bf16_dma.h): one workgroup per CU walks (image, 32x16 tile, 64-cout group) items
+  const bool dma_shape = L.taps == 9 && L.cout <= 512 && W % 32 == 0 && H % 16 == 0 && C0 % 32 == 0 && C1 % 32 == 0 && !(dma_env && dma_env[0] == '0');
+  const bool dma64 = dma_shape && L.cout % 64 == 0 && (fuse == 0 || fuse == UF_POOL);
+  // the 32-channel level: 32-cout items (SHOULDER_UNET_DMA32=0 keeps it on the two-barrier kernel)
+  const char* dma32_env = getenv("SHOULDER_UNET_DMA32");
+  const bool dma32 = dma_shape && !dma64 && L.cout % 32 == 0 && (fuse == 0 || fuse == UF_POOL || (fuse == UF_HEAD && L.cout == 32)) && !(dma32_env && dma32_env[0] == '0');
+  if (dma64 || dma32) {
+    // persistent LDS-DMA form (k_unet_bf16_dma.h): one workgroup per CU walks (image, 32x16 tile, 64- or 32-cout group) items
     int rc0;
     if ((rc0 = ensure(c, "unet16.zero", 256, 2)) != SH_OK) return rc0;
     if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
     if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
-    const int total = nimg * (W / 32) * (H / 16) * (L.cout / 64);
+    const int total = nimg * (W / 32) * (H / 16) * (L.cout / (dma64 ? 64 : 32));
     const dim3 g((unsigned)std::min(total, c->num_cus));
     const __bf16* zp = (const __bf16*)c->bufs["unet16.zero"].p;
-    if (fuse == UF_POOL) { LAUNCH(c, lname, k_conv3_dma_bf16<UF_POOL>, g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, fz.pooled); }
-    else { LAUNCH(c, lname, k_conv3_dma_bf16<0>, g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (__bf16*)nullptr); }
+    const float* nof = nullptr;
+    if (dma64) {
+      if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma_bf16<UF_POOL, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, fz.pooled, nof, nof, (float*)nullptr); }
+      else { LAUNCH(c, lname, (k_conv3_dma_bf16<0, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (__bf16*)nullptr, nof, nof, (float*)nullptr); }
+    } else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma_bf16<UF_POOL, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, fz.pooled, nof, nof, (float*)nullptr); }
+    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv3_dma_bf16<UF_HEAD, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (__bf16*)nullptr, fz.head_w, fz.head_b, fz.logits); }
+    else { LAUNCH(c, lname, (k_conv3_dma_bf16<0, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (__bf16*)nullptr, nof, nof, (float*)nullptr); }
   } else if (L.taps == 9 && L.cout % 64 == 0) {
     const dim3 g(tiles, L.cout / 64, nimg);
     if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 4, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
