@@ -38,7 +38,8 @@ __device__ inline void obb_basis(const double* n, double* u, double* v) { plane_
 __global__ void __launch_bounds__(SH_OBB_THREADS)
 k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
                  const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge,
-                 int* __restrict__ err, unsigned long long* __restrict__ best_enc /*[B]: bits of the smallest candidate volume so far, ~0 = none*/) {
+                 int* __restrict__ err, unsigned long long* __restrict__ best_enc /*[B]: bits of the smallest candidate volume so far, ~0 = none*/,
+                 int ntiles, int B) {
   constexpr int T = SH_OBB_TILE, G = SH_OBB_GROUP, NW = SH_OBB_THREADS / 64;
   __shared__ double tn[T][3], tu[T][3], tv[T][3];
   __shared__ double red[NW][2 * T];
@@ -49,9 +50,15 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
   __shared__ double2 sxy[G][SH_SIL_MAX];
   __shared__ unsigned long long g_area[G];
   __shared__ int g_edge[G];
-  __shared__ double g_hull2[G];      // twice the signed area of the projected hull (shoelace over the directed silhouette edges)
+  __shared__ double g_hull2[NW][G];  // per wave: twice the signed area of the projected hull (shoelace over the directed silhouette edges)
   __shared__ int g_skip[G];
-  const int b = blockIdx.y, f0 = blockIdx.x * T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware order: consecutive workgroups go to the 8 XCDs in turn, each with its own L2.  Linear id L -> humerus
+  // 8 * chunk + L % 8, so every tile of a humerus runs on one XCD and its hull record (160 KB, re-read by all 171 tiles)
+  // stays in that XCD's L2: 8 records at a time per XCD instead of all B of them.
+  const int Lid = blockIdx.x, chunk = Lid / (8 * ntiles), rr = Lid - chunk * 8 * ntiles;
+  const int b = chunk * 8 + (rr & 7);
+  if (b >= B) return;
+  const int f0 = (rr >> 3) * T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = nv_[b], nf = nf_[b], ne = ne_[b];
   if (f0 >= nf) return;
   const int nt = min(T, nf - f0);                      // directions in this tile
@@ -146,8 +153,11 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
       if (c > SH_SIL_MAX) { if (tid == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); c = SH_SIL_MAX; }
       ns[jj] = c; pre[jj + 1] = pre[jj] + c;
     }
-    if (tid < G) { g_area[tid] = (unsigned long long)__double_as_longlong(1e300); g_edge[tid] = 0x7fffffff; g_hull2[tid] = 0.0; g_skip[tid] = 0; }
+    if (tid < G) { g_area[tid] = (unsigned long long)__double_as_longlong(1e300); g_edge[tid] = 0x7fffffff; g_skip[tid] = 0; }
     __syncthreads();
+    double h2[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) h2[k] = 0.0;
     // (edge stored with its first face's winding: va -> vb; directed along the FRONT face every silhouette vertex
     //  is the start of exactly one edge, so the start vertices enumerate the projection's 2-D hull once)
     for (int it = tid; it < pre[G]; it += SH_OBB_THREADS) {
@@ -162,7 +172,16 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
       const double* q = P + 3 * (size_t)(fwd ? E[4 * e + 1] : E[4 * e]);
       const double2 a = make_double2(dot3(p, tu[j]), dot3(p, tv[j]));
       sxy[jj][s] = a;
-      atomicAdd(&g_hull2[jj], a.x * dot3(q, tv[j]) - dot3(q, tu[j]) * a.y);      // start x end of the directed edge
+      const double cr = a.x * dot3(q, tv[j]) - dot3(q, tu[j]) * a.y;      // start x end of the directed edge
+#pragma unroll
+      for (int k = 0; k < G; ++k) h2[k] += jj == k ? cr : 0.0;
+    }
+    // (sum in the lane, then over the wave, then over the four waves in a fixed order: a double atomicAdd from every edge onto
+    //  four LDS words was half of this kernel's time)
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      for (int off = 32; off > 0; off >>= 1) h2[k] += __shfl_down(h2[k], off);
+      if (lane == 0) g_hull2[wave][k] = h2[k];
     }
     __syncthreads();
     // Lower bound of a direction's box volume: area of the projected hull x height <= min-area rectangle x height.  A direction
@@ -170,7 +189,9 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     // skipped (the survivor set depends on scheduling, the minimum does not: an equal or smaller volume is never skipped).
     if (tid < G && g0 + tid < nt) {
       const unsigned long long ub = *(volatile unsigned long long*)&best_enc[b];
-      const double lb = 0.5 * fabs(g_hull2[tid]) * (hhi[g0 + tid] - hlo[g0 + tid]);
+      double hull2 = 0.0;
+      for (int w = 0; w < NW; ++w) hull2 += g_hull2[w][tid];
+      const double lb = 0.5 * fabs(hull2) * (hhi[g0 + tid] - hlo[g0 + tid]);
       if (ub != ~0ull && lb * (1.0 - 1e-9) > __longlong_as_double((long long)ub)) g_skip[tid] = 1;
     }
     __syncthreads();
@@ -190,10 +211,13 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
         for (int k = 1; k < G; ++k) jj += it >= pre[k] ? 1 : 0;
         const int s = it - pre[jj], j = g0 + jj, n2 = g_skip[jj] ? 0 : ns[jj];
         const int e = lists[j][s] & 0x7fff;
-        const double* pa3 = P + 3 * (size_t)E[4 * e]; const double* pc3 = P + 3 * (size_t)E[4 * e + 1];
-        double ex = dot3(pc3, tu[j]) - dot3(pa3, tu[j]), ey = dot3(pc3, tv[j]) - dot3(pa3, tv[j]);
-        const double l = sqrt(ex * ex + ey * ey);
-        if (l != 0.0 && n2 > 0) {
+        double ex = 0.0, ey = 0.0, l = 0.0;
+        if (n2 > 0) {      // (a skipped direction costs no gathers here)
+          const double* pa3 = P + 3 * (size_t)E[4 * e]; const double* pc3 = P + 3 * (size_t)E[4 * e + 1];
+          ex = dot3(pc3, tu[j]) - dot3(pa3, tu[j]); ey = dot3(pc3, tv[j]) - dot3(pa3, tv[j]);
+          l = sqrt(ex * ex + ey * ey);
+        }
+        if (l != 0.0) {
           ex /= l; ey /= l;
           double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
           const double2* sq = sxy[jj];

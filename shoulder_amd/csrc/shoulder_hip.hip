@@ -858,7 +858,7 @@ static int conv_layer_bf16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L
     if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
     if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
     const int total = nimg * (W / 32) * (H / 16) * (L.cout / (dma64 ? 64 : 32));
-    const dim3 g((unsigned)std::min(total, c->num_cus));
+    const dim3 g((unsigned)std::min(total, c->num_cus));      // (leaving 16..64 CUs to the other lane's kernels changes nothing: measured)
     const __bf16* zp = (const __bf16*)c->bufs["unet16.zero"].p;
     const float* nof = nullptr;
     if (dma64) {
@@ -1144,9 +1144,10 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(c, hipMemsetAsync(buf<unsigned long long>(c, "obb.best_enc"), 0xFF, (size_t)B * 8, c->stream));      // "no candidate volume yet"
     if (c->timing == 1) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
-    hipLaunchKernelGGL(k_obb_candidates, dim3((nfmax + SH_OBB_TILE - 1) / SH_OBB_TILE, B), dim3(SH_OBB_THREADS), 0, c->stream, buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"),
+    const int ntiles = (nfmax + SH_OBB_TILE - 1) / SH_OBB_TILE;
+    hipLaunchKernelGGL(k_obb_candidates, dim3((unsigned)(ntiles * ((B + 7) / 8) * 8)), dim3(SH_OBB_THREADS), 0, c->stream, buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"),
                        cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"),
-                       buf<unsigned long long>(c, "obb.best_enc"));
+                       buf<unsigned long long>(c, "obb.best_enc"), ntiles, B);
     if (c->timing == 1) { (void)hipEventRecord(e1, c->stream); c->pending.emplace_back("k_obb_candidates", e0, e1); }
     HIPCHK(c, hipGetLastError());
   }
