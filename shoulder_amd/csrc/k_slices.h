@@ -119,10 +119,17 @@ __global__ void k_make_planes(int kind, int N, const double* __restrict__ zb /*[
 // ---- K5: triangle-centric multi-plane section ------------------------------------------------
 // One lane per triangle; each crossing (triangle, plane) appends one Seg to that plane's slot
 // range.  Sign rule and crossing-point formula: oracle/section.py (canonical rules).
-__global__ void k_slice_emit(const double* __restrict__ vobb, const int* __restrict__ faces,
-                             const long long* __restrict__ voff, const long long* __restrict__ foff,
-                             const double* __restrict__ zeff, int N, int* __restrict__ seg_count,
-                             Seg* __restrict__ segs, int* __restrict__ err) {
+// Slots: returning atomics on one counter per (humerus, plane) are what bounded this kernel (~150 arrivals per counter,
+// executed at the memory side).  A workgroup therefore counts its crossings per plane in LDS first (pass A), reserves
+// one range per plane it touches with a single global add, and hands out the slots of that range from LDS (pass B):
+// file order keeps a workgroup's 256 triangles close in z, so ~90 segments share one global atomic instead of ~5.
+#define SH_EMIT_MAXN 640      // planes per set (SH_NPROX = 600 is the largest)
+__global__ void __launch_bounds__(256)
+k_slice_emit(const double* __restrict__ vobb, const int* __restrict__ faces,
+             const long long* __restrict__ voff, const long long* __restrict__ foff,
+             const double* __restrict__ zeff, int N, int* __restrict__ seg_count,
+             Seg* __restrict__ segs, int* __restrict__ err) {
+  __shared__ int hist[SH_EMIT_MAXN];
   int b = blockIdx.y;
   long long f0 = foff[b], nf = foff[b + 1] - f0;
   const double* vb = vobb + 3 * voff[b];
@@ -130,6 +137,7 @@ __global__ void k_slice_emit(const double* __restrict__ vobb, const int* __restr
   double z_first = zp[0], z_last = zp[N - 1];
   double inv_step = (double)(N - 1) / (z_last - z_first);
   for (long long f_base = blockIdx.x * (long long)blockDim.x; f_base < nf; f_base += (long long)gridDim.x * blockDim.x) {
+    for (int k = threadIdx.x; k < N; k += blockDim.x) hist[k] = 0;
     const long long fi = f_base + threadIdx.x;
     const bool live = fi < nf;
     const int* f = faces + 3 * (f0 + (live ? fi : 0));
@@ -139,42 +147,34 @@ __global__ void k_slice_emit(const double* __restrict__ vobb, const int* __restr
     double fzmin = fmin(Z[0], fmin(Z[1], Z[2])), fzmax = fmax(Z[0], fmax(Z[1], Z[2]));
     double ka = (fzmin - z_first) * inv_step, kb = (fzmax - z_first) * inv_step;
     double klo = fmin(ka, kb), khi = fmax(ka, kb);
-    int lo = 1, hi = 0;      // empty range: lanes without a triangle or without planes still take part in the wave-wide slot step
+    int lo = 1, hi = 0;      // empty range: a lane without a triangle or without planes
     if (live && !(khi < -1.0 || klo > (double)N)) {
       lo = (int)floor(fmax(klo, 0.0)) - 1; hi = (int)ceil(fmin(khi, (double)(N - 1))) + 1;
       lo = lo < 0 ? 0 : lo;
       hi = hi > N - 1 ? N - 1 : hi;
       if (N == 1) { lo = 0; hi = 0; }
     }
-    // every lane walks its own plane range; the wave stays together (uniform trip count) so that lanes that cross the SAME
-    // plane in a round share one slot atomic: same-address atomics are what bounds this kernel (~150 per counter)
-    int span = hi - lo + 1;
-    for (int off = 32; off > 0; off >>= 1) span = max(span, __shfl_xor(span, off));
-    for (int it = 0; it < span; ++it) {
-      const int k = lo + it;
-      const bool in_range = k <= hi;
-      double z = in_range ? zp[k] : 0.0;
+    __syncthreads();
+    // pass A: crossings per plane of this workgroup's triangles
+    for (int k = lo; k <= hi; ++k) {
+      const double z = zp[k];
+      const int s0 = Z[0] - z < -SH_SECTION_TOL ? -1 : 1, s1 = Z[1] - z < -SH_SECTION_TOL ? -1 : 1, s2 = Z[2] - z < -SH_SECTION_TOL ? -1 : 1;
+      if (!(s0 == s1 && s1 == s2)) atomicAdd(&hist[k], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+      const int n = hist[k];
+      if (n > 0) hist[k] = atomicAdd(&seg_count[(size_t)b * N + k], n);      // first slot of this workgroup's range
+    }
+    __syncthreads();
+    // pass B: the segments, slots handed out from LDS
+    for (int k = lo; k <= hi; ++k) {
+      const double z = zp[k];
       double d[3];
       int s[3];
       for (int j = 0; j < 3; ++j) { d[j] = Z[j] - z; s[j] = d[j] < -SH_SECTION_TOL ? -1 : 1; }
-      const bool cross = in_range && !(s[0] == s[1] && s[1] == s[2]);
-      // slot: one atomic per distinct plane among the wave's crossing lanes
-      int slot = 0;
-      {
-        unsigned long long todo = __ballot(cross);
-        const int lane_ = threadIdx.x & 63;
-        while (todo) {
-          const int leader = __ffsll((long long)todo) - 1;
-          const int kk = __shfl(k, leader);
-          const unsigned long long grp = __ballot(cross && k == kk);
-          int base = 0;
-          if (lane_ == leader) base = atomicAdd(&seg_count[(size_t)b * N + kk], __popcll(grp));
-          base = __shfl(base, leader);
-          if (cross && k == kk) slot = base + __popcll(grp & ((1ull << lane_) - 1ull));
-          todo &= ~grp;
-        }
-      }
-      if (!cross) continue;
+      if (s[0] == s[1] && s[1] == s[2]) continue;
+      const int slot = atomicAdd(&hist[k], 1);
       int up = 0, dn = 0;
       for (int j = 0; j < 3; ++j) {
         int jn = (j + 1) % 3;
@@ -198,6 +198,7 @@ __global__ void k_slice_emit(const double* __restrict__ vobb, const int* __restr
       if (slot < SH_MAXSEG) segs[((size_t)b * N + k) * SH_MAXSEG + slot] = sg;
       else atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
     }
+    __syncthreads();      // hist is zeroed again at the top of the next chunk
   }
 }
 

@@ -847,7 +847,9 @@ static int conv_layer_bf16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L
   const dim3 blk(UN_THREADS);
   const char* dma_env = getenv("SHOULDER_UNET_DMA");
   const bool dma_shape = L.taps == 9 && L.cout <= 512 && W % 32 == 0 && H % 16 == 0 && C0 % 32 == 0 && C1 % 32 == 0 && !(dma_env && dma_env[0] == '0');
-  const bool dma64 = dma_shape && L.cout % 64 == 0 && (fuse == 0 || fuse == UF_POOL);
+  static const int dma_minc = getenv("SHOULDER_UNET_DMA_MINC") ? atoi(getenv("SHOULDER_UNET_DMA_MINC")) : 0;
+  static const int dma_maxc = getenv("SHOULDER_UNET_DMA_MAXC") ? atoi(getenv("SHOULDER_UNET_DMA_MAXC")) : 1 << 30;
+  const bool dma64 = dma_shape && L.cout % 64 == 0 && (fuse == 0 || fuse == UF_POOL) && L.cout >= dma_minc && L.cout <= dma_maxc;
   // the 32-channel level: 32-cout items (SHOULDER_UNET_DMA32=0 keeps it on the two-barrier kernel)
   const char* dma32_env = getenv("SHOULDER_UNET_DMA32");
   const bool dma32 = dma_shape && !dma64 && L.cout % 32 == 0 && (fuse == 0 || fuse == UF_POOL || (fuse == UF_HEAD && L.cout == 32)) && !(dma32_env && dma32_env[0] == '0');
@@ -1019,6 +1021,7 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   LAUNCH(c, "k_make_planes", k_make_planes, dim3(B), dim3(256), kind, N, buf<double>(c, kind == 4 ? "obb.zb_pre" : "z_bounds"), buf<double>(c, "neck_z"), zs, zeff, B);
   double* atot = total_area ? buf<double>(c, (p + ".area_total").c_str()) : (double*)nullptr;
   HIPCHK(c, hipMemsetAsync(cnt, 0, (size_t)B * N * 4, c->stream));
+  if (N > SH_EMIT_MAXN) return fail(c, SH_ERR_CAPACITY, "slice set has more planes than k_slice_emit's LDS histogram");
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 4096), (unsigned)B);
   LAUNCH(c, "k_slice_emit", k_slice_emit, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
          buf<long long>(c, "foff"), zeff, N, cnt, segs, buf<int>(c, "err"));
