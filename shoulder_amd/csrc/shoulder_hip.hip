@@ -847,9 +847,7 @@ static int conv_layer_bf16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L
   const dim3 blk(UN_THREADS);
   const char* dma_env = getenv("SHOULDER_UNET_DMA");
   const bool dma_shape = L.taps == 9 && L.cout <= 512 && W % 32 == 0 && H % 16 == 0 && C0 % 32 == 0 && C1 % 32 == 0 && !(dma_env && dma_env[0] == '0');
-  static const int dma_minc = getenv("SHOULDER_UNET_DMA_MINC") ? atoi(getenv("SHOULDER_UNET_DMA_MINC")) : 0;
-  static const int dma_maxc = getenv("SHOULDER_UNET_DMA_MAXC") ? atoi(getenv("SHOULDER_UNET_DMA_MAXC")) : 1 << 30;
-  const bool dma64 = dma_shape && L.cout % 64 == 0 && (fuse == 0 || fuse == UF_POOL) && L.cout >= dma_minc && L.cout <= dma_maxc;
+  const bool dma64 = dma_shape && L.cout % 64 == 0 && (fuse == 0 || fuse == UF_POOL);
   // the 32-channel level: 32-cout items (SHOULDER_UNET_DMA32=0 keeps it on the two-barrier kernel)
   const char* dma32_env = getenv("SHOULDER_UNET_DMA32");
   const bool dma32 = dma_shape && !dma64 && L.cout % 32 == 0 && (fuse == 0 || fuse == UF_POOL || (fuse == UF_HEAD && L.cout == 32)) && !(dma32_env && dma32_env[0] == '0');
