@@ -21,6 +21,7 @@
 #include "k_unet_bf16_dma.h"
 #include "k_stl.h"
 #include "k_clip.h"
+#include "k_hullpre.h"
 #include "k_te.h"
 #include "k_obb.h"
 #include "sh_hull.h"
@@ -66,6 +67,11 @@ struct sh_ctx {
   bool obb_injected = false;
   std::vector<float> h_verts;                // host copy of the vertices (hull stage)
   bool h_verts_valid = false;
+  // device-generated batches: the hull's points come back through the prefilter (k_hullpre.h) into pinned memory
+  float* h_kept = nullptr; long long h_kept_cap = 0;
+  int* h_nkept = nullptr; int h_nkept_cap = 0;
+  const float* hull_src = nullptr;           // what hull_host_phase reads: h_verts.data() or h_kept, at 3 * h_voff[b]
+  std::vector<int> hull_cnt;                 // points of humerus b in hull_src
   // Window of the batch the stage runner is working on: sh_run walks the batch in windows so that the
   // host hull of window k+1 overlaps the device work of window k.  buf<T>() applies the offset.
   int b0 = 0, Bwin = 0;
@@ -219,6 +225,8 @@ void sh_ctx_destroy(sh_ctx* c) {
   if (c->unet_done_ev) (void)hipEventDestroy(c->unet_done_ev);
   drain_timers(c);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->h_kept) (void)hipHostFree(c->h_kept);
+  if (c->h_nkept) (void)hipHostFree(c->h_nkept);
   if (c->obb_done_ev) (void)hipEventDestroy(c->obb_done_ev);
   for (auto& tk : c->tickets) { if (tk.ev) (void)hipEventDestroy(tk.ev); if (tk.h_err) (void)hipHostFree(tk.h_err); }
   if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
@@ -332,6 +340,23 @@ static int alloc_batch(sh_ctx* c) {
   ENS("hull.nv", (size_t)B * 4, 4);
   ENS("hull.nf", (size_t)B * 4, 4);
   ENS("hull.ne", (size_t)B * 4, 4);
+  ENS("hullpre.ext", (size_t)B * SH_HP_NDIR * 4, 4);
+  ENS("hullpre.planes", (size_t)B * SH_HP_MAXPL * 4 * 8, 8);
+  ENS("hullpre.npl", (size_t)B * 4, 4);
+  ENS("hullpre.nkept", (size_t)B * 4, 4);
+  ENS("hullpre.kept", (size_t)c->sumV * 12, 4);
+  if (c->h_kept_cap < c->sumV) {
+    if (c->h_kept) (void)hipHostFree(c->h_kept);
+    c->h_kept = nullptr; c->h_kept_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_kept, (size_t)c->sumV * 12));
+    c->h_kept_cap = c->sumV;
+  }
+  if (c->h_nkept_cap < B) {
+    if (c->h_nkept) (void)hipHostFree(c->h_nkept);
+    c->h_nkept = nullptr; c->h_nkept_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_nkept, (size_t)B * 4));
+    c->h_nkept_cap = B;
+  }
   ENS("obb.cand_vol", (size_t)B * SH_HF * 8, 8);
   ENS("obb.cand_edge", (size_t)B * SH_HF * 4, 4);
   ENS("obb.best_enc", (size_t)B * 8, 8);
@@ -1039,6 +1064,48 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   return SH_OK;
 }
 
+// The hull's input points.  Host-provided batch: the caller's vertices.  Device-generated batch: the prefilter
+// (k_hullpre.h) drops the vertices strictly inside a 26-direction polytope on the device and only the rest comes back
+// (39 % of a humerus, into pinned memory).  Callable from the background thread: no buffer-map access, no timers.
+struct HullPre { const float* verts; const long long* voff; int* ext; double* planes; int* npl; float* kept; int* nkept; };
+static HullPre hullpre_ptrs(sh_ctx* c) {      // calling thread only (buffer map)
+  return HullPre{(const float*)c->bufs["verts"].p, (const long long*)c->bufs["voff"].p, (int*)c->bufs["hullpre.ext"].p, (double*)c->bufs["hullpre.planes"].p,
+                 (int*)c->bufs["hullpre.npl"].p, (float*)c->bufs["hullpre.kept"].p, (int*)c->bufs["hullpre.nkept"].p};
+}
+static hipError_t fetch_hull_points(sh_ctx* c, const HullPre& hp, hipStream_t st) {
+  const int B = c->B;
+  c->hull_cnt.resize(B);
+  if (c->h_verts_valid) {
+    for (int b = 0; b < B; ++b) c->hull_cnt[b] = (int)(c->h_voff[b + 1] - c->h_voff[b]);
+    c->hull_src = c->h_verts.data();
+    return hipSuccess;
+  }
+  static const bool prefilter = !(getenv("SHOULDER_HULL_PREFILTER") && getenv("SHOULDER_HULL_PREFILTER")[0] == '0');
+  hipError_t e;
+  if (!prefilter || !hp.kept) {
+    c->h_verts.resize(3 * (size_t)c->sumV);
+    if ((e = hipMemcpyAsync(c->h_verts.data(), hp.verts, c->sumV * 3 * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    for (int b = 0; b < B; ++b) c->hull_cnt[b] = (int)(c->h_voff[b + 1] - c->h_voff[b]);
+    c->hull_src = c->h_verts.data();
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(k_hullpre_extremes, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, hp.ext);
+  hipLaunchKernelGGL(k_hullpre_polytope, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, (const int*)hp.ext, hp.planes, hp.npl);
+  hipLaunchKernelGGL(k_hullpre_filter, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl, hp.kept, hp.nkept);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(c->h_nkept, hp.nkept, (size_t)B * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  for (int b = 0; b < B; ++b) {
+    const int n = c->h_nkept[b];
+    c->hull_cnt[b] = n;
+    if (n > 0 && (e = hipMemcpyAsync(c->h_kept + 3 * c->h_voff[b], hp.kept + 3 * c->h_voff[b], (size_t)n * 12, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  }
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  c->hull_src = c->h_kept;
+  return hipSuccess;
+}
+
 // mesh.py:63-125.  Host: one quickhull per humerus on worker threads (sh_hull.h).  Device: candidate
 // boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
 // Host phase of the OBB stage for meshes [b0, b0 + B): one quickhull per humerus on worker threads into pinned slot
@@ -1069,9 +1136,10 @@ static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, do
       int b = next.fetch_add(1);
       if (b >= B) break;
       counts[b] = counts[B + b] = counts[2 * B + b] = 0;
-      long long v0 = c->h_voff[b0 + b], nv = c->h_voff[b0 + b + 1] - v0;
+      long long v0 = c->h_voff[b0 + b], nv = c->hull_cnt[b0 + b];
       P.resize(3 * (size_t)nv);
-      for (long long i = 0; i < 3 * nv; ++i) P[i] = (double)c->h_verts[3 * v0 + i];
+      const float* src = c->hull_src + 3 * v0;
+      for (long long i = 0; i < 3 * nv; ++i) P[i] = (double)src[i];
       if (!shhull::convex_hull(P.data(), (int)nv, H)) { status[b] = SH_ERR_GEOMETRY; continue; }
       int hn = (int)H.vert_ids.size(), fn = (int)H.tris.size() / 3, en = (int)H.edges.size() / 4;
       if (hn > SH_HV || fn > SH_HF || en > SH_HE) { status[b] = SH_ERR_CAPACITY; continue; }
@@ -1314,20 +1382,17 @@ static void start_prepare(sh_ctx* c) {
   sh_ctx::Prepared& p = c->prep;
   p.active = true; p.slot = c->hslot; p.B = c->B; p.gen = c->batch_gen; p.rc = SH_OK; p.bad_mesh = -1; p.d2h_ms = p.hull_ms = 0; p.err.clear();
   p.uploaded = false;
-  const bool need_d2h = !c->h_verts_valid;
   // device pointers are looked up here: the buffer map belongs to the calling thread
-  const float* d_verts = buf<float>(c, "verts");
+  const HullPre hp = hullpre_ptrs(c);
   struct Dst { void* p[6]; } dst = {{buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), buf<int>(c, "hull.nv"), buf<int>(c, "hull.nf"), buf<int>(c, "hull.ne")}};
   const bool can_upload = c->obb_done_ev != nullptr;
-  p.th = std::thread([c, need_d2h, d_verts, dst, can_upload]() {
+  p.th = std::thread([c, hp, dst, can_upload]() {
     sh_ctx::Prepared& q = c->prep;
     if (hipSetDevice(c->device) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
     if (!c->copy_stream && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
-    if (need_d2h) {      // a device-generated batch is downloaded again for every run, on the copy stream, beside the kernels
+    {      // the points of a device-generated batch come back for every run, on the copy stream, beside the kernels
       auto t0 = std::chrono::steady_clock::now();
-      c->h_verts.resize(3 * (size_t)c->sumV);
-      if (hipMemcpyAsync(c->h_verts.data(), d_verts, c->sumV * 3 * 4, hipMemcpyDeviceToHost, c->copy_stream) != hipSuccess ||
-          hipStreamSynchronize(c->copy_stream) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
+      if (fetch_hull_points(c, hp, c->copy_stream) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
       q.d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     q.rc = hull_host_phase(c, q.slot, 0, q.B, &q.bad_mesh, &q.hull_ms, &q.err);
@@ -1395,13 +1460,11 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     int prc = join_prepared(c);
     if ((mask & SH_STAGE_OBB) && win == B && prc == SH_OK && c->prep.gen == c->batch_gen && c->prep.B == B) { prepared = c->prep.slot; c->hslot = prepared ^ 1; }
   }
-  if ((mask & SH_STAGE_OBB) && prepared < 0 && !c->h_verts_valid) {
-    // device-generated batch: the host hull needs the vertices (every run: a new batch is new data)
+  if ((mask & SH_STAGE_OBB) && prepared < 0) {
+    // the host hull needs its points (a device-generated batch: every run, a new batch is new data)
     auto t0 = std::chrono::steady_clock::now();
-    c->h_verts.resize(3 * (size_t)c->sumV);
-    HIPCHK(c, hipMemcpyAsync(c->h_verts.data(), buf<float>(c, "verts"), c->sumV * 3 * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->timing) { KTimer& a = c->timers["host.verts_d2h"]; a.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); a.n += 1; }
+    HIPCHK(c, fetch_hull_points(c, hullpre_ptrs(c), c->stream));
+    if (c->timing && !c->h_verts_valid) { KTimer& a = c->timers["host.verts_d2h"]; a.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); a.n += 1; }
   }
   int rc = SH_OK, widx = 0;
   for (int b0 = 0; b0 < B && rc == SH_OK; b0 += win, ++widx) {
