@@ -2,8 +2,9 @@
 
 Restates reference `src/shoulder/arthroplasty.py:13-175` on plain arrays: the resection plane lives in the canal /
 articular csys (`_tfrm_anp`), is moved there by the offset_* methods, and is mapped into the caller's csys by
-`plane()`.  The mesh operations go through oracle/clip.py.  Parity unpinned against the reference itself (it needs
-trimesh / skspatial / onnxruntime, none importable here); the algebra is a line-by-line restatement.
+`plane()`.  The mesh operations go through oracle/clip.py.  The algebra is PINNED: tests/golden/osteotomy_golden.npz holds
+the planes / angles the reference's own arthroplasty.py produced for a recorded script of operations on a stand-in humerus
+(tests/golden/make_osteotomy_golden.py, third-party modules stubbed), and tests/test_osteotomy_golden.py replays it here.
 """
 import numpy as np
 
