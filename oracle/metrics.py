@@ -5,7 +5,9 @@
   neckshaft         :88-112
   radius_curvature  :115-148 least-squares sphere through the articular mask points (OBB frame)
   unitxyz_to_spherical  utils.py:321-332
-`spherefit` / `unitxyz_to_spherical` are pinned by tests/golden/metrics_golden.npz."""
+`spherefit` / `unitxyz_to_spherical` are pinned by tests/golden/metrics_golden.npz; side / retroversion / neckshaft by
+tests/golden/metrics_landmarks_golden.npz (the reference's own Side / RetroVersion / NeckShaft classes run on stand-in
+landmark objects, tests/golden/make_metrics_golden.py)."""
 import numpy as np
 
 from .xform import construct_csys, transform_pts, unit_vector

@@ -118,3 +118,21 @@ def test_anp_golden():
     np.testing.assert_array_equal(m["points_obb"], g["points_obb"])
     assert len(m["articular_obb"]) == int(g["n_articular"])
     np.testing.assert_array_equal(anp.to_ct(m["points_obb"], c["T_obb"]), g["points_ct"])
+
+
+def test_metrics_against_reference_bone_props():
+    """oracle/metrics.py side / retroversion / neckshaft vs the reference's own bone_props.py:12-112
+    (tests/golden/make_metrics_golden.py; odd cases carry a non-identity current csys: the retroversion quirk)."""
+    from oracle import metrics as m
+    from oracle import xform
+    G = np.load(os.path.join(GOLDEN, "metrics_landmarks_golden.npz"))
+    sides = set()
+    for c in range(int(G["n"])):
+        g = lambda k: G[f"c{c}_{k}"]
+        s = m.side(g("canal"), g("central"), g("groove"))
+        assert s == str(g("side"))
+        sides.add(s)
+        an_cur = xform.transform_pts(g("normal"), g("T_current"))
+        assert m.retroversion(g("canal"), g("te"), an_cur, s) == pytest.approx(float(g("retroversion")), abs=1e-9)
+        assert m.neckshaft(g("canal"), g("normal")) == pytest.approx(float(g("neckshaft")), abs=1e-9)
+    assert sides == {"left", "right"}
