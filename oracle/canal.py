@@ -4,6 +4,8 @@ Restates reference `src/shoulder/humerus/canal.py`:
   canal_points :19-56  ([slice AABB centre, z] for the cut slices -> CT)
   canal_axis   :58-85  (line fit in the OBB frame, flipped proximally, endpoints
                         mean +- dir * z_length*mean(cutoff)/2 -> CT; row 0 proximal)
+Pinned by tests/golden/canal_golden.npz: the reference's own canal.py run on a stand-in slices object
+(tests/golden/make_canal_golden.py; `Line.best_fit` stubbed with the published SVD algorithm).
 """
 import numpy as np
 

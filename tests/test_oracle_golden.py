@@ -136,3 +136,28 @@ def test_metrics_against_reference_bone_props():
         assert m.retroversion(g("canal"), g("te"), an_cur, s) == pytest.approx(float(g("retroversion")), abs=1e-9)
         assert m.neckshaft(g("canal"), g("normal")) == pytest.approx(float(g("neckshaft")), abs=1e-9)
     assert sides == {"left", "right"}
+
+
+def test_canal_against_reference_canal_py():
+    """oracle/canal.py (points, axis) and the facade's get_transform frame vs the reference's own canal.py:19-124
+    (tests/golden/make_canal_golden.py; Line.best_fit there is the published SVD algorithm)."""
+    from oracle import canal as ocanal
+    G = np.load(os.path.join(GOLDEN, "canal_golden.npz"))
+    for c in range(int(G["n"])):
+        g = lambda k: G[f"c{c}_{k}"]
+        cut = tuple(g("cutoff").tolist())
+        pts_obb, pts_ct = ocanal.canal_points(g("centroids"), g("zs"), g("T_obb"), cut)
+        np.testing.assert_allclose(pts_ct, g("points_ct"), rtol=0, atol=1e-10)
+        np.testing.assert_allclose(xform.transform_pts(pts_ct, g("T_current")), g("points"), rtol=0, atol=1e-9)
+        _, ax_ct = ocanal.canal_axis(pts_obb, float(g("z_length")), g("T_obb"), cut)
+        np.testing.assert_allclose(ax_ct, g("axis_ct"), rtol=0, atol=1e-9)
+        # get_transform (canal.py:88-124) on the axis in the current csys, x from the OBB frame
+        ax = xform.transform_pts(ax_ct, g("T_current"))
+        z = (ax[0] - ax[1]) / np.linalg.norm(ax[0] - ax[1])
+        x = g("T_obb")[:3, :1].flatten().copy()
+        x -= z * np.dot(x, z) / np.dot(z, z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        y /= np.linalg.norm(y)
+        T = np.r_[np.c_[x, y, z, np.average(ax, axis=0)], np.array([[0, 0, 0, 1.0]])]
+        np.testing.assert_allclose(xform.inv_transform(T), g("get_transform"), rtol=0, atol=1e-9)
