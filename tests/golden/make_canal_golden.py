@@ -1,5 +1,5 @@
-"""Golden vectors for Canal.points / Canal.axis / Canal.get_transform from the reference's OWN code
-(src/shoulder/humerus/canal.py:19-124 with slice.Slices._cutoff and utils.transform_pts / inv_transform / unit_vector).
+"""Golden vectors for Canal.points / Canal.axis / Canal.get_transform and DeepGroove.axis from the reference's OWN code
+(src/shoulder/humerus/canal.py:19-124, bicipital_groove.py:244-265, with slice.Slices._cutoff and utils.transform_pts / inv_transform / unit_vector).
 
 Run in the build container only (needs /root/reference; never runs on the GPU box):
     python tests/golden/make_canal_golden.py
@@ -59,9 +59,11 @@ class Line:
 
 sys.modules["skspatial.objects"].Points = Points
 sys.modules["skspatial.objects"].Line = Line
+sys.modules["skspatial"].objects = sys.modules["skspatial.objects"]
 sys.path.insert(0, "/root/reference/src")
 
 from shoulder.base import Transform  # noqa: E402
+from shoulder.humerus import bicipital_groove as r_bg  # noqa: E402
 from shoulder.humerus import canal as r_canal  # noqa: E402
 from shoulder.humerus import slice as r_slice  # noqa: E402
 
@@ -118,6 +120,24 @@ def main():
         out.update({f"c{c}_centroids": cent, f"c{c}_zs": zs, f"c{c}_T_obb": T_obb, f"c{c}_T_current": T_cur, f"c{c}_z_length": np.float64(310.0 + c),
                     f"c{c}_cutoff": np.array(cut), f"c{c}_points": pts, f"c{c}_points_ct": cn._points_ct, f"c{c}_axis": axis, f"c{c}_axis_ct": cn._axis_ct,
                     f"c{c}_get_transform": Tc})
+    # DeepGroove.axis (bicipital_groove.py:244-265) on injected groove points: ends = fit point +- direction * (z range / 2),
+    # RAW sign of the fitted direction (no flip), OBB -> CT -> current csys
+    for c in range(3):
+        n = 330
+        z = np.linspace(95.0, 20.0, n)
+        pts_obb = np.c_[14 + 0.03 * z + rng.normal(0, 0.4, n), -6 + 0.01 * z + rng.normal(0, 0.4, n), z]
+        if c == 1:
+            pts_obb = pts_obb[::-1].copy()
+        T_obb, T_cur = rigid(rng), (np.identity(4) if c == 0 else rigid(rng))
+        bg = r_bg.DeepGroove.__new__(r_bg.DeepGroove)
+        slc = StandInSlices(None, None, T_obb, 0.0)
+        tf = Transform()
+        tf.matrix = T_cur
+        bg._slc, bg._tfrm, bg._axis_ct = slc, tf, None
+        bg._points_obb, bg._points_ct = pts_obb, pts_obb      # (_points_ct only has to be "already computed")
+        ax = bg.axis().copy()
+        out.update({f"g{c}_points_obb": pts_obb, f"g{c}_T_obb": T_obb, f"g{c}_T_current": T_cur, f"g{c}_axis": ax, f"g{c}_axis_ct": bg._axis_ct})
+    out["n_groove"] = np.int64(3)
     np.savez_compressed(os.path.join(HERE, "canal_golden.npz"), **out)
     print("canal_golden.npz", out["c0_points"].shape, out["c3_points"].shape, out["c0_axis"])
 

@@ -161,3 +161,20 @@ def test_canal_against_reference_canal_py():
         y /= np.linalg.norm(y)
         T = np.r_[np.c_[x, y, z, np.average(ax, axis=0)], np.array([[0, 0, 0, 1.0]])]
         np.testing.assert_allclose(xform.inv_transform(T), g("get_transform"), rtol=0, atol=1e-9)
+
+
+def test_groove_axis_against_reference():
+    """oracle/groove.py groove_axis vs the reference's own DeepGroove.axis (bicipital_groove.py:244-265).  The reference keeps
+    the RAW sign of the SVD direction (LAPACK's choice); canonical rule B-4 of the restatement fixes it to +z, so the two end
+    points may come in either order -- everything else (fit point, half length = z range / 2, OBB -> CT) must agree."""
+    G = np.load(os.path.join(GOLDEN, "canal_golden.npz"))
+    for c in range(int(G["n_groove"])):
+        g = lambda k: G[f"g{c}_{k}"]
+        ax_ct = groove.groove_axis(g("points_obb"), g("T_obb"))
+        ref = g("axis_ct")
+        if np.abs(ax_ct - ref).max() > 1e-9:
+            ref = ref[::-1]
+        np.testing.assert_allclose(ax_ct, ref, rtol=0, atol=1e-9)
+        # row 0 of the restatement is the +z end in the OBB frame
+        ends_obb = xform.transform_pts(ax_ct, g("T_obb"))
+        assert ends_obb[0, 2] > ends_obb[1, 2]
