@@ -260,3 +260,33 @@ def test_prox_canal_range(hc):
         k = hc.hc_prox_canal_range(dp(a), n, ctypes.byref(lo), ctypes.byref(hi))
         zs, pcts, grad = prox.canal_range(a)
         assert (lo.value, hi.value) == (int(zs[0]), int(zs[-1])) and k == len(zs)
+
+
+def test_prox_obb_against_reference(hc):
+    """ProxObb._obb of the reference itself (mesh.py:133-192, tests/golden/make_prox_golden.py: the reference's scan loop,
+    head-end decision, flip, savgol + gradient and longest-run logic on given area profiles) vs the oracle (oracle/prox.py)
+    and the product's scalar routine (sh::prox_canal_range)."""
+    import os
+    from conftest import GOLDEN
+    from oracle import obb as o_obb
+    from oracle import prox
+    G = np.load(os.path.join(GOLDEN, "prox_golden.npz"))
+    seen = set()
+    for c in range(int(G["n"])):
+        g = lambda k: G[f"c{c}_{k}"]
+        areas = g("areas")
+        z = np.linspace(float(g("zmin")) * 0.99, float(g("zmax")) * 0.99, prox.NUM_ZS).flatten()
+        flipped = bool(z[int(np.argmax(areas))] < 0)
+        assert flipped == bool(g("flipped"))
+        seen.add(flipped)
+        a = areas[::-1] if flipped else areas
+        zs, pcts, _ = prox.canal_range(a)
+        assert pcts == g("cutoff_pcts").tolist() and int(zs[0]) == int(g("cutoff_bot"))
+        T = np.matmul(o_obb.FLIP if flipped else np.identity(4), g("T_obb"))
+        np.testing.assert_array_equal(T, g("transform"))
+        assert abs(float(g("zmin"))) + abs(float(g("zmax"))) == float(g("z_length"))
+        lo, hi = ctypes.c_int(), ctypes.c_int()
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        hc.hc_prox_canal_range(dp(a), len(a), ctypes.byref(lo), ctypes.byref(hi))
+        assert [lo.value / prox.NUM_ZS, hi.value / prox.NUM_ZS] == g("cutoff_pcts").tolist()
+    assert seen == {True, False}
