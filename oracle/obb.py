@@ -110,6 +110,17 @@ def least_squares_circle(xy: np.ndarray):
 FLIP = np.array([[-1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]])
 
 
+def head_end_flip(z_bounds, residus):
+    """mesh.py:88-124: the end whose section fits a circle better (strictly smaller residual; the -z end is looked at
+    first, so it keeps a tie) is the head; flip iff it lies at negative z.  Pinned by tests/golden/prox_golden.npz (the
+    reference's own FullObb._obb run with given residuals, tests/golden/make_prox_golden.py)."""
+    humeral_end, residu_init = 0.0, np.inf
+    for z_limit, residu in zip(z_bounds, residus):
+        if residu < residu_init:
+            residu_init, humeral_end = residu, z_limit
+    return bool(humeral_end < 0)                                 # mesh.py:112
+
+
 def full_obb(verts: np.ndarray, faces: np.ndarray):
     """mesh.py:63-125 -> dict(transform, z_bounds, z_length, verts_obb, flipped, residus)."""
     T_obb, ext, vol = oriented_bounds(verts)
@@ -117,14 +128,8 @@ def full_obb(verts: np.ndarray, faces: np.ndarray):
     z_bounds = (float(v[:, 2].min()), float(v[:, 2].max()))      # mesh.py:85
     z_length = abs(z_bounds[0]) + abs(z_bounds[1])               # mesh.py:86
     sl = ZSlicer(v, faces)
-    humeral_end, residu_init, residus = 0.0, np.inf, []
-    for z_limit in z_bounds:                                     # mesh.py:91-107
-        pts = sl.points(0.95 * z_limit)
-        residu = least_squares_circle(pts)[3]
-        residus.append(residu)
-        if residu < residu_init:
-            residu_init, humeral_end = residu, z_limit
-    flipped = humeral_end < 0                                    # mesh.py:112
+    residus = [least_squares_circle(sl.points(0.95 * z_limit))[3] for z_limit in z_bounds]      # mesh.py:91-102
+    flipped = head_end_flip(z_bounds, residus)
     flip = FLIP if flipped else np.identity(4)
     if flipped:
         v = transform_pts(v, flip)

@@ -1,5 +1,6 @@
-"""Golden vectors for ProxObb._obb from the reference's OWN code (src/shoulder/humerus/mesh.py:133-192: z grid, head-end
-decision, flip, savgol + gradient, longest consecutive run, cut-off fractions).
+"""Golden vectors for ProxObb._obb and FullObb._obb from the reference's OWN code (src/shoulder/humerus/mesh.py:133-192: z
+grid, head-end decision, flip, savgol + gradient, longest consecutive run, cut-off fractions; :63-125: circle-fit residual
+comparison of the two ends, flip, composed transform).
 
 Run in the build container only (needs /root/reference; never runs on the GPU box):
     python tests/golden/make_prox_golden.py
@@ -49,6 +50,7 @@ from shoulder.humerus import mesh as r_mesh  # noqa: E402
 class _Planar:
     def __init__(self, area):
         self.area = area
+        self.vertices = np.zeros((3, 2))      # FullObb hands these to circle_fit, which is stubbed below
 
 
 class _Section:
@@ -104,6 +106,22 @@ def main():
         out.update({f"c{c}_areas": np.asarray(areas, dtype=np.float64), f"c{c}_T_obb": T, f"c{c}_zmin": np.float64(zmin), f"c{c}_zmax": np.float64(zmax),
                     f"c{c}_transform": transform, f"c{c}_cutoff_pcts": np.array(cutoff_pcts, dtype=np.float64), f"c{c}_cutoff_bot": np.int64(po.cutoff_bot),
                     f"c{c}_z_length": np.float64(po.z_length), f"c{c}_flipped": np.bool_(len(m.applied) > 0)})
+    # FullObb._obb (mesh.py:63-125) with the circle fit stubbed to return given residuals for the -z end and the +z end:
+    # which end is the head, the flip, the composed transform, z_length
+    full = [((-150.0, 160.0), (1.0, 2.0)), ((-150.0, 160.0), (2.0, 1.0)), ((-150.0, 160.0), (1.5, 1.5)), ((-140.0, 170.0), (0.3, 0.30000001))]
+    for c, ((zmin, zmax), res) in enumerate(full):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        T = np.identity(4)
+        T[:3, :3], T[:3, 3] = q, rng.uniform(-100, 100, 3)
+        m = StandInMesh(T, zmin, zmax, [0.0, 0.0])
+        seq = list(res)
+        r_mesh.circle_fit.least_squares_circle = lambda pts, seq=seq: (0.0, 0.0, 1.0, seq.pop(0))
+        fo = r_mesh.FullObb.__new__(r_mesh.FullObb)
+        fo.__dict__["mesh"] = m
+        transform = fo._obb()
+        out.update({f"f{c}_T_obb": T, f"f{c}_zmin": np.float64(zmin), f"f{c}_zmax": np.float64(zmax), f"f{c}_residus": np.array(res), f"f{c}_transform": transform,
+                    f"f{c}_z_length": np.float64(fo.z_length), f"f{c}_flipped": np.bool_(len(m.applied) > 0)})
+    out["n_full"] = np.int64(len(full))
     np.savez_compressed(os.path.join(HERE, "prox_golden.npz"), **out)
     print("prox_golden.npz", [(bool(out[f"c{c}_flipped"]), out[f"c{c}_cutoff_pcts"].tolist(), int(out[f"c{c}_cutoff_bot"])) for c in range(len(profiles))])
 

@@ -290,3 +290,22 @@ def test_prox_obb_against_reference(hc):
         hc.hc_prox_canal_range(dp(a), len(a), ctypes.byref(lo), ctypes.byref(hi))
         assert [lo.value / prox.NUM_ZS, hi.value / prox.NUM_ZS] == g("cutoff_pcts").tolist()
     assert seen == {True, False}
+
+
+def test_full_obb_head_end_rule_against_reference():
+    """FullObb._obb of the reference itself (mesh.py:63-125, circle fit stubbed with given residuals) vs oracle.obb.head_end_flip:
+    strictly smaller residual wins, the -z end keeps a tie, flip iff the head end is at negative z."""
+    import os
+    from conftest import GOLDEN
+    from oracle import obb as o_obb
+    G = np.load(os.path.join(GOLDEN, "prox_golden.npz"))
+    seen = set()
+    for c in range(int(G["n_full"])):
+        g = lambda k: G[f"f{c}_{k}"]
+        zb = (float(g("zmin")), float(g("zmax")))
+        flipped = o_obb.head_end_flip(zb, g("residus").tolist())
+        assert flipped == bool(g("flipped"))
+        seen.add(flipped)
+        np.testing.assert_array_equal(np.matmul(o_obb.FLIP if flipped else np.identity(4), g("T_obb")), g("transform"))
+        assert abs(zb[0]) + abs(zb[1]) == float(g("z_length"))
+    assert seen == {True, False}
