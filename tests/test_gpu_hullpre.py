@@ -25,8 +25,8 @@ def test_prefilter_keeps_every_hull_vertex(engine):
     assert (lm["status"] == 0).all()
     nk = engine.fetch("hullpre.nkept", np.int32)[:B]
     kept = engine.fetch("hullpre.kept", np.float32).reshape(-1, 3)
-    verts = engine.fetch("verts", np.float32).reshape(B, -1, 3)
     V = len(v)
+    verts = engine.fetch("verts", np.float32)[:B * V * 3].reshape(B, V, 3)      # (the buffer keeps the capacity of earlier batches)
     assert (nk > 0).all() and (nk < 0.6 * V).all()          # 61 % of a humerus lies strictly inside the 26-direction polytope
     for b in range(B):
         K = kept[b * V: b * V + nk[b]]
