@@ -11,7 +11,7 @@ include/shoulder_hip.h; see DESIGN.md and INTEGRATION.md.
 __version__ = "0.1.0"
 
 _LAZY = {"Humerus": "bone", "ProximalHumerus": "bone", "default_engine": "bone", "Engine": "engine", "ShoulderHipError": "engine",
-         "HumeralHeadOsteotomy": "arthroplasty"}
+         "HumeralHeadOsteotomy": "arthroplasty", "Plot": "plotting"}
 
 
 def __getattr__(name):

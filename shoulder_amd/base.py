@@ -9,7 +9,8 @@ class Landmark(ABC):
     """base.py:9-16"""
 
     def _graph_obj(self):
-        return None     # plotting (plotting.py) is out of scope of the hot path
+        """plotly trace(s) of the landmark, None while it has not been computed (base.py:10-12)"""
+        return None
 
     @abstractmethod
     def transform_landmark(self) -> None:
@@ -152,6 +153,11 @@ class Bone(ABC):
             if isinstance(attr, Landmark):
                 out.append(attr)
         return out
+
+    def _list_landmarks_graph_obj(self):
+        """graph objects of every computed landmark (base.py:37-42)"""
+        objs = [lm._graph_obj() for lm in self._list_landmarks()]
+        return [o for o in objs if o is not None]
 
     def _update_landmark_data(self):
         for land in self._list_landmarks():

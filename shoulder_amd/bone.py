@@ -42,6 +42,12 @@ def _inv(T):
     return np.linalg.inv(R) @ np.linalg.inv(t)
 
 
+def _scatter(pts, name, **kw):
+    """One plotly trace per landmark, as the reference's `_graph_obj` methods build them (e.g. canal.py:132-142)."""
+    import plotly.graph_objects as go
+    return go.Scatter3d(x=pts[:, 0], y=pts[:, 1], z=pts[:, 2], name=name, **kw)
+
+
 class _Lm(Landmark):
     def __init__(self, bone):
         self._b = bone
@@ -97,6 +103,9 @@ class Canal(_Lm):
         if self._points_ct is not None:
             self.points()
 
+    def _graph_obj(self):                                  # canal.py:132-142
+        return None if self._points_ct is None else _scatter(self._points, "Canal Axis")
+
 
 class SurgicalNeck(_Lm):
     """surgical_neck.py"""
@@ -123,6 +132,9 @@ class SurgicalNeck(_Lm):
     def transform_landmark(self) -> None:
         if self.points is not None:
             self.points = self._t(self.points_ct)
+
+    def _graph_obj(self):                                  # surgical_neck.py:82-93
+        return None if self.points is None else _scatter(self.points, "Surgical Neck")
 
 
 class DeepGroove(_Lm):
@@ -154,6 +166,9 @@ class DeepGroove(_Lm):
             self.axis()
         if self._points_ct is not None:
             self.points()
+
+    def _graph_obj(self):                                  # bicipital_groove.py:273-284
+        return None if self._points_ct is None else _scatter(self._points, "Bicipital Groove")
 
 
 class AnatomicNeck(_Lm):
@@ -221,6 +236,13 @@ class AnatomicNeck(_Lm):
         if self._central_axis_ct is not None:
             self.axis_central()
 
+    def _graph_obj(self):                                  # anatomic_neck.py:250-273
+        if self._points_ct is None:
+            return None
+        pp = self.plane_points()
+        return [_scatter(self._points, "Anatomic Neck", mode="markers", showlegend=True),
+                _scatter(pp, "Anatomic Neck Plane", mode="markers", showlegend=True)]
+
 
 class TransEpicondylar(_Lm):
     """epicondyle.py"""
@@ -239,6 +261,9 @@ class TransEpicondylar(_Lm):
     def transform_landmark(self) -> None:
         if self._axis_ct is not None:
             self.axis()
+
+    def _graph_obj(self):                                  # epicondyle.py:107-117
+        return None if self._axis_ct is None else _scatter(self._axis, "Transverse Epicondylar Axis")
 
 
 class Humerus(Bone):
