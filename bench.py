@@ -146,7 +146,7 @@ def main():
         cpu = cpu_baseline(verts, faces, synth.similarity_transforms(B, verts, seed=1234), weights, args.cpu_meshes, args.cpu_pool)
     # Lanes: independent engine contexts (own stream, own scratch) on this GPU.  Step s runs on lane s % lanes, so the launch-
     # and latency-bound geometry kernels of one step execute beside the chip-filling UNet kernels of the previous step.
-    lanes = max(1, args.lanes) if not (args.from_host or args.from_stl or args.no_pipeline) else 1
+    lanes = max(1, args.lanes) if not args.no_pipeline else 1
     engs = [Engine(local) for _ in range(lanes)]
     eng = engs[0]
     if use_dist:
@@ -177,11 +177,13 @@ def main():
     stl_blobs = None
     if args.from_stl:       # STL bytes -> landmarks: the files of the synthetic batch are serialised here, outside the timed region
         stl_blobs = [stl_bytes(synth.apply_similarity(T[i], verts), faces) for i in range(B)]
-        eng.upload_stl(stl_blobs)
+        for e in engs:
+            e.upload_stl(stl_blobs)
         host_batch = stl_blobs
     elif args.from_host:      # PCIe-inclusive variant (never the headline `value`): the meshes are handed over as host buffers every step
         host_batch = [(synth.apply_similarity(T[i], verts), faces) for i in range(B)]
-        eng.upload(host_batch)
+        for e in engs:
+            e.upload(host_batch)
     else:
         for e in engs:
             e.upload([(verts, faces)])
@@ -192,7 +194,13 @@ def main():
     # pipelined schedule: every run copies its records (device to device, on its engine's stream) into one of the send buffers
     nsend = 2 * lanes
     send = [torch.empty_like(lm_t) for _ in range(nsend)] if use_dist else None
-    pipelined = host_batch is None and not args.no_pipeline
+    pipelined = not args.no_pipeline
+
+    def hand_over(e):      # the PCIe-inclusive variants give every step its batch again (a new batch voids prepared hulls)
+        if stl_blobs is not None:
+            e.upload_stl(stl_blobs)
+        elif host_batch is not None:
+            e.upload(host_batch)
 
     def step():
         if stl_blobs is not None:
@@ -243,6 +251,7 @@ def main():
                 e.set_overlap(False)                           # the last step of a lane prepares nothing
             if len(pend) >= depth:
                 finish(*pend.pop(0))
+            hand_over(e)       # (the lane is idle here: its previous step was collected above)
             if use_dist:
                 e.submit(_lib.STAGE_ALL, fetch=False, out_ptr=send[s_ % nsend].data_ptr())
             else:
