@@ -127,14 +127,42 @@ def clip_halfplane_pieces(ring, c, m, w0):
     return pieces
 
 
+def first_max(dist):
+    """epicondyle.py:39 `dist.index(max(dist))`: the first row with the longest rectangle."""
+    dist = list(dist)
+    return dist.index(max(dist))
+
+
+def far_pair(cents):
+    """epicondyle.py:57-81 (canonical B-7): the two end pieces.  With more than two pieces the reference takes the pair of
+    centroids farthest apart (first maximum over itertools.combinations order); with exactly two, those two."""
+    cents = np.asarray(cents, dtype=np.float64)
+    d2 = ((cents[:, None, :] - cents[None, :, :]) ** 2).sum(axis=2)
+    i, j = np.unravel_index(int(np.argmax(d2)), d2.shape)
+    return min(i, j), max(i, j)
+
+
+def medial_first(end_pts, T_obb, canal_axis, central_axis):
+    """epicondyle.py:84-99: ends to CT, then row 0 = the end with the smaller x in construct_csys(canal, head-central).
+    -> (end_pts (2,3) OBB, end_ct (2,3))."""
+    end_ct = transform_pts(end_pts, inv_transform(T_obb))
+    tfrm = construct_csys(canal_axis, central_axis)               # :90
+    medial_idx = int(np.argmin(transform_pts(end_ct, tfrm)[:, 0]))
+    if medial_idx == 1:
+        end_pts, end_ct = end_pts[::-1], end_ct[::-1]
+    return end_pts, end_ct
+
+
 def te_axis(distal_largest_rings, distal_zs_all, T_obb, canal_axis_ct, central_axis_ct, cutoff=(0.8, 0.99)):
-    """epicondyle.py:29-101 -> dict(axis_obb (2,3), axis_ct (2,3), idx_max, dists)."""
+    """epicondyle.py:29-101 -> dict(axis_obb (2,3), axis_ct (2,3), idx_max, dists).  The glue (row choice, piece pair,
+    medial-first order) is pinned by tests/golden/te_golden.npz: the reference's own epicondyle.py run with the shapely
+    results injected (tests/golden/make_te_golden.py); the rectangles and the clipped pieces themselves are restated."""
     a, b = cutoff_range(len(distal_zs_all), cutoff)
     rings = distal_largest_rings[a:b]
     zs = distal_zs_all[a:b]
     rects = [min_area_rect(r[:-1]) for r in rings]
     dist = [r["L"] for r in rects]
-    k = dist.index(max(dist))                                    # :39 first maximum
+    k = first_max(dist)
     ring, rect, z = rings[k], rects[k], zs[k]
     half = 0.5 * 0.999 * rect["L"]
     pieces = clip_halfplane_pieces(ring, rect["center"], rect["major"], half)
@@ -142,12 +170,7 @@ def te_axis(distal_largest_rings, distal_zs_all, T_obb, canal_axis_ct, central_a
     if len(pieces) < 2:
         raise ValueError("trans-epicondylar axis: fewer than two end pieces")
     cents = np.array([p[0] for p in pieces])
-    d2 = ((cents[:, None, :] - cents[None, :, :]) ** 2).sum(axis=2)
-    i, j = np.unravel_index(int(np.argmax(d2)), d2.shape)
-    end_pts = np.c_[cents[[min(i, j), max(i, j)]], np.repeat(z, 2)]
-    end_ct = transform_pts(end_pts, inv_transform(T_obb))
-    tfrm = construct_csys(canal_axis_ct, central_axis_ct)        # :90
-    medial_idx = int(np.argmin(transform_pts(end_ct, tfrm)[:, 0]))
-    if medial_idx == 1:
-        end_pts, end_ct = end_pts[::-1], end_ct[::-1]
+    i, j = far_pair(cents)
+    end_pts = np.c_[cents[[i, j]], np.repeat(z, 2)]
+    end_pts, end_ct = medial_first(end_pts, T_obb, canal_axis_ct, central_axis_ct)
     return dict(axis_obb=end_pts, axis_ct=end_ct, idx_max=a + k, dists=np.array(dist))

@@ -178,3 +178,24 @@ def test_groove_axis_against_reference():
         # row 0 of the restatement is the +z end in the OBB frame
         ends_obb = xform.transform_pts(ax_ct, g("T_obb"))
         assert ends_obb[0, 2] > ends_obb[1, 2]
+
+
+def test_te_glue_against_reference():
+    """oracle/te.py first_max / far_pair / medial_first vs the reference's own TransEpicondylar.axis (epicondyle.py:29-101) run
+    with the shapely results injected (tests/golden/make_te_golden.py): row choice incl. a tie, 2 / 3 / 4 end pieces in shuffled
+    order, lift to 3-D, OBB -> CT, medial-first ordering."""
+    from oracle import te
+    G = np.load(os.path.join(GOLDEN, "te_golden.npz"))
+    for c in range(int(G["n"])):
+        g = lambda k: G[f"c{c}_{k}"]
+        a, b = slices.cutoff_range(len(g("zs")), (0.8, 0.99))
+        rects = g("rects")[a:b]
+        # utils.major_axis_dist (utils.py:89-97): the longer of the two sides at corner 0
+        d = [max(np.hypot(*(r[3] - r[0])), np.hypot(*(r[1] - r[0]))) for r in rects]
+        k = te.first_max(d)
+        cents = g("cents")[a:b][k]
+        i, j = te.far_pair(cents)
+        end_pts = np.c_[cents[[i, j]], np.repeat(g("zs")[a:b][k], 2)]
+        _, end_ct = te.medial_first(end_pts, g("T_obb"), g("canal"), g("central"))
+        np.testing.assert_allclose(end_ct, g("axis_ct"), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(g("axis"), g("axis_ct"), rtol=0, atol=0)      # identity Transform in the golden run
