@@ -6,8 +6,9 @@
 //   k_hullpre_extremes   per humerus the vertex farthest along each of 26 directions ({-1,0,1}^3 \ 0; ties -> lowest index)
 //   k_hullpre_polytope   supporting planes of those <= 26 points by brute force: a triple is a face iff every other
 //                        extreme point lies on or behind its plane (<= 2 600 triples x 26 tests per humerus)
-//   k_hullpre_filter     keep a vertex unless it is more than `margin` behind EVERY plane; kept vertices are compacted
-//                        in file order (block scan) -> the host hull sees a deterministic point list
+//   k_hullpre_filter     keep a vertex unless it is more than `margin` behind EVERY plane: a counting pass, the batch-wide
+//                        offsets (k_hullpre_offsets), then a writing pass that compacts the survivors of ALL humeri into one
+//                        array, each in file order (block scan) -> one read-back, a deterministic point list per hull
 // A humerus whose polytope cannot be built (flat input, > SH_HP_MAXPL planes) keeps all its vertices.
 #pragma once
 #include "sh_common.h"
@@ -116,9 +117,21 @@ k_hullpre_polytope(const float* __restrict__ verts, const long long* __restrict_
   if (tid == 0) nplanes[b] = (cnt >= 4 && cnt <= SH_HP_MAXPL) ? cnt : -1;
 }
 
+// keep test of one vertex against the planes staged in LDS
+__device__ inline bool hp_keep(const float* P, int i, const double* PL, int np) {
+  if (np < 0) return true;
+  const double x = P[3 * i], y = P[3 * i + 1], z = P[3 * i + 2];
+  for (int q = 0; q < np; ++q)
+    if (((PL[4 * q] * x + PL[4 * q + 1] * y) + PL[4 * q + 2] * z) - PL[4 * q + 3] >= -SH_HP_MARGIN) return true;
+  return false;
+}
+
+// WRITE = false: count the survivors of humerus b -> nkept[b].  WRITE = true: write them, in file order, at koff[b] of one
+// array shared by the batch (k_hullpre_offsets in between), so that ONE copy brings every humerus's points to the host.
+template <bool WRITE>
 __global__ void __launch_bounds__(SH_STL_SCAN_THREADS)
 k_hullpre_filter(const float* __restrict__ verts, const long long* __restrict__ voff, const double* __restrict__ planes,
-                 const int* __restrict__ nplanes, float* __restrict__ kept /* compacted at the humerus's own offset */, int* __restrict__ nkept) {
+                 const int* __restrict__ nplanes, const long long* __restrict__ koff, float* __restrict__ kept, int* __restrict__ nkept) {
   __shared__ double PL[SH_HP_MAXPL * 4];
   __shared__ int s_wave[SH_STL_SCAN_THREADS / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -128,23 +141,25 @@ k_hullpre_filter(const float* __restrict__ verts, const long long* __restrict__ 
   for (int i = tid; i < 4 * max(np, 0); i += SH_STL_SCAN_THREADS) PL[i] = planes[(size_t)b * SH_HP_MAXPL * 4 + i];
   __syncthreads();
   const float* P = verts + 3 * v0;
-  float* K = kept + 3 * v0;
   const int per = (nv + SH_STL_SCAN_THREADS - 1) / SH_STL_SCAN_THREADS;
   const int a = min(nv, tid * per), e = min(nv, a + per);
-  auto keep = [&](int i) -> bool {
-    if (np < 0) return true;
-    const double x = P[3 * i], y = P[3 * i + 1], z = P[3 * i + 2];
-    for (int q = 0; q < np; ++q)
-      if (((PL[4 * q] * x + PL[4 * q + 1] * y) + PL[4 * q + 2] * z) - PL[4 * q + 3] >= -SH_HP_MARGIN) return true;
-    return false;
-  };
   int c = 0;
-  for (int i = a; i < e; ++i) c += keep(i) ? 1 : 0;
+  for (int i = a; i < e; ++i) c += hp_keep(P, i, PL, np) ? 1 : 0;
   int total;
   int pos = stl_block_scan(c, s_wave, &total);
+  if (!WRITE) { if (tid == 0) nkept[b] = total; return; }
+  float* K = kept + 3 * koff[b];
   for (int i = a; i < e; ++i)
-    if (keep(i)) { K[3 * pos] = P[3 * i]; K[3 * pos + 1] = P[3 * i + 1]; K[3 * pos + 2] = P[3 * i + 2]; ++pos; }
-  if (tid == 0) nkept[b] = total;
+    if (hp_keep(P, i, PL, np)) { K[3 * pos] = P[3 * i]; K[3 * pos + 1] = P[3 * i + 1]; K[3 * pos + 2] = P[3 * i + 2]; ++pos; }
+}
+
+// koff[b] = survivors of the humeri before b; koff[B] = all of them (one workgroup; B is a batch size, not a mesh size)
+__global__ void k_hullpre_offsets(const int* __restrict__ nkept, long long* __restrict__ koff, int B) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    long long acc = 0;
+    for (int b = 0; b < B; ++b) { koff[b] = acc; acc += nkept[b]; }
+    koff[B] = acc;
+  }
 }
 
 }  // namespace sh

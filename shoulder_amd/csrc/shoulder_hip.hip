@@ -70,8 +70,10 @@ struct sh_ctx {
   // device-generated batches: the hull's points come back through the prefilter (k_hullpre.h) into pinned memory
   float* h_kept = nullptr; long long h_kept_cap = 0;
   int* h_nkept = nullptr; int h_nkept_cap = 0;
-  const float* hull_src = nullptr;           // what hull_host_phase reads: h_verts.data() or h_kept, at 3 * h_voff[b]
+  const float* hull_src = nullptr;           // what hull_host_phase reads: h_verts.data() or h_kept
+  std::vector<long long> hull_off;           // first point of humerus b in hull_src
   std::vector<int> hull_cnt;                 // points of humerus b in hull_src
+  long long* h_koff = nullptr;               // pinned: offsets of the survivors (B + 1)
   // Window of the batch the stage runner is working on: sh_run walks the batch in windows so that the
   // host hull of window k+1 overlaps the device work of window k.  buf<T>() applies the offset.
   int b0 = 0, Bwin = 0;
@@ -227,6 +229,7 @@ void sh_ctx_destroy(sh_ctx* c) {
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->h_kept) (void)hipHostFree(c->h_kept);
   if (c->h_nkept) (void)hipHostFree(c->h_nkept);
+  if (c->h_koff) (void)hipHostFree(c->h_koff);
   if (c->obb_done_ev) (void)hipEventDestroy(c->obb_done_ev);
   for (auto& tk : c->tickets) { if (tk.ev) (void)hipEventDestroy(tk.ev); if (tk.h_err) (void)hipHostFree(tk.h_err); }
   if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
@@ -344,6 +347,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("hullpre.planes", (size_t)B * SH_HP_MAXPL * 4 * 8, 8);
   ENS("hullpre.npl", (size_t)B * 4, 4);
   ENS("hullpre.nkept", (size_t)B * 4, 4);
+  ENS("hullpre.koff", (size_t)(B + 1) * 8, 8);
   ENS("hullpre.kept", (size_t)c->sumV * 12, 4);
   if (c->h_kept_cap < c->sumV) {
     if (c->h_kept) (void)hipHostFree(c->h_kept);
@@ -353,8 +357,10 @@ static int alloc_batch(sh_ctx* c) {
   }
   if (c->h_nkept_cap < B) {
     if (c->h_nkept) (void)hipHostFree(c->h_nkept);
-    c->h_nkept = nullptr; c->h_nkept_cap = 0;
+    if (c->h_koff) (void)hipHostFree(c->h_koff);
+    c->h_nkept = nullptr; c->h_koff = nullptr; c->h_nkept_cap = 0;
     HIPCHK(c, hipHostMalloc((void**)&c->h_nkept, (size_t)B * 4));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_koff, (size_t)(B + 1) * 8));
     c->h_nkept_cap = B;
   }
   ENS("obb.cand_vol", (size_t)B * SH_HF * 8, 8);
@@ -1067,15 +1073,16 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
 // The hull's input points.  Host-provided batch: the caller's vertices.  Device-generated batch: the prefilter
 // (k_hullpre.h) drops the vertices strictly inside a 26-direction polytope on the device and only the rest comes back
 // (39 % of a humerus, into pinned memory).  Callable from the background thread: no buffer-map access, no timers.
-struct HullPre { const float* verts; const long long* voff; int* ext; double* planes; int* npl; float* kept; int* nkept; };
+struct HullPre { const float* verts; const long long* voff; int* ext; double* planes; int* npl; float* kept; int* nkept; long long* koff; };
 static HullPre hullpre_ptrs(sh_ctx* c) {      // calling thread only (buffer map)
   return HullPre{(const float*)c->bufs["verts"].p, (const long long*)c->bufs["voff"].p, (int*)c->bufs["hullpre.ext"].p, (double*)c->bufs["hullpre.planes"].p,
-                 (int*)c->bufs["hullpre.npl"].p, (float*)c->bufs["hullpre.kept"].p, (int*)c->bufs["hullpre.nkept"].p};
+                 (int*)c->bufs["hullpre.npl"].p, (float*)c->bufs["hullpre.kept"].p, (int*)c->bufs["hullpre.nkept"].p, (long long*)c->bufs["hullpre.koff"].p};
 }
 static hipError_t fetch_hull_points(sh_ctx* c, const HullPre& hp, hipStream_t st) {
   const int B = c->B;
   c->hull_cnt.resize(B);
   if (c->h_verts_valid) {
+    c->hull_off.assign(c->h_voff.begin(), c->h_voff.begin() + B);
     for (int b = 0; b < B; ++b) c->hull_cnt[b] = (int)(c->h_voff[b + 1] - c->h_voff[b]);
     c->hull_src = c->h_verts.data();
     return hipSuccess;
@@ -1086,22 +1093,27 @@ static hipError_t fetch_hull_points(sh_ctx* c, const HullPre& hp, hipStream_t st
     c->h_verts.resize(3 * (size_t)c->sumV);
     if ((e = hipMemcpyAsync(c->h_verts.data(), hp.verts, c->sumV * 3 * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    c->hull_off.assign(c->h_voff.begin(), c->h_voff.begin() + B);
     for (int b = 0; b < B; ++b) c->hull_cnt[b] = (int)(c->h_voff[b + 1] - c->h_voff[b]);
     c->hull_src = c->h_verts.data();
     return hipSuccess;
   }
   hipLaunchKernelGGL(k_hullpre_extremes, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, hp.ext);
   hipLaunchKernelGGL(k_hullpre_polytope, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, (const int*)hp.ext, hp.planes, hp.npl);
-  hipLaunchKernelGGL(k_hullpre_filter, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl, hp.kept, hp.nkept);
+  hipLaunchKernelGGL(k_hullpre_filter<false>, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl,
+                     (const long long*)hp.koff, hp.kept, hp.nkept);
+  hipLaunchKernelGGL(k_hullpre_offsets, dim3(1), dim3(64), 0, st, (const int*)hp.nkept, hp.koff, B);
+  hipLaunchKernelGGL(k_hullpre_filter<true>, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl,
+                     (const long long*)hp.koff, hp.kept, hp.nkept);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(c->h_nkept, hp.nkept, (size_t)B * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(c->h_koff, hp.koff, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-  for (int b = 0; b < B; ++b) {
-    const int n = c->h_nkept[b];
-    c->hull_cnt[b] = n;
-    if (n > 0 && (e = hipMemcpyAsync(c->h_kept + 3 * c->h_voff[b], hp.kept + 3 * c->h_voff[b], (size_t)n * 12, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-  }
+  const long long total = c->h_koff[B];
+  if (total < 0 || total > c->sumV) return hipErrorUnknown;
+  if (total > 0 && (e = hipMemcpyAsync(c->h_kept, hp.kept, (size_t)total * 12, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;      // one copy for the batch
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  c->hull_off.resize(B);
+  for (int b = 0; b < B; ++b) { c->hull_off[b] = c->h_koff[b]; c->hull_cnt[b] = (int)(c->h_koff[b + 1] - c->h_koff[b]); }
   c->hull_src = c->h_kept;
   return hipSuccess;
 }
@@ -1136,7 +1148,7 @@ static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, do
       int b = next.fetch_add(1);
       if (b >= B) break;
       counts[b] = counts[B + b] = counts[2 * B + b] = 0;
-      long long v0 = c->h_voff[b0 + b], nv = c->hull_cnt[b0 + b];
+      long long v0 = c->hull_off[b0 + b], nv = c->hull_cnt[b0 + b];
       P.resize(3 * (size_t)nv);
       const float* src = c->hull_src + 3 * v0;
       for (long long i = 0; i < 3 * nv; ++i) P[i] = (double)src[i];

@@ -28,8 +28,10 @@ def test_prefilter_keeps_every_hull_vertex(engine):
     V = len(v)
     verts = engine.fetch("verts", np.float32)[:B * V * 3].reshape(B, V, 3)      # (the buffer keeps the capacity of earlier batches)
     assert (nk > 0).all() and (nk < 0.6 * V).all()          # 61 % of a humerus lies strictly inside the 26-direction polytope
+    koff = engine.fetch("hullpre.koff", np.int64)[:B + 1]        # survivors of the whole batch are compacted into one array
+    assert koff[0] == 0 and (np.diff(koff) == nk).all()
     for b in range(B):
-        K = kept[b * V: b * V + nk[b]]
+        K = kept[koff[b]: koff[b + 1]]
         P = verts[b]
         # a subsequence of the file order ...
         idx = {tuple(p): i for i, p in enumerate(map(tuple, P))}

@@ -1,13 +1,19 @@
 """Device occupancy over time from a rocprofv3 kernel trace: python tools/busy_union.py kernel_trace.csv [lo hi]
-Looks at the window [lo, hi] (fractions of the trace span, default 0.35 0.75 = steady state of a bench run): share of the
+Looks at the window [lo, hi] (fractions of the trace span; default: the steady state of a bench run, found from the
+per-step k_obb_candidates launches): share of the
 window with 0 / 1 / 2+ kernels in flight, and per kernel the time attributed to it (an instant shared by n kernels
 counts 1/n for each)."""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-lo, hi = (float(sys.argv[2]), float(sys.argv[3])) if len(sys.argv) > 3 else (0.35, 0.75)
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
 t0, t1 = min(e[0] for e in ev), max(e[1] for e in ev)
-a, b = t0 + lo * (t1 - t0), t0 + hi * (t1 - t0)
+if len(sys.argv) > 3:
+    lo, hi = float(sys.argv[2]), float(sys.argv[3])
+    a, b = t0 + lo * (t1 - t0), t0 + hi * (t1 - t0)
+else:
+    # steady state of a bench run: from the 8th step's first kernel to the 6th-last step's (one k_obb_candidates launch per step)
+    steps = sorted(s for s, e, n in ev if "k_obb_candidates" in n)
+    a, b = steps[min(8, len(steps) - 2)], steps[max(len(steps) - 6, min(8, len(steps) - 2) + 1)]
 pts = []
 for s, e, n in ev:
     s, e = max(s, a), min(e, b)
