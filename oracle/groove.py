@@ -102,13 +102,19 @@ def find_nearest_idx(array, value):
     return idx - 1 if idx == len(array) else idx
 
 
+KDE_TIE = 1e-9
+
+
 def kde_argmax_theta(theta_sel):
     """bicipital_groove.py:184-188 (sklearn KernelDensity(kernel='linear'), bandwidth 1.0)."""
     kde = sklearn.neighbors.KernelDensity(kernel="linear")
     kde.fit(np.asarray(theta_sel).reshape(-1, 1))
     tlin = np.linspace(-1 * np.pi, np.pi, 1024).reshape(-1, 1)
     bg_prob = np.exp(kde.score_samples(tlin))
-    return tlin[np.argmax(bg_prob)][0]
+    # canonical rule B-8: a linear-kernel density is exactly flat wherever as many samples lie within the bandwidth on either
+    # side, so a maximum can span many grid points and `np.argmax` then follows sklearn's rounding noise; ties within 1e-9
+    # (relative) go to the lowest grid index (off a plateau neighbouring values differ by >= 2e-5)
+    return tlin[int(np.nonzero(bg_prob >= bg_prob.max() * (1.0 - KDE_TIE))[0][0])][0]
 
 
 def groove_points(polar, zs, centroids, canal_axis_ct, T_obb, tables, interp_num=512, deg_window=7):

@@ -299,10 +299,17 @@ k_groove_rfc(const double* __restrict__ xraw, const int* __restrict__ npk, const
 }
 
 // KernelDensity(kernel="linear", bandwidth=1): rho(t) ~ sum_i max(0, 1 - |t - theta_i|) over the
-// peaks with P > 0.4; bg_theta = first argmax over linspace(-pi, pi, 1024)
+// peaks with P > 0.4; bg_theta = argmax over linspace(-pi, pi, 1024).
+// Canonical rule B-8: rho is piecewise linear, and wherever as many selected peaks lie within the bandwidth on one side of t
+// as on the other it is exactly FLAT -- a maximum on such a stretch spans every grid point between two neighbouring peaks, and
+// which of them `np.argmax` returns in the reference is decided by the rounding noise of sklearn's tree-ordered log-sum-exp
+// (found by a randomized sweep: one similarity copy in ~140 had a plateau 11 grid points wide).  Grid points within 1e-9
+// (relative) of the maximum count as tied and the LOWEST index wins; off a plateau neighbouring grid values differ by >= 2e-5.
+#define SH_KDE_TIE 1e-9
 __global__ void k_groove_kde(const double* __restrict__ ptheta, const float* __restrict__ proba, double* __restrict__ bg_theta,
                              int* __restrict__ err) {
   __shared__ double sel[SH_GSLOTS];
+  __shared__ double dens[1024];
   __shared__ int nsel;
   __shared__ double wv[4];
   __shared__ int wi[4];
@@ -317,7 +324,6 @@ __global__ void k_groove_kde(const double* __restrict__ ptheta, const float* __r
   const int n = nsel;
   if (n == 0) { if (tid == 0) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); bg_theta[b] = 0.0; } return; }
   double best = -1.0;
-  int bi = 0x7fffffff;
   for (int j = tid; j < 1024; j += blockDim.x) {
     double t = linspace_at(-1.0 * M_PI, M_PI, 1024, j);
     double acc = 0.0;
@@ -325,18 +331,23 @@ __global__ void k_groove_kde(const double* __restrict__ ptheta, const float* __r
       double d = 1.0 - fabs(t - sel[i]);
       if (d > 0.0) acc += d;
     }
-    if (acc > best || (acc == best && j < bi)) { best = acc; bi = j; }
+    dens[j] = acc;
+    best = fmax(best, acc);
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    double ob = __shfl_down(best, off);
-    int oi = __shfl_down(bi, off);
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-  }
-  if ((tid & 63) == 0) { wv[tid >> 6] = best; wi[tid >> 6] = bi; }
+  for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_down(best, off));
+  if ((tid & 63) == 0) wv[tid >> 6] = best;
+  __syncthreads();
+  best = wv[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) best = fmax(best, wv[w]);
+  const double thr = best * (1.0 - SH_KDE_TIE);
+  int bi = 0x7fffffff;
+  for (int j = tid; j < 1024; j += blockDim.x)
+    if (dens[j] >= thr) bi = min(bi, j);
+  for (int off = 32; off > 0; off >>= 1) bi = min(bi, __shfl_down(bi, off));
+  if ((tid & 63) == 0) wi[tid >> 6] = bi;
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
-      if (wv[w] > best || (wv[w] == best && wi[w] < bi)) { best = wv[w]; bi = wi[w]; }
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) bi = min(bi, wi[w]);
     bg_theta[b] = linspace_at(-1.0 * M_PI, M_PI, 1024, bi);
   }
 }
