@@ -252,8 +252,14 @@ k_groove_scale(const double* __restrict__ xraw, const int* __restrict__ npk, dou
       double v = 0.0;
       for (int p = 0; p < P; ++p) { double d = c[p] - mean; v += d * d; }
       const double var = P ? v / (double)P : 0.0;
-      double scale = sqrt(var);
-      if (scale < 10.0 * 2.220446049250313e-16) scale = 1.0;
+      // sklearn StandardScaler (1.6): a feature is "constant" -- scale 1 -- when its variance is within the error bound of the
+      // two-pass algorithm, var <= n eps var + (n mean eps)^2 (`_is_constant_feature`), not only when it is exactly zero.
+      // A feature that is constant in exact arithmetic (the cut humerus has one) comes out of a similarity copy with a
+      // standard deviation of ~1e-13: dividing by that turned the column into +-1 noise and moved bg_theta (randomized
+      // sweep of the proximal path: 8 of 24 copies).
+      const double eps_ = 2.220446049250313e-16, nn = (double)P;
+      const double ub = nn * eps_ * var + (nn * mean * eps_) * (nn * mean * eps_);
+      double scale = var <= ub ? 1.0 : sqrt(var);
       stats[(size_t)b * 18 + f0 + tid] = mean;
       stats[(size_t)b * 18 + 9 + f0 + tid] = scale;
     }

@@ -138,3 +138,33 @@ def test_proximal_facade(engine, oracle_prox):
         np.testing.assert_allclose(p.canal.axis(), L["canal_axis"], rtol=0, atol=MM)
     finally:
         engine.set_params()
+
+
+def test_prox_similarity_copies(engine, rfc_tables, unet_weights):
+    """Regression from a randomized sweep: in a similarity copy of the cut humerus the one feature that is constant in
+    exact arithmetic has a standard deviation of ~1e-13; sklearn's StandardScaler calls it constant (`_is_constant_feature`)
+    and so must the device, or the scaled column is noise, the forest probabilities change and bg_theta jumps."""
+    from oracle.prox import OracleProximalHumerus
+    from shoulder_amd import synth
+    from shoulder_amd.stl import load_stl
+    from tests.conftest import BONES, _ensure_chain_lib
+    _ensure_chain_lib()
+    v, f = load_stl(os.path.join(BONES, "proximal_left_cut.stl"))
+    T = synth.similarity_transforms(24, v, seed=900)
+    meshes = [(synth.apply_similarity(T[i], v), f) for i in (4, 10)]
+    engine.set_params(bone_kind=_lib.BONE_PROXIMAL)
+    try:
+        engine.upload(meshes)
+        lm = engine.run(PROX_MASK).copy()
+        xs = engine.fetch("groove.xs", np.float64, (2, 330 * 7, 9)).copy()
+        npk = engine.fetch("groove.npk", np.int32, (2, 330)).copy()
+    finally:
+        engine.set_params()
+    for b, (mv, mf) in enumerate(meshes):
+        h = OracleProximalHumerus(mv, mf, rfc_tables, unet_weights, unet_eval="chain")
+        L = h.landmarks()
+        valid = (np.arange(7)[None, :] < npk[b][:, None]).ravel()
+        np.testing.assert_allclose(xs[b][valid], h.groove["X"], rtol=0, atol=1e-9)      # the scaled features incl. the constant column
+        assert lm["status"][b] == 0 and lm["bg_theta"][b] == L["bg_theta"] and lm["n_anp"][b] == len(L["anp_points"])
+        np.testing.assert_allclose(lm["anp_points"][b].reshape(-1, 3)[: lm["n_anp"][b]], L["anp_points"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(lm["canal_axis"][b], L["canal_axis"], rtol=0, atol=1e-6)
