@@ -78,3 +78,25 @@ def test_osteotomy_against_oracle(engine, oracle_bones, start_csys):
     same_plane(ost.plane, O.plane(hum.transform))
     pts2 = ost.points()
     assert np.abs((pts2 - ost.plane.point) @ (ost.plane.normal / np.linalg.norm(ost.plane.normal))).max() < 1e-6
+
+
+def test_osteotomy_on_a_proximal_humerus(engine):
+    """arthroplasty.py:16 takes `bone.ProximalHumerus | bone.Humerus`: the cut-humerus facade supplies everything the class
+    touches (apply_csys_canal_articular, anatomic_neck.plane, side, mesh)."""
+    import shoulder_amd as shoulder
+    hum = shoulder.ProximalHumerus(os.path.join(BONES, "proximal_left_cut.stl"), engine=engine)
+    ost = shoulder.HumeralHeadOsteotomy(hum)
+    np.testing.assert_array_equal(hum.transform, np.identity(4))
+    p = hum.anatomic_neck.plane()
+    np.testing.assert_allclose(ost.plane.point, p.point, rtol=0, atol=1e-9)          # native resection plane = anatomic-neck plane
+    np.testing.assert_allclose(ost.plane.normal, p.normal, rtol=0, atol=1e-12)
+    ost.offset_depth(3.0)
+    ost.offest_neckshaft(4.0)
+    assert ost.neckshaft_rel == pytest.approx(4.0, abs=1e-9)
+    pts = ost.points()
+    n = ost.plane.normal / np.linalg.norm(ost.plane.normal)
+    assert len(pts) > 50 and np.abs((pts - ost.plane.point) @ n).max() < 1e-6
+    head, rest = ost.resect_mesh()
+    A = area(hum.mesh.vertices, hum.mesh.faces)
+    assert abs(area(head.vertices, head.faces) + area(rest.vertices, rest.faces) - A) < 1e-9 * A
+    assert len(head.faces) > 100 and len(rest.faces) > 100
