@@ -48,3 +48,42 @@ def test_missing_parameters_and_stage_order(oracle_bones):
             e.set_params(groove_cutoff=(0.1, 0.9))
     finally:
         e.close()
+
+
+def test_failed_run_in_a_lane_does_not_wedge_the_other(oracle_bones):
+    """Two contexts with UNet turns: a run that ends with a geometry error on one lane is reported by its collect, the
+    other lane's runs before and after it are unaffected, and the failing lane works again with a good batch."""
+    from conftest import _teacher_weights
+    from shoulder_amd import unet_spec
+    from shoulder_amd.engine import Engine
+    h = oracle_bones("humerus_left")
+    zc = h.verts[:, 2][h.faces].mean(axis=1)
+    keep = ~((zc > np.percentile(zc, 45)) & (zc < np.percentile(zc, 47)) & (h.verts[:, 0][h.faces].mean(axis=1) > np.median(h.verts[:, 0])))
+    lanes = []
+    try:
+        for _ in range(2):
+            e = Engine(0)
+            e.load_rfc()
+            e.load_unet(_teacher_weights(), unet_spec.BASE, unet_spec.DEPTH)
+            e.set_unet_turns(True)
+            lanes.append(e)
+        good, bad = lanes
+        good.upload([(h.verts, h.faces)])
+        bad.upload([(h.verts, h.faces[keep])])
+        ref = good.run(_lib.STAGE_ALL).copy()
+        good.submit(_lib.STAGE_ALL)
+        bad.submit(_lib.STAGE_ALL)
+        good_1 = good.collect().copy()
+        good.submit(_lib.STAGE_ALL)
+        with pytest.raises(ShoulderHipError) as err:
+            bad.collect()
+        assert err.value.code == -5
+        assert good.collect().tobytes() == ref.tobytes() == good_1.tobytes()
+        bad.upload([(h.verts, h.faces)])
+        bad.submit(_lib.STAGE_ALL)
+        good.submit(_lib.STAGE_ALL)
+        assert bad.collect().tobytes() == ref.tobytes()
+        assert good.collect().tobytes() == ref.tobytes()
+    finally:
+        for e in lanes:
+            e.close()
