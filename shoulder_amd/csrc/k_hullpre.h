@@ -18,8 +18,12 @@ namespace sh {
 
 #define SH_HP_NDIR 26
 #define SH_HP_MAXPL 128
-#define SH_HP_TOL 1e-8        // |distance| below this = on the plane (coordinates ~1e3 mm: rounding ~1e-12)
-#define SH_HP_MARGIN 1e-6     // a vertex closer than this to the polytope's surface is kept
+// Safety of the test: a vertex is dropped only if it lies behind EVERY accepted plane, so accepting more planes can only keep
+// more vertices; what must not happen is that a true face of the polytope is rejected (the test region would then reach
+// outside the polytope).  A triple is therefore accepted as soon as no extreme point is more than TOL in front of it, with
+// TOL far above the evaluation error of a badly conditioned (sliver) triple (~1e-7 at 300 mm), and the margin far above TOL.
+#define SH_HP_TOL 1e-6        // |distance| below this = on the plane
+#define SH_HP_MARGIN 1e-4     // a vertex closer than this to the polytope's surface is kept
 
 __device__ inline void hp_dir(int k, int* d) {      // k in [0, 26): the 27 sign triples without (0,0,0)
   const int t = k >= 13 ? k + 1 : k;
