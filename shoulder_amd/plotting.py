@@ -1,36 +1,51 @@
-"""`Plot` -- 3-D figure of a bone with its landmarks, or of a resected humerus.
+"""`Plot` -- a plotly figure of a bone with the landmarks computed so far, or of the two halves of a resection.
 
-Mirror of reference `src/shoulder/plotting.py:13-128` (same class names, arguments, trace settings and error text).  A
-plotly figure is a host-side view of results the device path already produced; nothing here computes geometry.
-plotly is imported on use and its absence is an ImportError, not a silent no-op.
+Public surface of reference `src/shoulder/plotting.py:13-128`: `Plot(obj, opacity=0.7).figure`, `PlotLandmarks`,
+`PlotSurgery`, `trimesh2plotly`, `bone_mesh_settings`, the same bone colour / lighting / trace names / layout and the
+same ValueError for anything that is neither a Bone nor a HumeralHeadOsteotomy.  A figure is a host-side view of
+results the device path already produced; nothing here computes geometry.  plotly is imported on first use and its
+absence is an ImportError, not a silent no-op.
 """
 import numpy as np
 
 from . import arthroplasty, base
 
+_BONE_COLOUR = "#DFDAC0"
+_BONE_LIGHTING = dict(ambient=0.18, diffuse=0.8, fresnel=0.1, specular=0.6, roughness=0.05,
+                      facenormalsepsilon=1e-15, vertexnormalsepsilon=1e-15)
+_LIGHT_POSITION = dict(x=1000, y=1000, z=-1000)
 
-def mesh2plotly(mesh):
-    """plotting.py:13-25 (`trimesh2plotly`): a Mesh3d trace from vertices and faces."""
+
+def _go():
     import plotly.graph_objects as go
-    v, f = np.asarray(mesh.vertices), np.asarray(mesh.faces)
-    return go.Mesh3d(x=v[:, 0], y=v[:, 1], z=v[:, 2], i=f[:, 0], j=f[:, 1], k=f[:, 2])
+    return go
 
 
-trimesh2plotly = mesh2plotly      # the reference's name
+def trimesh2plotly(mesh):
+    """vertices + faces -> `go.Mesh3d` (plotting.py:13-25); any object with `.vertices` (V,3) and `.faces` (F,3) will do"""
+    xyz = np.asarray(mesh.vertices, dtype=np.float64).T
+    ijk = np.asarray(mesh.faces).T
+    return _go().Mesh3d(x=xyz[0], y=xyz[1], z=xyz[2], i=ijk[0], j=ijk[1], k=ijk[2])
+
+
+mesh2plotly = trimesh2plotly
 
 
 def bone_mesh_settings(trace):
-    """plotting.py:28-42."""
-    trace.color = "#DFDAC0"
-    trace.lighting = dict(ambient=0.18, diffuse=0.8, fresnel=0.1, specular=0.6, roughness=0.05,
-                          facenormalsepsilon=1e-15, vertexnormalsepsilon=1e-15)
-    trace.lightposition = dict(x=1000, y=1000, z=-1000)
-    trace.flatshading = False
+    """bone colour, smooth shading and the reference's light (plotting.py:28-42)"""
+    trace.update(color=_BONE_COLOUR, lighting=_BONE_LIGHTING, lightposition=_LIGHT_POSITION, flatshading=False)
+    return trace
+
+
+def _bone_trace(mesh, opacity=None):
+    trace = bone_mesh_settings(trimesh2plotly(mesh))
+    if opacity is not None:
+        trace.opacity = opacity
     return trace
 
 
 class PlotSurgery:
-    """plotting.py:75-101: the two halves of `HumeralHeadOsteotomy.resect_mesh()`."""
+    """head (at the requested opacity) and resected humerus (opaque) of `ost.resect_mesh()` -- plotting.py:75-101"""
 
     def __init__(self, ost, opacity):
         self.mesh_top, self.mesh_bot = ost.resect_mesh()
@@ -39,17 +54,11 @@ class PlotSurgery:
 
     @property
     def figure(self):
-        import plotly.graph_objects as go
-        fig = go.Figure()
-        top = bone_mesh_settings(mesh2plotly(self.mesh_top))
-        top.opacity = self.opacity
-        bot = bone_mesh_settings(mesh2plotly(self.mesh_bot))
-        fig.add_traces([top, bot])
-        return fig
+        return _go().Figure(data=[_bone_trace(self.mesh_top, self.opacity), _bone_trace(self.mesh_bot)])
 
 
 class PlotLandmarks:
-    """plotting.py:104-128: the bone plus the graph object(s) of every landmark computed so far."""
+    """the bone plus one trace (the anatomic neck: two) per landmark that has been computed -- plotting.py:104-128"""
 
     def __init__(self, bone, opacity):
         self.mesh = bone.mesh
@@ -59,26 +68,22 @@ class PlotLandmarks:
 
     @property
     def figure(self):
-        import plotly.graph_objects as go
-        fig = go.Figure()
-        m = bone_mesh_settings(mesh2plotly(self.mesh))
-        m.opacity = self.opacity
-        fig.add_trace(m)
-        for lgo in self._landmarks_graph_obj:
-            for tr in (lgo if isinstance(lgo, list) else [lgo]):
-                fig.add_trace(tr)
-        return fig
+        traces = [_bone_trace(self.mesh, self.opacity)]
+        for obj in self._landmarks_graph_obj:
+            traces.extend(obj if isinstance(obj, list) else [obj])
+        return _go().Figure(data=traces)
 
 
 class Plot:
-    """plotting.py:45-72.  obj2plot: a Bone or a HumeralHeadOsteotomy; opacity of the bone (default 0.7)."""
+    """`Plot(bone_or_osteotomy, opacity=0.7).figure` -- plotting.py:45-72"""
 
     def __init__(self, obj2plot, opacity=0.7):
         if isinstance(obj2plot, arthroplasty.HumeralHeadOsteotomy):
-            self._plotter = PlotSurgery(obj2plot, opacity)
+            plotter = PlotSurgery(obj2plot, opacity)
         elif isinstance(obj2plot, base.Bone):
-            self._plotter = PlotLandmarks(obj2plot, opacity)
+            plotter = PlotLandmarks(obj2plot, opacity)
         else:
-            raise ValueError("Object to plot must be either a Bone or HumeralHeadOjson")      # (the reference's text)
-        self.figure = self._plotter.figure
-        self.figure.update_layout(title=self._plotter.name, scene_aspectmode="data")
+            raise ValueError("Object to plot must be either a Bone or HumeralHeadOjson")      # the reference's text
+        self._plotter = plotter
+        self.figure = plotter.figure
+        self.figure.update_layout(title=plotter.name, scene_aspectmode="data")      # "data": no distortion
