@@ -52,6 +52,12 @@ double hc_linspace(double a, double b, int n, int k) { return linspace_at(a, b, 
 }
 
 #include "../../shoulder_amd/csrc/sh_hull.h"
+extern "C" int hc_hull_eps(const double* pts, int n, double eps_rel, int* nv, int* nf) {
+  shhull::Hull H;
+  if (!shhull::convex_hull_eps(pts, n, H, eps_rel)) return -shhull::hull_fail_reason();
+  *nv = (int)H.vert_ids.size(); *nf = (int)H.tris.size() / 3;
+  return 0;
+}
 extern "C" int hc_hull(const double* pts, int n, int* vert_ids, int cap_v, int* tris, int cap_f, int* n_edges) {
   shhull::Hull H;
   if (!shhull::convex_hull(pts, n, H)) return -1;

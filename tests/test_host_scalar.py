@@ -25,7 +25,7 @@ def dp(a):
 def hc():
     so = os.path.join(HC, "libhostcheck.so")
     src = os.path.join(HC, "hostcheck.cpp")
-    hdrs = [os.path.join(ROOT, "shoulder_amd", "csrc", h) for h in ("sh_scalar.h", "sh_common.h")]
+    hdrs = [os.path.join(ROOT, "shoulder_amd", "csrc", h) for h in ("sh_scalar.h", "sh_common.h", "sh_hull.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in [src] + hdrs):
         subprocess.check_call(["g++", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
     lib = ctypes.CDLL(so)
@@ -309,3 +309,49 @@ def test_full_obb_head_end_rule_against_reference():
         np.testing.assert_array_equal(np.matmul(o_obb.FLIP if flipped else np.identity(4), g("T_obb")), g("transform"))
         assert abs(zb[0]) + abs(zb[1]) == float(g("z_length"))
     assert seen == {True, False}
+
+
+def test_hull_on_nearly_coplanar_clouds(hc):
+    """Subdivided surfaces: float32 midpoints sit ~1e-5 mm off their parent triangles, so thousands of points are nearly
+    coplanar with hull facets.  The quickhull used to lose its adjacency (or crash) on the 16x mesh; with horizon validation,
+    the widened retry and re-insertion rounds it must return a closed hull whose volume is qhull's and from which no input
+    point sticks out by more than the float32 noise."""
+    from oracle.stl import load_stl
+    from conftest import BONES
+
+    def subdivide(v, f):
+        v = v.astype(np.float64)
+        e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+        ue, inv = np.unique(e, axis=0, return_inverse=True)
+        m = len(v) + inv.reshape(3, -1)
+        a, b, c = f[:, 0], f[:, 1], f[:, 2]
+        nf = np.concatenate([np.c_[a, m[0], m[2]], np.c_[m[0], b, m[1]], np.c_[m[2], m[1], c], np.c_[m[0], m[1], m[2]]])
+        return np.concatenate([v, 0.5 * (v[ue[:, 0]] + v[ue[:, 1]])]).astype(np.float32), nf.astype(np.int32)
+
+    v, f = load_stl(os.path.join(BONES, "humerus_left.stl"))
+    v2, f2 = subdivide(v, f)
+    v3, _ = subdivide(v2, f2)
+    for P, out_tol in ((v2, 3e-4), (v3, 3e-3)):      # 16x needs the joggle (<= 3e-7 of the diagonal) + re-insertion allowance
+        P = np.ascontiguousarray(P.astype(np.float64))
+        vid = np.zeros(16384, dtype=np.int32)
+        tri = np.zeros(3 * 32768, dtype=np.int32)
+        ne = ctypes.c_int()
+        rc = hc.hc_hull(dp(P), len(P), vid.ctypes.data_as(I), 16384, tri.ctypes.data_as(I), 32768, ctypes.byref(ne))
+        assert rc > 0
+        nv, nf = rc // 100000, rc % 100000
+        assert nf == 2 * nv - 4 and ne.value == 3 * nv - 6
+        t = vid[tri[:3 * nf].reshape(-1, 3)]
+        Q = P - P.mean(axis=0)
+        vol = np.einsum("ij,ij->i", Q[t[:, 0]], np.cross(Q[t[:, 1]], Q[t[:, 2]])).sum() / 6
+        ref = scipy.spatial.ConvexHull(P)
+        assert abs(vol - ref.volume) <= 1e-7 * ref.volume
+        # no input point farther than 3e-4 mm in front of any facet (checked on qhull's extreme points: the candidates)
+        n = np.cross(P[t[:, 1]] - P[t[:, 0]], P[t[:, 2]] - P[t[:, 0]])
+        a2 = np.linalg.norm(n, axis=1)
+        emax = np.maximum.reduce([np.linalg.norm(P[t[:, i]] - P[t[:, (i + 1) % 3]], axis=1) for i in range(3)])
+        good = a2 > 2e-2 * emax ** 2           # needles between nearly coplanar points have no usable normal (height < 2 % of the long edge)
+        assert good.sum() > 0.5 * len(good)
+        n = n[good] / a2[good][:, None]
+        d0 = np.einsum("ij,ij->i", n, P[t[good, 0]])
+        ext = P[ref.vertices]
+        assert (ext @ n.T - d0[None, :]).max() < out_tol
