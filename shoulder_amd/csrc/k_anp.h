@@ -134,7 +134,7 @@ k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, co
     counts[2 * b] = acc;
     counts[2 * b + 1] = tm;
     if (acc > SH_ANP_CAP) atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
-    if (acc < 6) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+    if (acc < 6) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
   }
   __syncthreads();
   // pass 2: the edge pixels as points (r cos t, r sin t, z), in row-major order
@@ -231,7 +231,7 @@ k_anp_plane(const double* __restrict__ pts_obb, const int* __restrict__ counts, 
     for (int a = 0; a < 6; ++a)
       for (int e = a; e < 6; ++e) { S6[a * 6 + e] = S[q]; S6[e * 6 + a] = S[q]; ++q; }
     double ex, ey;
-    if (!ellipse_center_from_scatter(S6, &ex, &ey)) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); ex = ey = 0.0; }
+    if (!ellipse_center_from_scatter(S6, &ex, &ey)) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); ex = ey = 0.0; }
     for (int k = 0; k < 3; ++k) { out[k] = c[k] + ex * u[k] + ey * v[k]; out[3 + k] = nrm[k]; }
   }
 }
@@ -279,7 +279,7 @@ k_rays(const double* __restrict__ vobb, const int* __restrict__ faces, const lon
   if (tid == 0) {
     for (int w = 1; w < 4; ++w) tbest = fmin(tbest, wt[w]);
     double* a = axes_obb + ((size_t)b * 4 + ray) * 3;
-    if (tbest > 1e299) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); a[0] = a[1] = a[2] = 0.0; }
+    if (tbest > 1e299) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); a[0] = a[1] = a[2] = 0.0; }
     else for (int k = 0; k < 3; ++k) a[k] = o[k] + d[k] * tbest;
   }
 }

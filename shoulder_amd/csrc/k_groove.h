@@ -214,7 +214,7 @@ __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][51
     X[6] = s_pk[k].width_height; X[7] = sqrt(dx * dx + dy * dy); X[8] = (double)np_ / 7.0;
     ptheta[(size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK + k] = th;
     // a NaN feature = the reference's IndexError (all other peaks within 0.005 rad)
-    for (int q = 0; q < 9; ++q) if (X[q] != X[q]) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+    for (int q = 0; q < 9; ++q) if (X[q] != X[q]) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
   }
   if (lane == 0) npk[gid] = np_;
   (void)B;
@@ -328,7 +328,7 @@ __global__ void k_groove_kde(const double* __restrict__ ptheta, const float* __r
   }
   __syncthreads();
   const int n = nsel;
-  if (n == 0) { if (tid == 0) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); bg_theta[b] = 0.0; } return; }
+  if (n == 0) { if (tid == 0) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); bg_theta[b] = 0.0; } return; }
   double best = -1.0;
   for (int j = tid; j < 1024; j += blockDim.x) {
     double t = linspace_at(-1.0 * M_PI, M_PI, 1024, j);

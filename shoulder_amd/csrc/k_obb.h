@@ -274,7 +274,7 @@ k_obb_pick(const double* __restrict__ hv, const double* __restrict__ normals, co
   __syncthreads();
   if (tid == 0) {
     for (int w = 1; w < 4; ++w) if (wv[w] < best || (wv[w] == best && wi[w] < bf)) { best = wv[w]; bf = wi[w]; }
-    if (bf == 0x7fffffff || !(best < 1e299)) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); bf = 0; }
+    if (bf == 0x7fffffff || !(best < 1e299)) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); bf = 0; }
     const double* N = normals + ((size_t)b * SH_HF + bf) * 3;
     double n[3] = {N[0], N[1], N[2]}, u[3], v[3];
     obb_basis(n, u, v);
@@ -430,7 +430,7 @@ k_obb_ends(const double* __restrict__ endpts, const int* __restrict__ endcnt, co
   int n = endcnt[2 * b + e];
   double r;
   if (n > SH_ENDCAP) { if (lane == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); n = SH_ENDCAP; }
-  if (n < 3) { if (lane == 0) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); r = 1e300; }
+  if (n < 3) { if (lane == 0) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); r = 1e300; }
   else r = wave_circle_fit_residual(endpts + ((size_t)b * 2 + e) * SH_ENDCAP * 2, n);
   if (lane == 0) { res[e] = r; resid[2 * b + e] = r; }
   __syncthreads();

@@ -255,7 +255,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     if (tid == 0) {
       centroids[2 * (size_t)pl] = 0; centroids[2 * (size_t)pl + 1] = 0; areas[pl] = 0; nloops[pl] = 0; ring_n[pl] = 0;
       if (areas_total) areas_total[pl] = 0;      // an empty section of the area scan is legal (plane past a ragged cut)
-      else atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+      else atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
     }
     return;
   }
@@ -415,7 +415,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     }
     nloops[pl] = nl;
     ring_n[pl] = l_len[best];
-    if (bad) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+    if (bad) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
   }
   __syncthreads();
   if (ring) {

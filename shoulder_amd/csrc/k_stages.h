@@ -174,7 +174,7 @@ __global__ void k_prox_obb(const double* __restrict__ area_scan /*[B][SH_NPSCAN]
   double ar[SH_NPSCAN], tmp[2 * SH_NPSCAN];
   for (int j = 0; j < SH_NPSCAN; ++j) ar[j] = flip ? A[SH_NPSCAN - 1 - j] : A[j];      // z_area[::-1]
   int lo, hi;
-  if (prox_canal_range(ar, SH_NPSCAN, tmp, &lo, &hi) < 1) atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+  if (prox_canal_range(ar, SH_NPSCAN, tmp, &lo, &hi) < 1) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
   cutoff_idx[2 * b] = lo; cutoff_idx[2 * b + 1] = hi;
   cutoff[2 * b] = (double)lo / (double)SH_NPSCAN;
   cutoff[2 * b + 1] = (double)hi / (double)SH_NPSCAN;
@@ -218,7 +218,7 @@ __global__ void k_canal(const double* __restrict__ centroids, const double* __re
   cutoff_range(SH_NFULL, c0, c1, &a, &e);
   int n = e - a;
   if (n > SH_CANAL_MAXPTS) n = SH_CANAL_MAXPTS;
-  if (n < 2) { if (lane == 0) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); for (int k = 0; k < 6; ++k) { axis_obb[6 * b + k] = 0; axis_ct[6 * b + k] = 0; } } return; }
+  if (n < 2) { if (lane == 0) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); for (int k = 0; k < 6; ++k) { axis_obb[6 * b + k] = 0; axis_ct[6 * b + k] = 0; } } return; }
   double* P = pts_obb + (size_t)b * SH_CANAL_MAXPTS * 3;
   for (int i = lane; i < n; i += 64) {
     P[3 * i] = centroids[2 * ((size_t)b * SH_NFULL + a + i)];

@@ -123,7 +123,7 @@ __global__ void k_te_final(const double* __restrict__ ring, const int* __restric
   if (n2 > 8) n2 = 8;
   int np_ = n1 + n2;
   double* out = te_axis_ct + 6 * b;
-  if (np_ < 2) { atomicExch(&err[b], SH_ERR_GEOMETRY_DEV); for (int q = 0; q < 6; ++q) out[q] = 0.0; return; }
+  if (np_ < 2) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); for (int q = 0; q < 6; ++q) out[q] = 0.0; return; }
   int bi = 0, bj = 1;
   double bd = -1.0;
   for (int i = 0; i < np_; ++i)
@@ -271,7 +271,7 @@ k_metrics(sh_landmarks* __restrict__ lm, const double* __restrict__ partial, int
         double C[4];
         for (int r = 0; r < 4; ++r) C[r] = ((Ni[r * 4] * g[0] + Ni[r * 4 + 1] * g[1]) + Ni[r * 4 + 2] * g[2]) + Ni[r * 4 + 3] * g[3];
         radius = sqrt(((C[0] * C[0] + C[1] * C[1]) + C[2] * C[2]) + C[3]);
-      } else atomicExch(&err[b], SH_ERR_GEOMETRY_DEV);
+      } else atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
     }
   }
   if (tid != 0) return;

@@ -25,6 +25,9 @@
 #define SH_GROOVE_NROWS 330
 #define SH_MAXPEAK 7        // bicipital_groove.py:122
 #define SH_SECTION_TOL 1e-8 // trimesh tol.merge used by intersections.mesh_plane
+// Per-humerus status word written by the kernels.  A capacity overflow is recorded unconditionally (atomicExch), a geometry
+// failure only where nothing is recorded yet (atomicCAS from 0): a truncated slice also fails to close its contours, and the
+// status should name the cause, not the consequence.
 #define SH_ERR_CAPACITY_DEV (-4)
 #define SH_ERR_GEOMETRY_DEV (-5)
 

@@ -54,3 +54,17 @@ def test_over_capacity_is_an_error(engine):
     with pytest.raises(ShoulderHipError) as err:
         engine.run(_lib.STAGE_ALL)
     assert err.value.code == -4 and "mesh 0" in str(err.value)
+
+
+def test_slice_capacity_overflow_is_an_error(engine, oracle_bones):
+    """The 16x mesh past the hull stage (box frame injected): ~1 300 crossing segments per plane exceed SH_MAXSEG = 1024; the slice
+    stage must flag the humerus (SH_ERR_CAPACITY), and the engine must still work afterwards."""
+    h = oracle_bones("humerus_left")
+    v3, f3 = subdivide(*subdivide(h.verts, h.faces))
+    engine.upload([(v3, f3)])
+    engine.store("obb_transform", h.T_obb[None])
+    with pytest.raises(ShoulderHipError) as err:
+        engine.run(_lib.STAGE_FULL | _lib.STAGE_PROXIMAL | _lib.STAGE_NECK)
+    assert err.value.code == -4
+    engine.upload([(h.verts, h.faces)])
+    assert engine.run(_lib.STAGE_ALL)["status"][0] == 0
