@@ -68,3 +68,23 @@ def test_slice_capacity_overflow_is_an_error(engine, oracle_bones):
     assert err.value.code == -4
     engine.upload([(h.verts, h.faces)])
     assert engine.run(_lib.STAGE_ALL)["status"][0] == 0
+
+
+def test_plane_cuts_of_the_dense_mesh(engine):
+    """sh_slice_mesh_planes on the 130 k-triangle mesh, 16 planes in one pass: bit-identical to oracle/clip.py (the midpoints make
+    many vertices lie within the 1e-8 on-plane tolerance of axis-aligned planes: the sign-0 branches get exercised)."""
+    from oracle import clip
+    v, f = load_stl(os.path.join(BONES, "humerus_left.stl"))
+    v2, f2 = subdivide(v, f)
+    v2 = v2.astype(np.float64)
+    rng = np.random.default_rng(31)
+    P = 16
+    normals = rng.normal(size=(P, 3))
+    normals[:3] = np.identity(3)                                   # axis-aligned planes through existing vertices
+    origins = v2[rng.integers(0, len(v2), P)].copy()
+    origins[3:] += rng.normal(scale=1.0, size=(P - 3, 3))
+    got = engine.slice_mesh_planes(v2, f2, origins, normals, edges=True)
+    for (gv, gf, ge), o, n in zip(got, origins, normals):
+        wv, wf, we = clip.slice_plane(v2, f2, o, n)
+        assert gv.shape == wv.shape and np.array_equal(gv.view(np.int64), wv.view(np.int64))
+        assert np.array_equal(gf, wf) and np.array_equal(ge, we)
