@@ -88,3 +88,22 @@ def test_plane_cuts_of_the_dense_mesh(engine):
         wv, wf, we = clip.slice_plane(v2, f2, o, n)
         assert gv.shape == wv.shape and np.array_equal(gv.view(np.int64), wv.view(np.int64))
         assert np.array_equal(gf, wf) and np.array_equal(ge, we)
+
+
+def test_stl_ingest_of_the_dense_mesh(engine, tmp_path):
+    """sh_upload_stl on a 130 k-triangle file beside a fixture file (ragged, 4x larger hash table): vertices and faces bit-identical
+    to the host loader."""
+    import bench
+    v, f = load_stl(os.path.join(BONES, "humerus_left.stl"))
+    v2, f2 = subdivide(v, f)
+    p = tmp_path / "dense.stl"
+    p.write_bytes(bench.stl_bytes(v2, f2))
+    hv, hf = load_stl(str(p))
+    assert len(hf) == len(f2) and len(hv) == len(v2)
+    engine.upload_stl([str(p), os.path.join(BONES, "humerus_right.stl")])
+    gv = engine.fetch("verts", np.float32, (int(engine.voff[-1]), 3))
+    gf = engine.fetch("faces", np.int32, (int(engine.foff[-1]), 3))
+    assert np.array_equal(gv[: engine.voff[1]].view(np.uint32), hv.view(np.uint32)) and np.array_equal(gf[: engine.foff[1]], hf)
+    rv, rf = load_stl(os.path.join(BONES, "humerus_right.stl"))
+    assert np.array_equal(gv[engine.voff[1]:].view(np.uint32), rv.view(np.uint32)) and np.array_equal(gf[engine.foff[1]:], rf)
+    assert (engine.run(_lib.STAGE_ALL)["status"] == 0).all()
