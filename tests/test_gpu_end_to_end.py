@@ -236,3 +236,45 @@ def test_two_contexts_on_one_device(engine, oracle_bones):
     finally:
         for e in lanes:
             e.close()
+
+
+def test_contexts_driven_from_different_host_threads(oracle_bones):
+    """Contexts are independent: two engines driven concurrently from two Python threads (ctypes releases the GIL; one with UNet
+    turns, one without) return what they return alone."""
+    import threading
+    from conftest import _teacher_weights
+    from shoulder_amd import unet_spec
+    from shoulder_amd.engine import Engine
+    h = oracle_bones("humerus_left")
+    engs, refs, bad = [], [], []
+    try:
+        for seed, turns in ((41, True), (42, False)):
+            e = Engine(0)
+            e.load_rfc()
+            e.load_unet(_teacher_weights(), unet_spec.BASE, unet_spec.DEPTH)
+            e.set_params(unet_dtype=_lib.UNET_BF16)
+            e.upload([(h.verts, h.faces)])
+            e.synth_batch(synth.similarity_transforms(6, h.verts, seed=seed))
+            e.set_overlap(True)
+            e.set_unet_turns(turns)
+            engs.append(e)
+            refs.append(e.run(_lib.STAGE_ALL).copy())
+
+        def worker(i):
+            for k in range(12):
+                if k % 3 == 0:
+                    out = engs[i].run(_lib.STAGE_ALL)
+                else:
+                    engs[i].submit(_lib.STAGE_ALL)
+                    out = engs[i].collect()
+                if out.tobytes() != refs[i].tobytes():
+                    bad.append((i, k))
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert bad == []
+    finally:
+        for e in engs:
+            e.close()
