@@ -114,7 +114,8 @@ int  sh_load_rfc(sh_ctx*, const int32_t* feat, const float* thr, const int32_t* 
                  const int32_t* roots, int n_trees);
 /* UNet: `packed` = concatenation, in this order, of enc{i}a_w,enc{i}a_b,enc{i}b_w,enc{i}b_b (i=0..depth-1),
  * bota_w,bota_b,botb_w,botb_b, then for i=depth-1..0: up{i}_w,up{i}_b,dec{i}a_w,dec{i}a_b,dec{i}b_w,dec{i}b_b,
- * then head_w, head_b; conv weights laid out [ky][kx][cin][cout] float32. */
+ * then head_w, head_b; conv weights laid out [ky][kx][cin][cout] float32.
+ * base_channels: a multiple of 32, at most 256; depth 1..6. */
 int  sh_load_unet(sh_ctx*, int base_channels, int depth, const float* packed, size_t n_floats);
 /* Device address + size of the packed parameter block (UNet then RFC), for a collective
  * broadcast by the caller (torch.distributed over RCCL); valid until the next sh_load_*. */

@@ -129,9 +129,9 @@ k_conv_mfma_f32(const float* __restrict__ src0, const float* __restrict__ src1, 
 // First layer: Cin = 1 (the radius image), Cout = C (<= 64): 9-tap fma chain per output, VALU.
 __global__ void k_conv_first(const float* __restrict__ img, const float* __restrict__ wgt /*[9][1][C]*/, const float* __restrict__ bias,
                              float* __restrict__ dst, int H, int W, int C, int nimg) {
-  __shared__ float sw[9 * 64 + 64];
+  __shared__ float sw[9 * SH_UNET_MAXBASE + SH_UNET_MAXBASE];      // [9][C] weights, then the bias (C <= SH_UNET_MAXBASE, checked by sh_load_unet)
   for (int e = threadIdx.x; e < 9 * C; e += blockDim.x) sw[e] = wgt[e];
-  for (int e = threadIdx.x; e < C; e += blockDim.x) sw[9 * 64 + e] = bias[e];
+  for (int e = threadIdx.x; e < C; e += blockDim.x) sw[9 * SH_UNET_MAXBASE + e] = bias[e];
   __syncthreads();
   size_t total = (size_t)nimg * H * W;
   for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
@@ -146,7 +146,7 @@ __global__ void k_conv_first(const float* __restrict__ img, const float* __restr
     }
     float* o = dst + p * C;
     for (int c = 0; c < C; ++c) {
-      float a = sw[9 * 64 + c];
+      float a = sw[9 * SH_UNET_MAXBASE + c];
 #pragma unroll
       for (int t = 0; t < 9; ++t) a = __builtin_fmaf(v[t], sw[t * C + c], a);
       o[c] = fmaxf(a, 0.0f);
@@ -179,15 +179,17 @@ __global__ void k_maxpool2(const float* __restrict__ src, float* __restrict__ ds
 // per-pixel channel walk below is bank-conflict free), then one sequential chain per lane.
 __global__ void __launch_bounds__(256)
 k_head(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bp, float* __restrict__ logits, int C, size_t npix) {
-  __shared__ float tile[256 * 65];
-  __shared__ float sw[64];
+  constexpr int TILE = 256 * 65;               // floats: 256 pixels per pass up to 64 channels, fewer pixels per pass above
+  __shared__ float tile[TILE];
+  __shared__ float sw[SH_UNET_MAXBASE];
   const int tid = threadIdx.x;
   const float b = bp[0];
-  if (tid < C) sw[tid] = w[tid];
+  for (int i = tid; i < C; i += 256) sw[i] = w[i];
   const int C4 = C / 4, ld = C + 1;
-  for (size_t p0 = (size_t)blockIdx.x * 256; p0 < npix; p0 += (size_t)gridDim.x * 256) {
+  const int ppx = min(256, TILE / ld);         // pixels per pass
+  for (size_t p0 = (size_t)blockIdx.x * ppx; p0 < npix; p0 += (size_t)gridDim.x * ppx) {
     __syncthreads();
-    size_t np_ = npix - p0 < 256 ? npix - p0 : 256;
+    size_t np_ = npix - p0 < (size_t)ppx ? npix - p0 : (size_t)ppx;
     for (int e = tid; e < (int)np_ * C4; e += 256) {
       int px = e / C4, c4 = e % C4;
       f32x4 v = *(const f32x4*)(src + (p0 + px) * C + c4 * 4);

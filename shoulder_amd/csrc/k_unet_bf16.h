@@ -300,9 +300,9 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
 
 __global__ void k_conv_first_bf16(const float* __restrict__ img, const float* __restrict__ wgt, const float* __restrict__ bias,
                                   __bf16* __restrict__ dst, int H, int W, int C, int nimg) {
-  __shared__ float sw[9 * 64 + 64];
+  __shared__ float sw[9 * SH_UNET_MAXBASE + SH_UNET_MAXBASE];      // [9][C] weights, then the bias (C <= SH_UNET_MAXBASE, checked by sh_load_unet)
   for (int e = threadIdx.x; e < 9 * C; e += blockDim.x) sw[e] = wgt[e];
-  for (int e = threadIdx.x; e < C; e += blockDim.x) sw[9 * 64 + e] = bias[e];
+  for (int e = threadIdx.x; e < C; e += blockDim.x) sw[9 * SH_UNET_MAXBASE + e] = bias[e];
   __syncthreads();
   size_t total = (size_t)nimg * H * W;
   for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
@@ -321,7 +321,7 @@ __global__ void k_conv_first_bf16(const float* __restrict__ img, const float* __
       bf16x8 ov;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        float a = sw[9 * 64 + c8 + k];
+        float a = sw[9 * SH_UNET_MAXBASE + c8 + k];
 #pragma unroll
         for (int t = 0; t < 9; ++t) a = __builtin_fmaf(v[t], sw[t * C + c8 + k], a);
         ov[k] = (__bf16)fmaxf(a, 0.0f);
@@ -350,8 +350,8 @@ __global__ void k_maxpool2_bf16(const __bf16* __restrict__ src, __bf16* __restri
 
 __global__ void k_head_bf16(const __bf16* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bp,
                             float* __restrict__ logits, int C, size_t npix, size_t HW) {
-  __shared__ float sw[64];
-  if (threadIdx.x < C) sw[threadIdx.x] = w[threadIdx.x];
+  __shared__ float sw[SH_UNET_MAXBASE];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) sw[i] = w[i];
   __syncthreads();
   const float b = bp[0];
   for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {

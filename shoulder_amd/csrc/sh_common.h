@@ -13,6 +13,7 @@
 #define SH_HD inline
 #endif
 
+#define SH_UNET_MAXBASE 256  // first-level channels the UNet kernels are sized for (first-conv weight tile in LDS)
 #define SH_MAXSEG 1024      // capacity: crossing segments per (mesh, plane)
 #define SH_NFULL 200        // slice.py:213
 #define SH_NDIST 200        // slice.py:260

@@ -1608,7 +1608,8 @@ int sh_load_rfc(sh_ctx* c, const int32_t* feat, const float* thr, const int32_t*
 }
 
 int sh_load_unet(sh_ctx* c, int base, int depth, const float* packed, size_t n_floats) {
-  if (!c || !packed || depth < 1 || depth > 6 || base < 32 || base % 32 != 0) return fail(c, SH_ERR_ARG, "sh_load_unet: bad argument (base must be a multiple of 32)");
+  if (!c || !packed || depth < 1 || depth > 6 || base < 32 || base % 32 != 0 || base > SH_UNET_MAXBASE)
+    return fail(c, SH_ERR_ARG, "sh_load_unet: bad argument (base must be a multiple of 32, at most 256; depth 1..6)");
   HIPCHK(c, hipSetDevice(c->device));
   c->ulayers.clear();
   c->packtab_ready = false;

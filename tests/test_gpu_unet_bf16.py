@@ -96,3 +96,28 @@ def test_fused_ends_match_layerwise(engine, monkeypatch):
         assert float(np.abs(a - plain).max()) < 0.06      # logits of this noise image reach +-3
         band = np.abs(plain) > 0.08
         assert np.array_equal((a > 0)[band], (plain > 0)[band])
+
+
+@pytest.mark.parametrize("base,depth,H,W", [(96, 2, 64, 64), (160, 1, 32, 64), (64, 3, 128, 256), (256, 1, 32, 32)])
+def test_other_widths_and_depths(base, depth, H, W):
+    """Networks other than the default 4 x base-32 one (a user's ONNX import may have any base % 32 == 0 up to 256): both paths
+    against the float64 evaluation.  Regression: the first-conv and head kernels used to stage their weights in LDS arrays sized
+    for 64 channels, so base 96 / 160 gave garbage on the f32 path."""
+    from oracle import unet as ounet
+    from shoulder_amd import unet_spec
+    from shoulder_amd.engine import Engine
+    rng = np.random.default_rng(base + depth)
+    w = unet_spec.make_teacher_weights(seed=9, base=base, depth=depth)
+    x = rng.uniform(0, 1, (2, H, W)).astype(np.float32)
+    want = np.stack([ounet.forward_f64(w, xi) for xi in x])
+    e = Engine(0)
+    try:
+        e.load_unet(w, base, depth)
+        e.set_params(unet_dtype=_lib.UNET_F32)
+        assert np.abs(e.unet_infer(x) - want).max() < 5e-5
+        e.set_params(unet_dtype=_lib.UNET_BF16)
+        assert np.abs(e.unet_infer(x) - want).max() < 0.08
+        with pytest.raises(Exception):
+            e.load_unet(unet_spec.make_teacher_weights(seed=1, base=288, depth=1), 288, 1)      # above SH_UNET_MAXBASE
+    finally:
+        e.close()
