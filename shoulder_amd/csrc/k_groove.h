@@ -370,6 +370,7 @@ __global__ void k_groove_localmin(const double* __restrict__ itr_cs, const doubl
   int loc = groove_local_min(row, r0 + (size_t)gid * SH_MPROX, SH_MPROX, bg_theta[b], ivar);
   local_idx[gid] = loc;
   int k = loc < 0 ? loc + SH_MPROX : loc;      // python negative index
+  k = k < 0 ? 0 : (k >= SH_MPROX ? SH_MPROX - 1 : k);      // never off the row (sh_set_params keeps the window within half a turn; the reference raises IndexError beyond)
   double t = row[k], r = row[SH_MPROX + k];
   const double* c = prox_centroids + 2 * ((size_t)b * SH_NPROX + row0 + i);
   double* p = pts_obb + (size_t)gid * 3;

@@ -381,6 +381,7 @@ SH_HD int groove_local_min(const double* theta, const double* r0, int M, double 
   if (ivar > esti) {
     // polar_0[:, (esti-ivar):] (negative start = tail) ++ polar_0[:, :(esti+ivar)]
     int start = M + (esti - ivar);
+    if (start < 0) start = 0;      // a Python slice start below -M clamps to the beginning of the row
     for (int k = start; k < M; ++k, ++pos) if (first || r0[k] < bv) { bv = r0[k]; best = pos; first = false; }
     for (int k = 0; k < esti + ivar && k < M; ++k, ++pos) if (first || r0[k] < bv) { bv = r0[k]; best = pos; first = false; }
   } else {

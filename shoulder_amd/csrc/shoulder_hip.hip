@@ -249,11 +249,17 @@ const char* sh_last_error(const sh_ctx* c) { return c ? c->err.c_str() : "null c
 
 int sh_set_params(sh_ctx* c, const sh_params* p) {
   if (!c || !p) return SH_ERR_ARG;
+  for (double x : {p->groove_cutoff[0], p->groove_cutoff[1], p->canal_cutoff[0], p->canal_cutoff[1]})
+    if (!(x >= 0.0 && x <= 1.0)) return fail(c, SH_ERR_ARG, "cut-off fractions must lie in [0, 1]");
   int a, b;
   cutoff_range(SH_NPROX, p->groove_cutoff[0], p->groove_cutoff[1], &a, &b);
   if (b - a != SH_GROOVE_NROWS) return fail(c, SH_ERR_ARG, "groove_cutoff must select 330 proximal rows");
   cutoff_range(SH_NFULL, p->canal_cutoff[0], p->canal_cutoff[1], &a, &b);
   if (b - a < 2 || a < 0 || b > SH_NFULL) return fail(c, SH_ERR_ARG, "canal_cutoff selects fewer than 2 slices");
+  // the search window of the groove's local minimum is +-round(deg_window / (360 / 512)) samples of a 512-sample row
+  // (bicipital_groove.py:190-229); beyond half a turn the reference's negative indices run off the row (IndexError there)
+  if (!(p->groove_deg_window >= 0.0 && p->groove_deg_window <= 180.0)) return fail(c, SH_ERR_ARG, "groove_deg_window must lie in [0, 180] degrees");
+  if (p->unet_dtype != SH_UNET_F32 && p->unet_dtype != SH_UNET_BF16) return fail(c, SH_ERR_ARG, "unet_dtype must be SH_UNET_F32 or SH_UNET_BF16");
   if (p->bone_kind != SH_BONE_HUMERUS && p->bone_kind != SH_BONE_PROXIMAL) return fail(c, SH_ERR_ARG, "bone_kind must be SH_BONE_HUMERUS or SH_BONE_PROXIMAL");
   if (c->prep.active && p->bone_kind != c->params.bone_kind) (void)join_prepared(c);
   c->params = *p;

@@ -87,3 +87,23 @@ def test_failed_run_in_a_lane_does_not_wedge_the_other(oracle_bones):
     finally:
         for e in lanes:
             e.close()
+
+
+def test_parameter_ranges(engine, oracle_bones):
+    """sh_set_params refuses values the kernels (and the reference) cannot index with: a groove window beyond half a turn used
+    to run the local-minimum search off the 512-sample row (a GPU memory fault at 1e9 degrees); NaN, negatives, unknown
+    enumerators and cut-offs outside [0, 1] are argument errors.  Legal extremes run."""
+    h = oracle_bones("humerus_left")
+    engine.upload([(h.verts, h.faces)])
+    try:
+        for bad in (dict(groove_deg_window=1e9), dict(groove_deg_window=float("nan")), dict(groove_deg_window=-1.0), dict(groove_deg_window=181.0),
+                    dict(unet_dtype=7), dict(bone_kind=3), dict(canal_cutoff=(float("nan"), 0.75)), dict(canal_cutoff=(-0.1, 0.75)),
+                    dict(canal_cutoff=(0.75, 0.35)), dict(groove_cutoff=(0.1, 0.9))):
+            with pytest.raises(ShoulderHipError) as err:
+                engine.set_params(**bad)
+            assert err.value.code == -1, bad
+        for ok in (dict(groove_deg_window=0.0), dict(groove_deg_window=180.0), dict(canal_cutoff=(0.0, 1.0)), dict(canal_cutoff=(0.5, 0.52))):
+            engine.set_params(**ok)
+            assert engine.run(_lib.STAGE_ALL)["status"][0] == 0, ok
+    finally:
+        engine.set_params()
