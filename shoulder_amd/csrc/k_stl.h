@@ -22,7 +22,7 @@ __device__ inline unsigned stl_hash3(unsigned x, unsigned y, unsigned z) {
 }
 
 __global__ void k_stl_corners(const unsigned char* __restrict__ raw, const long long* __restrict__ file_off, const long long* __restrict__ coff,
-                              float* __restrict__ corners) {
+                              float* __restrict__ corners, int* __restrict__ nonfinite /* [B]: set when a coordinate is NaN / inf */) {
   const int b = blockIdx.y;
   const long long c0 = coff[b], n = coff[b + 1] - c0;
   const unsigned short* base = (const unsigned short*)(raw + file_off[b] + 84);      // file starts are 4-byte aligned, 84 + 50 t + 12 is even
@@ -35,6 +35,7 @@ __global__ void k_stl_corners(const unsigned char* __restrict__ raw, const long 
     for (int k = 0; k < 3; ++k) {
       const unsigned u = (unsigned)p[2 * k] | ((unsigned)p[2 * k + 1] << 16);
       o[k] = __uint_as_float(u) + 0.0f;      // -0.0 -> +0.0: equal values share one bit pattern
+      if ((u & 0x7f800000u) == 0x7f800000u) atomicOr(&nonfinite[b], 1);
     }
   }
 }

@@ -424,6 +424,8 @@ int sh_upload_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const 
     for (long long i = 3 * f_off[b]; i < 3 * f_off[b + 1]; ++i)
       if (faces[i] < 0 || faces[i] >= nv) return fail(c, SH_ERR_ARG, "sh_upload_meshes: face index out of range");
   }
+  for (long long i = 0; i < 3 * c->sumV; ++i)
+    if (!std::isfinite(verts[i])) return fail(c, SH_ERR_ARG, "sh_upload_meshes: NaN / infinite vertex coordinate");
   c->B = B;
   c->h_verts.assign(verts, verts + 3 * c->sumV);
   c->h_verts_valid = true;
@@ -471,6 +473,9 @@ int sh_upload_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int
   if ((rc = ensure(c, "stl.vid", (size_t)sumC * 4, 4)) != SH_OK) return rc;
   if ((rc = ensure(c, "stl.fpos", (size_t)(sumC / 3) * 4, 4)) != SH_OK) return rc;
   if ((rc = ensure(c, "stl.counts", (size_t)B * 8, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "stl.nonfinite", (size_t)B * 4, 4)) != SH_OK) return rc;
+  c->bufs["stl.nonfinite"].per_mesh = 0;
+  HIPCHK(c, hipMemsetAsync(c->bufs["stl.nonfinite"].p, 0, (size_t)B * 4, c->stream));
   for (const char* nm : {"stl.raw", "stl.file_off", "stl.coff", "stl.corners", "stl.table", "stl.slot", "stl.vid", "stl.fpos", "stl.counts"}) c->bufs[nm].per_mesh = 0;
   c->b0 = 0;
   unsigned char* raw = buf<unsigned char>(c, "stl.raw");
@@ -478,17 +483,19 @@ int sh_upload_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int
   HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "stl.file_off"), file_off.data(), (B + 1) * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "stl.coff"), coff.data(), (B + 1) * 8, hipMemcpyHostToDevice, c->stream));
   const dim3 gc((unsigned)std::min<long long>((maxc + 255) / 256, 1024), (unsigned)B);
-  LAUNCH(c, "k_stl_corners", k_stl_corners, gc, dim3(256), raw, buf<long long>(c, "stl.file_off"), buf<long long>(c, "stl.coff"), buf<float>(c, "stl.corners"));
+  LAUNCH(c, "k_stl_corners", k_stl_corners, gc, dim3(256), raw, buf<long long>(c, "stl.file_off"), buf<long long>(c, "stl.coff"), buf<float>(c, "stl.corners"), (int*)c->bufs["stl.nonfinite"].p);
   LAUNCH(c, "k_stl_table_init", k_stl_table_init, dim3(1024), dim3(256), buf<int2>(c, "stl.table"), (size_t)B * tsize);
   LAUNCH(c, "k_stl_hash", k_stl_hash, gc, dim3(256), buf<float>(c, "stl.corners"), buf<long long>(c, "stl.coff"), buf<int2>(c, "stl.table"), tsize, buf<int>(c, "stl.slot"));
   LAUNCH(c, "k_stl_rank", k_stl_rank, dim3(B), dim3(SH_STL_SCAN_THREADS), buf<long long>(c, "stl.coff"), buf<int2>(c, "stl.table"), tsize, buf<int>(c, "stl.slot"),
          buf<int>(c, "stl.vid"), buf<int>(c, "stl.fpos"), buf<int>(c, "stl.counts"));
-  std::vector<int> counts(2 * B);
+  std::vector<int> counts(2 * B), nonfin(B);
   HIPCHK(c, hipMemcpyAsync(counts.data(), buf<int>(c, "stl.counts"), (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(nonfin.data(), c->bufs["stl.nonfinite"].p, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->h_voff.assign(B + 1, 0); c->h_foff.assign(B + 1, 0);
   c->maxV = c->maxF = 0;
   for (int b = 0; b < B; ++b) {
+    if (nonfin[b]) return fail(c, SH_ERR_ARG, "sh_upload_stl: a file holds NaN / infinite coordinates");
     if (counts[2 * b] < 4 || counts[2 * b + 1] < 4) return fail(c, SH_ERR_ARG, "sh_upload_stl: a mesh has fewer than 4 vertices/faces after merging");
     c->h_voff[b + 1] = c->h_voff[b] + counts[2 * b];
     c->h_foff[b + 1] = c->h_foff[b] + counts[2 * b + 1];

@@ -1,5 +1,7 @@
 """Failure behaviour through the C-ABI: bad input is rejected with an error code and message, degenerate
 geometry is reported per mesh -- nothing aborts, nothing silently falls back."""
+import os
+
 import numpy as np
 import pytest
 
@@ -107,3 +109,22 @@ def test_parameter_ranges(engine, oracle_bones):
             assert engine.run(_lib.STAGE_ALL)["status"][0] == 0, ok
     finally:
         engine.set_params()
+
+
+def test_non_finite_coordinates_are_refused(engine, oracle_bones, tmp_path):
+    """NaN / inf vertices never reach the kernels: sh_upload_meshes checks the host array, sh_upload_stl flags them while parsing."""
+    import bench
+    h = oracle_bones("humerus_left")
+    for badval in (np.nan, np.inf, -np.inf):
+        v = h.verts.copy()
+        v[1234, 1] = badval
+        with pytest.raises(ShoulderHipError) as err:
+            engine.upload([(v, h.faces)])
+        assert err.value.code == -1
+        p = tmp_path / "bad.stl"
+        p.write_bytes(bench.stl_bytes(v, h.faces))
+        with pytest.raises(ShoulderHipError) as err:
+            engine.upload_stl([os.path.join(os.path.dirname(__file__), "golden", "bones", "humerus_right.stl"), str(p)])
+        assert err.value.code == -1 and "NaN" in str(err.value)
+    engine.upload([(h.verts, h.faces)])
+    assert engine.run(_lib.STAGE_ALL)["status"][0] == 0
