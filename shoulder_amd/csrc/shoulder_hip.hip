@@ -1613,6 +1613,19 @@ int sh_load_rfc(sh_ctx* c, const int32_t* feat, const float* thr, const int32_t*
     if ((ti[i] < 0) != (fi[i] < 0) || ti[i] >= n_nodes || fi[i] >= n_nodes) return fail(c, SH_ERR_ARG, "sh_load_rfc: bad child index");
   }
   for (int t = 0; t < n_trees; ++t) if (roots[t] < 0 || roots[t] >= n_nodes) return fail(c, SH_ERR_ARG, "sh_load_rfc: bad root");
+  {      // the walk on the device loops until it meets a leaf: every node must be reached once at most (a forest, no cycle)
+    std::vector<char> seen(n_nodes, 0);
+    std::vector<int> stack;
+    for (int t = 0; t < n_trees; ++t) {
+      stack.push_back(roots[t]);
+      while (!stack.empty()) {
+        const int i = stack.back(); stack.pop_back();
+        if (seen[i]) return fail(c, SH_ERR_ARG, "sh_load_rfc: the node tables do not describe a forest (a node is reachable twice)");
+        seen[i] = 1;
+        if (ti[i] >= 0) { stack.push_back(ti[i]); stack.push_back(fi[i]); }
+      }
+    }
+  }
   HIPCHK(c, hipSetDevice(c->device));
   c->h_feat.assign(feat, feat + n_nodes); c->h_thr.assign(thr, thr + n_nodes); c->h_ti.assign(ti, ti + n_nodes);
   c->h_fi.assign(fi, fi + n_nodes); c->h_lw.assign(lw, lw + n_nodes); c->h_roots.assign(roots, roots + n_trees);

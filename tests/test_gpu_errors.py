@@ -128,3 +128,30 @@ def test_non_finite_coordinates_are_refused(engine, oracle_bones, tmp_path):
         assert err.value.code == -1 and "NaN" in str(err.value)
     engine.upload([(h.verts, h.faces)])
     assert engine.run(_lib.STAGE_ALL)["status"][0] == 0
+
+
+def test_malformed_forest_is_refused(tmp_path):
+    """The forest walk on the device loops until it meets a leaf, so sh_load_rfc must not accept tables with a cycle or a shared
+    subtree; the shipped tables load."""
+    from shoulder_amd.engine import Engine
+    models = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "shoulder_amd", "models", "rfc_bg3.npz")
+    z = dict(np.load(models))
+    e = Engine(0)
+    try:
+        e.load_rfc()
+        branch = np.nonzero(z["true_idx"] >= 0)[0]
+        bad = dict(z)
+        bad["true_idx"] = z["true_idx"].copy()
+        bad["true_idx"][branch[5]] = z["roots"][0]                      # a branch points back at its root: a cycle
+        p = tmp_path / "cyclic.npz"
+        np.savez(p, **bad)
+        with pytest.raises(ShoulderHipError) as err:
+            e.load_rfc(str(p))
+        assert err.value.code == -1 and "forest" in str(err.value)
+        bad["true_idx"] = z["true_idx"].copy()
+        bad["true_idx"][branch[7]] = len(z["feat"]) + 3                  # out of range
+        np.savez(p, **bad)
+        with pytest.raises(ShoulderHipError):
+            e.load_rfc(str(p))
+    finally:
+        e.close()
