@@ -38,6 +38,14 @@ def _ptr(a):
     return ctypes.c_void_p(a.ctypes.data)
 
 
+def _mat4(T):
+    """a C-contiguous float64 4x4 (the C side reads 16 doubles); anything else is the reference's ValueError (base.py:57-58)"""
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    if T.shape != (4, 4):
+        raise ValueError("Invalid transformation matrix shape")
+    return T
+
+
 class Engine:
     def __init__(self, device=0, stream=None):
         self.L = _lib.load()
@@ -47,6 +55,7 @@ class Engine:
             raise ShoulderHipError(rc, f"sh_ctx_create(device={device}) failed (is a HIP device visible?)")
         self.h = h
         self.device = device
+        self._inflight, self._pin_slot = [], 0
 
     def close(self):
         if getattr(self, "h", None):
@@ -105,6 +114,8 @@ class Engine:
     # ---- meshes ----------------------------------------------------------------------------------
     def upload(self, meshes):
         """meshes: list of (verts float32 (V,3), faces int32 (F,3))."""
+        if len(meshes) == 0:
+            raise ValueError("upload() needs at least one mesh")
         verts = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float32).reshape(-1, 3) for v, _ in meshes]))
         faces = np.ascontiguousarray(np.concatenate([np.asarray(f, dtype=np.int32).reshape(-1, 3) for _, f in meshes]))
         voff = np.zeros(len(meshes) + 1, dtype=np.int64)
@@ -155,8 +166,6 @@ class Engine:
         device; out_ptr: raw address of B records of page-locked host or DEVICE memory (e.g. a gather's send buffer)."""
         if fetch not in ("view", False):
             raise ValueError('submit(fetch=...) takes "view" or False')
-        if not hasattr(self, "_inflight"):
-            self._inflight, self._pin_slot = [], 0
         out = None
         if out_ptr is not None:
             ptr = ctypes.c_void_p(int(out_ptr))
@@ -174,7 +183,7 @@ class Engine:
             raise
 
     def collect(self):
-        out = self._inflight.pop(0)
+        out = self._inflight.pop(0) if self._inflight else None      # (nothing in flight: sh_collect reports it)
         self._chk(self.L.sh_collect(self.h))
         return out
 
@@ -202,7 +211,9 @@ class Engine:
         return p.value, n.value
 
     def mesh_transformed(self, b, T):
-        T = np.ascontiguousarray(T, dtype=np.float64)
+        T = _mat4(T)
+        if not 0 <= int(b) < len(self.voff) - 1:
+            raise IndexError("mesh index out of range")
         out = np.empty((int(self.voff[b + 1] - self.voff[b]), 3), dtype=np.float64)
         self._chk(self.L.sh_mesh_transformed(self.h, int(b), _ptr(T), _ptr(out)))
         return out
@@ -210,7 +221,7 @@ class Engine:
     def transform_points(self, pts, T):
         """utils.transform_pts on the device: (n,3) float64 host points -> (n,3)."""
         pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
-        T = np.ascontiguousarray(T, dtype=np.float64)
+        T = _mat4(T)
         out = np.empty_like(pts)
         self._chk(self.L.sh_transform_points(self.h, _ptr(T), _ptr(pts), len(pts), _ptr(out)))
         return out

@@ -155,3 +155,23 @@ def test_malformed_forest_is_refused(tmp_path):
             e.load_rfc(str(p))
     finally:
         e.close()
+
+
+def test_wrapper_argument_checks(engine, oracle_bones):
+    """The Python side hands the C-ABI only arrays of the size it will read: a 3x3 'transform' is the reference's ValueError, not an
+    out-of-bounds host read; an empty mesh list and a collect() with nothing in flight are errors too."""
+    h = oracle_bones("humerus_left")
+    engine.upload([(h.verts, h.faces)])
+    with pytest.raises(ValueError, match="Invalid transformation matrix shape"):
+        engine.mesh_transformed(0, np.zeros((3, 3)))
+    with pytest.raises(ValueError, match="Invalid transformation matrix shape"):
+        engine.transform_points(np.zeros((4, 3)), np.identity(3))
+    with pytest.raises(IndexError):
+        engine.mesh_transformed(3, np.identity(4))
+    with pytest.raises(ValueError):
+        engine.upload([])
+    with pytest.raises(ShoulderHipError) as err:
+        engine.collect()
+    assert err.value.code == -3
+    assert engine.transform_points(np.zeros((0, 3)), np.identity(4)).shape == (0, 3)
+    assert engine.run(_lib.STAGE_ALL)["status"][0] == 0
