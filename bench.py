@@ -99,15 +99,62 @@ def geom_bytes(B, V, F):
     }
 
 
+UNET_ENUM = {"f32": 0, "bf16": 1, "f16": 2}
+
+
+def sym_key(name, unet, cout, fused_net=True):
+    """Kernel symbol (as rocprofv3 --stats groups launches) of UNet layer `name`; element type spelled bf16 / f16 / f32."""
+    if name in ("unet.head", "unet.enc0a", "unet.pool"):
+        return name
+    nt = 4 if cout % 64 == 0 else 2
+    up = name.startswith("unet.up")
+    if unet == "f32":
+        return "k_conv_mfma_f32<%d,%d>" % (1 if up else 9, nt)
+    # third template argument = fused ends (k_unet_bf16.h): UF_FIRST 1, UF_HEAD 2, UF_POOL 4
+    fuse = 5 if name == "unet.enc0b" else 2 if name == "unet.dec0b" else 4 if name in ("unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
+    if not fused_net:
+        fuse = 0
+    dma = (not up and not (fuse & 1) and os.environ.get("SHOULDER_UNET_DMA") != "0" and (cout % 64 == 0 or os.environ.get("SHOULDER_UNET_DMA32") != "0"))
+    if dma:
+        return "k_conv3_dma16<%s,%d,%d>" % (unet, fuse, nt)      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h)
+    return "k_conv_mfma16<%s,%d,%d,%d>" % (unet, 1 if up else 9, nt, fuse)
+
+
+def rocprof_name(key):
+    """bench symbol key -> the kernel name rocprofv3 prints (profiles/*.json are keyed by it)."""
+    return "sh::" + key.replace("<bf16,", "<__bf16, ").replace("<f16,", "<_Float16, ").replace(",", ", ").replace(",  ", ", ")
+
+
+def host_info():
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "affinity_cores": len(os.sched_getaffinity(0))}
+
+
+def hull_threads(world_local):
+    """What hull_host_phase (shoulder_hip.hip) will use per context: hardware threads / LOCAL_WORLD_SIZE, at most 32."""
+    if os.environ.get("SHOULDER_HULL_THREADS"):
+        return int(os.environ["SHOULDER_HULL_THREADS"])
+    return max(1, min(32, (os.cpu_count() or 1) // max(1, world_local)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="humeri per GPU per step")
-    ap.add_argument("--unet", choices=["f32", "bf16"], default="bf16",
-                    help="UNet arithmetic: bf16 = BASELINE configs[2]/[3] (throughput), f32 = configs[1] parity path (bit-exact vs the oracle)")
+    ap.add_argument("--unet", choices=["f32", "bf16", "f16"], default="bf16",
+                    help="UNet arithmetic of the headline leg: bf16 = BASELINE configs[2]/[3] (throughput), f16 = configs[4]'s element type, "
+                         "f32 = configs[1] parity path (bit-exact vs the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32-UNet leg and the one-lane leg that follow the headline leg at N=1")
     ap.add_argument("--cpu-meshes", type=int, default=4, help="humeri of the batch the single-core oracle leg processes")
     ap.add_argument("--cpu-pool", type=int, default=-1, help="worker processes of the pooled oracle leg (one humerus each); -1 = host cores of this process, at most 16; 0 = skip")
     ap.add_argument("--no-pipeline", action="store_true", help="wait for every step before enqueueing the next one (sh_run instead of sh_submit / sh_collect)")
@@ -116,6 +163,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not compute the host hulls of step k+1 during the device work of step k")
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     ap.add_argument("--from-stl", action="store_true", help="every step starts from the bytes of B binary STL files (device-side parse + vertex merge, sh_upload_stl)")
+    ap.add_argument("--check-gather", action="store_true", help="after the timed region rank 0 compares the records the last gather delivered for its own shard with a run of its own engine")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,8 +216,9 @@ def main():
         for e in engs[1:]:                                                          # the other lanes copy the block device to device
             shd.as_byte_tensor(e.param_block(), device=f"cuda:{local}").copy_(src_blk)
         torch.cuda.synchronize()
+        for e in engs:
+            e.param_block_commit()      # host mirrors follow the device block (a later sh_load_* re-uploads from them)
     for e in engs:
-        e.set_params(unet_dtype=_lib.UNET_BF16 if args.unet == "bf16" else _lib.UNET_F32)
         e.set_unet_turns(lanes > 1 and os.environ.get("SH_BENCH_NO_TURNS") != "1")
 
     T = synth.similarity_transforms(B, verts, seed=1234, start=rank * B)
@@ -194,7 +243,8 @@ def main():
     # pipelined schedule: every run copies its records (device to device, on its engine's stream) into one of the send buffers
     nsend = 2 * lanes
     send = [torch.empty_like(lm_t) for _ in range(nsend)] if use_dist else None
-    pipelined = not args.no_pipeline
+    send_free = [None] * nsend      # event recorded behind the gather that last read send[k]
+    overlap = not args.no_overlap and host_batch is None
 
     def hand_over(e):      # the PCIe-inclusive variants give every step its batch again (a new batch voids prepared hulls)
         if stl_blobs is not None:
@@ -202,97 +252,143 @@ def main():
         elif host_batch is not None:
             e.upload(host_batch)
 
-    def step():
-        if stl_blobs is not None:
-            eng.upload_stl(stl_blobs)
-        elif host_batch is not None:
-            eng.upload(host_batch)
-        eng.run(_lib.STAGE_ALL, fetch=False if use_dist else "view")      # records land in the engine's page-locked buffer (or are gathered device to device)
+    def run_leg(leg_engs, unet, steps, warmup, pipelined):
+        """`warmup` untimed steps, then exactly `steps` timed steps of SH_STAGE_ALL on `leg_engs` (step s on lane s % len),
+        bracketed by barrier + synchronize on both sides.  -> (seconds: max over ranks, per-layer HIP-event times of the region)."""
+        nl = len(leg_engs)
+        for e in leg_engs:
+            e.set_params(unet_dtype=UNET_ENUM[unet])
+            e.set_overlap(False)
+        for w_ in range(warmup):
+            for e in (leg_engs if w_ == 0 else leg_engs[:1]):      # every lane's scratch is allocated before t0
+                hand_over(e)
+                e.run(_lib.STAGE_ALL, fetch=False)
+            if use_dist:
+                dist.gather(lm_t, gather_list, dst=0)
+        # HIP events around the UNet layers only inside the timed region (level 2): the dominant kernel is one of them, and
+        # events around all ~150 launches of a step stretch the step by ~0.7 ms.  The other kernels are timed in one extra
+        # pass after the region (level 1).
+        for e in leg_engs:
+            e.enable_timing(2)
+            e.reset_timers()
+        # Streaming schedule: inside the timed region the hulls of step k+1 are computed by host threads while the device
+        # works on step k.  Nothing is carried in from the warmup (discard) and nothing is prepared for a step K+1 (overlap
+        # off before the last step): K hull passes and K device passes lie between t0 and t1.
+        for e in leg_engs:
+            e.discard_prepared()
+            e.set_overlap(overlap)
         if use_dist:
-            dist.gather(lm_t, gather_list, dst=0)      # landmark records of every rank to rank 0 (device to device)
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if pipelined:
+            # Steps in flight: step s is enqueued (sh_submit) on lane s % lanes while the steps before it still execute, so the
+            # device goes from one step to the next without waiting for the host and the lanes' streams overlap; the records of a
+            # step are collected (and gathered) once `depth` later steps are enqueued.  All K submits and all K collects lie
+            # inside the timed region.
+            depth = nl if nl > 1 else 2
+            pend = []
 
-    overlap = not args.no_overlap and host_batch is None
-    for _ in range(args.warmup):
-        step()
-        for e in engs[1:]:
-            e.run(_lib.STAGE_ALL, fetch=False)
-    # HIP events around the UNet layers only inside the timed region (level 2): the dominant kernel is one of them, and
-    # events around all ~150 launches of a step stretch the step by ~0.7 ms.  The other kernels are timed in one extra
-    # pass after the region (level 1).
-    for e in engs:
-        e.enable_timing(2)
-        e.reset_timers()
-    # Streaming schedule: inside the timed region the hulls of step k+1 are computed by host threads while the device
-    # works on step k.  Nothing is carried in from the warmup (discard) and nothing is prepared for a step K+1 (overlap
-    # off before the last step): K hull passes and K device passes lie between t0 and t1.
-    for e in engs:
-        e.discard_prepared()
-        e.set_overlap(overlap)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if pipelined:
-        # Steps in flight: step s is enqueued (sh_submit) on lane s % lanes while the steps before it still execute, so the
-        # device goes from one step to the next without waiting for the host and the lanes' streams overlap; the records of a
-        # step are collected (and gathered) once `depth` later steps are enqueued.  All K submits and all K collects lie
-        # inside the timed region.
-        depth = lanes if lanes > 1 else 2
-        pend = []
+            def finish(k, e):
+                e.collect()
+                if use_dist:
+                    # asynchronous on the host: the gather is enqueued on torch's stream behind the finished run (collect waited
+                    # for its event) and an event behind it says when send[k] may be overwritten -- the host goes straight on
+                    # to the next submit, the ranks are coupled on the device side only
+                    dist.gather(send[k % nsend], gather_list, dst=0)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    send_free[k % nsend] = ev
+            for s_ in range(steps):
+                e = leg_engs[s_ % nl]
+                if steps - s_ <= nl:
+                    e.set_overlap(False)                           # the last step of a lane prepares nothing
+                if len(pend) >= depth:
+                    finish(*pend.pop(0))
+                hand_over(e)       # (the lane is idle here: its previous step was collected above)
+                if use_dist:
+                    if send_free[s_ % nsend] is not None:
+                        send_free[s_ % nsend].synchronize()       # (2 * lanes steps old: long done)
+                    e.submit(_lib.STAGE_ALL, fetch=False, out_ptr=send[s_ % nsend].data_ptr())
+                else:
+                    e.submit(_lib.STAGE_ALL, fetch="view")
+                pend.append((s_, e))
+            for k_e in pend:
+                finish(*k_e)
+        else:
+            e = leg_engs[0]
+            for s_ in range(steps):
+                if s_ == steps - 1:
+                    e.set_overlap(False)
+                hand_over(e)
+                e.run(_lib.STAGE_ALL, fetch=False if use_dist else "view")      # records land in the engine's page-locked buffer (or are gathered device to device)
+                if use_dist:
+                    dist.gather(lm_t, gather_list, dst=0)      # landmark records of every rank to rank 0 (device to device)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        ul_ = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512, eb=4 if unet == "f32" else 2)
 
-        def finish(k, e):
-            e.collect()
-            if use_dist:
-                dist.gather(send[k % nsend], gather_list, dst=0)
-                torch.cuda.current_stream().synchronize()      # the send buffer is free before a later step reuses it
-        for s_ in range(args.steps):
-            e = engs[s_ % lanes]
-            if args.steps - s_ <= lanes:
-                e.set_overlap(False)                           # the last step of a lane prepares nothing
-            if len(pend) >= depth:
-                finish(*pend.pop(0))
-            hand_over(e)       # (the lane is idle here: its previous step was collected above)
-            if use_dist:
-                e.submit(_lib.STAGE_ALL, fetch=False, out_ptr=send[s_ % nsend].data_ptr())
-            else:
-                e.submit(_lib.STAGE_ALL, fetch="view")
-            pend.append((s_, e))
-        for k_e in pend:
-            finish(*k_e)
-    else:
-        for s_ in range(args.steps):
-            if s_ == args.steps - 1:
-                eng.set_overlap(False)
-            step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-    ul = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512, eb=2 if args.unet == "bf16" else 4)
-    def merged(name):       # (average ms, launches) over all lanes
-        parts = [e.kernel_time_ms(name) for e in engs]
-        n = sum(p[1] for p in parts)
-        return (sum(p[0] * p[1] for p in parts) / n if n else 0.0, n)
-    region_times = {name: merged(name) for name in list(ul) + ["unet.pool", "host.verts_d2h", "host.hull"]}
-    for e in engs:
-        e.reset_timers()
-        e.enable_timing(0)
+        def merged(name):       # (average ms, launches) over all lanes
+            parts = [e.kernel_time_ms(name) for e in leg_engs]
+            n = sum(p[1] for p in parts)
+            return (sum(p[0] * p[1] for p in parts) / n if n else 0.0, n)
+        region = {name: merged(name) for name in list(ul_) + ["unet.pool", "host.verts_d2h", "host.hull"]}
+        for e in leg_engs:
+            e.reset_timers()
+            e.enable_timing(0)
+        return el, region, ul_
+
+    pipelined = not args.no_pipeline
+    el, region_times, ul = run_leg(engs, args.unet, args.steps, args.warmup, pipelined)
+
     eng.enable_timing(1)
     eng.run(_lib.STAGE_ALL, fetch=False)      # profiling pass outside the timed region, one lane alone: every kernel between events
     extra_times = {name: eng.kernel_time_ms(name) for name in GEOM_KERNELS + ["k_synth_batch", "k_pack_w_bf16"]}
     alone_times = {name: eng.kernel_time_ms(name) for name in ul}
     eng.enable_timing(0)
 
+    gather_check = None
     if use_dist and rank == 0:      # what rank 0 holds after the last gather: every rank's records, in rank order
         lm = torch.cat(gather_list).cpu().numpy().view(_lib.LANDMARKS_DTYPE)
         assert len(lm) == world * B
+        if args.check_gather:
+            own = eng.run(_lib.STAGE_ALL)
+            gather_check = {"records": int(len(lm)), "own_shard_equal_to_local_run": bool(lm[:B].tobytes() == own.tobytes())}
     else:
         lm = eng.run(_lib.STAGE_ALL)
     n_bad = int((lm["status"] != 0).sum())
+
+    # Extra legs, N=1 only (the driver's SCALE runs keep to the headline leg): the tolerance-conformant configuration -- f32
+    # UNet, landmarks within 1e-4 mm of the oracle (tests/test_gpu_end_to_end.py) -- timed by the same protocol in the same
+    # invocation, and the headline configuration on ONE lane (what a caller without the two-context schedule gets).
+    extra = {}
+    if world == 1 and not use_dist and not args.no_extra_legs and host_batch is None:
+        k32 = max(3, min(args.steps, 10))
+        el32, reg32, ul32 = run_leg(engs, "f32", k32, 1, pipelined)
+        c32 = unet_couts(unet_spec.BASE, unet_spec.DEPTH)
+        g = {}
+        for name, (ms, n) in reg32.items():
+            if name in ul32 and n and name not in ("unet.head", "unet.enc0a"):
+                a = g.setdefault(sym_key(name, "f32", c32[name]), [0.0, 0.0, 0])
+                a[0] += ms * n; a[1] += ul32[name][0] * B * n; a[2] += n
+        dom32 = max(g, key=lambda k: g[k][0]) if g else None
+        extra["f32_unet"] = {"value": round(B * k32 / el32, 3), "unit": "meshes/s", "steps": k32, "warmup": 1, "ms_per_step": round(1e3 * el32 / k32, 3),
+                             "dtype": "f64 geometry + f32 UNet", "lanes": lanes,
+                             "parity": "landmarks within 1e-4 mm of the oracle, f32 logits bit-exact (tests/test_gpu_end_to_end.py, test_gpu_landmarks.py)"}
+        if dom32:
+            ach = g[dom32][1] / (g[dom32][0] * 1e-3) / 1e12
+            extra["f32_unet"]["roofline"] = {"bound": "mfma", "kernel": dom32, "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s",
+                                             "frac": round(ach / PEAK_MFMA_F32_TF, 4), "avg_ms": round(g[dom32][0] / g[dom32][2], 4), "launches": g[dom32][2]}
+        if lanes > 1:
+            el1, _, _ = run_leg(engs[:1], args.unet, args.steps, 1, pipelined)
+            extra["one_lane"] = {"value": round(B * args.steps / el1, 3), "unit": "meshes/s", "steps": args.steps, "warmup": 1,
+                                 "ms_per_step": round(1e3 * el1 / args.steps, 3), "lanes": 1}
 
     if rank == 0:
         ul_cout = unet_couts(unet_spec.BASE, unet_spec.DEPTH)
@@ -307,21 +403,10 @@ def main():
             if n:
                 times[name] = (ms, n * args.steps)
         total_dev = sum(ms * n for ms, n in times.values())
-        # group the launches by kernel symbol (what rocprofv3 --stats reports): the UNet layers run one of
-        # four instantiations of k_conv_mfma_f32<TAPS, NT>
+        # group the launches by kernel symbol (what rocprofv3 --stats reports)
         sym, sym_of = {}, {}
         for name, (ms, n) in times.items():
-            if name in ul and name not in ("unet.head", "unet.enc0a"):
-                cout = ul_cout[name]
-                key = "k_conv_mfma_%s<%d,%d>" % (args.unet, 1 if name.startswith("unet.up") else 9, 4 if cout % 64 == 0 else 2)
-                if args.unet == "bf16":      # third template argument = fused ends (k_unet_bf16.h): UF_FIRST 1, UF_HEAD 2, UF_POOL 4
-                    fuse = 5 if name == "unet.enc0b" else 2 if name == "unet.dec0b" else 4 if name in ("unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
-                    key = key[:-1] + ",%d>" % fuse
-                    if not name.startswith("unet.up") and not (fuse & 1) and os.environ.get("SHOULDER_UNET_DMA") != "0" and \
-                            (cout % 64 == 0 or os.environ.get("SHOULDER_UNET_DMA32") != "0"):
-                        key = "k_conv3_dma_bf16<%d,%d>" % (fuse, 4 if cout % 64 == 0 else 2)      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h)
-            else:
-                key = name
+            key = sym_key(name, args.unet, ul_cout[name]) if (name in ul and name in ul_cout) else name
             sym_of[name] = key
             g = sym.setdefault(key, dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
             g["ms"] += ms * n
@@ -337,7 +422,7 @@ def main():
             g = sym[dom]
             common = dict(kernel=dom, avg_ms=round(g["ms"] / g["n"], 4), launches=g["n"], share_of_device_time=round(g["ms"] / total_dev, 3), traffic=None)
             if g["flops"] > 0:
-                peak = PEAK_MFMA_BF16_TF if args.unet == "bf16" else PEAK_MFMA_F32_TF
+                peak = PEAK_MFMA_F32_TF if args.unet == "f32" else PEAK_MFMA_BF16_TF
                 ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
                 roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                             algorithmic_gbytes_per_launch=round(g["bytes"] / g["n"] / 1e9, 4), **common)
@@ -353,34 +438,53 @@ def main():
             else:
                 ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
                 roof = dict(bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), **common)
-        # HBM traffic of the dominant kernel from the committed PMC profile of this same command (rocprofv3 cannot
-        # run inside the bench); null when no profile matches the configuration
+        # HBM traffic and MFMA-busy fraction of the dominant kernel from the committed PMC profiles of this same command
+        # (rocprofv3 cannot run inside the bench); null when no profile matches the configuration
         if roof:
-            pmc_path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{B}_{args.unet}.json")
-            if os.path.exists(pmc_path):
-                pk = json.load(open(pmc_path))["kernels"]
-                key = "sh::" + dom.replace(",", ", ") if dom.startswith("k_conv") else "sh::" + dom
-                if key in pk:
-                    roof["traffic"] = pk[key]["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = os.path.relpath(pmc_path, ROOT)
+            for rnd in ("r02", "r01"):
+                pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b{B}_{args.unet}.json")
+                if os.path.exists(pmc_path):
+                    pk = json.load(open(pmc_path))["kernels"]
+                    key = rocprof_name(dom)
+                    if key in pk:
+                        roof["traffic"] = pk[key]["hbm_bytes_per_launch"]
+                        roof["traffic_source"] = os.path.relpath(pmc_path, ROOT)
+                        break
+            sq_path = os.path.join(ROOT, "profiles", f"r02_pmc_sq_b{B}_{args.unet}.json")
+            if os.path.exists(sq_path):
+                pk = json.load(open(sq_path))["kernels"]
+                key = rocprof_name(dom)
+                if key in pk and "mfma_busy_frac" in pk[key]:
+                    roof["mfma_busy_frac"] = pk[key]["mfma_busy_frac"]
+                    roof["mfma_busy_source"] = os.path.relpath(sq_path, ROOT)
         unet_ms = sum(times[k][0] for k in times if k.startswith("unet."))
         unet_tf = sum(v[0] for v in ul.values()) * B / (unet_ms * 1e-3) / 1e12 if unet_ms else None
         top = sorted(((k, round(v["ms"] / args.steps, 3)) for k, v in sym.items()), key=lambda kv: -kv[1])[:10]
+        # per-kernel table of the geometry stage: algorithmic bytes (geom_bytes) / average duration vs the 8 TB/s roof
+        geom_tab = {}
+        for name, (ms, n) in extra_times.items():
+            if n and name in gb and ms > 0:
+                gbs = gb[name] / (ms * 1e-3) / 1e9
+                geom_tab[name] = {"avg_ms": round(ms, 4), "algorithmic_mb": round(gb[name] / 1e6, 2), "gb_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4)}
 
         value = world * B * args.steps / el
         out = {"metric": "humerus meshes/s end-to-end (all 4 landmarks)", "value": round(value, 3), "unit": "meshes/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry + " + ("bf16" if args.unet == "bf16" else "f32") + " UNet",
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64 geometry + " + args.unet + " UNet",
                "data": "synthetic (similarity copies of humerus_left.stl, seed 1234; seeded teacher UNet weights)",
-               "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: batch {B} synthetic humeri per GPU, all stages (SH_STAGE_ALL)",
+               "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: batch {B} synthetic humeri per GPU, all stages (SH_STAGE_ALL incl. the batch's apply_csys)",
                           "batch_per_gpu": B, "global_batch": B * world, "vertices": V, "triangles": F, "unet": f"base{unet_spec.BASE} depth{unet_spec.DEPTH} 512x512",
                           "parallelism": f"dp{world}", "input": "binary STL bytes every step (device parse + merge, PCIe inclusive)" if args.from_stl else "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM",
-                          "lanes": lanes,
+                          "lanes": lanes, "hull_threads_per_context": hull_threads(int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), "host": host_info(),
                           "schedule": ((f"{lanes} engine contexts per GPU, step s on lane s % {lanes}, their streams overlap on the device (sh_submit / sh_collect); " if lanes > 1 else "two steps in flight (sh_submit / sh_collect); ") if pipelined else "") + ("host hulls of step k+1 overlap the device work of step k; pipeline filled and drained inside the timed region" if overlap else "serial hulls"),
                           "meshes_with_error_status": n_bad},
-               "roofline": roof, "cpu_baseline": cpu,
-               "unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top,
-               "device_ms_per_step_total": round(total_dev / args.steps, 3), "host_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()}}
+               "roofline": roof, "cpu_baseline": cpu}
+        out.update(extra)
+        if gather_check is not None:
+            out["gather_check"] = gather_check
+        out.update({"unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top,
+                    "device_ms_per_step_total": round(total_dev / args.steps, 3), "host_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()},
+                    "geometry_kernels": geom_tab})
         print(json.dumps(out))
     for e in engs:
         e.close()
@@ -430,6 +534,7 @@ def cpu_baseline(verts, faces, T, weights, n_meshes, pool):
     el = time.perf_counter() - t0
     out = {"value": round(n_meshes / el, 4), "unit": "meshes/s", "cores": 1, "kind": "port",
            "sample": f"{n_meshes} of the batch's synthetic humeri, all stages, NumPy/SciPy oracle, BLAS limited to 1 thread, {el:.1f} s"}
+    out.update(host_info())
     if pool < 0:
         pool = min(16, len(os.sched_getaffinity(0)))
     pool = min(pool, len(T))
@@ -438,10 +543,13 @@ def cpu_baseline(verts, faces, T, weights, n_meshes, pool):
         from concurrent.futures import ProcessPoolExecutor
         t0 = time.perf_counter()
         with ProcessPoolExecutor(max_workers=pool, mp_context=mp.get_context("spawn")) as ex:
-            list(ex.map(_oracle_one, range(pool)))
+            per = list(ex.map(_oracle_one, range(pool)))
         elp = time.perf_counter() - t0
-        out["pool"] = {"value": round(pool / elp, 4), "unit": "meshes/s", "cores": pool,
-                       "sample": f"{pool} humeri, one per worker process (spawn, start-up and imports included), {elp:.1f} s"}
+        # wall includes interpreter start-up and imports of every worker; `value_compute_only` counts the slowest worker's
+        # oracle time alone (all workers run side by side), which is what a long-running pool would sustain
+        out["pool"] = {"value": round(pool / elp, 4), "unit": "meshes/s", "cores": pool, "value_compute_only": round(pool / max(per), 4),
+                       "per_worker_s": [round(x, 2) for x in per],
+                       "sample": f"{pool} humeri, one per worker process (spawn), wall {elp:.1f} s incl. start-up and imports; slowest worker's oracle time {max(per):.1f} s"}
     return out
 
 

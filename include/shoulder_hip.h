@@ -48,10 +48,17 @@ enum {
   SH_STAGE_DISTAL   = 1u << 7, /* slice.py:256-276 DistalSlices sections                             */
   SH_STAGE_TE       = 1u << 8, /* epicondyle.py:29-101                                               */
   SH_STAGE_CSYS     = 1u << 9, /* bone.py:146-157 construct_csys + re-expression of landmarks        */
-  SH_STAGE_ALL      = 0x3FFu
+  SH_STAGE_APPLY    = 1u << 10,/* bone.py:155 `mesh_ct.copy().apply_transform(csys)` for the whole batch: device buffer
+                                  "verts_csys" (sumV x 3 float64) = csys[b] * vertices of mesh b; needs SH_STAGE_CSYS in
+                                  the same run                                                        */
+  SH_STAGE_ALL      = 0x7FFu
 };
 
-enum { SH_UNET_F32 = 0, SH_UNET_BF16 = 1 };
+/* Arithmetic of the anatomic-neck network (the ONNX session of anatomic_neck.py:62-76 computes in float32):
+ * F32  one float32 fma chain per output on v_mfma_f32_16x16x4_f32 -- bit-exact against oracle/unet_chain.c;
+ * BF16 / F16  16-bit activations and weights on v_mfma_f32_16x16x32_{bf16,f16}, float32 accumulate (throughput paths;
+ *      F16 carries 11 significant bits instead of 8 and needs activations below 65504). */
+enum { SH_UNET_F32 = 0, SH_UNET_BF16 = 1, SH_UNET_F16 = 2 };
 /* Which facade class of bone.py the meshes are: `Humerus` (bone.py:110-157) or `ProximalHumerus` (bone.py:24-64: a
  * humerus cut in the shaft -- ProxObb head-end rule and canal range mesh.py:128-192, neck cut-off (0.2, 0.99)
  * surgical_neck.py:25-26, canal cut-offs from the box canal.py:33-38, no distal / trans-epicondylar stage,
@@ -77,6 +84,7 @@ typedef struct sh_landmarks {
   double anp_axis_central[6]; /* AnatomicNeck.axis_central(): [upper, lower] (anatomic_neck.py:202-236) */
   double csys[16];            /* apply_csys_canal_transepiconylar() matrix, CT -> canal/TE (bone.py:146-157);
                                  SH_BONE_PROXIMAL: apply_csys_canal_articular() (bone.py:53-62) */
+  double csys_articular[16];  /* apply_csys_canal_articular() matrix, CT -> canal / head-normal axis (bone.py:53-62), both bone kinds */
   double neckshaft;           /* NeckShaft.calc(), degrees (bone_props.py:88-112) */
   double retroversion;        /* RetroVersion.calc() with landmarks in CT, degrees (bone_props.py:50-85); NaN for SH_BONE_PROXIMAL */
   double radius_curvature;    /* RadiusCurvature.calc(), mm (bone_props.py:115-148) */
@@ -96,7 +104,7 @@ typedef struct sh_params {
   double canal_cutoff[2];     /* canal.py:19          default (0.35, 0.75) */
   double groove_cutoff[2];    /* bicipital_groove.py:26 default (0.2, 0.75); rows must stay 330 */
   double groove_deg_window;   /* bicipital_groove.py:26 default 7 */
-  int32_t unet_dtype;         /* SH_UNET_F32 (parity) or SH_UNET_BF16 (throughput) */
+  int32_t unet_dtype;         /* SH_UNET_F32 (parity), SH_UNET_BF16 or SH_UNET_F16 (throughput) */
   int32_t bone_kind;          /* SH_BONE_HUMERUS (default) or SH_BONE_PROXIMAL */
 } sh_params;
 
@@ -106,6 +114,7 @@ void sh_ctx_destroy(sh_ctx*);
 const char* sh_last_error(const sh_ctx*);      /* owned by ctx, valid until the next call */
 int  sh_default_params(sh_params* out);
 int  sh_set_params(sh_ctx*, const sh_params*);
+int  sh_get_params(const sh_ctx*, sh_params* out);   /* the values in force (read-modify-write with sh_set_params) */
 
 /* ---- parameters (replace the ONNX files read at bicipital_groove.py:174-180 and
  *      anatomic_neck.py:62-69; host pointers, copied) ---------------------------------- */
@@ -120,6 +129,10 @@ int  sh_load_unet(sh_ctx*, int base_channels, int depth, const float* packed, si
 /* Device address + size of the packed parameter block (UNet then RFC), for a collective
  * broadcast by the caller (torch.distributed over RCCL); valid until the next sh_load_*. */
 int  sh_param_block(sh_ctx*, void** dev_ptr, size_t* nbytes);
+/* After the caller has overwritten the device parameter block (the receiving ranks of a broadcast): re-read the host
+ * mirrors from it, so that a later sh_load_rfc / sh_load_unet -- which re-uploads the whole block from the mirrors --
+ * does not put stale values back.  The forest's topology (child indices, roots) is validated like in sh_load_rfc. */
+int  sh_param_block_commit(sh_ctx*);
 
 /* ---- meshes (replace MeshLoader, mesh.py:14-41; vertices already merged) ------------- */
 int  sh_upload_meshes(sh_ctx*, const float* verts /* sumV x 3 */, const int32_t* faces /* sumF x 3, per-mesh local ids */,
@@ -182,6 +195,9 @@ int  sh_slice_mesh_planes(sh_ctx*, const double* verts /* nv x 3 */, int nv, con
  * "distal.*" "prox.*" "prox.ixy" "prox.itr_start" "prox.itr_centered_start" "canal.points"
  * "groove.X" "groove.nX" "groove.proba" "anp.image" "anp.logits" "anp.roll" ... (see sh_buffer_info) */
 int  sh_buffer_info(sh_ctx*, const char* name, size_t* nbytes, int* elem_size);
+/* Device address of a named buffer (e.g. "verts_obb", "verts_csys": inputs / outputs of sh_affine_apply; valid until the
+ * next upload). */
+int  sh_buffer_device(sh_ctx*, const char* name, void** dev_ptr, size_t* nbytes);
 int  sh_fetch(sh_ctx*, const char* name, void* host, size_t nbytes);
 int  sh_store(sh_ctx*, const char* name, const void* host, size_t nbytes);
 

@@ -93,5 +93,31 @@ def axis_central(verts_obb, faces, point, normal):
     return _axis(verts_obb, faces, point, n)
 
 
+def plane_points(verts_ct, faces, origin, normal):
+    """anatomic_neck.py:155-172: `mesh_ct.section(plane_origin, plane_normal).vertices` -- the crossing points of the
+    CT mesh with the anatomic-neck plane, one per crossing triangle (every crossed mesh edge is the "downward" edge of
+    exactly one triangle of a closed surface, so these are the unique vertices of the section path), unordered.
+    trimesh `mesh_plane` semantics restated as in oracle/section.py, for a general plane: signed distance
+    d = (v - origin) . n with n normalised, a vertex is "below" iff d < -1e-8, and the crossing point of an edge is
+    computed from its lower to its higher vertex id: p = p_lo + d_lo / (d_lo - d_hi) * (p_hi - p_lo).  [3P unpinned]"""
+    v = np.asarray(verts_ct, dtype=np.float64)
+    f = np.asarray(faces, dtype=np.int64)
+    o = np.asarray(origin, dtype=np.float64)
+    n = np.asarray(normal, dtype=np.float64)
+    n = n / np.sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2])
+    rel = v - o
+    d = (rel[:, 0] * n[0] + rel[:, 1] * n[1]) + rel[:, 2] * n[2]
+    s = np.where(d < -1e-8, -1, 1)
+    sf = s[f]
+    cross = sf.min(axis=1) != sf.max(axis=1)
+    f, sf = f[cross], sf[cross]
+    dn = np.argmax((sf == 1) & (np.roll(sf, -1, axis=1) == -1), axis=1)       # the edge crossed downwards (+ -> -)
+    r = np.arange(len(f))
+    a, b = f[r, dn], f[r, (dn + 1) % 3]
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    t = d[lo] / (d[lo] - d[hi])
+    return v[lo] + t[:, None] * (v[hi] - v[lo])
+
+
 def to_ct(pts_obb, T_obb):
     return transform_pts(pts_obb, inv_transform(T_obb))

@@ -140,6 +140,11 @@ class OracleHumerus:
             return m
         return self._memo("anp", f)
 
+    def anp_plane_points(self):
+        """AnatomicNeck.plane_points() in CT (anatomic_neck.py:155-172)."""
+        return self._memo("anp_plane_points", lambda: anp.plane_points(self.verts.astype(np.float64), self.faces,
+                                                                      self.anp["plane_point_ct"], self.anp["plane_normal_ct"]))
+
     # epicondyle.py ---------------------------------------------------------------------
     @property
     def te(self):
@@ -149,6 +154,10 @@ class OracleHumerus:
     # bone.py:146-157 -------------------------------------------------------------------
     def csys_canal_transepicondylar(self):
         return construct_csys(self.canal["axis_ct"], self.te["axis_ct"])
+
+    def csys_canal_articular(self):
+        """bone.py:53-62"""
+        return construct_csys(self.canal["axis_ct"], self.anp["axis_normal_ct"])
 
     # bone_props.py (bone.py:134-144) -----------------------------------------------------
     def metrics(self, axis_normal_current=None):
@@ -172,5 +181,5 @@ class OracleHumerus:
             out.update(anp_points=self.anp["points_ct"], anp_plane_point=self.anp["plane_point_ct"],
                        anp_plane_normal=self.anp["plane_normal_ct"], anp_axis_normal=self.anp["axis_normal_ct"],
                        anp_axis_central=self.anp["axis_central_ct"], te_axis=self.te["axis_ct"],
-                       csys=self.csys_canal_transepicondylar())
+                       csys=self.csys_canal_transepicondylar(), csys_articular=self.csys_canal_articular())
         return out

@@ -12,8 +12,9 @@ ANP_MAX_PTS = 4096
 
 STAGE_OBB, STAGE_FULL, STAGE_NECK, STAGE_CANAL, STAGE_PROXIMAL = 1, 2, 4, 8, 16
 STAGE_GROOVE, STAGE_ANP, STAGE_DISTAL, STAGE_TE, STAGE_CSYS = 32, 64, 128, 256, 512
-STAGE_ALL = 0x3FF
-UNET_F32, UNET_BF16 = 0, 1
+STAGE_APPLY = 1024
+STAGE_ALL = 0x7FF
+UNET_F32, UNET_BF16, UNET_F16 = 0, 1, 2
 BONE_HUMERUS, BONE_PROXIMAL = 0, 1
 
 
@@ -31,6 +32,7 @@ class Landmarks(ctypes.Structure):
         ("anp_axis_normal", ctypes.c_double * 6),
         ("anp_axis_central", ctypes.c_double * 6),
         ("csys", ctypes.c_double * 16),
+        ("csys_articular", ctypes.c_double * 16),
         ("neckshaft", ctypes.c_double),
         ("retroversion", ctypes.c_double),
         ("radius_curvature", ctypes.c_double),
@@ -50,7 +52,7 @@ LANDMARKS_DTYPE = np.dtype([
     ("obb_transform", "<f8", (4, 4)), ("z_length", "<f8"), ("neck_z", "<f8"), ("canal_axis", "<f8", (2, 3)),
     ("te_axis", "<f8", (2, 3)), ("groove_axis", "<f8", (2, 3)), ("bg_theta", "<f8"), ("anp_plane_point", "<f8", (3,)),
     ("anp_plane_normal", "<f8", (3,)), ("anp_axis_normal", "<f8", (2, 3)), ("anp_axis_central", "<f8", (2, 3)),
-    ("csys", "<f8", (4, 4)), ("neckshaft", "<f8"), ("retroversion", "<f8"), ("radius_curvature", "<f8"), ("canal_cutoff", "<f8", (2,)), ("groove_points", "<f8", (GROOVE_ROWS, 3)), ("anp_points", "<f8", (ANP_MAX_PTS, 3)),
+    ("csys", "<f8", (4, 4)), ("csys_articular", "<f8", (4, 4)), ("neckshaft", "<f8"), ("retroversion", "<f8"), ("radius_curvature", "<f8"), ("canal_cutoff", "<f8", (2,)), ("groove_points", "<f8", (GROOVE_ROWS, 3)), ("anp_points", "<f8", (ANP_MAX_PTS, 3)),
     ("n_anp", "<i4"), ("n_articular", "<i4"), ("neck_index", "<i4"), ("flipped", "<i4"), ("status", "<i4"), ("side", "<i4")])
 assert LANDMARKS_DTYPE.itemsize == ctypes.sizeof(Landmarks)
 
@@ -64,7 +66,7 @@ EXPORTS = ["sh_ctx_create", "sh_ctx_destroy", "sh_last_error", "sh_default_param
            "sh_load_unet", "sh_param_block", "sh_upload_meshes", "sh_synth_batch", "sh_batch_size", "sh_run",
            "sh_landmarks_device", "sh_affine_apply", "sh_mesh_transformed", "sh_transform_points", "sh_section_plane", "sh_buffer_info", "sh_fetch", "sh_store",
            "sh_kernel_time_ms", "sh_enable_timing", "sh_set_overlap", "sh_discard_prepared", "sh_unet_infer", "sh_host_alloc", "sh_host_free", "sh_upload_stl", "sh_submit", "sh_collect",
-           "sh_slice_mesh_planes", "sh_set_unet_turns"]
+           "sh_slice_mesh_planes", "sh_set_unet_turns", "sh_get_params", "sh_buffer_device", "sh_param_block_commit"]
 
 _lib = None
 
@@ -101,6 +103,9 @@ def load(build_if_missing=True):
     L.sh_last_error.restype = cp
     L.sh_default_params.argtypes = [ctypes.POINTER(Params)]
     L.sh_set_params.argtypes = [vp, ctypes.POINTER(Params)]
+    L.sh_get_params.argtypes = [vp, ctypes.POINTER(Params)]
+    L.sh_buffer_device.argtypes = [vp, cp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    L.sh_param_block_commit.argtypes = [vp]
     L.sh_load_rfc.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_int]
     L.sh_load_unet.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t]
     L.sh_param_block.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]

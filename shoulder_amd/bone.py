@@ -6,7 +6,10 @@ return shapes, float64 NumPy arrays, lazy + memoised evaluation, landmarks cache
 re-expressed through one shared `Transform`.  Every number comes from libshoulder_hip.so through
 `Engine` (one sh_run over a batch of one); nothing here falls back to the CPU.
 """
+import os
 import pathlib
+import threading
+import warnings
 
 import numpy as np
 
@@ -16,19 +19,38 @@ from .engine import Engine
 from .stl import load_stl
 
 _DEFAULT_ENGINE = None
+_DEFAULT_LOCK = threading.Lock()
 
 EARLY = _lib.STAGE_OBB | _lib.STAGE_FULL | _lib.STAGE_NECK | _lib.STAGE_CANAL
-LATE = _lib.STAGE_PROXIMAL | _lib.STAGE_GROOVE | _lib.STAGE_ANP | _lib.STAGE_DISTAL | _lib.STAGE_TE | _lib.STAGE_CSYS
+LATE = _lib.STAGE_PROXIMAL | _lib.STAGE_GROOVE | _lib.STAGE_ANP | _lib.STAGE_DISTAL | _lib.STAGE_TE | _lib.STAGE_CSYS | _lib.STAGE_APPLY
 
 
-def default_engine(device=0, unet_weights=None):
-    """Process-wide engine on `device` with the packaged forest and the teacher UNet loaded."""
+def default_engine(device=0, unet_weights=None, unet_onnx=None):
+    """Process-wide engine on `device` (created once, under a lock; an Engine itself is single-threaded like the
+    reference's objects -- give threads their own engines).
+
+    The anatomic-neck network: `unet_onnx` (or the environment variable SHOULDER_UNET_ONNX) names an ONNX file of the
+    supported UNet family -- the reference opens its packaged `humerus/models/unetcrf_anp.onnx` (anatomic_neck.py:62-66),
+    which is not part of this tree; `unet_weights` takes a parameter dict.  With neither, the seeded TEACHER weights of
+    `unet_spec` are loaded and a RuntimeWarning says so: they make every stage computable and testable, but anatomic-neck
+    dependent values (anatomic_neck.*, neckshaft, retroversion, radius_curvature, side, apply_csys_canal_articular) are then
+    NOT those of a trained model."""
     global _DEFAULT_ENGINE
-    if _DEFAULT_ENGINE is None:
-        e = Engine(device)
-        e.load_rfc()
-        e.load_unet(unet_weights if unet_weights is not None else unet_spec.make_teacher_weights(), unet_spec.BASE, unet_spec.DEPTH)
-        _DEFAULT_ENGINE = e
+    with _DEFAULT_LOCK:
+        if _DEFAULT_ENGINE is None:
+            e = Engine(device)
+            e.load_rfc()
+            onnx_path = unet_onnx or os.environ.get("SHOULDER_UNET_ONNX")
+            if onnx_path:
+                e.load_unet_onnx(onnx_path)
+            elif unet_weights is not None:
+                e.load_unet(unet_weights, unet_spec.BASE, unet_spec.DEPTH)
+            else:
+                warnings.warn("shoulder_amd: no anatomic-neck model given (SHOULDER_UNET_ONNX / default_engine(unet_onnx=...)): loading the "
+                              "seeded TEACHER stand-in -- anatomic-neck dependent landmarks and metrics are not those of a trained model",
+                              RuntimeWarning, stacklevel=3)
+                e.load_unet(unet_spec.make_teacher_weights(), unet_spec.BASE, unet_spec.DEPTH)
+            _DEFAULT_ENGINE = e
     return _DEFAULT_ENGINE
 
 
@@ -266,11 +288,15 @@ class TransEpicondylar(_Lm):
         return None if self._axis_ct is None else _scatter(self._axis, "Transverse Epicondylar Axis")
 
 
-class Humerus(Bone):
-    """bone.py:109-157"""
-    _BONE_KIND = _lib.BONE_HUMERUS
+class ProximalHumerus(Bone):
+    """bone.py:24-105 -- a humerus whose scan ends in the shaft (and, as in the reference, the base class of `Humerus`:
+    `isinstance(Humerus(...), ProximalHumerus)` holds).  The device runs the ProxObb head-end rule and canal range
+    (mesh.py:128-192), the (0.2, 0.99) neck cut-off (surgical_neck.py:25-26) and the canal cut-offs taken from the box
+    (canal.py:33-38); there is no trans-epicondylar axis and no retroversion, and the coordinate system is
+    `apply_csys_canal_articular` (bone.py:53-62)."""
+    _BONE_KIND = _lib.BONE_PROXIMAL
     _EARLY = EARLY
-    _LATE = LATE
+    _LATE = _lib.STAGE_PROXIMAL | _lib.STAGE_GROOVE | _lib.STAGE_ANP | _lib.STAGE_CSYS | _lib.STAGE_APPLY
 
     def __init__(self, stl_file, engine=None):
         self._tfrm = Transform()
@@ -280,8 +306,9 @@ class Humerus(Bone):
         verts, faces = load_stl(self.stl_file)
         self._verts, self._faces = verts, faces
         self._engine.upload([(verts, faces)])
-        self._engine.set_params(bone_kind=self._BONE_KIND)
+        self._engine.set_params(bone_kind=self._BONE_KIND)      # (read-modify-write: the engine's UNet dtype and cut-offs stay as configured)
         self._lm_all = None
+        self._groove_params = None      # (cutoff_pcts, deg_window) this bone's late stages ran with
         # eager part of the reference constructor: OBB, full slices, surgical neck, canal axis
         self._early = self._engine.run(self._EARLY)[0].copy()
         self._canal_cutoff = tuple(float(x) for x in self._early["canal_cutoff"])
@@ -296,21 +323,23 @@ class Humerus(Bone):
         self._init_kind_specific()
 
     def _init_kind_specific(self):
-        self.trans_epiconylar = TransEpicondylar(self)
-        # metrics (bone.py:134-144 -> bone_props.py); values come from the device record (k_metrics)
+        # metrics (bone.py:46-51 -> bone_props.py); values come from the device record (k_metrics)
         self.side = self._side
-        self.retroversion = self._retroversion
         self.neckshaft = self._neckshaft
         self.radius_curvature = self._radius_curvature
+        e = self._engine
+        self.cutoff_pcts = [float(x) for x in self._canal_cutoff]           # ProxObb.cutoff_pcts (mesh.py:190)
+        self.cutoff_bot = int(e.fetch("pobb.cutoff_idx", np.int32, (1, 2))[0][0])      # mesh.py:187
 
     def _ensure_loaded(self):
         """The shared engine may have been used for another bone since: bring this one back."""
         e = self._engine
         if e.B != 1 or not np.array_equal(e.fetch("obb_transform", np.float64, (1, 4, 4))[0], self._obb_transform):
             e.upload([(self._verts, self._faces)])
-            e.set_params(bone_kind=self._BONE_KIND)
+            e.set_params(bone_kind=self._BONE_KIND, canal_cutoff=self._canal_cutoff if self._BONE_KIND == _lib.BONE_HUMERUS else None)
             e.run(self._EARLY, fetch=False)
-            if self._lm_all is not None:
+            if self._lm_all is not None:      # device buffers fetched later (e.g. anp.points_obb beyond 4096 rows) must match the cached record
+                e.set_params(groove_cutoff=self._groove_params[0], groove_deg_window=self._groove_params[1])
                 e.run(self._LATE, fetch=False)
 
     # -- the late stages, once ------------------------------------------------------------------------
@@ -322,6 +351,7 @@ class Humerus(Bone):
                 e.set_params(groove_cutoff=tuple(groove_cutoff), groove_deg_window=float(deg_window), bone_kind=self._BONE_KIND)
             except Exception as ex:
                 raise ValueError(f"bicipital_groove cutoff_pcts {groove_cutoff} is not supported: {ex}") from ex
+            self._groove_params = (tuple(float(x) for x in groove_cutoff), float(deg_window))
             self._lm_all = e.run(self._LATE)[0].copy()
             if int(self._lm_all["status"]) != 0:
                 raise ValueError(f"landmark stage failed with status {int(self._lm_all['status'])}")
@@ -370,19 +400,21 @@ class Humerus(Bone):
         self.transform = self._tfrm.matrix
         return self.transform
 
-    def apply_csys_canal_transepiconylar(self) -> np.ndarray:
-        self.canal.axis()
-        self.trans_epiconylar.axis()
-        T = np.array(self._all()["csys"], dtype=np.float64)           # construct_csys on the device (k_pack)
-        return self._apply(T, self._mesh_in(T))
+    def _mesh_in_record_csys(self, T):
+        """The mesh in the record's own csys: the batch path's device buffer (SH_STAGE_APPLY, k_apply_csys) rather than a
+        second transform pass, when this bone's late stages are what the engine holds."""
+        e = self._engine
+        self._ensure_loaded()
+        V = len(self._verts)
+        return Mesh(e.fetch("verts_csys", np.float64, (V, 3)), self._faces, e)
 
     def apply_csys_canal_articular(self) -> np.ndarray:
         self.canal.axis()
         self.anatomic_neck.axis_central()
         self.anatomic_neck.axis_normal()
-        from .csys import construct_csys
-        T = construct_csys(self.canal._axis_ct, self.anatomic_neck._normal_axis_ct)
-        return self._apply(T, self._mesh_in(T))
+        T = np.array(self._all()["csys_articular"], dtype=np.float64)     # construct_csys(canal, neck-normal axis) on the device (k_pack)
+        mesh = self._mesh_in_record_csys(T) if self._BONE_KIND == _lib.BONE_PROXIMAL else self._mesh_in(T)
+        return self._apply(T, mesh)
 
     def apply_csys_obb(self) -> np.ndarray:
         T = self._obb_transform.copy()
@@ -417,28 +449,22 @@ class Humerus(Bone):
         return self.transform
 
 
-class ProximalHumerus(Humerus):
-    """bone.py:24-105 -- a humerus whose scan ends in the shaft.  Same landmark classes; the device runs the ProxObb
-    head-end rule and canal range (mesh.py:128-192), the (0.2, 0.99) neck cut-off (surgical_neck.py:25-26) and the canal
-    cut-offs taken from the box (canal.py:33-38); there is no trans-epicondylar axis and no retroversion, and the
-    coordinate system is `apply_csys_canal_articular` (bone.py:53-62)."""
-    _BONE_KIND = _lib.BONE_PROXIMAL
-    _LATE = _lib.STAGE_PROXIMAL | _lib.STAGE_GROOVE | _lib.STAGE_ANP | _lib.STAGE_CSYS
+# we are inheriting the functions but the init will be unique (bone.py:108-109)
+class Humerus(ProximalHumerus):
+    """bone.py:109-157"""
+    _BONE_KIND = _lib.BONE_HUMERUS
+    _LATE = LATE
 
     def _init_kind_specific(self):
+        self.trans_epiconylar = TransEpicondylar(self)
+        # metrics (bone.py:134-144 -> bone_props.py); values come from the device record (k_metrics)
         self.side = self._side
+        self.retroversion = self._retroversion
         self.neckshaft = self._neckshaft
         self.radius_curvature = self._radius_curvature
-        e = self._engine
-        self.cutoff_pcts = [float(x) for x in self._canal_cutoff]           # ProxObb.cutoff_pcts (mesh.py:190)
-        self.cutoff_bot = int(e.fetch("pobb.cutoff_idx", np.int32, (1, 2))[0][0])      # mesh.py:187
 
-    def apply_csys_canal_transepiconylar(self):
-        raise AttributeError("ProximalHumerus has no trans-epicondylar axis (bone.py:24-64); use apply_csys_canal_articular")
-
-    def apply_csys_canal_articular(self) -> np.ndarray:
+    def apply_csys_canal_transepiconylar(self) -> np.ndarray:
         self.canal.axis()
-        self.anatomic_neck.axis_central()
-        self.anatomic_neck.axis_normal()
-        T = np.array(self._all()["csys"], dtype=np.float64)           # construct_csys(canal, neck-normal axis) on the device (k_pack)
-        return self._apply(T, self._mesh_in(T))
+        self.trans_epiconylar.axis()
+        T = np.array(self._all()["csys"], dtype=np.float64)           # construct_csys on the device (k_pack)
+        return self._apply(T, self._mesh_in_record_csys(T))

@@ -201,8 +201,27 @@ __global__ void k_pack(sh_landmarks* __restrict__ lm, const double* __restrict__
   L->canal_cutoff[0] = canal_cut ? canal_cut[2 * b] : cc0;
   L->canal_cutoff[1] = canal_cut ? canal_cut[2 * b + 1] : cc1;
   if (mask & SH_STAGE_CSYS) {
-    if (bone_kind == SH_BONE_PROXIMAL) construct_csys(L->canal_axis, L->anp_axis_normal, L->csys);     // bone.py:57-59 apply_csys_canal_articular
+    if (mask & SH_STAGE_ANP) construct_csys(L->canal_axis, L->anp_axis_normal, L->csys_articular);     // bone.py:57-59 apply_csys_canal_articular
+    if (bone_kind == SH_BONE_PROXIMAL) { for (int i = 0; i < 16; ++i) L->csys[i] = L->csys_articular[i]; }
     else construct_csys(L->canal_axis, L->te_axis, L->csys);                                          // bone.py:150
+  }
+}
+
+// bone.py:155 `mesh_ct.copy().apply_transform(T)` for the batch: float32 CT vertices of mesh b -> float64 vertices in the
+// coordinate system of its record (T = landmarks[b].csys: canal / trans-epicondylar, or canal / articular for a cut
+// humerus).  HBM bound: 12 B read + 24 B written per vertex, coalesced.
+__global__ void k_apply_csys(const sh_landmarks* __restrict__ lm, const float* __restrict__ verts, const long long* __restrict__ voff,
+                             double* __restrict__ out) {
+  const int b = blockIdx.y;
+  double T[16];
+  for (int i = 0; i < 16; ++i) T[i] = lm[b].csys[i];
+  const long long v0 = voff[b], n = voff[b + 1] - v0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float* p = verts + 3 * (v0 + i);
+    double o[3];
+    xform_pt(T, (double)p[0], (double)p[1], (double)p[2], o);
+    double* q = out + 3 * (v0 + i);
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
   }
 }
 

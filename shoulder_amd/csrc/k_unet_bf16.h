@@ -1,5 +1,7 @@
-// k_unet_bf16.h -- UNet forward in bf16 on v_mfma_f32_16x16x32_bf16 (throughput path, BASELINE
-// config 3 "UNet bf16"); f32 accumulate, bias f32, activations NHWC bf16 in HBM.
+// k_unet_bf16.h -- UNet forward with 16-bit activations and weights on v_mfma_f32_16x16x32_{bf16,f16} (throughput paths:
+// BASELINE config 3 "UNet bf16", config 5 "fp16 MFMA conv"); f32 accumulate, bias f32.  Every kernel is a template on
+// the element type ET (__bf16 or _Float16): same tiling, same LDS image, same instruction count -- the two MFMA forms have
+// the same shape and rate -- so "bf16" in the comments below reads "ET".
 //
 // Transposed implicit GEMM: A = weights (rows = 16 couts), B = activations (cols = 16 pixels of one
 // image row), K = 32 input channels of one tap.  D then has the pixel on the lane and 4 consecutive
@@ -25,29 +27,26 @@ namespace sh {
 // (PMC: 1.34 GB per launch against 0.65 GB algorithmic).  A 32-channel tensor is plain NHWC either way.
 __device__ __host__ inline size_t act_off(size_t HW, size_t pix, int c) { return ((size_t)(c >> 5) * HW + pix) * 32 + (size_t)(c & 31); }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// element-type trait: vector types and the 16x16x32 MFMA (A = 8 k-values of 16 rows, B = 8 k-values of 16 columns)
+template <typename ET> struct E16;
+template <> struct E16<__bf16> {
+  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 v4 __attribute__((ext_vector_type(4)));
+  static __device__ inline f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct E16<_Float16> {
+  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+  static __device__ inline f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
 
 #define UB_PSTR 32      // bf16 elements per LDS row: 32 channels = 64 B = four 16-B slots, unpadded
 // XOR swizzle of the 16-B slot inside a row: slot' = slot ^ ((row >> 1) & 2).  With it the 16 lanes of every
 // ds_read_b128 lane group (rows p0 + (lane & 15), slot lane >> 4) hit 16 distinct slots of the 256-B bank row for
 // every p0 (checked exhaustively), so fragment reads are bank-conflict free without padding.
 #define UB_OFF(row, slot) ((row) * UB_PSTR + (((slot) ^ (((row) >> 1) & 2)) << 3))
-
-// src f32 [T][Cin][Cout]  ->  dst bf16 [T][Cin/32][Cout][32]
-__global__ void k_pack_w_bf16(const float* __restrict__ src, __bf16* __restrict__ dst, int T, int Cin, int Cout) {
-  size_t total = (size_t)T * Cin * Cout;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    int k = (int)(e % 32);
-    size_t r = e / 32;
-    int co = (int)(r % Cout);
-    r /= Cout;
-    int cc = (int)(r % (Cin / 32));
-    int t = (int)(r / (Cin / 32));
-    dst[e] = (__bf16)src[((size_t)t * Cin + cc * 32 + k) * Cout + co];
-  }
-}
 
 // Fusions at the memory-bound ends of the network (the 32-channel level moves 1.07 GB per tensor at B = 64):
 //   UF_FIRST  the layer's input is the 1-channel image: the 32-channel activations of the first conv (enc0a) are
@@ -64,13 +63,14 @@ struct ConvFuse {
   const float* head_w;     // UF_HEAD:  [Cout] f32
   const float* head_b;     // UF_HEAD:  [1]
   float* logits;           // UF_HEAD:  [nimg][H][W] f32
-  __bf16* pooled;          // UF_POOL:  [nimg][H/2][W/2][Cout] bf16
+  void* pooled;            // UF_POOL:  [nimg][H/2][W/2][Cout] ET
 };
 
 // All MFMA layers in one launch (the forward re-packs every time -- the parameter block may have been re-broadcast -- and
 // 21 separate 5-us launches cost more in launch gaps than in work).  tab[l] = {first element, w_off, T, Cin, Cout}.
 struct PackEntry { long long first; long long w_off; int T, Cin, Cout, pad; };
-__global__ void k_pack_w_bf16_all(const float* __restrict__ P, __bf16* __restrict__ PW, const PackEntry* __restrict__ tab, int nlayers, long long total) {
+template <typename ET>
+__global__ void k_pack_w16_all(const float* __restrict__ P, ET* __restrict__ PW, const PackEntry* __restrict__ tab, int nlayers, long long total) {
   for (long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     int l = 0;
     while (l + 1 < nlayers && tab[l + 1].first <= g) ++l;
@@ -82,22 +82,24 @@ __global__ void k_pack_w_bf16_all(const float* __restrict__ P, __bf16* __restric
     r /= t.Cout;
     const int cc = (int)(r % (t.Cin / 32));
     const int tp = (int)(r / (t.Cin / 32));
-    PW[t.w_off + e] = (__bf16)P[t.w_off + ((long long)tp * t.Cin + cc * 32 + k) * t.Cout + co];
+    PW[t.w_off + e] = (ET)P[t.w_off + ((long long)tp * t.Cin + cc * 32 + k) * t.Cout + co];
   }
 }
 
-template <int TAPS, int NT, int FUSE = 0>
+template <typename ET, int TAPS, int NT, int FUSE = 0>
 __global__ void __launch_bounds__(UN_THREADS)
-k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src1, int C0, int C1,
-                 const __bf16* __restrict__ wgt, const float* __restrict__ bias, __bf16* __restrict__ dst, int H, int W, int Cout, int relu,
-                 ConvFuse fz) {
+k_conv_mfma16(const ET* __restrict__ src0, const ET* __restrict__ src1, int C0, int C1,
+              const ET* __restrict__ wgt, const float* __restrict__ bias, ET* __restrict__ dst, int H, int W, int Cout, int relu,
+              ConvFuse fz) {
+  using v8 = typename E16<ET>::v8;
+  using v4 = typename E16<ET>::v4;
   constexpr int HALO = TAPS == 9 ? 1 : 0;
   constexpr int PW = UN_TW + 2 * HALO, PH = UN_TH + 2 * HALO;
   constexpr int NC = 16 * NT;
   constexpr int IN_PIECES = PH * PW * 4, WT_PIECES = TAPS * NC * 4;
   constexpr int NIN = (IN_PIECES + UN_THREADS - 1) / UN_THREADS, NWT = (WT_PIECES + UN_THREADS - 1) / UN_THREADS;
-  __shared__ __attribute__((aligned(16))) __bf16 s_in[PH * PW * UB_PSTR];
-  __shared__ __attribute__((aligned(16))) __bf16 s_w[TAPS * NC * UB_PSTR];
+  __shared__ __attribute__((aligned(16))) ET s_in[PH * PW * UB_PSTR];
+  __shared__ __attribute__((aligned(16))) ET s_w[TAPS * NC * UB_PSTR];
   __shared__ float s_img[(FUSE & UF_FIRST) ? (UN_TH + 4) * (UN_TW + 4) : 1];
   const int Cin = C0 + C1;
   const int tiles_x = W / UN_TW;
@@ -108,10 +110,10 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int x0 = tx * UN_TW, y0 = ty * UN_TH;
-  const __bf16* in0 = src0 + (size_t)img * H * W * C0;
-  const __bf16* in1 = src1 ? src1 + (size_t)img * H * W * C1 : nullptr;
+  const ET* in0 = src0 + (size_t)img * H * W * C0;
+  const ET* in1 = src1 ? src1 + (size_t)img * H * W * C1 : nullptr;
   const int nchunk = Cin / 32;
-  const __bf16* wp = wgt + (size_t)phase * TAPS * nchunk * Cout * 32;
+  const ET* wp = wgt + (size_t)phase * TAPS * nchunk * Cout * 32;
 
   // ---- staging plan, fixed for the whole K loop
   int in_pix[NIN], in_lds[NIN], wt_off[NWT], wt_lds[NWT];
@@ -137,7 +139,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
   auto load_chunk = [&](int cc) {
     const int c0 = cc * 32;
     const bool first = c0 < C0;
-    const __bf16* src = first ? in0 : in1;
+    const ET* src = first ? in0 : in1;
     const int cb = first ? c0 : c0 - C0;
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
@@ -164,7 +166,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
       const int gy = y0 - 2 + e / IW, gx = x0 - 2 + e % IW;
       s_img[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.0f;
     }
-    bf16x8 wA[2];
+    v8 wA[2];
     f32x4 b0v[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -172,7 +174,7 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
       for (int j = 0; j < 8; ++j) {
         const int k = lk * 8 + j, t = k < 9 ? k : (k < 18 ? k - 9 : 0);
         const float wv = fz.w0[t * 32 + n * 16 + li];
-        wA[n][j] = k < 18 ? (__bf16)wv : (__bf16)0.0f;
+        wA[n][j] = k < 18 ? (ET)wv : (ET)0.0f;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) b0v[n][r] = fz.b0[n * 16 + lk * 4 + r];
@@ -184,23 +186,23 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
       const int gy = y0 - 1 + py, gx = x0 - 1 + px;
       const bool inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
       const int base = py * IW + px;          // patch index of tap (0,0) of this pixel
-      bf16x8 bf;
+      v8 bf;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = lk * 8 + j, t = k < 9 ? k : (k < 18 ? k - 9 : 0);
         const int t3 = (t * 11) >> 5;         // t / 3 for t <= 8
         const float v = s_img[base + t + (IW - 3) * t3];
-        const __bf16 hi = (__bf16)v;
-        const __bf16 lo = (__bf16)(v - (float)hi);
-        bf[j] = k < 9 ? hi : (k < 18 ? lo : (__bf16)0.0f);
+        const ET hi = (ET)v;
+        const ET lo = (ET)(v - (float)hi);
+        bf[j] = k < 9 ? hi : (k < 18 ? lo : (ET)0.0f);
       }
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[n], bf, b0v[n], 0, 0, 0);
-        bf16x4 o;
+        const f32x4 a = E16<ET>::mfma(wA[n], bf, b0v[n]);
+        v4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = inside ? (__bf16)fmaxf(a[r], 0.0f) : (__bf16)0.0f;      // outside the image: enc0b's zero padding
-        if (p < PH * PW) *(bf16x4*)(s_in + UB_OFF(p, n * 2 + (lk >> 1)) + (lk & 1) * 4) = o;
+        for (int r = 0; r < 4; ++r) o[r] = inside ? (ET)fmaxf(a[r], 0.0f) : (ET)0.0f;      // outside the image: enc0b's zero padding
+        if (p < PH * PW) *(v4*)(s_in + UB_OFF(p, n * 2 + (lk >> 1)) + (lk & 1) * 4) = o;
       }
     }
   }
@@ -224,15 +226,15 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
-      bf16x8 xf[4], wf[NT];
+      v8 xf[4], wf[NT];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) { const int row = (wave * 4 + m + dy) * PW + li + dx; xf[m] = *(const bf16x8*)(s_in + UB_OFF(row, lk)); }
+      for (int m = 0; m < 4; ++m) { const int row = (wave * 4 + m + dy) * PW + li + dx; xf[m] = *(const v8*)(s_in + UB_OFF(row, lk)); }
 #pragma unroll
-      for (int n = 0; n < NT; ++n) { const int row = tap * NC + n * 16 + li; wf[n] = *(const bf16x8*)(s_w + UB_OFF(row, lk)); }
+      for (int n = 0; n < NT; ++n) { const int row = tap * NC + n * 16 + li; wf[n] = *(const v8*)(s_w + UB_OFF(row, lk)); }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[m][n], 0, 0, 0);
+        for (int n = 0; n < NT; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xf[m], acc[m][n]);
     }
   }
   const int OW = TAPS == 9 ? W : 2 * W, OH = TAPS == 9 ? H : 2 * H;
@@ -259,47 +261,49 @@ k_conv_mfma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
     }
     return;
   }
-  __bf16* out = dst + (size_t)img * OH * OW * Cout;
+  ET* out = dst + (size_t)img * OH * OW * Cout;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     int gy = y0 + wave * 4 + m, gx = x0 + li;
     int oy = TAPS == 9 ? gy : 2 * gy + (phase >> 1), ox = TAPS == 9 ? gx : 2 * gx + (phase & 1);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      bf16x4 o;
+      v4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[m][n][r];
         if (relu) v = fmaxf(v, 0.0f);
-        o[r] = (__bf16)v;
+        o[r] = (ET)v;
       }
-      *(bf16x4*)(out + act_off((size_t)OH * OW, (size_t)oy * OW + ox, n0 + n * 16 + lk * 4)) = o;
+      *(v4*)(out + act_off((size_t)OH * OW, (size_t)oy * OW + ox, n0 + n * 16 + lk * 4)) = o;
     }
   }
   if (FUSE & UF_POOL) {
     // 2x2 max pool of this wave's 4 rows x 16 pixels: rows pair inside the lane, columns pair with lane li ^ 1
     // (max commutes with the monotone bf16 rounding, so this equals pooling the stored tensor)
-    __bf16* po = fz.pooled + (size_t)img * (H / 2) * (W / 2) * Cout;
+    ET* po = (ET*)fz.pooled + (size_t)img * (H / 2) * (W / 2) * Cout;
 #pragma unroll
     for (int mp = 0; mp < 2; ++mp)
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        bf16x4 o;
+        v4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = fmaxf(acc[2 * mp][n][r], acc[2 * mp + 1][n][r]);
           v = fmaxf(v, __shfl_xor(v, 1));
           if (relu) v = fmaxf(v, 0.0f);
-          o[r] = (__bf16)v;
+          o[r] = (ET)v;
         }
         if ((li & 1) == 0)
-          *(bf16x4*)(po + act_off((size_t)(H / 2) * (W / 2), (size_t)((y0 + wave * 4) / 2 + mp) * (W / 2) + (x0 + li) / 2, n0 + n * 16 + lk * 4)) = o;
+          *(v4*)(po + act_off((size_t)(H / 2) * (W / 2), (size_t)((y0 + wave * 4) / 2 + mp) * (W / 2) + (x0 + li) / 2, n0 + n * 16 + lk * 4)) = o;
       }
   }
 }
 
-__global__ void k_conv_first_bf16(const float* __restrict__ img, const float* __restrict__ wgt, const float* __restrict__ bias,
-                                  __bf16* __restrict__ dst, int H, int W, int C, int nimg) {
+template <typename ET>
+__global__ void k_conv_first16(const float* __restrict__ img, const float* __restrict__ wgt, const float* __restrict__ bias,
+                               ET* __restrict__ dst, int H, int W, int C, int nimg) {
+  using v8 = typename E16<ET>::v8;
   __shared__ float sw[9 * SH_UNET_MAXBASE + SH_UNET_MAXBASE];      // [9][C] weights, then the bias (C <= SH_UNET_MAXBASE, checked by sh_load_unet)
   for (int e = threadIdx.x; e < 9 * C; e += blockDim.x) sw[e] = wgt[e];
   for (int e = threadIdx.x; e < C; e += blockDim.x) sw[9 * SH_UNET_MAXBASE + e] = bias[e];
@@ -315,23 +319,25 @@ __global__ void k_conv_first_bf16(const float* __restrict__ img, const float* __
       int gy = y + t / 3 - 1, gx = x + t % 3 - 1;
       v[t] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
     }
-    __bf16* o = dst + im * H * W * C;
+    ET* o = dst + im * H * W * C;
     const size_t pin = p - im * (size_t)H * W;
     for (int c8 = 0; c8 < C; c8 += 8) {
-      bf16x8 ov;
+      v8 ov;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float a = sw[9 * SH_UNET_MAXBASE + c8 + k];
 #pragma unroll
         for (int t = 0; t < 9; ++t) a = __builtin_fmaf(v[t], sw[t * C + c8 + k], a);
-        ov[k] = (__bf16)fmaxf(a, 0.0f);
+        ov[k] = (ET)fmaxf(a, 0.0f);
       }
-      *(bf16x8*)(o + act_off((size_t)H * W, pin, c8)) = ov;
+      *(v8*)(o + act_off((size_t)H * W, pin, c8)) = ov;
     }
   }
 }
 
-__global__ void k_maxpool2_bf16(const __bf16* __restrict__ src, __bf16* __restrict__ dst, int H, int W, int C, int nimg) {
+template <typename ET>
+__global__ void k_maxpool2_16(const ET* __restrict__ src, ET* __restrict__ dst, int H, int W, int C, int nimg) {
+  using v8 = typename E16<ET>::v8;
   const int OH = H / 2, OW = W / 2, C8 = C / 8;
   size_t total = (size_t)nimg * OH * OW * C8;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -339,27 +345,29 @@ __global__ void k_maxpool2_bf16(const __bf16* __restrict__ src, __bf16* __restri
     size_t p = e / C8;
     int ox = (int)(p % OW), oy = (int)((p / OW) % OH);
     size_t im = p / ((size_t)OH * OW);
-    const __bf16* s = src + im * H * W * C + act_off((size_t)H * W, (size_t)(2 * oy) * W + 2 * ox, c8 * 8);
-    bf16x8 a = *(const bf16x8*)s, b = *(const bf16x8*)(s + 32), c = *(const bf16x8*)(s + (size_t)W * 32), d = *(const bf16x8*)(s + (size_t)W * 32 + 32);
-    bf16x8 r;
+    const ET* s = src + im * H * W * C + act_off((size_t)H * W, (size_t)(2 * oy) * W + 2 * ox, c8 * 8);
+    v8 a = *(const v8*)s, b = *(const v8*)(s + 32), c = *(const v8*)(s + (size_t)W * 32), d = *(const v8*)(s + (size_t)W * 32 + 32);
+    v8 r;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = (__bf16)fmaxf(fmaxf((float)a[k], (float)b[k]), fmaxf((float)c[k], (float)d[k]));
-    *(bf16x8*)(dst + im * OH * OW * C + act_off((size_t)OH * OW, (size_t)oy * OW + ox, c8 * 8)) = r;
+    for (int k = 0; k < 8; ++k) r[k] = (ET)fmaxf(fmaxf((float)a[k], (float)b[k]), fmaxf((float)c[k], (float)d[k]));
+    *(v8*)(dst + im * OH * OW * C + act_off((size_t)OH * OW, (size_t)oy * OW + ox, c8 * 8)) = r;
   }
 }
 
-__global__ void k_head_bf16(const __bf16* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bp,
-                            float* __restrict__ logits, int C, size_t npix, size_t HW) {
+template <typename ET>
+__global__ void k_head16(const ET* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bp,
+                         float* __restrict__ logits, int C, size_t npix, size_t HW) {
+  using v8 = typename E16<ET>::v8;
   __shared__ float sw[SH_UNET_MAXBASE];
   for (int i = threadIdx.x; i < C; i += blockDim.x) sw[i] = w[i];
   __syncthreads();
   const float b = bp[0];
   for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
     const size_t im = p / HW, pin = p - im * HW;
-    const __bf16* s = src + im * HW * C;
+    const ET* s = src + im * HW * C;
     float a = b;
     for (int c8 = 0; c8 < C; c8 += 8) {
-      bf16x8 v = *(const bf16x8*)(s + act_off(HW, pin, c8));
+      v8 v = *(const v8*)(s + act_off(HW, pin, c8));
 #pragma unroll
       for (int k = 0; k < 8; ++k) a = __builtin_fmaf((float)v[k], sw[c8 + k], a);
     }

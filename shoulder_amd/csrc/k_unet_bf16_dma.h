@@ -30,7 +30,8 @@ namespace sh {
 typedef const __attribute__((address_space(1))) void* ud_gptr;
 typedef __attribute__((address_space(3))) void* ud_lptr;
 
-__device__ inline void ud_store8(__bf16* p, bf16x4 v) {      // exactly one vector-memory instruction (counted by s_waitcnt vmcnt)
+template <typename ET, typename V4>
+__device__ inline void ud_store8(ET* p, V4 v) {      // exactly one vector-memory instruction (counted by s_waitcnt vmcnt)
   asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(__builtin_bit_cast(unsigned long long, v)) : "memory");
 }
 __device__ inline void ud_store4(float* p, float v) {
@@ -47,12 +48,14 @@ template <int N> __device__ inline void ud_wait_vm() {      // s_waitcnt takes a
 
 // FUSE: 0, UF_POOL (2x2 max pool written beside the output) or UF_HEAD (1x1 head: only the logits leave the kernel).
 // NN: 16-cout tiles per item: 4 (64-cout groups) or 2 (the 32-channel level: 288 weight rows, 8 DMA pieces per step).
-template <int FUSE, int NN = 4>
+template <typename ET, int FUSE, int NN = 4>
 __global__ void __launch_bounds__(UD_THREADS)
-k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src1, int C0, int C1,
-                 const __bf16* __restrict__ wgt, const float* __restrict__ bias, __bf16* __restrict__ dst,
-                 int H, int W, int Cout, int relu, int nimg, const __bf16* __restrict__ zero_page, __bf16* __restrict__ pooled,
-                 const float* __restrict__ head_w, const float* __restrict__ head_b, float* __restrict__ logits) {
+k_conv3_dma16(const ET* __restrict__ src0, const ET* __restrict__ src1, int C0, int C1,
+              const ET* __restrict__ wgt, const float* __restrict__ bias, ET* __restrict__ dst,
+              int H, int W, int Cout, int relu, int nimg, const ET* __restrict__ zero_page, ET* __restrict__ pooled,
+              const float* __restrict__ head_w, const float* __restrict__ head_b, float* __restrict__ logits) {
+  using v8 = typename E16<ET>::v8;
+  using v4 = typename E16<ET>::v4;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[UD_SMEM];
   static_assert(NN == 4 || NN == 2, "64- or 32-cout items");
   static_assert(!(FUSE & UF_HEAD) || NN == 2, "the head reads all 32 channels of a pixel from one item");
@@ -115,7 +118,7 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
       pixoff[k] = ok ? gy * W + gx : -1;
     }
   };
-  const __bf16* n_simg; const __bf16* n_wbase; int n_Cs, n_cb; unsigned char* n_lbase;      // step being staged (wave-uniform)
+  const ET* n_simg; const ET* n_wbase; int n_Cs, n_cb; unsigned char* n_lbase;      // step being staged (wave-uniform)
   auto describe = [&](int cc, int buf) {
     const int c0 = cc * 32;
     const bool first = c0 < C0;
@@ -127,11 +130,11 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
   };
   auto piece = [&](int k) {      // k is a compile-time constant at every call site
     if (k < 5) {
-      const __bf16* p = pixoff[k] >= 0 ? n_simg + (unsigned)((n_cb + pixoff[k]) * 32 + q8) : zero_page;
+      const ET* p = pixoff[k] >= 0 ? n_simg + (unsigned)((n_cb + pixoff[k]) * 32 + q8) : zero_page;
       __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + k * 8192), 16, 0, 0);
     } else if (k == 5) {
-      const __bf16* pi = pixoff[5] >= 0 ? n_simg + (unsigned)((n_cb + pixoff[5]) * 32 + q8) : zero_page;
-      const __bf16* p = in5 ? pi : n_wbase + wrel5;
+      const ET* pi = pixoff[5] >= 0 ? n_simg + (unsigned)((n_cb + pixoff[5]) * 32 + q8) : zero_page;
+      const ET* p = in5 ? pi : n_wbase + wrel5;
       __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + 5 * 8192), 16, 0, 0);
     } else if (k < NPIECE - 1) {
       __builtin_amdgcn_global_load_lds((ud_gptr)(n_wbase + (wrel5 + (k - 5) * wstep)), (ud_lptr)(n_lbase + k * 8192), 16, 0, 0);
@@ -179,11 +182,11 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
-        bf16x8 xf[4], wf[NN];
+        v8 xf[4], wf[NN];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { const int s = m + dy; xf[m] = *(const bf16x8*)(xb[s & 1][dx] + (s & ~1) * UD_PW * 64); }
+        for (int m = 0; m < 4; ++m) { const int s = m + dy; xf[m] = *(const v8*)(xb[s & 1][dx] + (s & ~1) * UD_PW * 64); }
 #pragma unroll
-        for (int n = 0; n < NN; ++n) wf[n] = *(const bf16x8*)(wbp + (tap * WR + n * 16) * 64);
+        for (int n = 0; n < NN; ++n) wf[n] = *(const v8*)(wbp + (tap * WR + n * 16) * 64);
         if (has_next) { if (tap < NPIECE) piece(tap); if (tap == 8 && NPIECE == 10) piece(9); }
 #ifdef SH_DMA_SETPRIO
         __builtin_amdgcn_s_setprio(1);      // +4..7 % per layer in tools/conv_lab, -1..3 % inside this library (co-compiled kernels shift the schedule): off
@@ -191,7 +194,7 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int n = 0; n < NN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], xf[m], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < NN; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xf[m], acc[m][n]);
 #ifdef SH_DMA_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -214,36 +217,36 @@ k_conv3_dma_bf16(const __bf16* __restrict__ src0, const __bf16* __restrict__ src
         ud_store4(lo + (size_t)(c_y0 + rg * 4 + m) * W + c_x0 + xh * 16 + li, hb + sacc);
       }
     } else {
-    __bf16* out = dst + (size_t)c_img * H * W * Cout;
+    ET* out = dst + (size_t)c_img * H * W * Cout;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int gy = c_y0 + rg * 4 + m, gx = c_x0 + xh * 16 + li;
 #pragma unroll
       for (int n = 0; n < NN; ++n) {
-        bf16x4 o;
+        v4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[m][n][r];
           if (relu) v = fmaxf(v, 0.0f);
-          o[r] = (__bf16)v;
+          o[r] = (ET)v;
         }
         ud_store8(out + act_off((size_t)H * W, (size_t)gy * W + gx, c_n0 + n * 16 + lk * 4), o);
       }
     }
     }
     if (FUSE & UF_POOL) {      // 2x2 max pool of this wave's 4 rows x 16 pixels (rows pair inside the lane, columns with lane li ^ 1)
-      __bf16* po = pooled + (size_t)c_img * (H / 2) * (W / 2) * Cout;
+      ET* po = pooled + (size_t)c_img * (H / 2) * (W / 2) * Cout;
 #pragma unroll
       for (int mp = 0; mp < 2; ++mp)
 #pragma unroll
         for (int n = 0; n < NN; ++n) {
-          bf16x4 o;
+          v4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = fmaxf(acc[2 * mp][n][r], acc[2 * mp + 1][n][r]);
             v = fmaxf(v, __shfl_xor(v, 1));
             if (relu) v = fmaxf(v, 0.0f);
-            o[r] = (__bf16)v;
+            o[r] = (ET)v;
           }
           // odd lanes store too (same value, the pixel of their even neighbour): the store count per wave stays exact
           ud_store8(po + act_off((size_t)(H / 2) * (W / 2), (size_t)((c_y0 + rg * 4) / 2 + mp) * (W / 2) + (c_x0 + xh * 16 + li) / 2, c_n0 + n * 16 + lk * 4), o);

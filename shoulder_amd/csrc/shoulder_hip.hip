@@ -259,10 +259,16 @@ int sh_set_params(sh_ctx* c, const sh_params* p) {
   // the search window of the groove's local minimum is +-round(deg_window / (360 / 512)) samples of a 512-sample row
   // (bicipital_groove.py:190-229); beyond half a turn the reference's negative indices run off the row (IndexError there)
   if (!(p->groove_deg_window >= 0.0 && p->groove_deg_window <= 180.0)) return fail(c, SH_ERR_ARG, "groove_deg_window must lie in [0, 180] degrees");
-  if (p->unet_dtype != SH_UNET_F32 && p->unet_dtype != SH_UNET_BF16) return fail(c, SH_ERR_ARG, "unet_dtype must be SH_UNET_F32 or SH_UNET_BF16");
+  if (p->unet_dtype != SH_UNET_F32 && p->unet_dtype != SH_UNET_BF16 && p->unet_dtype != SH_UNET_F16) return fail(c, SH_ERR_ARG, "unet_dtype must be SH_UNET_F32, SH_UNET_BF16 or SH_UNET_F16");
   if (p->bone_kind != SH_BONE_HUMERUS && p->bone_kind != SH_BONE_PROXIMAL) return fail(c, SH_ERR_ARG, "bone_kind must be SH_BONE_HUMERUS or SH_BONE_PROXIMAL");
   if (c->prep.active && p->bone_kind != c->params.bone_kind) (void)join_prepared(c);
   c->params = *p;
+  return SH_OK;
+}
+
+int sh_get_params(const sh_ctx* c, sh_params* out) {
+  if (!c || !out) return SH_ERR_ARG;
+  *out = c->params;
   return SH_OK;
 }
 
@@ -279,6 +285,8 @@ static int alloc_batch(sh_ctx* c) {
   } while (0)
   ENS("verts_obb", c->sumV * 3 * 8, 8);
   c->bufs["verts_obb"].per_mesh = 0;        // ragged: indexed through voff
+  ENS("verts_csys", c->sumV * 3 * 8, 8);
+  c->bufs["verts_csys"].per_mesh = 0;
   c->bufs["voff"].per_mesh = 8;             // a window sees voff[b0 + b] (absolute vertex offsets) as voff[b]
   c->bufs["foff"].per_mesh = 8;
   c->b0 = 0; c->Bwin = B;
@@ -412,21 +420,25 @@ static int alloc_prox(sh_ctx* c) {
 int sh_upload_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const int64_t* v_off, const int64_t* f_off, int B) {
   if (!c || !verts || !faces || !v_off || !f_off || B <= 0) return fail(c, SH_ERR_ARG, "sh_upload_meshes: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
-  (void)join_prepared(c); ++c->batch_gen;      // hulls prepared for the previous batch are void
-  c->h_voff.assign(v_off, v_off + B + 1);
-  c->h_foff.assign(f_off, f_off + B + 1);
-  c->sumV = v_off[B]; c->sumF = f_off[B];
-  c->maxV = c->maxF = 0;
+  // Validate first, into locals: a rejected upload leaves the resident batch (B, offsets, device buffers) untouched.
+  if (v_off[0] != 0 || f_off[0] != 0) return fail(c, SH_ERR_ARG, "sh_upload_meshes: offsets must start at 0");
+  long long maxV = 0, maxF = 0;
   for (int b = 0; b < B; ++b) {
     long long nv = v_off[b + 1] - v_off[b], nf = f_off[b + 1] - f_off[b];
     if (nv < 4 || nf < 4) return fail(c, SH_ERR_ARG, "sh_upload_meshes: a mesh has fewer than 4 vertices/faces");
-    c->maxV = std::max(c->maxV, nv); c->maxF = std::max(c->maxF, nf);
+    if (nv > 0x7fffffffLL / 3 || nf > 0x7fffffffLL / 3) return fail(c, SH_ERR_ARG, "sh_upload_meshes: a mesh is too large");
+    maxV = std::max(maxV, nv); maxF = std::max(maxF, nf);
     for (long long i = 3 * f_off[b]; i < 3 * f_off[b + 1]; ++i)
       if (faces[i] < 0 || faces[i] >= nv) return fail(c, SH_ERR_ARG, "sh_upload_meshes: face index out of range");
   }
-  for (long long i = 0; i < 3 * c->sumV; ++i)
+  const long long sumV = v_off[B], sumF = f_off[B];
+  for (long long i = 0; i < 3 * sumV; ++i)
     if (!std::isfinite(verts[i])) return fail(c, SH_ERR_ARG, "sh_upload_meshes: NaN / infinite vertex coordinate");
-  c->B = B;
+  (void)join_prepared(c); ++c->batch_gen;      // hulls prepared for the previous batch are void
+  c->B = 0;                                     // (a HIP / allocation failure below leaves "no meshes uploaded", never a half-committed batch)
+  c->h_voff.assign(v_off, v_off + B + 1);
+  c->h_foff.assign(f_off, f_off + B + 1);
+  c->sumV = sumV; c->sumF = sumF; c->maxV = maxV; c->maxF = maxF;
   c->h_verts.assign(verts, verts + 3 * c->sumV);
   c->h_verts_valid = true;
   int rc;
@@ -439,7 +451,9 @@ int sh_upload_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const 
   HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "voff"), c->h_voff.data(), (B + 1) * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(buf<long long>(c, "foff"), c->h_foff.data(), (B + 1) * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return alloc_batch(c);
+  c->B = B;
+  if ((rc = alloc_batch(c)) != SH_OK) c->B = 0;
+  return rc;
 }
 
 // Binary STL files -> merged meshes, on the device (k_stl.h; replaces `trimesh.load_mesh(stl)` of mesh.py:22-27 incl. the
@@ -447,7 +461,6 @@ int sh_upload_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const 
 int sh_upload_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int B, int64_t* v_off_out, int64_t* f_off_out) {
   if (!c || !files || !nbytes || B <= 0) return fail(c, SH_ERR_ARG, "sh_upload_stl: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
-  (void)join_prepared(c); ++c->batch_gen;
   std::vector<long long> file_off(B + 1, 0), coff(B + 1, 0);
   long long maxc = 0;
   for (int b = 0; b < B; ++b) {
@@ -492,17 +505,22 @@ int sh_upload_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int
   HIPCHK(c, hipMemcpyAsync(counts.data(), buf<int>(c, "stl.counts"), (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(nonfin.data(), c->bufs["stl.nonfinite"].p, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->h_voff.assign(B + 1, 0); c->h_foff.assign(B + 1, 0);
-  c->maxV = c->maxF = 0;
+  // Validate into locals: a rejected file set leaves the resident batch (B, offsets, "verts" / "faces") untouched -- only
+  // the stl.* scratch buffers were written so far.
+  std::vector<long long> n_voff(B + 1, 0), n_foff(B + 1, 0);
+  long long maxV = 0, maxF = 0;
   for (int b = 0; b < B; ++b) {
     if (nonfin[b]) return fail(c, SH_ERR_ARG, "sh_upload_stl: a file holds NaN / infinite coordinates");
     if (counts[2 * b] < 4 || counts[2 * b + 1] < 4) return fail(c, SH_ERR_ARG, "sh_upload_stl: a mesh has fewer than 4 vertices/faces after merging");
-    c->h_voff[b + 1] = c->h_voff[b] + counts[2 * b];
-    c->h_foff[b + 1] = c->h_foff[b] + counts[2 * b + 1];
-    c->maxV = std::max<long long>(c->maxV, counts[2 * b]); c->maxF = std::max<long long>(c->maxF, counts[2 * b + 1]);
+    n_voff[b + 1] = n_voff[b] + counts[2 * b];
+    n_foff[b + 1] = n_foff[b] + counts[2 * b + 1];
+    maxV = std::max<long long>(maxV, counts[2 * b]); maxF = std::max<long long>(maxF, counts[2 * b + 1]);
   }
+  (void)join_prepared(c); ++c->batch_gen;
+  c->B = 0;                        // (a HIP / allocation failure below leaves "no meshes uploaded")
+  c->h_voff.swap(n_voff); c->h_foff.swap(n_foff);
+  c->maxV = maxV; c->maxF = maxF;
   c->sumV = c->h_voff[B]; c->sumF = c->h_foff[B];
-  c->B = B;
   c->h_verts_valid = false;      // the hull stage downloads the merged vertices (as for a device-generated batch)
   if ((rc = ensure(c, "verts", c->sumV * 3 * 4, 4)) != SH_OK) return rc;
   if ((rc = ensure(c, "faces", c->sumF * 3 * 4, 4)) != SH_OK) return rc;
@@ -516,7 +534,9 @@ int sh_upload_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (v_off_out) for (int b = 0; b <= B; ++b) v_off_out[b] = c->h_voff[b];
   if (f_off_out) for (int b = 0; b <= B; ++b) f_off_out[b] = c->h_foff[b];
-  return alloc_batch(c);
+  c->B = B;
+  if ((rc = alloc_batch(c)) != SH_OK) c->B = 0;
+  return rc;
 }
 
 int sh_synth_batch(sh_ctx* c, const double* T, int B) {
@@ -532,7 +552,7 @@ int sh_synth_batch(sh_ctx* c, const double* T, int B) {
   HIPCHK(c, hipMemcpyAsync(buf<float>(c, "tmpl_verts"), buf<float>(c, "verts") + 3 * c->h_voff[0], V * 3 * 4, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(buf<int>(c, "tmpl_faces"), buf<int>(c, "faces") + 3 * c->h_foff[0], F * 3 * 4, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->B = B;
+  c->B = 0;                        // (a failure below leaves "no meshes uploaded", never a half-committed batch)
   c->h_verts_valid = false;
   c->sumV = V * B; c->sumF = F * B; c->maxV = V; c->maxF = F;
   c->h_voff.resize(B + 1); c->h_foff.resize(B + 1);
@@ -549,7 +569,9 @@ int sh_synth_batch(sh_ctx* c, const double* T, int B) {
   LAUNCH(c, "k_synth_batch", k_synth_batch, grid, dim3(256), buf<float>(c, "tmpl_verts"), buf<int>(c, "tmpl_faces"),
          (long long)V, (long long)F, buf<double>(c, "synth_T"), buf<float>(c, "verts"), buf<int>(c, "faces"));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return alloc_batch(c);
+  c->B = B;
+  if ((rc = alloc_batch(c)) != SH_OK) c->B = 0;
+  return rc;
 }
 
 // ---- named buffers -----------------------------------------------------------------------------
@@ -559,6 +581,15 @@ int sh_buffer_info(sh_ctx* c, const char* name, size_t* nbytes, int* elem) {
   if (it == c->bufs.end()) return fail(c, SH_ERR_ARG, std::string("no buffer named ") + name);
   if (nbytes) *nbytes = it->second.bytes;
   if (elem) *elem = it->second.elem;
+  return SH_OK;
+}
+
+int sh_buffer_device(sh_ctx* c, const char* name, void** dev_ptr, size_t* nbytes) {
+  if (!c || !name || !dev_ptr) return SH_ERR_ARG;
+  auto it = c->bufs.find(name);
+  if (it == c->bufs.end() || !it->second.p) return fail(c, SH_ERR_ARG, std::string("no buffer named ") + name);
+  *dev_ptr = it->second.p;
+  if (nbytes) *nbytes = it->second.bytes;
   return SH_OK;
 }
 
@@ -881,11 +912,14 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
   return SH_OK;
 }
 
-// ---- UNet forward (bf16 MFMA path) ---------------------------------------------------------------------
-static int conv_layer_bf16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const __bf16* src0, const __bf16* src1, int C0, int C1,
-                           __bf16* dst, int H, int W, int nimg, int relu, int fuse = 0, ConvFuse fz = ConvFuse{}) {
+}  // extern "C" (the templates below need C++ linkage)
+
+// ---- UNet forward (16-bit MFMA paths: ET = __bf16 or _Float16) -----------------------------------------
+template <typename ET>
+static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const ET* src0, const ET* src1, int C0, int C1,
+                           ET* dst, int H, int W, int nimg, int relu, int fuse = 0, ConvFuse fz = ConvFuse{}) {
   if (H % UN_TH || W % UN_TW) return fail(c, SH_ERR_ARG, "unet: feature map is not a multiple of 16");
-  const __bf16* w = buf<__bf16>(c, "params_bf16") + L.w_off;
+  const ET* w = buf<ET>(c, "params_bf16") + L.w_off;
   const float* b = buf<float>(c, "params") + L.b_off;
   const int tiles = (H / UN_TH) * (W / UN_TW);
   const dim3 blk(UN_THREADS);
@@ -903,30 +937,30 @@ static int conv_layer_bf16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L
     if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
     const int total = nimg * (W / 32) * (H / 16) * (L.cout / (dma64 ? 64 : 32));
     const dim3 g((unsigned)std::min(total, c->num_cus));      // (leaving 16..64 CUs to the other lane's kernels changes nothing: measured)
-    const __bf16* zp = (const __bf16*)c->bufs["unet16.zero"].p;
+    const ET* zp = (const ET*)c->bufs["unet16.zero"].p;
     const float* nof = nullptr;
     if (dma64) {
-      if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma_bf16<UF_POOL, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, fz.pooled, nof, nof, (float*)nullptr); }
-      else { LAUNCH(c, lname, (k_conv3_dma_bf16<0, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (__bf16*)nullptr, nof, nof, (float*)nullptr); }
-    } else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma_bf16<UF_POOL, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, fz.pooled, nof, nof, (float*)nullptr); }
-    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv3_dma_bf16<UF_HEAD, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (__bf16*)nullptr, fz.head_w, fz.head_b, fz.logits); }
-    else { LAUNCH(c, lname, (k_conv3_dma_bf16<0, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (__bf16*)nullptr, nof, nof, (float*)nullptr); }
+      if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma16<ET, UF_POOL, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (ET*)fz.pooled, nof, nof, (float*)nullptr); }
+      else { LAUNCH(c, lname, (k_conv3_dma16<ET, 0, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (ET*)nullptr, nof, nof, (float*)nullptr); }
+    } else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma16<ET, UF_POOL, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (ET*)fz.pooled, nof, nof, (float*)nullptr); }
+    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv3_dma16<ET, UF_HEAD, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (ET*)nullptr, fz.head_w, fz.head_b, fz.logits); }
+    else { LAUNCH(c, lname, (k_conv3_dma16<ET, 0, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (ET*)nullptr, nof, nof, (float*)nullptr); }
   } else if (L.taps == 9 && L.cout % 64 == 0) {
     const dim3 g(tiles, L.cout / 64, nimg);
-    if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 4, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 4, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 4, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 4, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
     else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
   } else if (L.taps == 9) {
     const dim3 g(tiles, L.cout / 32, nimg);
-    if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 2, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == (UF_FIRST | UF_POOL)) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 2, UF_FIRST | UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 2, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv_mfma_bf16<9, 2, UF_HEAD>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 2, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == (UF_FIRST | UF_POOL)) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 2, UF_FIRST | UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 2, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 2, UF_HEAD>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
     else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
   } else if (L.cout % 64 == 0) {
-    LAUNCH(c, lname, (k_conv_mfma_bf16<1, 4, 0>), dim3(tiles, L.cout / 64, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
+    LAUNCH(c, lname, (k_conv_mfma16<ET, 1, 4, 0>), dim3(tiles, L.cout / 64, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
   } else {
-    LAUNCH(c, lname, (k_conv_mfma_bf16<1, 2, 0>), dim3(tiles, L.cout / 32, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
+    LAUNCH(c, lname, (k_conv_mfma16<ET, 1, 2, 0>), dim3(tiles, L.cout / 32, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
   }
   return SH_OK;
 }
@@ -934,13 +968,14 @@ static int conv_layer_bf16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L
 // 4-level double-conv UNet, bf16.  With 32 base channels the memory-bound ends are fused (k_unet_bf16.h): the first
 // conv into the staging of enc0b, every 2x2 max pool into the epilogue of the conv before it, the 1x1 head into the
 // epilogue of dec0b.  SHOULDER_UNET_UNFUSED=1 (or another base width) runs the layer-by-layer form.
-static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
+template <typename ET>
+static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
   const int D = c->unet_depth, base = c->unet_base;
   if ((H >> D) % 16 || (W >> D) % 16) return fail(c, SH_ERR_ARG, "unet: input size must be a multiple of 16 << depth");
   int rc;
   if ((rc = ensure(c, "params_bf16", c->unet_floats * 2, 2)) != SH_OK) return rc;
   const float* P = buf<float>(c, "params");
-  __bf16* PW = buf<__bf16>(c, "params_bf16");
+  ET* PW = buf<ET>(c, "params_bf16");
   {     // repack the MFMA layers' weights (cheap; stays correct after a parameter broadcast): one launch for all layers
     std::vector<PackEntry> tab;
     long long total = 0;
@@ -956,21 +991,21 @@ static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int n
       HIPCHK(c, hipStreamSynchronize(c->stream));      // `tab` is a local
       c->packtab_ready = true;
     }
-    LAUNCH(c, "k_pack_w_bf16", k_pack_w_bf16_all, dim3(2048), dim3(256), P, PW, (const PackEntry*)c->bufs["unet16.packtab"].p, (int)tab.size(), total);
+    LAUNCH(c, "k_pack_w_bf16", k_pack_w16_all<ET>, dim3(2048), dim3(256), P, PW, (const PackEntry*)c->bufs["unet16.packtab"].p, (int)tab.size(), total);
   }
   const char* unf = getenv("SHOULDER_UNET_UNFUSED");
   const bool fused = base == 32 && !(unf && unf[0] == '1');
   const size_t full = (size_t)nimg * H * W * base * 2;
   if ((rc = ensure(c, "unet16.a", full, 2)) != SH_OK) return rc;
   if ((rc = ensure(c, "unet16.b", full, 2)) != SH_OK) return rc;
-  std::vector<__bf16*> skip(D);
+  std::vector<ET*> skip(D);
   for (int i = 0; i < D; ++i) {
     std::string nm = "unet16.skip" + std::to_string(i);
     if ((rc = ensure(c, nm.c_str(), full >> i, 2)) != SH_OK) return rc;
-    skip[i] = buf<__bf16>(c, nm.c_str());
+    skip[i] = buf<ET>(c, nm.c_str());
   }
-  __bf16* A = buf<__bf16>(c, "unet16.a");
-  __bf16* Bq = buf<__bf16>(c, "unet16.b");
+  ET* A = buf<ET>(c, "unet16.a");
+  ET* Bq = buf<ET>(c, "unet16.b");
   auto L = [&](const std::string& n) -> const sh_ctx::ULayer& { return c->ulayers[n]; };
   int h = H, w = W;
   const char* ff = getenv("SHOULDER_UNET_FUSE_FIRST");
@@ -978,58 +1013,68 @@ static int unet_forward_bf16(sh_ctx* c, const float* image, float* logits, int n
     const sh_ctx::ULayer& l = L("enc0a");
     ConvFuse fz{};
     fz.image = image; fz.w0 = P + l.w_off; fz.b0 = P + l.b_off; fz.pooled = A;
-    if ((rc = conv_layer_bf16(c, "unet.enc0b", L("enc0b"), nullptr, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_FIRST | UF_POOL, fz)) != SH_OK) return rc;
+    if ((rc = conv_layer16<ET>(c, "unet.enc0b", L("enc0b"), nullptr, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_FIRST | UF_POOL, fz)) != SH_OK) return rc;
   } else if (fused) {
     const sh_ctx::ULayer& l = L("enc0a");
     size_t npx = (size_t)nimg * h * w;
-    LAUNCH(c, "unet.enc0a", k_conv_first_bf16, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, Bq, h, w, l.cout, nimg);
+    LAUNCH(c, "unet.enc0a", k_conv_first16<ET>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, Bq, h, w, l.cout, nimg);
     ConvFuse fz{};
     fz.pooled = A;
-    if ((rc = conv_layer_bf16(c, "unet.enc0b", L("enc0b"), Bq, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_POOL, fz)) != SH_OK) return rc;
+    if ((rc = conv_layer16<ET>(c, "unet.enc0b", L("enc0b"), Bq, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_POOL, fz)) != SH_OK) return rc;
   } else {
     const sh_ctx::ULayer& l = L("enc0a");
     size_t npx = (size_t)nimg * h * w;
-    LAUNCH(c, "unet.enc0a", k_conv_first_bf16, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, A, h, w, l.cout, nimg);
-    if ((rc = conv_layer_bf16(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1)) != SH_OK) return rc;
+    LAUNCH(c, "unet.enc0a", k_conv_first16<ET>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, A, h, w, l.cout, nimg);
+    if ((rc = conv_layer16<ET>(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1)) != SH_OK) return rc;
   }
   int ch = base;
   for (int i = 1; i <= D; ++i) {
     if (!fused) {
       size_t e = (size_t)nimg * (h / 2) * (w / 2) * (ch / 8);
-      LAUNCH(c, "unet.pool", k_maxpool2_bf16, dim3((unsigned)std::min<size_t>((e + 255) / 256, 8192)), dim3(256), skip[i - 1], A, h, w, ch, nimg);
+      LAUNCH(c, "unet.pool", k_maxpool2_16<ET>, dim3((unsigned)std::min<size_t>((e + 255) / 256, 8192)), dim3(256), skip[i - 1], A, h, w, ch, nimg);
     }
     h /= 2; w /= 2;
     std::string na = i < D ? "enc" + std::to_string(i) + "a" : "bota", nb = i < D ? "enc" + std::to_string(i) + "b" : "botb";
-    if ((rc = conv_layer_bf16(c, ("unet." + na).c_str(), L(na), A, nullptr, ch, 0, Bq, h, w, nimg, 1)) != SH_OK) return rc;
+    if ((rc = conv_layer16<ET>(c, ("unet." + na).c_str(), L(na), A, nullptr, ch, 0, Bq, h, w, nimg, 1)) != SH_OK) return rc;
     ch *= 2;
-    __bf16* dst = i < D ? skip[i] : A;
+    ET* dst = i < D ? skip[i] : A;
     ConvFuse fz{};
     fz.pooled = A;      // (A was consumed by the conv above; the next level reads it)
-    if ((rc = conv_layer_bf16(c, ("unet." + nb).c_str(), L(nb), Bq, nullptr, ch, 0, dst, h, w, nimg, 1, (fused && i < D) ? UF_POOL : 0, fz)) != SH_OK) return rc;
+    if ((rc = conv_layer16<ET>(c, ("unet." + nb).c_str(), L(nb), Bq, nullptr, ch, 0, dst, h, w, nimg, 1, (fused && i < D) ? UF_POOL : 0, fz)) != SH_OK) return rc;
   }
-  __bf16* x = A; __bf16* y = Bq;
+  ET* x = A; ET* y = Bq;
   for (int i = D - 1; i >= 0; --i) {
     std::string nu = "up" + std::to_string(i), na = "dec" + std::to_string(i) + "a", nb = "dec" + std::to_string(i) + "b";
-    if ((rc = conv_layer_bf16(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
+    if ((rc = conv_layer16<ET>(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
     h *= 2; w *= 2; ch /= 2;
-    if ((rc = conv_layer_bf16(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;
+    if ((rc = conv_layer16<ET>(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;
     if (fused && i == 0) {
       const sh_ctx::ULayer& l = L("head");
       ConvFuse fz{};
       fz.head_w = P + l.w_off; fz.head_b = P + l.b_off; fz.logits = logits;
-      if ((rc = conv_layer_bf16(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1, UF_HEAD, fz)) != SH_OK) return rc;
+      if ((rc = conv_layer16<ET>(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1, UF_HEAD, fz)) != SH_OK) return rc;
       return SH_OK;
     }
-    if ((rc = conv_layer_bf16(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1)) != SH_OK) return rc;
+    if ((rc = conv_layer16<ET>(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1)) != SH_OK) return rc;
     std::swap(x, y);
   }
   {
     const sh_ctx::ULayer& l = L("head");
     size_t npx = (size_t)nimg * H * W;
-    LAUNCH(c, "unet.head", k_head_bf16, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx, (size_t)H * W);
+    LAUNCH(c, "unet.head", k_head16<ET>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx, (size_t)H * W);
   }
   return SH_OK;
 }
+
+static int unet_dispatch(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
+  switch (c->params.unet_dtype) {
+    case SH_UNET_BF16: return unet_forward16<__bf16>(c, image, logits, nimg, H, W);
+    case SH_UNET_F16: return unet_forward16<_Float16>(c, image, logits, nimg, H, W);
+    default: return unet_forward(c, image, logits, nimg, H, W);
+  }
+}
+
+extern "C" {
 
 // The network alone (the `ort.InferenceSession.run` call of anatomic_neck.py:67-76): n images
 // [n][H][W] float32 on the host -> logits [n][H][W] float32 on the host, in the precision sh_params.unet_dtype selects.
@@ -1043,8 +1088,7 @@ int sh_unet_infer(sh_ctx* c, const float* images, int n, int H, int W, float* lo
   if ((rc = ensure(c, "infer.logits", bytes, 4)) != SH_OK) return rc;
   const int b0 = c->b0; c->b0 = 0;      // named buffers below are whole-batch
   HIPCHK(c, hipMemcpyAsync(buf<float>(c, "infer.image"), images, bytes, hipMemcpyHostToDevice, c->stream));
-  rc = c->params.unet_dtype == SH_UNET_BF16 ? unet_forward_bf16(c, buf<float>(c, "infer.image"), buf<float>(c, "infer.logits"), n, H, W)
-                                            : unet_forward(c, buf<float>(c, "infer.image"), buf<float>(c, "infer.logits"), n, H, W);
+  rc = unet_dispatch(c, buf<float>(c, "infer.image"), buf<float>(c, "infer.logits"), n, H, W);
   c->b0 = b0;
   if (rc != SH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
   HIPCHK(c, hipMemcpyAsync(logits, buf<float>(c, "infer.logits"), bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1348,8 +1392,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     LAUNCH(c, "k_anp_minmax", k_anp_minmax_reduce, dim3(16, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"));
     LAUNCH(c, "k_anp_scale", k_anp_scale, dim3(64, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"), buf<float>(c, "anp.image"));
     if ((rc = unet_turn_enter(c)) != SH_OK) return rc;
-    if (c->params.unet_dtype == SH_UNET_BF16) rc = unet_forward_bf16(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
-    else rc = unet_forward(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
+    rc = unet_dispatch(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
     (void)unet_turn_leave(c);      // also after a failed pass: whatever was enqueued is what the next context waits for
     if (rc != SH_OK) return rc;
     LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(B), dim3(512), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
@@ -1382,6 +1425,10 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
              buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.plane"), buf<double>(c, "metrics.partial"));
       LAUNCH(c, "k_metrics", k_metrics, dim3(B), dim3(64), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "metrics.partial"), buf<int>(c, "err"), (int)c->params.bone_kind);
     }
+  }
+  if (mask & SH_STAGE_APPLY) {      // bone.py:155: the mesh of every humerus in its own canal / trans-epicondylar (or canal / articular) frame
+    dim3 g((unsigned)std::min<long long>((c->maxV + 255) / 256, 1024), (unsigned)B);
+    LAUNCH(c, "k_apply_csys", k_apply_csys, g, dim3(256), buf<sh_landmarks>(c, "landmarks"), buf<float>(c, "verts"), buf<long long>(c, "voff"), buf<double>(c, "verts_csys"));
   }
   return SH_OK;
 }
@@ -1472,6 +1519,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     if (prc != SH_OK) return prc;
   }
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "err"), 0, B * 4, c->stream));
+  if ((mask & SH_STAGE_APPLY) && !(mask & SH_STAGE_CSYS)) return fail(c, SH_ERR_ARG, "sh_run: SH_STAGE_APPLY needs SH_STAGE_CSYS in the same run");
   if (!(mask & SH_STAGE_OBB) && !c->obb_injected)
     return fail(c, SH_ERR_STATE, "sh_run: no OBB transform (run SH_STAGE_OBB or sh_store(\"obb_transform\"))");
   // Windows: with the host hull in play the batch can be walked in windows of SHOULDER_WINDOW humeri; all device work of
@@ -1637,15 +1685,16 @@ int sh_load_unet(sh_ctx* c, int base, int depth, const float* packed, size_t n_f
   if (!c || !packed || depth < 1 || depth > 6 || base < 32 || base % 32 != 0 || base > SH_UNET_MAXBASE)
     return fail(c, SH_ERR_ARG, "sh_load_unet: bad argument (base must be a multiple of 32, at most 256; depth 1..6)");
   HIPCHK(c, hipSetDevice(c->device));
-  c->ulayers.clear();
-  c->packtab_ready = false;
+  // The layer table is built aside and swapped in together with the parameters only after the size check: a rejected
+  // call leaves the loaded network (table, host copy, device block) as it was.
+  std::map<std::string, sh_ctx::ULayer> layers;
   size_t o = 0;
   auto add = [&](const std::string& name, int taps, int cin, int cout) {
     sh_ctx::ULayer L;
     L.taps = taps; L.cin = cin; L.cout = cout;
     L.w_off = o; o += (size_t)taps * cin * cout;
     L.b_off = o; o += cout;
-    c->ulayers[name] = L;
+    layers[name] = L;
   };
   std::vector<int> ch(depth + 1);
   for (int i = 0; i <= depth; ++i) ch[i] = base << i;
@@ -1662,15 +1711,68 @@ int sh_load_unet(sh_ctx* c, int base, int depth, const float* packed, size_t n_f
     add("dec" + std::to_string(i) + "a", 9, 2 * ch[i], ch[i]);
     add("dec" + std::to_string(i) + "b", 9, ch[i], ch[i]);
   }
-  { sh_ctx::ULayer L; L.taps = 1; L.cin = ch[0]; L.cout = 1; L.w_off = o; o += ch[0]; L.b_off = o; o += 1; c->ulayers["head"] = L; }
+  { sh_ctx::ULayer L; L.taps = 1; L.cin = ch[0]; L.cout = 1; L.w_off = o; o += ch[0]; L.b_off = o; o += 1; layers["head"] = L; }
   if (o != n_floats) {
     char m[160];
     snprintf(m, sizeof m, "sh_load_unet: expected %zu floats for base=%d depth=%d, got %zu", o, base, depth, n_floats);
     return fail(c, SH_ERR_ARG, m);
   }
+  for (size_t i = 0; i < n_floats; ++i)
+    if (!std::isfinite(packed[i])) return fail(c, SH_ERR_ARG, "sh_load_unet: NaN / infinite parameter");
+  (void)hipStreamSynchronize(c->stream);      // no forward of the previous network is still reading the block
+  c->ulayers.swap(layers);
+  c->packtab_ready = false;
   c->h_unet.assign(packed, packed + n_floats);
   c->unet_floats = n_floats; c->unet_base = base; c->unet_depth = depth; c->have_unet = true;
-  return upload_params(c);
+  int rc = upload_params(c);
+  if (rc != SH_OK) { c->have_unet = false; c->ulayers.clear(); }
+  return rc;
+}
+
+int sh_param_block_commit(sh_ctx* c) {
+  if (!c) return SH_ERR_ARG;
+  auto it = c->bufs.find("params");
+  if (it == c->bufs.end()) return fail(c, SH_ERR_STATE, "sh_param_block_commit: no parameters loaded");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t N = c->h_feat.size(), T = c->h_roots.size();
+  std::vector<float> unet(c->unet_floats), thr(N), lw(N);
+  std::vector<int32_t> feat(N), ti(N), fi(N), roots(T);
+  const char* p = (const char*)it->second.p;
+  size_t o = 0;
+  auto get = [&](void* dst, size_t n) -> hipError_t {
+    hipError_t e = n ? hipMemcpyAsync(dst, p + o, n, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+    o += n;
+    return e;
+  };
+  HIPCHK(c, get(unet.data(), c->unet_floats * 4));
+  HIPCHK(c, get(feat.data(), N * 4));
+  HIPCHK(c, get(thr.data(), N * 4));
+  HIPCHK(c, get(ti.data(), N * 4));
+  HIPCHK(c, get(fi.data(), N * 4));
+  HIPCHK(c, get(lw.data(), N * 4));
+  HIPCHK(c, get(roots.data(), T * 4));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // the device walks the forest until it meets a leaf: what arrived must still be a forest over the same node count
+  for (size_t i = 0; i < N; ++i) {
+    if (feat[i] < 0 || feat[i] >= 9) return fail(c, SH_ERR_ARG, "sh_param_block_commit: feature id out of range in the device block");
+    if ((ti[i] < 0) != (fi[i] < 0) || ti[i] >= (int)N || fi[i] >= (int)N) return fail(c, SH_ERR_ARG, "sh_param_block_commit: bad child index in the device block");
+  }
+  {
+    std::vector<char> seen(N, 0);
+    std::vector<int> stack;
+    for (size_t t = 0; t < T; ++t) {
+      if (roots[t] < 0 || roots[t] >= (int)N) return fail(c, SH_ERR_ARG, "sh_param_block_commit: bad root in the device block");
+      stack.push_back(roots[t]);
+      while (!stack.empty()) {
+        const int i = stack.back(); stack.pop_back();
+        if (seen[i]) return fail(c, SH_ERR_ARG, "sh_param_block_commit: the device block does not describe a forest");
+        seen[i] = 1;
+        if (ti[i] >= 0) { stack.push_back(ti[i]); stack.push_back(fi[i]); }
+      }
+    }
+  }
+  c->h_unet.swap(unet); c->h_feat.swap(feat); c->h_thr.swap(thr); c->h_ti.swap(ti); c->h_fi.swap(fi); c->h_lw.swap(lw); c->h_roots.swap(roots);
+  return SH_OK;
 }
 
 int sh_param_block(sh_ctx* c, void** p, size_t* n) {

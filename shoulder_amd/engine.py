@@ -95,21 +95,42 @@ class Engine:
         self.load_unet(w, base, depth)
         return base, depth
 
-    def set_params(self, canal_cutoff=(0.35, 0.75), groove_cutoff=(0.2, 0.75), groove_deg_window=7.0, unet_dtype=_lib.UNET_F32,
-                   bone_kind=_lib.BONE_HUMERUS):
+    def set_params(self, canal_cutoff=None, groove_cutoff=None, groove_deg_window=None, unet_dtype=None, bone_kind=None):
+        """Read-modify-write of sh_params: fields left at None keep the value in force (an engine configured for a bf16
+        UNet stays so when a facade object only sets its bone kind)."""
+        p = _lib.Params()
+        self._chk(self.L.sh_get_params(self.h, ctypes.byref(p)))
+        if canal_cutoff is not None:
+            p.canal_cutoff[0], p.canal_cutoff[1] = canal_cutoff
+        if groove_cutoff is not None:
+            p.groove_cutoff[0], p.groove_cutoff[1] = groove_cutoff
+        if groove_deg_window is not None:
+            p.groove_deg_window = groove_deg_window
+        if unet_dtype is not None:
+            p.unet_dtype = unet_dtype
+        if bone_kind is not None:
+            p.bone_kind = bone_kind
+        self._chk(self.L.sh_set_params(self.h, ctypes.byref(p)))
+
+    def get_params(self):
+        p = _lib.Params()
+        self._chk(self.L.sh_get_params(self.h, ctypes.byref(p)))
+        return dict(canal_cutoff=tuple(p.canal_cutoff), groove_cutoff=tuple(p.groove_cutoff), groove_deg_window=p.groove_deg_window,
+                    unet_dtype=p.unet_dtype, bone_kind=p.bone_kind)
+
+    def reset_params(self):
         p = _lib.Params()
         self.L.sh_default_params(ctypes.byref(p))
-        p.canal_cutoff[0], p.canal_cutoff[1] = canal_cutoff
-        p.groove_cutoff[0], p.groove_cutoff[1] = groove_cutoff
-        p.groove_deg_window = groove_deg_window
-        p.unet_dtype = unet_dtype
-        p.bone_kind = bone_kind
         self._chk(self.L.sh_set_params(self.h, ctypes.byref(p)))
 
     def param_block(self):
         p, n = ctypes.c_void_p(), ctypes.c_size_t()
         self._chk(self.L.sh_param_block(self.h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    def param_block_commit(self):
+        """The device parameter block was overwritten from outside (a broadcast): refresh the host mirrors (sh_param_block_commit)."""
+        self._chk(self.L.sh_param_block_commit(self.h))
 
     # ---- meshes ----------------------------------------------------------------------------------
     def upload(self, meshes):
@@ -209,6 +230,23 @@ class Engine:
         p, n = ctypes.c_void_p(), ctypes.c_size_t()
         self._chk(self.L.sh_landmarks_device(self.h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    def buffer_device(self, name):
+        """(device address, bytes) of a named buffer (sh_buffer_device)."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._chk(self.L.sh_buffer_device(self.h, name.encode(), ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def affine_apply(self, T, dev_in, dev_out, off):
+        """utils.transform_pts for B point sets resident on the device (sh_affine_apply): out[off[b]:off[b+1]] = T[b] * in[...];
+        dev_in / dev_out are device addresses of float64 xyz arrays, T (B,4,4), off (B+1,) point offsets."""
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        if T.ndim != 3 or T.shape[1:] != (4, 4):
+            raise ValueError("Invalid transformation matrix shape")
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        if off.shape != (len(T) + 1,):
+            raise ValueError("off must hold B + 1 offsets")
+        self._chk(self.L.sh_affine_apply(self.h, _ptr(T), ctypes.c_void_p(int(dev_in)), ctypes.c_void_p(int(dev_out)), _ptr(off), len(T)))
 
     def mesh_transformed(self, b, T):
         T = _mat4(T)

@@ -29,3 +29,28 @@ def test_bench_line():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and r["kernel"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "meshes/s" and c["sample"]
+    assert c["cpu_model"] and c["os_cpu_count"] >= 1
+    # the tolerance-conformant configuration (f32 UNet) is timed in the same invocation, and the one-lane figure beside the two-lane value
+    f = d["f32_unet"]
+    assert f["value"] > 0 and "f32" in f["dtype"] and abs(f["value"] - 8 * 1e3 / f["ms_per_step"]) < 1e-2 * f["value"]
+    assert f["roofline"]["peak"] == 157.3 and 0 < f["roofline"]["frac"] < 1
+    assert d["one_lane"]["lanes"] == 1 and d["one_lane"]["value"] > 0
+    assert d["config"]["hull_threads_per_context"] >= 1 and d["config"]["host"]["os_cpu_count"] >= 1
+    assert "k_slice_link" in d["geometry_kernels"] and d["geometry_kernels"]["k_slice_link"]["frac_of_hbm_peak"] > 0
+
+
+def test_rccl_leg_single_rank():
+    """The collective code path of bench.py on hardware (SH_BENCH_FORCE_DIST=1: process group "nccl" = RCCL with one rank): RCCL
+    broadcast of the device parameter block wrapped through __cuda_array_interface__, sh_param_block_commit, every step's
+    records written by sh_submit into a device send buffer and gathered asynchronously; rank 0's gathered records equal a
+    run of its own engine."""
+    env = dict(os.environ, SH_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--batch", "8",
+                          "--no-cpu-baseline", "--check-gather"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["meshes_with_error_status"] == 0
+    assert d["gather_check"] == {"records": 8, "own_shard_equal_to_local_run": True}
+    assert "f32_unet" not in d            # extra legs belong to the plain N=1 run

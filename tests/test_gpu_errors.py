@@ -108,7 +108,7 @@ def test_parameter_ranges(engine, oracle_bones):
             engine.set_params(**ok)
             assert engine.run(_lib.STAGE_ALL)["status"][0] == 0, ok
     finally:
-        engine.set_params()
+        engine.reset_params()
 
 
 def test_non_finite_coordinates_are_refused(engine, oracle_bones, tmp_path):
@@ -175,3 +175,60 @@ def test_wrapper_argument_checks(engine, oracle_bones):
     assert err.value.code == -3
     assert engine.transform_points(np.zeros((0, 3)), np.identity(4)).shape == (0, 3)
     assert engine.run(_lib.STAGE_ALL)["status"][0] == 0
+
+
+def test_rejected_upload_leaves_the_resident_batch_usable(engine, oracle_bones, tmp_path):
+    """A rejected sh_upload_meshes / sh_upload_stl must not leave the context half way between two batches (the rejected
+    batch's offsets over the old batch's device buffers): the resident batch (here TWO meshes, rejected ones hold ONE) still
+    runs and gives the same records, section and mesh transforms as before."""
+    import bench
+    a, b = oracle_bones("humerus_left"), oracle_bones("humerus_right")
+    engine.upload([(a.verts, a.faces), (b.verts, b.faces)])
+    before = engine.run(_lib.STAGE_ALL).copy()
+    assert (before["status"] == 0).all()
+    bad_faces = a.faces.copy(); bad_faces[11, 2] = -4
+    nan_verts = a.verts.copy(); nan_verts[77, 0] = np.nan
+    p = tmp_path / "nan.stl"
+    p.write_bytes(bench.stl_bytes(nan_verts, a.faces))
+    for attempt in (lambda: engine.upload([(a.verts, bad_faces)]), lambda: engine.upload([(nan_verts, a.faces)]),
+                    lambda: engine.upload([(a.verts[:3], a.faces[:1] * 0 + np.array([[0, 1, 2]], dtype=np.int32))]),
+                    lambda: engine.upload_stl([str(p)])):
+        with pytest.raises(ShoulderHipError) as err:
+            attempt()
+        assert err.value.code == -1
+        assert engine.B == 2
+        after = engine.run(_lib.STAGE_ALL)
+        for key in ("obb_transform", "canal_axis", "te_axis", "groove_axis", "anp_axis_central", "csys", "n_anp", "status"):
+            np.testing.assert_array_equal(after[key], before[key], err_msg=key)
+        assert len(engine.section_plane(1, before["anp_plane_point"][1], before["anp_plane_normal"][1])) > 50
+        assert engine.mesh_transformed(1, np.identity(4)).shape == (len(b.verts), 3)
+
+
+def test_rejected_unet_load_keeps_the_loaded_network(oracle_bones):
+    """sh_load_unet with a wrong parameter count (another base / depth) used to swap the layer table before the size check:
+    the next forward then read weights past the parameter block.  Now the loaded network stays in force."""
+    from conftest import _teacher_weights
+    from shoulder_amd import unet_spec
+    from shoulder_amd.engine import Engine, unet_pack_order
+    h = oracle_bones("humerus_left")
+    w = _teacher_weights()
+    e = Engine(0)
+    try:
+        e.load_rfc(); e.load_unet(w, unet_spec.BASE, unet_spec.DEPTH)
+        e.upload([(h.verts, h.faces)])
+        before = e.run(_lib.STAGE_ALL).copy()
+        img = np.random.default_rng(3).random((1, 256, 256), dtype=np.float32)
+        lg = e.unet_infer(img)
+        for base, depth in ((64, 4), (32, 3), (32, 5)):
+            with pytest.raises(ShoulderHipError, match="expected") as err:
+                e.load_unet(w, base, depth) if depth == unet_spec.DEPTH else e.load_unet({k: w.get(k, np.zeros(1, np.float32)) for k in unet_pack_order(depth)}, base, depth)
+            assert err.value.code == -1
+            np.testing.assert_array_equal(e.unet_infer(img), lg)
+        bad = dict(w); bad["dec1a_b"] = w["dec1a_b"].copy(); bad["dec1a_b"][3] = np.nan
+        with pytest.raises(ShoulderHipError, match="NaN"):
+            e.load_unet(bad, unet_spec.BASE, unet_spec.DEPTH)
+        after = e.run(_lib.STAGE_ALL)
+        for key in ("anp_axis_central", "anp_plane_point", "n_anp", "csys"):
+            np.testing.assert_array_equal(after[key], before[key], err_msg=key)
+    finally:
+        e.close()

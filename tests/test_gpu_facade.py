@@ -44,10 +44,19 @@ def test_accessors_in_ct(hum, oracle_bones):
     np.testing.assert_allclose(hum.anatomic_neck.axis_normal(), L["anp_axis_normal"], rtol=0, atol=MM)
     np.testing.assert_allclose(hum.anatomic_neck.axis_central(), L["anp_axis_central"], rtol=0, atol=MM)
     np.testing.assert_allclose(hum.trans_epiconylar.axis(), L["te_axis"], rtol=0, atol=MM)
-    # plane_points: every returned point lies on the plane and on the mesh surface section
+    # plane_points (anatomic_neck.py:155-172): the section of the CT mesh by the neck plane, vs the oracle -- once on the
+    # device's own plane (same input: same crossing triangles, coordinates to rounding), once end to end
+    from oracle import anp as oanp
     pp = hum.anatomic_neck.plane_points()
     assert len(pp) > 50
     assert np.abs((pp - p.point) @ p.normal).max() < 1e-9
+    key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+    same_plane = oanp.plane_points(h.verts.astype(np.float64), h.faces, p.point, p.normal)
+    assert len(same_plane) == len(pp)
+    np.testing.assert_allclose(key(pp), key(same_plane), rtol=0, atol=1e-9)
+    ref_pp = h.anp_plane_points()
+    assert len(ref_pp) == len(pp)
+    np.testing.assert_allclose(key(pp), key(ref_pp), rtol=0, atol=MM)
 
 
 def test_apply_csys_roundtrip(hum, oracle_bones):
@@ -98,6 +107,58 @@ def test_metrics_right_side(engine, oracle_bones):
     assert r.side() == m["side"]
     assert r.retroversion() == pytest.approx(m["retroversion"], abs=1e-6)
     assert r.radius_curvature() == pytest.approx(m["radius_curvature"], abs=1e-6)
+
+
+def test_class_hierarchy_and_articular_csys(hum, oracle_bones):
+    """bone.py:24,109: `Humerus(ProximalHumerus)`; the inherited apply_csys_canal_articular (bone.py:53-62) takes its matrix from
+    the device record (k_pack) and is checked against the oracle's construct_csys(canal axis, neck-normal axis)."""
+    import shoulder_amd as shoulder
+    assert isinstance(hum, shoulder.ProximalHumerus) and issubclass(shoulder.Humerus, shoulder.ProximalHumerus)
+    import shoulder as ref_name                      # the reference's package name resolves to the same classes
+    assert ref_name.Humerus is shoulder.Humerus and ref_name.bone.ProximalHumerus is shoulder.ProximalHumerus
+    h = oracle_bones("humerus_left")
+    L = h.landmarks()
+    T = hum.apply_csys_canal_articular()
+    np.testing.assert_allclose(T, L["csys_articular"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(hum.mesh.vertices, xform.transform_pts(h.verts.astype(np.float64), L["csys_articular"]), rtol=0, atol=MM)
+    hum.apply_csys_ct()
+
+
+def test_default_engine_warns_about_teacher_weights(monkeypatch):
+    """Without a model the facade still runs (teacher stand-in) but says so loudly (RuntimeWarning)."""
+    from shoulder_amd import bone
+    monkeypatch.setattr(bone, "_DEFAULT_ENGINE", None)
+    monkeypatch.delenv("SHOULDER_UNET_ONNX", raising=False)
+    with pytest.warns(RuntimeWarning, match="TEACHER"):
+        e = bone.default_engine()
+    try:
+        assert bone.default_engine() is e            # created once
+    finally:
+        e.close()
+        monkeypatch.setattr(bone, "_DEFAULT_ENGINE", None)
+
+
+def test_caller_engine_configuration_survives_the_facade(oracle_bones):
+    """Engine.set_params is read-modify-write: a caller's bf16 engine stays bf16 when a facade object sets its bone kind, and a
+    second bone on the same engine brings its own groove parameters back (_ensure_loaded)."""
+    import shoulder_amd as shoulder
+    from conftest import _teacher_weights
+    from shoulder_amd import _lib, unet_spec
+    from shoulder_amd.engine import Engine
+    e = Engine(0)
+    try:
+        e.load_rfc(); e.load_unet(_teacher_weights(), unet_spec.BASE, unet_spec.DEPTH)
+        e.set_params(unet_dtype=_lib.UNET_BF16)
+        a = shoulder.Humerus(os.path.join(BONES, "humerus_left.stl"), engine=e)
+        assert e.get_params()["unet_dtype"] == _lib.UNET_BF16 and e.get_params()["bone_kind"] == _lib.BONE_HUMERUS
+        pa = a.bicipital_groove.points(deg_window=9).copy()
+        b = shoulder.Humerus(os.path.join(BONES, "humerus_right.stl"), engine=e)
+        b.bicipital_groove.points()                  # default window 7 on the shared engine
+        a._ensure_loaded()
+        assert e.get_params()["groove_deg_window"] == 9.0 and e.get_params()["unet_dtype"] == _lib.UNET_BF16
+        np.testing.assert_array_equal(a.bicipital_groove.points(), pa)
+    finally:
+        e.close()
 
 
 def test_errors(hum):

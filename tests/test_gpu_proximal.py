@@ -30,7 +30,7 @@ def ran(engine, oracle_prox):
         scan = engine.fetch("pobb.area_total", np.float64, (1, 100))[0].copy()
         cut_idx = engine.fetch("pobb.cutoff_idx", np.int32, (1, 2))[0].copy()
     finally:
-        engine.set_params()
+        engine.reset_params()
     return lm, scan, cut_idx
 
 
@@ -76,7 +76,7 @@ def test_prox_rejects_distal_stages(engine, oracle_prox):
         with pytest.raises(Exception):
             engine.run(_lib.STAGE_ALL)
     finally:
-        engine.set_params()
+        engine.reset_params()
 
 
 def test_prox_batch_equivariance(engine, oracle_prox):
@@ -99,7 +99,7 @@ def test_prox_batch_equivariance(engine, oracle_prox):
         engine.synth_batch(T)
         lm = engine.run(PROX_MASK).copy()
     finally:
-        engine.set_params()
+        engine.reset_params()
     assert (lm["status"] == 0).all()
     assert (lm["neck_index"] == lm["neck_index"][0]).all()
     np.testing.assert_array_equal(lm["canal_cutoff"], np.repeat(lm["canal_cutoff"][:1], B, axis=0))
@@ -137,7 +137,7 @@ def test_proximal_facade(engine, oracle_prox):
         p.apply_csys_ct()
         np.testing.assert_allclose(p.canal.axis(), L["canal_axis"], rtol=0, atol=MM)
     finally:
-        engine.set_params()
+        engine.reset_params()
 
 
 def test_prox_similarity_copies(engine, rfc_tables, unet_weights):
@@ -159,7 +159,7 @@ def test_prox_similarity_copies(engine, rfc_tables, unet_weights):
         xs = engine.fetch("groove.xs", np.float64, (2, 330 * 7, 9)).copy()
         npk = engine.fetch("groove.npk", np.int32, (2, 330)).copy()
     finally:
-        engine.set_params()
+        engine.reset_params()
     for b, (mv, mf) in enumerate(meshes):
         h = OracleProximalHumerus(mv, mf, rfc_tables, unet_weights, unet_eval="chain")
         L = h.landmarks()
