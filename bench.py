@@ -114,6 +114,8 @@ def sym_key(name, unet, cout, fused_net=True):
     fuse = 5 if name == "unet.enc0b" else 2 if name == "unet.dec0b" else 4 if name in ("unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
     if not fused_net:
         fuse = 0
+    if name == "unet.enc0b" and fused_net and os.environ.get("SHOULDER_UNET_L0") != "0" and os.environ.get("SHOULDER_UNET_FUSE_FIRST") != "0":
+        return "k_enc0_fused16<%s>" % unet      # level-0 encoder as one persistent kernel (k_unet16_l0.h)
     dma = (not up and not (fuse & 1) and os.environ.get("SHOULDER_UNET_DMA") != "0" and (cout % 64 == 0 or os.environ.get("SHOULDER_UNET_DMA32") != "0"))
     if dma:
         return "k_conv3_dma16<%s,%d,%d>" % (unet, fuse, nt)      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h)
@@ -121,8 +123,9 @@ def sym_key(name, unet, cout, fused_net=True):
 
 
 def rocprof_name(key):
-    """bench symbol key -> the kernel name rocprofv3 prints (profiles/*.json are keyed by it)."""
-    return "sh::" + key.replace("<bf16,", "<__bf16, ").replace("<f16,", "<_Float16, ").replace(",", ", ").replace(",  ", ", ")
+    """bench symbol key -> the kernel name rocprofv3 prints (profiles/*.json are keyed by it).  The 16-bit kernels are
+    templates on an element-kind integer (k_unet_bf16.h: 0 = __bf16, 1 = _Float16), spelled bf16 / f16 in bench keys."""
+    return "sh::" + key.replace("<bf16", "<0").replace("<f16", "<1").replace(",", ", ")
 
 
 def host_info():

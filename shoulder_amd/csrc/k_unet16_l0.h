@@ -1,0 +1,222 @@
+// k_unet16_l0.h -- the full-resolution (32-channel) level of the 16-bit UNet as persistent fused kernels.
+//
+// Level 0 moves 1.07 GB per 32-channel tensor at B = 64 and carries 21 % of the flops: layer by layer it is bound by
+// neither roof (round 1: enc0a+enc0b+pool 1.05 ms = 0.12 of the MFMA peak and 0.19 of HBM; up0 / dec0a / dec0b+head
+// 1.7 + 3.7 + 1.3 GB of traffic).  Here a 32-channel full-resolution tensor that is produced and consumed inside the level
+// never reaches HBM:
+//   k_enc0_fused16   image -> [enc0a: 1 -> 32, 3x3] -> LDS -> [enc0b: 32 -> 32, 3x3] -> skip0 (+ 2x2 max pool -> level 1)
+// One workgroup (8 waves) per CU walks (image, 32x16-pixel tile) items.  The conv weights stay in LDS for the whole
+// launch (the two-barrier kernel re-read 18 KB of weights per 16 KB of output); the first conv of item i+1 is computed on
+// the matrix cores into the other LDS halo buffer BETWEEN the MFMA groups of item i's second conv (its fragment building is
+// VALU work that the matrix pipe's 16-cycle instructions cover), so one s_barrier per item separates producer and consumer.
+// HBM floor: 4 B/px image in, 64 + 16 B/px out = 1.41 GB per launch at B = 64.
+//
+// Numerics are those of k_conv_mfma16<EK, 9, 2, UF_FIRST | UF_POOL> operation for operation (first conv: K = 9 taps of
+// the image's high part + 9 taps of its low part against ET-rounded weights, f32 accumulate from the bias, ReLU, rounded
+// to ET; second conv: one accumulator per output from the bias over the taps in order), so both forms give the same bits
+// (tests/test_gpu_unet_bf16.py::test_level0_fused_matches_two_barrier_kernel).
+#pragma once
+#include "k_unet_bf16_dma.h"
+
+namespace sh {
+
+#define L0_THREADS 512
+#define L0_PW 36                                   // halo-tile pitch in pixels (34 used), as in k_conv3_dma16
+#define L0_INROWS (18 * L0_PW)                     // 648 halo rows of 64 B
+#define L0_BUF (L0_INROWS * 64)                    // 41472
+#define L0_WOFF (2 * L0_BUF)                       // 82944: [9 taps][32 couts] rows of 64 B
+#define L0_WBYTES (288 * 64)
+#define L0_IMGOFF (L0_WOFF + L0_WBYTES)            // 101376: two image patches, 20 rows x 36 floats (+ slack for the pitch's 2 unused columns)
+#define L0_IMGFLOATS 768
+#define L0_BIASOFF (L0_IMGOFF + 2 * L0_IMGFLOATS * 4)
+#define L0_SMEM (L0_BIASOFF + 256)                 // 107776
+
+template <int EK>
+__global__ void __launch_bounds__(L0_THREADS)
+k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[9][32] f32*/, const float* __restrict__ b0 /*[32]*/,
+               const u16* __restrict__ wgt_ /*enc0b, packed [9][1][32][32]*/, const float* __restrict__ bias /*[32]*/,
+               u16* __restrict__ skip_, u16* __restrict__ pooled_, int H, int W, int nimg) {
+  using ET = typename EKT<EK>::type;
+  using v8 = typename E16<ET>::v8;
+  using v4 = typename E16<ET>::v4;
+  const ET* wgt = (const ET*)wgt_;
+  ET* skip = (ET*)skip_;
+  ET* pooled = (ET*)pooled_;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[L0_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int xh = wave & 1, rg = wave >> 1;
+  const int tiles_x = W / 32, tiles_y = H / 16;
+  const int total = nimg * tiles_x * tiles_y;
+  const int per = (total + gridDim.x - 1) / gridDim.x;
+  const int w_begin = blockIdx.x * per, w_end = min(total, w_begin + per);
+  if (w_begin >= w_end) return;
+  const int nitems = w_end - w_begin;
+
+  // ---- once per workgroup: enc0b weights -> LDS (swizzled rows), bias, first-conv fragments in registers
+  {
+    ET* s_w = (ET*)(smem + L0_WOFF);
+    for (int e = tid; e < 288 * 4; e += L0_THREADS) {
+      const int q = e & 3, r = e >> 2;
+      *(u32x4*)(s_w + UB_OFF(r, q)) = *(const u32x4*)(wgt + (size_t)r * 32 + q * 8);
+    }
+    float* s_bias = (float*)(smem + L0_BIASOFF);
+    if (tid < 32) s_bias[tid] = bias[tid];
+  }
+  v8 wA[2];
+  f32x4 b0v[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = lk * 8 + j, t = k < 9 ? k : (k < 18 ? k - 9 : 0);
+      const float wv = w0[t * 32 + n * 16 + li];
+      wA[n][j] = k < 18 ? (ET)wv : (ET)0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b0v[n][r] = b0[n * 16 + lk * 4 + r];
+  }
+
+  // fragment read offsets of the second conv (bytes inside a halo buffer / the weight region)
+  int xoff[2][3], woff;
+  {
+    const int rowbase = rg * 4 * L0_PW + xh * 16 + li;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) xoff[sp][dx] = UB_OFF(rowbase + sp * L0_PW + dx, lk) * 2;
+    woff = UB_OFF(li, lk) * 2;
+  }
+
+  auto item_coords = [&](int w, int& img, int& x0, int& y0) {
+    const int tx = w % tiles_x; w /= tiles_x;
+    const int ty = w % tiles_y; img = w / tiles_y;
+    x0 = tx * 32; y0 = ty * 16;
+  };
+  // image patch of an item: rows y0-2 .. y0+17, columns x0-2 .. x0+33 (zero outside the image), 720 floats
+  auto patch_load = [&](int w, float (&r)[2]) {
+    int img, x0, y0;
+    item_coords(w, img, x0, y0);
+    const float* im = image + (size_t)img * H * W;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + k * L0_THREADS;
+      const int py = e / L0_PW, px = e - py * L0_PW;
+      const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+      r[k] = (e < 20 * L0_PW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.0f;
+    }
+  };
+  auto patch_store = [&](int slot, const float (&r)[2]) {
+    float* s = (float*)(smem + L0_IMGOFF) + slot * L0_IMGFLOATS;
+    s[tid] = r[0];
+    if (tid + L0_THREADS < L0_IMGFLOATS) s[tid + L0_THREADS] = r[1];      // (also clears the slack behind the patch)
+  };
+  // first conv for 16 halo pixels (group g) of the item at (x0, y0): patch slot -> halo buffer
+  auto enc0a_group = [&](int g, int slot, int hb, int x0, int y0) {
+    const float* s_img = (const float*)(smem + L0_IMGOFF) + slot * L0_IMGFLOATS;
+    ET* s_in = (ET*)(smem + hb * L0_BUF);
+    const int p = 16 * g + li, pc = p < L0_INROWS ? p : L0_INROWS - 1;
+    const int py = pc / L0_PW, px = pc - py * L0_PW;
+    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+    const bool inside = px < 34 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const int base = py * L0_PW + px;          // patch index of tap (0,0) of this pixel
+    v8 bf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = lk * 8 + j, t = k < 9 ? k : (k < 18 ? k - 9 : 0);
+      const int t3 = (t * 11) >> 5;         // t / 3 for t <= 8
+      const float v = s_img[base + t + (L0_PW - 3) * t3];
+      const ET hi = (ET)v;
+      const ET lo = (ET)(v - (float)hi);
+      bf[j] = k < 9 ? hi : (k < 18 ? lo : (ET)0.0f);
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const f32x4 a = E16<ET>::mfma(wA[n], bf, b0v[n]);
+      v4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = inside ? (ET)fmaxf(a[r], 0.0f) : (ET)0.0f;      // outside the image: the second conv's zero padding
+      if (p < L0_INROWS) *(v4*)(s_in + UB_OFF(p, n * 2 + (lk >> 1)) + (lk & 1) * 4) = o;
+    }
+  };
+
+  // ---- prologue: patch 0 -> LDS, first conv of item 0 into buffer 0, patch 1 -> LDS
+  float pr[2];
+  {
+    patch_load(w_begin, pr);
+    patch_store(0, pr);
+    if (nitems > 1) patch_load(w_begin + 1, pr);
+    __syncthreads();
+    int img, x0, y0;
+    item_coords(w_begin, img, x0, y0);
+    for (int g = wave; g < (L0_INROWS + 15) / 16; g += L0_THREADS / 64) enc0a_group(g, 0, 0, x0, y0);
+    if (nitems > 1) patch_store(1, pr);
+    __syncthreads();
+  }
+  const float* s_bias = (const float*)(smem + L0_BIASOFF);
+  for (int i = 0; i < nitems; ++i) {
+    int c_img, c_x0, c_y0;
+    item_coords(w_begin + i, c_img, c_x0, c_y0);
+    int n_img = 0, n_x0 = 0, n_y0 = 0;
+    const bool has_next = i + 1 < nitems;
+    if (has_next) item_coords(w_begin + i + 1, n_img, n_x0, n_y0);
+    const bool has_next2 = i + 2 < nitems;
+    if (has_next2) patch_load(w_begin + i + 2, pr);      // in flight during the MFMAs below
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const f32x4 bv = *(const f32x4*)(s_bias + n * 16 + lk * 4);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m][n] = bv;
+    }
+    const unsigned char* sb = smem + (i & 1) * L0_BUF;
+    const unsigned char* wbp = smem + L0_WOFF + woff;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      v8 xf[4], wf[2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { const int s = m + dy; xf[m] = *(const v8*)(sb + xoff[s & 1][dx] + (s & ~1) * L0_PW * 64); }
+#pragma unroll
+      for (int n = 0; n < 2; ++n) wf[n] = *(const v8*)(wbp + (tap * 32 + n * 16) * 64);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xf[m], acc[m][n]);
+      // the next item's first conv, one 16-pixel group per tap: patch slot (i+1)&1 -> halo buffer (i+1)&1
+      if (has_next && tap < 6 && wave + 8 * tap < (L0_INROWS + 15) / 16) enc0a_group(wave + 8 * tap, (i + 1) & 1, (i + 1) & 1, n_x0, n_y0);
+    }
+    // epilogue: bias is in the accumulators; ReLU, round, store 4 consecutive couts per lane (+ the 2x2 max pool)
+    ET* out = skip + (size_t)c_img * H * W * 32;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int gy = c_y0 + rg * 4 + m, gx = c_x0 + xh * 16 + li;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        v4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (ET)fmaxf(acc[m][n][r], 0.0f);
+        *(v4*)(out + ((size_t)gy * W + gx) * 32 + n * 16 + lk * 4) = o;
+      }
+    }
+    ET* po = pooled + (size_t)c_img * (H / 2) * (W / 2) * 32;
+#pragma unroll
+    for (int mp = 0; mp < 2; ++mp)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        v4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaxf(acc[2 * mp][n][r], acc[2 * mp + 1][n][r]);
+          v = fmaxf(v, __shfl_xor(v, 1));
+          o[r] = (ET)fmaxf(v, 0.0f);
+        }
+        if ((li & 1) == 0)
+          *(v4*)(po + ((size_t)((c_y0 + rg * 4) / 2 + mp) * (W / 2) + (c_x0 + xh * 16 + li) / 2) * 32 + n * 16 + lk * 4) = o;
+      }
+    if (has_next2) patch_store(i & 1, pr);      // patch of item i+2 (slot (i+2)&1; its last reader was the first conv of item i, one barrier ago)
+    __syncthreads();
+  }
+}
+
+}  // namespace sh

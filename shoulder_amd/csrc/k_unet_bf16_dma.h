@@ -48,12 +48,20 @@ template <int N> __device__ inline void ud_wait_vm() {      // s_waitcnt takes a
 
 // FUSE: 0, UF_POOL (2x2 max pool written beside the output) or UF_HEAD (1x1 head: only the logits leave the kernel).
 // NN: 16-cout tiles per item: 4 (64-cout groups) or 2 (the 32-channel level: 288 weight rows, 8 DMA pieces per step).
-template <typename ET, int FUSE, int NN = 4>
+template <int EK, int FUSE, int NN = 4>
 __global__ void __launch_bounds__(UD_THREADS)
-k_conv3_dma16(const ET* __restrict__ src0, const ET* __restrict__ src1, int C0, int C1,
-              const ET* __restrict__ wgt, const float* __restrict__ bias, ET* __restrict__ dst,
-              int H, int W, int Cout, int relu, int nimg, const ET* __restrict__ zero_page, ET* __restrict__ pooled,
+k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int C0, int C1,
+              const u16* __restrict__ wgt_, const float* __restrict__ bias, u16* __restrict__ dst_,
+              int H, int W, int Cout, int relu, int nimg, const u16* __restrict__ zero_page_, u16* __restrict__ pooled_,
               const float* __restrict__ head_w, const float* __restrict__ head_b, float* __restrict__ logits) {
+  using ET = typename EKT<EK>::type;
+  const ET* src0 = (const ET*)src0_;
+  const ET* src1 = (const ET*)src1_;
+  const ET* wgt = (const ET*)wgt_;
+  ET* dst = (ET*)dst_;
+  const ET* zero_page = (const ET*)zero_page_;
+  ET* pooled = (ET*)pooled_;
+
   using v8 = typename E16<ET>::v8;
   using v4 = typename E16<ET>::v4;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[UD_SMEM];

@@ -19,6 +19,7 @@
 #include "k_unet.h"
 #include "k_unet_bf16.h"
 #include "k_unet_bf16_dma.h"
+#include "k_unet16_l0.h"
 #include "k_stl.h"
 #include "k_clip.h"
 #include "k_hullpre.h"
@@ -914,12 +915,12 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
 
 }  // extern "C" (the templates below need C++ linkage)
 
-// ---- UNet forward (16-bit MFMA paths: ET = __bf16 or _Float16) -----------------------------------------
-template <typename ET>
-static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const ET* src0, const ET* src1, int C0, int C1,
-                           ET* dst, int H, int W, int nimg, int relu, int fuse = 0, ConvFuse fz = ConvFuse{}) {
+// ---- UNet forward (16-bit MFMA paths: EK = 0 __bf16, 1 _Float16; tensors as raw u16) -----------------------------------------
+template <int EK>
+static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const u16* src0, const u16* src1, int C0, int C1,
+                           u16* dst, int H, int W, int nimg, int relu, int fuse = 0, ConvFuse fz = ConvFuse{}) {
   if (H % UN_TH || W % UN_TW) return fail(c, SH_ERR_ARG, "unet: feature map is not a multiple of 16");
-  const ET* w = buf<ET>(c, "params_bf16") + L.w_off;
+  const u16* w = buf<u16>(c, "params_bf16") + L.w_off;
   const float* b = buf<float>(c, "params") + L.b_off;
   const int tiles = (H / UN_TH) * (W / UN_TW);
   const dim3 blk(UN_THREADS);
@@ -937,30 +938,30 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
     const int total = nimg * (W / 32) * (H / 16) * (L.cout / (dma64 ? 64 : 32));
     const dim3 g((unsigned)std::min(total, c->num_cus));      // (leaving 16..64 CUs to the other lane's kernels changes nothing: measured)
-    const ET* zp = (const ET*)c->bufs["unet16.zero"].p;
+    const u16* zp = (const u16*)c->bufs["unet16.zero"].p;
     const float* nof = nullptr;
     if (dma64) {
-      if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma16<ET, UF_POOL, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (ET*)fz.pooled, nof, nof, (float*)nullptr); }
-      else { LAUNCH(c, lname, (k_conv3_dma16<ET, 0, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (ET*)nullptr, nof, nof, (float*)nullptr); }
-    } else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma16<ET, UF_POOL, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (ET*)fz.pooled, nof, nof, (float*)nullptr); }
-    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv3_dma16<ET, UF_HEAD, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (ET*)nullptr, fz.head_w, fz.head_b, fz.logits); }
-    else { LAUNCH(c, lname, (k_conv3_dma16<ET, 0, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (ET*)nullptr, nof, nof, (float*)nullptr); }
+      if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma16<EK, UF_POOL, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr); }
+      else { LAUNCH(c, lname, (k_conv3_dma16<EK, 0, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr); }
+    } else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma16<EK, UF_POOL, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr); }
+    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv3_dma16<EK, UF_HEAD, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits); }
+    else { LAUNCH(c, lname, (k_conv3_dma16<EK, 0, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr); }
   } else if (L.taps == 9 && L.cout % 64 == 0) {
     const dim3 g(tiles, L.cout / 64, nimg);
-    if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 4, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 4, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 4, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 4, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
     else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
   } else if (L.taps == 9) {
     const dim3 g(tiles, L.cout / 32, nimg);
-    if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 2, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == (UF_FIRST | UF_POOL)) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 2, UF_FIRST | UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 2, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv_mfma16<ET, 9, 2, UF_HEAD>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == (UF_FIRST | UF_POOL)) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, UF_FIRST | UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
+    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, UF_HEAD>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
     else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
   } else if (L.cout % 64 == 0) {
-    LAUNCH(c, lname, (k_conv_mfma16<ET, 1, 4, 0>), dim3(tiles, L.cout / 64, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
+    LAUNCH(c, lname, (k_conv_mfma16<EK, 1, 4, 0>), dim3(tiles, L.cout / 64, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
   } else {
-    LAUNCH(c, lname, (k_conv_mfma16<ET, 1, 2, 0>), dim3(tiles, L.cout / 32, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
+    LAUNCH(c, lname, (k_conv_mfma16<EK, 1, 2, 0>), dim3(tiles, L.cout / 32, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
   }
   return SH_OK;
 }
@@ -968,14 +969,14 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
 // 4-level double-conv UNet, bf16.  With 32 base channels the memory-bound ends are fused (k_unet_bf16.h): the first
 // conv into the staging of enc0b, every 2x2 max pool into the epilogue of the conv before it, the 1x1 head into the
 // epilogue of dec0b.  SHOULDER_UNET_UNFUSED=1 (or another base width) runs the layer-by-layer form.
-template <typename ET>
+template <int EK>
 static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
   const int D = c->unet_depth, base = c->unet_base;
   if ((H >> D) % 16 || (W >> D) % 16) return fail(c, SH_ERR_ARG, "unet: input size must be a multiple of 16 << depth");
   int rc;
   if ((rc = ensure(c, "params_bf16", c->unet_floats * 2, 2)) != SH_OK) return rc;
   const float* P = buf<float>(c, "params");
-  ET* PW = buf<ET>(c, "params_bf16");
+  u16* PW = buf<u16>(c, "params_bf16");
   {     // repack the MFMA layers' weights (cheap; stays correct after a parameter broadcast): one launch for all layers
     std::vector<PackEntry> tab;
     long long total = 0;
@@ -991,85 +992,95 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
       HIPCHK(c, hipStreamSynchronize(c->stream));      // `tab` is a local
       c->packtab_ready = true;
     }
-    LAUNCH(c, "k_pack_w_bf16", k_pack_w16_all<ET>, dim3(2048), dim3(256), P, PW, (const PackEntry*)c->bufs["unet16.packtab"].p, (int)tab.size(), total);
+    LAUNCH(c, "k_pack_w_bf16", k_pack_w16_all<EK>, dim3(2048), dim3(256), P, PW, (const PackEntry*)c->bufs["unet16.packtab"].p, (int)tab.size(), total);
   }
   const char* unf = getenv("SHOULDER_UNET_UNFUSED");
   const bool fused = base == 32 && !(unf && unf[0] == '1');
   const size_t full = (size_t)nimg * H * W * base * 2;
   if ((rc = ensure(c, "unet16.a", full, 2)) != SH_OK) return rc;
   if ((rc = ensure(c, "unet16.b", full, 2)) != SH_OK) return rc;
-  std::vector<ET*> skip(D);
+  std::vector<u16*> skip(D);
   for (int i = 0; i < D; ++i) {
     std::string nm = "unet16.skip" + std::to_string(i);
     if ((rc = ensure(c, nm.c_str(), full >> i, 2)) != SH_OK) return rc;
-    skip[i] = buf<ET>(c, nm.c_str());
+    skip[i] = buf<u16>(c, nm.c_str());
   }
-  ET* A = buf<ET>(c, "unet16.a");
-  ET* Bq = buf<ET>(c, "unet16.b");
+  u16* A = buf<u16>(c, "unet16.a");
+  u16* Bq = buf<u16>(c, "unet16.b");
   auto L = [&](const std::string& n) -> const sh_ctx::ULayer& { return c->ulayers[n]; };
   int h = H, w = W;
   const char* ff = getenv("SHOULDER_UNET_FUSE_FIRST");
-  if (fused && !(ff && ff[0] == '0')) {
+  const char* l0env = getenv("SHOULDER_UNET_L0");
+  const bool l0 = fused && !(ff && ff[0] == '0') && !(l0env && l0env[0] == '0') && w % 32 == 0 && h % 16 == 0;
+  if (l0) {
+    // level-0 encoder as one persistent kernel (k_unet16_l0.h): image -> enc0a -> LDS -> enc0b -> skip0 + pooled
+    const sh_ctx::ULayer& la = L("enc0a");
+    const sh_ctx::ULayer& lb = L("enc0b");
+    if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
+    const int total = nimg * (w / 32) * (h / 16);
+    LAUNCH(c, "unet.enc0b", (k_enc0_fused16<EK>), dim3((unsigned)std::min(total, c->num_cus)), dim3(L0_THREADS), image, P + la.w_off, P + la.b_off,
+           PW + lb.w_off, P + lb.b_off, skip[0], A, h, w, nimg);
+  } else if (fused && !(ff && ff[0] == '0')) {
     const sh_ctx::ULayer& l = L("enc0a");
     ConvFuse fz{};
     fz.image = image; fz.w0 = P + l.w_off; fz.b0 = P + l.b_off; fz.pooled = A;
-    if ((rc = conv_layer16<ET>(c, "unet.enc0b", L("enc0b"), nullptr, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_FIRST | UF_POOL, fz)) != SH_OK) return rc;
+    if ((rc = conv_layer16<EK>(c, "unet.enc0b", L("enc0b"), nullptr, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_FIRST | UF_POOL, fz)) != SH_OK) return rc;
   } else if (fused) {
     const sh_ctx::ULayer& l = L("enc0a");
     size_t npx = (size_t)nimg * h * w;
-    LAUNCH(c, "unet.enc0a", k_conv_first16<ET>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, Bq, h, w, l.cout, nimg);
+    LAUNCH(c, "unet.enc0a", k_conv_first16<EK>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, Bq, h, w, l.cout, nimg);
     ConvFuse fz{};
     fz.pooled = A;
-    if ((rc = conv_layer16<ET>(c, "unet.enc0b", L("enc0b"), Bq, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_POOL, fz)) != SH_OK) return rc;
+    if ((rc = conv_layer16<EK>(c, "unet.enc0b", L("enc0b"), Bq, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_POOL, fz)) != SH_OK) return rc;
   } else {
     const sh_ctx::ULayer& l = L("enc0a");
     size_t npx = (size_t)nimg * h * w;
-    LAUNCH(c, "unet.enc0a", k_conv_first16<ET>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, A, h, w, l.cout, nimg);
-    if ((rc = conv_layer16<ET>(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1)) != SH_OK) return rc;
+    LAUNCH(c, "unet.enc0a", k_conv_first16<EK>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, A, h, w, l.cout, nimg);
+    if ((rc = conv_layer16<EK>(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1)) != SH_OK) return rc;
   }
   int ch = base;
   for (int i = 1; i <= D; ++i) {
     if (!fused) {
       size_t e = (size_t)nimg * (h / 2) * (w / 2) * (ch / 8);
-      LAUNCH(c, "unet.pool", k_maxpool2_16<ET>, dim3((unsigned)std::min<size_t>((e + 255) / 256, 8192)), dim3(256), skip[i - 1], A, h, w, ch, nimg);
+      LAUNCH(c, "unet.pool", k_maxpool2_16<EK>, dim3((unsigned)std::min<size_t>((e + 255) / 256, 8192)), dim3(256), skip[i - 1], A, h, w, ch, nimg);
     }
     h /= 2; w /= 2;
     std::string na = i < D ? "enc" + std::to_string(i) + "a" : "bota", nb = i < D ? "enc" + std::to_string(i) + "b" : "botb";
-    if ((rc = conv_layer16<ET>(c, ("unet." + na).c_str(), L(na), A, nullptr, ch, 0, Bq, h, w, nimg, 1)) != SH_OK) return rc;
+    if ((rc = conv_layer16<EK>(c, ("unet." + na).c_str(), L(na), A, nullptr, ch, 0, Bq, h, w, nimg, 1)) != SH_OK) return rc;
     ch *= 2;
-    ET* dst = i < D ? skip[i] : A;
+    u16* dst = i < D ? skip[i] : A;
     ConvFuse fz{};
     fz.pooled = A;      // (A was consumed by the conv above; the next level reads it)
-    if ((rc = conv_layer16<ET>(c, ("unet." + nb).c_str(), L(nb), Bq, nullptr, ch, 0, dst, h, w, nimg, 1, (fused && i < D) ? UF_POOL : 0, fz)) != SH_OK) return rc;
+    if ((rc = conv_layer16<EK>(c, ("unet." + nb).c_str(), L(nb), Bq, nullptr, ch, 0, dst, h, w, nimg, 1, (fused && i < D) ? UF_POOL : 0, fz)) != SH_OK) return rc;
   }
-  ET* x = A; ET* y = Bq;
+  u16* x = A; u16* y = Bq;
   for (int i = D - 1; i >= 0; --i) {
     std::string nu = "up" + std::to_string(i), na = "dec" + std::to_string(i) + "a", nb = "dec" + std::to_string(i) + "b";
-    if ((rc = conv_layer16<ET>(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
+    if ((rc = conv_layer16<EK>(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
     h *= 2; w *= 2; ch /= 2;
-    if ((rc = conv_layer16<ET>(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;
+    if ((rc = conv_layer16<EK>(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;
     if (fused && i == 0) {
       const sh_ctx::ULayer& l = L("head");
       ConvFuse fz{};
       fz.head_w = P + l.w_off; fz.head_b = P + l.b_off; fz.logits = logits;
-      if ((rc = conv_layer16<ET>(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1, UF_HEAD, fz)) != SH_OK) return rc;
+      if ((rc = conv_layer16<EK>(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1, UF_HEAD, fz)) != SH_OK) return rc;
       return SH_OK;
     }
-    if ((rc = conv_layer16<ET>(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1)) != SH_OK) return rc;
+    if ((rc = conv_layer16<EK>(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1)) != SH_OK) return rc;
     std::swap(x, y);
   }
   {
     const sh_ctx::ULayer& l = L("head");
     size_t npx = (size_t)nimg * H * W;
-    LAUNCH(c, "unet.head", k_head16<ET>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx, (size_t)H * W);
+    LAUNCH(c, "unet.head", k_head16<EK>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx, (size_t)H * W);
   }
   return SH_OK;
 }
 
 static int unet_dispatch(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
   switch (c->params.unet_dtype) {
-    case SH_UNET_BF16: return unet_forward16<__bf16>(c, image, logits, nimg, H, W);
-    case SH_UNET_F16: return unet_forward16<_Float16>(c, image, logits, nimg, H, W);
+    case SH_UNET_BF16: return unet_forward16<0>(c, image, logits, nimg, H, W);
+    case SH_UNET_F16: return unet_forward16<1>(c, image, logits, nimg, H, W);
     default: return unet_forward(c, image, logits, nimg, H, W);
   }
 }

@@ -114,6 +114,32 @@ def test_fused_ends_match_layerwise(engine, monkeypatch, name):
         assert np.array_equal((a > 0)[band], (plain > 0)[band])
 
 
+@pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_level0_fused_matches_two_barrier_kernel(engine, monkeypatch, name):
+    """k_enc0_fused16 (image -> enc0a -> LDS -> enc0b -> skip0 + pool, persistent, weights resident in LDS) performs the
+    operations of the two-barrier kernel k_conv_mfma16<EK, 9, 2, UF_FIRST | UF_POOL> in the same order: skip0, the pooled
+    tensor (through skip1's input: level 1 is bit-identical) and the logits are equal bit for bit -- incl. a ragged last
+    work range (5 images of 256 x 256: 640 items over 256 workgroups) and image borders."""
+    rng = np.random.default_rng(7)
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        for shape in ((5, 256, 256), (2, 256, 512)):
+            img = rng.random(shape, dtype=np.float32)
+            n0, n1 = shape[0] * shape[1] * shape[2] * 32, shape[0] * shape[1] * shape[2] // 4 * 64
+            monkeypatch.setenv("SHOULDER_UNET_L0", "1")
+            a = engine.unet_infer(img)
+            s0a = engine.fetch("unet16.skip0", np.uint16)[:n0].copy()
+            s1a = engine.fetch("unet16.skip1", np.uint16)[:n1].copy()
+            monkeypatch.setenv("SHOULDER_UNET_L0", "0")
+            b = engine.unet_infer(img)
+            s0b = engine.fetch("unet16.skip0", np.uint16)[:n0].copy()
+            s1b = engine.fetch("unet16.skip1", np.uint16)[:n1].copy()
+            assert np.array_equal(s0a, s0b) and np.array_equal(s1a, s1b) and np.array_equal(a, b), shape
+    finally:
+        monkeypatch.delenv("SHOULDER_UNET_L0", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+
+
 @pytest.mark.parametrize("base,depth,H,W", [(96, 2, 64, 64), (160, 1, 32, 64), (64, 3, 128, 256), (256, 1, 32, 32)])
 def test_other_widths_and_depths(base, depth, H, W):
     """Networks other than the default 4 x base-32 one (a user's ONNX import may have any base % 32 == 0 up to 256): both paths

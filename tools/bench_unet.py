@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--unet", choices=["bf16", "f16", "f32"], default="bf16")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--layers", action="store_true", help="also print the per-layer device times (ms per forward)")
 args = ap.parse_args()
 eng = Engine(0)
 eng.load_unet(unet_spec.make_teacher_weights(), unet_spec.BASE, unet_spec.DEPTH)
@@ -33,6 +34,9 @@ for H, W in ((256, 512), (512, 512)):
         tot_ms += ms * n / args.reps
         if name in layers and name not in ("unet.enc0a", "unet.head") and n:      # the MFMA layers
             conv_ms += ms * n / args.reps; conv_fl += layers[name][0] * args.batch
+    if args.layers:
+        per = {name: round(eng.kernel_time_ms(name)[0] * eng.kernel_time_ms(name)[1] / args.reps, 4) for name in list(layers) + ["unet.pool", "k_pack_w_bf16"] if eng.kernel_time_ms(name)[1]}
+        print(json.dumps({"layers_ms": per}))
     eng.enable_timing(False)
     print(json.dumps({"workload": f"UNet alone f32[{args.batch},1,{H},{W}] U(0,1) seed 1234", "dtype": args.unet,
                       "device_ms_per_forward": round(tot_ms, 3), "images_per_s": round(args.batch / tot_ms * 1e3, 1),

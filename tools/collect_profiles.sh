@@ -1,16 +1,21 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): kernel-trace stats + the two HBM counter passes of the default bench command.
-# Outputs under gpurun_out/prof_r01/; summarise afterwards with tools/rocpd_stats.py and tools/pmc_traffic.py.
+# Run on the GPU box (gpurun): kernel-trace stats, the two HBM counter passes and the SQ (MFMA busy) pass of the default
+# bench command.  Outputs under gpurun_out/prof_r02/; summarise afterwards with tools/rocpd_stats.py / tools/pmc_traffic.py /
+# tools/pmc_sq.py and copy the summaries into profiles/.
+# Counters are collected in their own runs (no trace domains beside --pmc), the program directly after `--`.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/prof_r01
+O=gpurun_out/prof_r02
+UNET=${1:-bf16}
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+python3 bench.py --unet $UNET > $O/bench_$UNET.log 2>&1
+tail -1 $O/bench_$UNET.log | cut -c1-300
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$UNET -o stats -- python3 bench.py --unet $UNET --steps 20 --warmup 2 --no-cpu-baseline --no-extra-legs > $O/bench_under_rocprof_$UNET.log 2>&1
 echo stats done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$UNET -o fetch -- python3 bench.py --unet $UNET --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs > $O/fetch_$UNET.log 2>&1
 echo fetch done
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_$UNET -o write -- python3 bench.py --unet $UNET --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs > $O/write_$UNET.log 2>&1
 echo write done
-python3 bench.py > $O/bench.log 2>&1
-tail -1 $O/bench.log | cut -c1-400
-find $O -name "*.csv" | head -20
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --output-format csv -d $O/sq_$UNET -o sq -- python3 bench.py --unet $UNET --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --lanes 1 > $O/sq_$UNET.log 2>&1
+echo sq done
+find $O -name "*.csv" | head -30
