@@ -141,7 +141,7 @@ def host_info():
 
 
 def hull_threads(world_local):
-    """What hull_host_phase (shoulder_hip.hip) will use per context: hardware threads / LOCAL_WORLD_SIZE, at most 32."""
+    """The worker pool of the host hull phase (HullPool, shoulder_hip.hip), one per process shared by its lanes: hardware threads / LOCAL_WORLD_SIZE, at most 32."""
     if os.environ.get("SHOULDER_HULL_THREADS"):
         return int(os.environ["SHOULDER_HULL_THREADS"])
     return max(1, min(32, (os.cpu_count() or 1) // max(1, world_local)))
@@ -478,7 +478,7 @@ def main():
                "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: batch {B} synthetic humeri per GPU, all stages (SH_STAGE_ALL incl. the batch's apply_csys)",
                           "batch_per_gpu": B, "global_batch": B * world, "vertices": V, "triangles": F, "unet": f"base{unet_spec.BASE} depth{unet_spec.DEPTH} 512x512",
                           "parallelism": f"dp{world}", "input": "binary STL bytes every step (device parse + merge, PCIe inclusive)" if args.from_stl else "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM",
-                          "lanes": lanes, "hull_threads_per_context": hull_threads(int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), "host": host_info(),
+                          "lanes": lanes, "hull_threads_per_process": hull_threads(int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), "host": host_info(),
                           "schedule": ((f"{lanes} engine contexts per GPU, step s on lane s % {lanes}, their streams overlap on the device (sh_submit / sh_collect); " if lanes > 1 else "two steps in flight (sh_submit / sh_collect); ") if pipelined else "") + ("host hulls of step k+1 overlap the device work of step k; pipeline filled and drained inside the timed region" if overlap else "serial hulls"),
                           "meshes_with_error_status": n_bad},
                "roofline": roof, "cpu_baseline": cpu}

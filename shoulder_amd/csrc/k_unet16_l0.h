@@ -11,10 +11,13 @@
 // VALU work that the matrix pipe's 16-cycle instructions cover), so one s_barrier per item separates producer and consumer.
 // HBM floor: 4 B/px image in, 64 + 16 B/px out = 1.41 GB per launch at B = 64.
 //
-// Numerics are those of k_conv_mfma16<EK, 9, 2, UF_FIRST | UF_POOL> operation for operation (first conv: K = 9 taps of
-// the image's high part + 9 taps of its low part against ET-rounded weights, f32 accumulate from the bias, ReLU, rounded
-// to ET; second conv: one accumulator per output from the bias over the taps in order), so both forms give the same bits
-// (tests/test_gpu_unet_bf16.py::test_level0_fused_matches_two_barrier_kernel).
+// First conv on the matrix cores without per-fragment VALU work: the image patch of an item is split once into its ET high
+// part and ET low part (v - hi) and written to LDS as 8 copies shifted by 0..7 elements, so that the 8 consecutive patch
+// values e[q .. q + 7] any lane needs are ONE aligned ds_read_b128 from copy q & 7.  K layout of the MFMA: lane group
+// lk = patch row ty (0..2), element j = column offset (weights w[ty][j] for j < 3, zero beyond; lk = 3 reads zeros), one
+// MFMA on the high parts and one on the low parts per 16 pixels x 16 channels (image precision ~2^-17, ET-rounded weights,
+// f32 accumulate from the bias -- the arithmetic of k_conv_mfma16<EK, 9, 2, UF_FIRST | UF_POOL>, summed in another order;
+// the second conv is the same operation for operation: tests/test_gpu_unet_bf16.py::test_level0_fused_matches_two_barrier_kernel).
 #pragma once
 #include "k_unet_bf16_dma.h"
 
@@ -26,10 +29,14 @@ namespace sh {
 #define L0_BUF (L0_INROWS * 64)                    // 41472
 #define L0_WOFF (2 * L0_BUF)                       // 82944: [9 taps][32 couts] rows of 64 B
 #define L0_WBYTES (288 * 64)
-#define L0_IMGOFF (L0_WOFF + L0_WBYTES)            // 101376: two image patches, 20 rows x 36 floats (+ slack for the pitch's 2 unused columns)
-#define L0_IMGFLOATS 768
-#define L0_BIASOFF (L0_IMGOFF + 2 * L0_IMGFLOATS * 4)
-#define L0_SMEM (L0_BIASOFF + 256)                 // 107776
+#define L0_IMGOFF (L0_WOFF + L0_WBYTES)            // 101376: two patch slots, each 8 shifted copies of the high part, then of the low part
+#define L0_PATCH 744                               // patch elements written: 20 rows x 36 = 720, + zeros up to the reach of the last rows' 8-element reads
+#define L0_CPAD 16                                 // bytes in front of a copy's element 0: copy s is written at indices -s .. 743 - s without a bounds test
+#define L0_CSTR 1568                               // bytes between copies (16 + 2 * 744 = 1504 used): 1568 % 256 == 32, so the 16 lanes of a fragment read hit distinct 16-B slots
+#define L0_SLOT (16 * L0_CSTR)                     // 25088 bytes per patch slot
+#define L0_ZEROOFF (L0_IMGOFF + 2 * L0_SLOT)       // 16 zero bytes (fragment of lane group lk = 3)
+#define L0_BIASOFF (L0_ZEROOFF + 128)
+#define L0_SMEM (L0_BIASOFF + 256)                 // 151936
 
 template <int EK>
 __global__ void __launch_bounds__(L0_THREADS)
@@ -38,7 +45,6 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
                u16* __restrict__ skip_, u16* __restrict__ pooled_, int H, int W, int nimg) {
   using ET = typename EKT<EK>::type;
   using v8 = typename E16<ET>::v8;
-  using v4 = typename E16<ET>::v4;
   const ET* wgt = (const ET*)wgt_;
   ET* skip = (ET*)skip_;
   ET* pooled = (ET*)pooled_;
@@ -56,9 +62,12 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
   // ---- once per workgroup: enc0b weights -> LDS (swizzled rows), bias, first-conv fragments in registers
   {
     ET* s_w = (ET*)(smem + L0_WOFF);
+    // LDS row 32 tap + 16 n + i holds output channel 8 (i >> 2) + 4 n + (i & 3): lane group lk then owns channels
+    // 8 lk .. 8 lk + 7 of its pixels -- one 16-byte store per pixel row instead of two 8-byte ones (k_unet_bf16_dma.h)
     for (int e = tid; e < 288 * 4; e += L0_THREADS) {
-      const int q = e & 3, r = e >> 2;
-      *(u32x4*)(s_w + UB_OFF(r, q)) = *(const u32x4*)(wgt + (size_t)r * 32 + q * 8);
+      const int q = e & 3, r = e >> 2, j = r & 31;
+      const int ch = 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);
+      *(u32x4*)(s_w + UB_OFF(r, q)) = *(const u32x4*)(wgt + (size_t)((r & ~31) + ch) * 32 + q * 8);
     }
     float* s_bias = (float*)(smem + L0_BIASOFF);
     if (tid < 32) s_bias[tid] = bias[tid];
@@ -69,13 +78,13 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
   for (int n = 0; n < 2; ++n) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int k = lk * 8 + j, t = k < 9 ? k : (k < 18 ? k - 9 : 0);
-      const float wv = w0[t * 32 + n * 16 + li];
-      wA[n][j] = k < 18 ? (ET)wv : (ET)0.0f;
+      const float wv = w0[(min(lk, 2) * 3 + min(j, 2)) * 32 + 8 * (li >> 2) + 4 * n + (li & 3)];
+      wA[n][j] = (lk < 3 && j < 3) ? (ET)wv : (ET)0.0f;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b0v[n][r] = b0[n * 16 + lk * 4 + r];
+    for (int r = 0; r < 4; ++r) b0v[n][r] = b0[8 * lk + 4 * n + r];
   }
+  if (tid < 4) ((unsigned*)(smem + L0_ZEROOFF))[tid] = 0u;
 
   // fragment read offsets of the second conv (bytes inside a halo buffer / the weight region)
   int xoff[2][3], woff;
@@ -93,7 +102,7 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
     const int ty = w % tiles_y; img = w / tiles_y;
     x0 = tx * 32; y0 = ty * 16;
   };
-  // image patch of an item: rows y0-2 .. y0+17, columns x0-2 .. x0+33 (zero outside the image), 720 floats
+  // image patch of an item: rows y0-2 .. y0+17, columns x0-2 .. x0+33 (zero outside the image), 720 values e[row * 36 + col]
   auto patch_load = [&](int w, float (&r)[2]) {
     int img, x0, y0;
     item_coords(w, img, x0, y0);
@@ -106,38 +115,51 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
       r[k] = (e < 20 * L0_PW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.0f;
     }
   };
+  // split into high and low parts; copy s holds e[i + s] at index i (i = -s .. 743 - s; the first s entries are padding)
   auto patch_store = [&](int slot, const float (&r)[2]) {
-    float* s = (float*)(smem + L0_IMGOFF) + slot * L0_IMGFLOATS;
-    s[tid] = r[0];
-    if (tid + L0_THREADS < L0_IMGFLOATS) s[tid + L0_THREADS] = r[1];      // (also clears the slack behind the patch)
-  };
-  // first conv for 16 halo pixels (group g) of the item at (x0, y0): patch slot -> halo buffer
-  auto enc0a_group = [&](int g, int slot, int hb, int x0, int y0) {
-    const float* s_img = (const float*)(smem + L0_IMGOFF) + slot * L0_IMGFLOATS;
-    ET* s_in = (ET*)(smem + hb * L0_BUF);
-    const int p = 16 * g + li, pc = p < L0_INROWS ? p : L0_INROWS - 1;
-    const int py = pc / L0_PW, px = pc - py * L0_PW;
-    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-    const bool inside = px < 34 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const int base = py * L0_PW + px;          // patch index of tap (0,0) of this pixel
-    v8 bf;
+    unsigned char* base = smem + L0_IMGOFF + slot * L0_SLOT + L0_CPAD;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = lk * 8 + j, t = k < 9 ? k : (k < 18 ? k - 9 : 0);
-      const int t3 = (t * 11) >> 5;         // t / 3 for t <= 8
-      const float v = s_img[base + t + (L0_PW - 3) * t3];
-      const ET hi = (ET)v;
-      const ET lo = (ET)(v - (float)hi);
-      bf[j] = k < 9 ? hi : (k < 18 ? lo : (ET)0.0f);
+    for (int k = 0; k < 2; ++k) {
+      const int e = tid + k * L0_THREADS;
+      if (k == 0 || e < L0_PATCH) {
+        const ET hi = (ET)r[k];
+        const ET lo = (ET)(r[k] - (float)hi);
+        unsigned char* pe = base + 2 * e;
+#pragma unroll
+        for (int sft = 0; sft < 8; ++sft) {
+          *(ET*)(pe + sft * (L0_CSTR - 2)) = hi;                       // copy sft, index e - sft
+          *(ET*)(pe + sft * (L0_CSTR - 2) + 8 * L0_CSTR) = lo;
+        }
+      }
     }
+  };
+  // first conv for 16 halo pixels (group g = wave + 8 t) of the item at (x0, y0): patch slot -> halo buffer.  Everything that
+  // depends only on the lane and the group is computed once per launch.
+  int g_px[6], g_py[6], g_frag[6], g_out[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    const int p = 16 * (wave + 8 * t) + li, pc = p < L0_INROWS ? p : L0_INROWS - 1;
+    g_py[t] = pc / L0_PW; g_px[t] = pc - g_py[t] * L0_PW;
+    const int q = pc + lk * L0_PW;              // first of the 8 consecutive patch values of this lane: row py + ty, columns px ..
+    const int sft = q & 7;
+    g_frag[t] = lk < 3 ? L0_IMGOFF + L0_CPAD + sft * L0_CSTR + 2 * (q - sft) : -1;
+    g_out[t] = p < L0_INROWS ? UB_OFF(p, lk) * 2 : -1;
+  }
+  auto enc0a_group = [&](int t, int slot, int hb, int x0, int y0) {
+    const int gy = y0 - 1 + g_py[t], gx = x0 - 1 + g_px[t];
+    const bool inside = g_px[t] < 34 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const unsigned char* fp = g_frag[t] >= 0 ? smem + g_frag[t] + slot * L0_SLOT : smem + L0_ZEROOFF;
+    const v8 hi = *(const v8*)fp;
+    const v8 lo = *(const v8*)(g_frag[t] >= 0 ? fp + 8 * L0_CSTR : fp);
+    v8 o;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-      const f32x4 a = E16<ET>::mfma(wA[n], bf, b0v[n]);
-      v4 o;
+      f32x4 a = E16<ET>::mfma(wA[n], hi, b0v[n]);
+      a = E16<ET>::mfma(wA[n], lo, a);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = inside ? (ET)fmaxf(a[r], 0.0f) : (ET)0.0f;      // outside the image: the second conv's zero padding
-      if (p < L0_INROWS) *(v4*)(s_in + UB_OFF(p, n * 2 + (lk >> 1)) + (lk & 1) * 4) = o;
+      for (int r = 0; r < 4; ++r) o[4 * n + r] = inside ? (ET)fmaxf(a[r], 0.0f) : (ET)0.0f;      // outside the image: the second conv's zero padding
     }
+    if (g_out[t] >= 0) *(v8*)(smem + hb * L0_BUF + g_out[t]) = o;      // channels 8 lk .. 8 lk + 7 = 16-byte slot lk of the pixel's row
   };
 
   // ---- prologue: patch 0 -> LDS, first conv of item 0 into buffer 0, patch 1 -> LDS
@@ -149,7 +171,9 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
     __syncthreads();
     int img, x0, y0;
     item_coords(w_begin, img, x0, y0);
-    for (int g = wave; g < (L0_INROWS + 15) / 16; g += L0_THREADS / 64) enc0a_group(g, 0, 0, x0, y0);
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+      if (wave + 8 * t < (L0_INROWS + 15) / 16) enc0a_group(t, 0, 0, x0, y0);
     if (nitems > 1) patch_store(1, pr);
     __syncthreads();
   }
@@ -165,7 +189,7 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
     f32x4 acc[4][2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-      const f32x4 bv = *(const f32x4*)(s_bias + n * 16 + lk * 4);
+      const f32x4 bv = *(const f32x4*)(s_bias + 8 * lk + 4 * n);
 #pragma unroll
       for (int m = 0; m < 4; ++m) acc[m][n] = bv;
     }
@@ -184,36 +208,31 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xf[m], acc[m][n]);
       // the next item's first conv, one 16-pixel group per tap: patch slot (i+1)&1 -> halo buffer (i+1)&1
-      if (has_next && tap < 6 && wave + 8 * tap < (L0_INROWS + 15) / 16) enc0a_group(wave + 8 * tap, (i + 1) & 1, (i + 1) & 1, n_x0, n_y0);
+      if (has_next && tap < 6 && wave + 8 * tap < (L0_INROWS + 15) / 16) enc0a_group(tap, (i + 1) & 1, (i + 1) & 1, n_x0, n_y0);
     }
     // epilogue: bias is in the accumulators; ReLU, round, store 4 consecutive couts per lane (+ the 2x2 max pool)
     ET* out = skip + (size_t)c_img * H * W * 32;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int gy = c_y0 + rg * 4 + m, gx = c_x0 + xh * 16 + li;
+      v8 o;
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (ET)fmaxf(acc[m][n][r], 0.0f);
-        *(v4*)(out + ((size_t)gy * W + gx) * 32 + n * 16 + lk * 4) = o;
-      }
+      for (int r = 0; r < 8; ++r) o[r] = (ET)fmaxf(acc[m][r >> 2][r & 3], 0.0f);
+      *(v8*)(out + ((size_t)gy * W + gx) * 32 + 8 * lk) = o;
     }
     ET* po = pooled + (size_t)c_img * (H / 2) * (W / 2) * 32;
 #pragma unroll
-    for (int mp = 0; mp < 2; ++mp)
+    for (int mp = 0; mp < 2; ++mp) {
+      v8 o;
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        v4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = fmaxf(acc[2 * mp][n][r], acc[2 * mp + 1][n][r]);
-          v = fmaxf(v, __shfl_xor(v, 1));
-          o[r] = (ET)fmaxf(v, 0.0f);
-        }
-        if ((li & 1) == 0)
-          *(v4*)(po + ((size_t)((c_y0 + rg * 4) / 2 + mp) * (W / 2) + (c_x0 + xh * 16 + li) / 2) * 32 + n * 16 + lk * 4) = o;
+      for (int r = 0; r < 8; ++r) {
+        float v = fmaxf(acc[2 * mp][r >> 2][r & 3], acc[2 * mp + 1][r >> 2][r & 3]);
+        v = fmaxf(v, __shfl_xor(v, 1));
+        o[r] = (ET)fmaxf(v, 0.0f);
       }
+      if ((li & 1) == 0)
+        *(v8*)(po + ((size_t)((c_y0 + rg * 4) / 2 + mp) * (W / 2) + (c_x0 + xh * 16 + li) / 2) * 32 + 8 * lk) = o;
+    }
     if (has_next2) patch_store(i & 1, pr);      // patch of item i+2 (slot (i+2)&1; its last reader was the first conv of item i, one barrier ago)
     __syncthreads();
   }

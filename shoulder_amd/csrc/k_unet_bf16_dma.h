@@ -34,11 +34,20 @@ template <typename ET, typename V4>
 __device__ inline void ud_store8(ET* p, V4 v) {      // exactly one vector-memory instruction (counted by s_waitcnt vmcnt)
   asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(__builtin_bit_cast(unsigned long long, v)) : "memory");
 }
+template <typename ET, typename V8>
+__device__ inline void ud_store16(ET* p, V8 v) {      // one dwordx4 store: 8 consecutive channels of a pixel
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  // s_nop 1 inside the string: hipcc pads nothing around an asm statement, and a store of more than 64 bits must not have
+  // its data registers overwritten in the next two issue slots (cdna_hip_programming.md 5.7; without it the later lanes
+  // of the wave stored the NEXT tile's values)
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u4, v)) : "memory");
+}
 __device__ inline void ud_store4(float* p, float v) {
   asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
 }
 template <int N> __device__ inline void ud_wait_vm() {      // s_waitcnt takes an immediate
   if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -48,7 +57,16 @@ template <int N> __device__ inline void ud_wait_vm() {      // s_waitcnt takes a
 
 // FUSE: 0, UF_POOL (2x2 max pool written beside the output) or UF_HEAD (1x1 head: only the logits leave the kernel).
 // NN: 16-cout tiles per item: 4 (64-cout groups) or 2 (the 32-channel level: 288 weight rows, 8 DMA pieces per step).
-template <int EK, int FUSE, int NN = 4>
+// Output channels of an item are dealt to the accumulator tiles so that a lane ends up with CONSECUTIVE channels: weight
+// row j = 16 n + i of the LDS image (tile n, MFMA row i) holds channel 4 NN (i >> 2) + 4 n + (i & 3) of the item's group, so
+// lane group lk owns channels 4 NN lk .. 4 NN lk + 4 NN - 1 of a pixel and the epilogue stores 16 bytes per instruction
+// (half the store instructions of the 4-channel form: the epilogue is store-ISSUE bound, cdna_hip_programming.md T21).  The
+// permutation is applied where the LDS-DMA computes its source rows; the packed weights in HBM keep channel order.
+// SCHED: order of the 9 taps inside a step.  0: row-major taps, 4 pixel + NN weight fragments read per tap (72 reads at
+// NN = 4).  1: column (dx) major -- the 6 pixel-row fragments of a dx serve its three dy taps (rows m + dy), so a step reads
+// 18 pixel + 9 NN weight fragments (54 at NN = 4): a quarter less LDS traffic per MFMA (what the chip spends per MFMA
+// decides the clock it holds, cdna_hip_programming.md 5.4 rule 28).
+template <int EK, int FUSE, int NN = 4, int SCHED = 1>
 __global__ void __launch_bounds__(UD_THREADS)
 k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int C0, int C1,
               const u16* __restrict__ wgt_, const float* __restrict__ bias, u16* __restrict__ dst_,
@@ -63,7 +81,6 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   ET* pooled = (ET*)pooled_;
 
   using v8 = typename E16<ET>::v8;
-  using v4 = typename E16<ET>::v4;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[UD_SMEM];
   static_assert(NN == 4 || NN == 2, "64- or 32-cout items");
   static_assert(!(FUSE & UF_HEAD) || NN == 2, "the head reads all 32 channels of a pixel from one item");
@@ -71,7 +88,7 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   constexpr int WSH = NN == 4 ? 6 : 5;               // log2(WR)
   constexpr int SLOTS = (UD_INROWS + 9 * WR) * 4;    // 16-byte slots of a step: 4896 / 3744
   constexpr int NPIECE = (SLOTS + UD_THREADS - 1) / UD_THREADS;      // 10 / 8
-  constexpr int NSTORE = (FUSE & UF_HEAD) ? 4 : 4 * NN + ((FUSE & UF_POOL) ? 2 * NN : 0);
+  constexpr int NSTORE = (FUSE & UF_HEAD) ? 4 : 2 * NN + ((FUSE & UF_POOL) ? NN : 0);      // dwordx4 stores per wave and item
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int xh = wave & 1, rg = wave >> 1;
@@ -93,7 +110,9 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   const int q8 = ((tid & 3) ^ ((r0 >> 1) & 2)) * 8;
   const int rw5 = r0 + 640 - UD_INROWS;
   const int wstep = (128 / WR) * nchunk * Cout * 32;      // 128 rows per piece = 2 (4) taps
-  const int wrel5 = ((rw5 >> WSH) * nchunk * Cout + (rw5 & (WR - 1))) * 32 + q8;
+  const int wj5 = rw5 & (WR - 1);                                                     // LDS weight row inside its tap: 16 n + i
+  const int wch5 = 4 * NN * ((wj5 & 15) >> 2) + 4 * (wj5 >> 4) + (wj5 & 3);            // the channel it holds
+  const int wrel5 = ((rw5 >> WSH) * nchunk * Cout + wch5) * 32 + q8;
   const bool in5 = rw5 < 0;
   const bool wlast = tid + 512 * (NPIECE - 1) < SLOTS;
 
@@ -162,7 +181,7 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     f32x4 acc[4][NN];
 #pragma unroll
     for (int n = 0; n < NN; ++n) {
-      const f32x4 bv = *(const f32x4*)(s_bias + c_n0 + n * 16 + lk * 4);
+      const f32x4 bv = *(const f32x4*)(s_bias + c_n0 + 4 * NN * lk + 4 * n);
 #pragma unroll
       for (int m = 0; m < 4; ++m) acc[m][n] = bv;
     }
@@ -187,6 +206,7 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) xb[sp][dx] = sb + xoff[sp][dx];
       const unsigned char* wbp = sb + woff;
+      if constexpr (SCHED == 0) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap % 3;
@@ -196,16 +216,30 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
 #pragma unroll
         for (int n = 0; n < NN; ++n) wf[n] = *(const v8*)(wbp + (tap * WR + n * 16) * 64);
         if (has_next) { if (tap < NPIECE) piece(tap); if (tap == 8 && NPIECE == 10) piece(9); }
-#ifdef SH_DMA_SETPRIO
-        __builtin_amdgcn_s_setprio(1);      // +4..7 % per layer in tools/conv_lab, -1..3 % inside this library (co-compiled kernels shift the schedule): off
-#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int n = 0; n < NN; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xf[m], acc[m][n]);
-#ifdef SH_DMA_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
+      }
+      } else {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        v8 xq[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) xq[s] = *(const v8*)(xb[s & 1][dx] + (s & ~1) * UD_PW * 64);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int tap = dy * 3 + dx, slot = dx * 3 + dy;
+          v8 wf[NN];
+#pragma unroll
+          for (int n = 0; n < NN; ++n) wf[n] = *(const v8*)(wbp + (tap * WR + n * 16) * 64);
+          if (has_next) { if (slot < NPIECE) piece(slot); if (slot == 8 && NPIECE == 10) piece(9); }
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < NN; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xq[m + dy], acc[m][n]);
+        }
+      }
       }
       buf ^= 1;
     }
@@ -218,7 +252,7 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
 #pragma unroll
         for (int n = 0; n < NN; ++n)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sacc = __builtin_fmaf(fmaxf(acc[m][n][r], 0.0f), s_bias[256 + n * 16 + lk * 4 + r], sacc);
+          for (int r = 0; r < 4; ++r) sacc = __builtin_fmaf(fmaxf(acc[m][n][r], 0.0f), s_bias[256 + 8 * lk + 4 * n + r], sacc);
         sacc += __shfl_xor(sacc, 16);
         sacc += __shfl_xor(sacc, 32);
         // all four lanes of a pixel store the same value: the store count per wave stays exact
@@ -230,15 +264,15 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     for (int m = 0; m < 4; ++m) {
       const int gy = c_y0 + rg * 4 + m, gx = c_x0 + xh * 16 + li;
 #pragma unroll
-      for (int n = 0; n < NN; ++n) {
-        v4 o;
+      for (int h = 0; h < NN / 2; ++h) {
+        v8 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[m][n][r];
+        for (int r = 0; r < 8; ++r) {
+          float v = acc[m][2 * h + (r >> 2)][r & 3];
           if (relu) v = fmaxf(v, 0.0f);
           o[r] = (ET)v;
         }
-        ud_store8(out + act_off((size_t)H * W, (size_t)gy * W + gx, c_n0 + n * 16 + lk * 4), o);
+        ud_store16(out + act_off((size_t)H * W, (size_t)gy * W + gx, c_n0 + 4 * NN * lk + 8 * h), o);
       }
     }
     }
@@ -247,17 +281,17 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
 #pragma unroll
       for (int mp = 0; mp < 2; ++mp)
 #pragma unroll
-        for (int n = 0; n < NN; ++n) {
-          v4 o;
+        for (int h = 0; h < NN / 2; ++h) {
+          v8 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = fmaxf(acc[2 * mp][n][r], acc[2 * mp + 1][n][r]);
+          for (int r = 0; r < 8; ++r) {
+            float v = fmaxf(acc[2 * mp][2 * h + (r >> 2)][r & 3], acc[2 * mp + 1][2 * h + (r >> 2)][r & 3]);
             v = fmaxf(v, __shfl_xor(v, 1));
             if (relu) v = fmaxf(v, 0.0f);
             o[r] = (ET)v;
           }
           // odd lanes store too (same value, the pixel of their even neighbour): the store count per wave stays exact
-          ud_store8(po + act_off((size_t)(H / 2) * (W / 2), (size_t)((c_y0 + rg * 4) / 2 + mp) * (W / 2) + (c_x0 + xh * 16 + li) / 2, c_n0 + n * 16 + lk * 4), o);
+          ud_store16(po + act_off((size_t)(H / 2) * (W / 2), (size_t)((c_y0 + rg * 4) / 2 + mp) * (W / 2) + (c_x0 + xh * 16 + li) / 2, c_n0 + 4 * NN * lk + 8 * h), o);
         }
     }
     (void)NSTORE;

@@ -29,6 +29,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <thread>
 
 using namespace sh;
@@ -940,12 +943,19 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     const dim3 g((unsigned)std::min(total, c->num_cus));      // (leaving 16..64 CUs to the other lane's kernels changes nothing: measured)
     const u16* zp = (const u16*)c->bufs["unet16.zero"].p;
     const float* nof = nullptr;
+    static const int sched = (getenv("SHOULDER_DMA_SCHED") && getenv("SHOULDER_DMA_SCHED")[0] == '0') ? 0 : 1;      // tap order inside a step (k_unet_bf16_dma.h)
+#define DMA_LAUNCH(F, N, ...)                                                                                                     \
+  do {                                                                                                                            \
+    if (sched == 0) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                          \
+    else { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1>), g, dim3(UD_THREADS), __VA_ARGS__); }                                     \
+  } while (0)
     if (dma64) {
-      if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma16<EK, UF_POOL, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr); }
-      else { LAUNCH(c, lname, (k_conv3_dma16<EK, 0, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr); }
-    } else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_dma16<EK, UF_POOL, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr); }
-    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv3_dma16<EK, UF_HEAD, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits); }
-    else { LAUNCH(c, lname, (k_conv3_dma16<EK, 0, 2>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr); }
+      if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr);
+      else DMA_LAUNCH(0, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr);
+    } else if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr);
+    else if (fuse == UF_HEAD) DMA_LAUNCH(UF_HEAD, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits);
+    else DMA_LAUNCH(0, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr);
+#undef DMA_LAUNCH
   } else if (L.taps == 9 && L.cout % 64 == 0) {
     const dim3 g(tiles, L.cout / 64, nimg);
     if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 4, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
@@ -1186,6 +1196,69 @@ static hipError_t fetch_hull_points(sh_ctx* c, const HullPre& hp, hipStream_t st
   return hipSuccess;
 }
 
+// Process-wide worker pool of the host hull phase.  A job is a callable every participating thread runs to completion
+// (the callable itself hands out mesh indices through an atomic counter); run() returns when all workers that picked
+// the job up have left it.  Jobs of different contexts queue up FIFO and are served by the same threads.
+class HullPool {
+ public:
+  static HullPool& instance() { static HullPool p; return p; }
+  static unsigned thread_count() {
+    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(e); if (v > 1) nt = std::max(1u, nt / (unsigned)v); }
+    nt = std::min(nt, 32u);
+    if (const char* e = getenv("SHOULDER_HULL_THREADS")) { int v = atoi(e); if (v > 0) nt = (unsigned)v; }
+    return nt;
+  }
+  void run(const std::function<void()>& fn, int items) {
+    Job job;
+    job.fn = fn;
+    job.want = (int)std::min<unsigned>(std::max(1, items), (unsigned)workers_.size() + 1) - 1;      // helpers besides the caller
+    if (job.want > 0) {
+      { std::lock_guard<std::mutex> lk(mu_); queue_.push_back(&job); }
+      cv_.notify_all();
+    }
+    fn();                                    // the caller takes part
+    if (job.want > 0) {
+      std::unique_lock<std::mutex> lk(mu_);
+      // helpers that have not started yet are no longer needed (the counter inside fn is exhausted): withdraw the job
+      auto it = std::find(queue_.begin(), queue_.end(), &job);
+      if (it != queue_.end()) queue_.erase(it);
+      done_cv_.wait(lk, [&] { return job.active == 0; });
+    }
+  }
+
+ private:
+  struct Job { std::function<void()> fn; int want = 0, taken = 0, active = 0; };
+  HullPool() {
+    const unsigned nt = thread_count();
+    for (unsigned t = 1; t < nt; ++t) workers_.emplace_back([this] { loop(); });
+  }
+  ~HullPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+      if (stop_) return;
+      Job* j = queue_.front();
+      ++j->taken; ++j->active;
+      if (j->taken >= j->want) queue_.pop_front();
+      lk.unlock();
+      j->fn();
+      lk.lock();
+      if (--j->active == 0) done_cv_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_cv_;
+  std::deque<Job*> queue_;
+  std::vector<std::thread> workers_;
+  bool stop_ = false;
+};
+
 // mesh.py:63-125.  Host: one quickhull per humerus on worker threads (sh_hull.h).  Device: candidate
 // boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
 // Host phase of the OBB stage for meshes [b0, b0 + B): one quickhull per humerus on worker threads into pinned slot
@@ -1230,17 +1303,11 @@ static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, do
       counts[b] = hn; counts[B + b] = fn; counts[2 * B + b] = en;
     }
   };
-  // worker threads: the host's hardware threads shared between the ranks of this node (torchrun exports
-  // LOCAL_WORLD_SIZE), at most 32 per rank; SHOULDER_HULL_THREADS overrides
-  unsigned nt = std::max(1u, std::thread::hardware_concurrency());
-  if (const char* e = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(e); if (v > 1) nt = std::max(1u, nt / (unsigned)v); }
-  nt = std::min(nt, 32u);
-  if (const char* e = getenv("SHOULDER_HULL_THREADS")) { int v = atoi(e); if (v > 0) nt = (unsigned)v; }
-  nt = std::min<unsigned>(nt, (unsigned)B);
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
-  work();
-  for (auto& t : pool) t.join();
+  // One pool of worker threads per process, started once and shared by every context (lane) of the process: the host's
+  // hardware threads divided between the ranks of this node (torchrun exports LOCAL_WORLD_SIZE), at most 32 per process;
+  // SHOULDER_HULL_THREADS overrides.  The calling thread works on its own batch too.  (Round 1 started up to 32 threads
+  // per batch: a third of the 4.8 ms hull phase was thread start-up, and two lanes doubled the thread count.)
+  HullPool::instance().run(work, B);
   *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (int b = 0; b < B; ++b)
     if (status[b] != 0) { *bad_mesh = b0 + b; return status[b]; }

@@ -116,25 +116,32 @@ def test_fused_ends_match_layerwise(engine, monkeypatch, name):
 
 @pytest.mark.parametrize("name", ["bf16", "f16"])
 def test_level0_fused_matches_two_barrier_kernel(engine, monkeypatch, name):
-    """k_enc0_fused16 (image -> enc0a -> LDS -> enc0b -> skip0 + pool, persistent, weights resident in LDS) performs the
-    operations of the two-barrier kernel k_conv_mfma16<EK, 9, 2, UF_FIRST | UF_POOL> in the same order: skip0, the pooled
-    tensor (through skip1's input: level 1 is bit-identical) and the logits are equal bit for bit -- incl. a ragged last
-    work range (5 images of 256 x 256: 640 items over 256 workgroups) and image borders."""
+    """k_enc0_fused16 (image -> enc0a -> LDS -> enc0b -> skip0 + pool, persistent, weights resident in LDS) against the
+    two-barrier kernel k_conv_mfma16<EK, 9, 2, UF_FIRST | UF_POOL>: the same arithmetic (hi + lo split image, ET weights,
+    f32 accumulate) with the first conv's 18 products summed in another order, so skip0 agrees to an ulp or two of the
+    element type and the logits far inside the type's tolerance -- incl. a ragged last work range (5 images of 256 x 256:
+    640 items over 256 workgroups) and the image borders (zero padding of both convs)."""
     rng = np.random.default_rng(7)
+    tof = (lambda u: (u.astype(np.uint32) << 16).view(np.float32)) if name == "bf16" else (lambda u: u.view(np.float16).astype(np.float32))
+    ulp = 2.0 ** -8 if name == "bf16" else 2.0 ** -11
     engine.set_params(unet_dtype=DTYPES[name][0])
     try:
         for shape in ((5, 256, 256), (2, 256, 512)):
             img = rng.random(shape, dtype=np.float32)
-            n0, n1 = shape[0] * shape[1] * shape[2] * 32, shape[0] * shape[1] * shape[2] // 4 * 64
+            n0 = shape[0] * shape[1] * shape[2] * 32
             monkeypatch.setenv("SHOULDER_UNET_L0", "1")
             a = engine.unet_infer(img)
-            s0a = engine.fetch("unet16.skip0", np.uint16)[:n0].copy()
-            s1a = engine.fetch("unet16.skip1", np.uint16)[:n1].copy()
+            s0a = tof(engine.fetch("unet16.skip0", np.uint16)[:n0].copy()).reshape(shape + (32,))
             monkeypatch.setenv("SHOULDER_UNET_L0", "0")
             b = engine.unet_infer(img)
-            s0b = engine.fetch("unet16.skip0", np.uint16)[:n0].copy()
-            s1b = engine.fetch("unet16.skip1", np.uint16)[:n1].copy()
-            assert np.array_equal(s0a, s0b) and np.array_equal(s1a, s1b) and np.array_equal(a, b), shape
+            s0b = tof(engine.fetch("unet16.skip0", np.uint16)[:n0].copy()).reshape(shape + (32,))
+            d = np.abs(s0a - s0b)
+            scale = max(1.0, float(np.abs(s0b).max()))
+            # a first-conv activation that rounds the other way (1 ulp) moves a second-conv output by a few ulps of the tensor's scale
+            assert float(d.max()) <= 8 * ulp * scale and float(d.mean()) < ulp * scale / 8, (shape, float(d.max()), float(d.mean()))
+            for sl in (np.s_[:, 0], np.s_[:, -1], np.s_[:, :, 0], np.s_[:, :, -1]):      # borders: no stale halo data
+                assert float(d[sl].max()) <= 8 * ulp * scale
+            assert float(np.abs(a - b).max()) < DTYPES[name][1] / 4
     finally:
         monkeypatch.delenv("SHOULDER_UNET_L0", raising=False)
         engine.set_params(unet_dtype=_lib.UNET_F32)
