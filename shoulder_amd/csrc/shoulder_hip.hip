@@ -940,7 +940,10 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
     if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
     const int total = nimg * (W / 32) * (H / 16) * (L.cout / (dma64 ? 64 : 32));
-    const dim3 g((unsigned)std::min(total, c->num_cus));      // (leaving 16..64 CUs to the other lane's kernels changes nothing: measured)
+    // SHOULDER_DMA_GRIDMUL workgroups per CU (default 1): with more, shorter work ranges the hardware dispatcher balances the
+    // launch over the CUs another lane's kernels leave free (a workgroup takes a whole CU's LDS, so it waits for a free CU)
+    static const int gridmul = getenv("SHOULDER_DMA_GRIDMUL") ? std::max(1, atoi(getenv("SHOULDER_DMA_GRIDMUL"))) : 1;
+    const dim3 g((unsigned)std::min(total, c->num_cus * gridmul));
     const u16* zp = (const u16*)c->bufs["unet16.zero"].p;
     const float* nof = nullptr;
     static const int sched = (getenv("SHOULDER_DMA_SCHED") && getenv("SHOULDER_DMA_SCHED")[0] == '0') ? 0 : 1;      // tap order inside a step (k_unet_bf16_dma.h)
@@ -968,6 +971,9 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
     else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, UF_HEAD>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
     else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
+  } else if (L.cout % 32 == 0 && C1 == 0 && C0 % 32 == 0 && !(getenv("SHOULDER_UNET_UPCONV") && getenv("SHOULDER_UNET_UPCONV")[0] == '0')) {
+    // 2x2 transposed conv, all four phases per workgroup (k_unet16_l0.h)
+    LAUNCH(c, lname, (k_upconv16<EK>), dim3(tiles, L.cout / 32, nimg), dim3(UPC_THREADS), src0, C0, w, b, dst, H, W, L.cout);
   } else if (L.cout % 64 == 0) {
     LAUNCH(c, lname, (k_conv_mfma16<EK, 1, 4, 0>), dim3(tiles, L.cout / 64, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
   } else {

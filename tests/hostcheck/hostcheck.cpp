@@ -68,3 +68,26 @@ extern "C" int hc_hull(const double* pts, int n, int* vert_ids, int cap_v, int* 
   *n_edges = (int)H.edges.size() / 4;
   return nv * 100000 + nf;
 }
+
+#include "hull_rounds_ref.h"
+// Round-based quickhull (reference restatement of the device kernel): returns the number of faces (>= 0) or -fail code.
+// tris: point indices, 3 per face; info: {n hull vertices, rounds, insertions}.
+extern "C" int hc_hull_rounds(const float* pts, int n, int K, int* tris, int cap_f, int* info) {
+  hullref::Out o;
+  int rc = hullref::hull_rounds(pts, n, o, K);
+  info[0] = (int)o.vert_ids.size(); info[1] = o.rounds; info[2] = o.insertions;
+  if (rc) return -rc;
+  int nf = (int)o.tris.size() / 3;
+  if (nf > cap_f) return -99;
+  for (int i = 0; i < 3 * nf; ++i) tris[i] = o.tris[i];
+  return nf;
+}
+// the host quickhull's faces as point indices (for set comparison with the round-based one)
+extern "C" int hc_hull_tris_pts(const double* pts, int n, int* tris, int cap_f) {
+  shhull::Hull H;
+  if (!shhull::convex_hull(pts, n, H)) return -1;
+  int nf = (int)H.tris.size() / 3;
+  if (nf > cap_f) return -2;
+  for (int i = 0; i < 3 * nf; ++i) tris[i] = H.vert_ids[H.tris[i]];
+  return nf;
+}

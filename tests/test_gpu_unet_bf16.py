@@ -147,6 +147,26 @@ def test_level0_fused_matches_two_barrier_kernel(engine, monkeypatch, name):
         engine.set_params(unet_dtype=_lib.UNET_F32)
 
 
+@pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_all_phase_upconv_matches_per_phase_kernel(engine, monkeypatch, name):
+    """k_upconv16 (16x16 source tile x 32 channels x all four phases per workgroup, input staged once, full output lines per
+    wave) sums every output in the order of the per-phase two-barrier kernel: logits and a decoder tensor are bit-identical."""
+    rng = np.random.default_rng(11)
+    img = rng.random((3, 256, 512), dtype=np.float32)
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        monkeypatch.setenv("SHOULDER_UNET_UPCONV", "1")
+        a = engine.unet_infer(img)
+        ua = engine.fetch("unet16.b", np.uint16).copy()
+        monkeypatch.setenv("SHOULDER_UNET_UPCONV", "0")
+        b = engine.unet_infer(img)
+        ub = engine.fetch("unet16.b", np.uint16).copy()
+        assert np.array_equal(a, b) and np.array_equal(ua, ub)
+    finally:
+        monkeypatch.delenv("SHOULDER_UNET_UPCONV", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+
+
 @pytest.mark.parametrize("base,depth,H,W", [(96, 2, 64, 64), (160, 1, 32, 64), (64, 3, 128, 256), (256, 1, 32, 32)])
 def test_other_widths_and_depths(base, depth, H, W):
     """Networks other than the default 4 x base-32 one (a user's ONNX import may have any base % 32 == 0 up to 256): both paths
