@@ -242,14 +242,17 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
 
 namespace sh {
 
-// ---- 2x2 stride-2 transposed convolution (the decoder's up-sampling), all four output phases in one workgroup ------------
+// ---- 2x2 stride-2 transposed convolution (the decoder's up-sampling), both column phases of an output row per workgroup --
 // out[2y + dy][2x + dx][co] = b[co] + sum_ci in[y][x][ci] * w[dy * 2 + dx][ci][co]: per output pixel one K = Cin product, no
 // spatial reuse -- a memory-bound layer (up0 at B = 64: 0.54 GB in, 1.07 GB out, 0.07 TFLOP).  The two-barrier kernel ran
 // it as one launch of 4 x Cout/64 workgroups per tile: every workgroup re-read the input tile, and the two dx phases of an
 // output row -- the two 64-byte halves of each 128-byte line -- were written by different workgroups.  Here a workgroup
-// (4 waves) owns a 16x16 source tile x 32 output channels x all 4 phases: the tile is staged once per 32-channel chunk
-// and multiplied against the four phases' weights (pixel fragments reused across phases), and both halves of every output
-// line leave the same wave back to back.  Channels are dealt to the MFMA rows as in k_conv3_dma16 (16-byte stores).
+// (4 waves) owns a 16x16 source tile x 32 output channels x the two dx phases of one row parity dy: the tile is staged
+// once per 32-channel chunk and multiplied against both phases' weights (pixel fragments reused), and both halves of
+// every output line leave the same wave back to back.  Channels are dealt to the MFMA rows as in k_conv3_dma16 (16-byte stores).
+// A workgroup takes one output-row parity dy (both dx): 32 accumulator tiles for all four phases cost 128 VGPRs and left two
+// workgroups per CU, which made the kernel the slowest one beside another lane's kernels (0.47 ms average in the two-lane
+// bench against 0.27 ms alone); with 16 tiles four to five workgroups fit.
 #define UPC_THREADS 256
 
 template <int EK>
@@ -260,41 +263,39 @@ k_upconv16(const u16* __restrict__ src_, int Cin, const u16* __restrict__ wgt_ /
   using v8 = typename E16<ET>::v8;
   const ET* wgt = (const ET*)wgt_;
   __shared__ __attribute__((aligned(16))) ET s_in[256 * UB_PSTR];
-  __shared__ __attribute__((aligned(16))) ET s_w[128 * UB_PSTR];
+  __shared__ __attribute__((aligned(16))) ET s_w[64 * UB_PSTR];
   const int tiles_x = W / 16;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int n0 = blockIdx.y * 32, img = blockIdx.z;
+  const int n0 = blockIdx.y * 32, img = blockIdx.z >> 1, dy = blockIdx.z & 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int x0 = tx * 16, y0 = ty * 16;
   const int nchunk = Cin / 32;
   const ET* in = (const ET*)src_ + (size_t)img * H * W * Cin;
 
-  // staging plan: 4 input pieces + 2 weight pieces of 16 bytes per thread and chunk
-  int in_src[4], in_lds[4], wt_src[2], wt_lds[2];
+  // staging plan: 4 input pieces + 1 weight piece of 16 bytes per thread and chunk
+  int in_src[4], in_lds[4], wt_src[1], wt_lds[1];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int e = tid + k * UPC_THREADS, q = e & 3, p = e >> 2;
     in_src[k] = ((y0 + (p >> 4)) * W + x0 + (p & 15)) * 32 + q * 8;
     in_lds[k] = UB_OFF(p, q);
   }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int e = tid + k * UPC_THREADS, q = e & 3, r = e >> 2, ph = r >> 5, j = r & 31;
+  {
+    const int e = tid, q = e & 3, r = e >> 2, dx = r >> 5, j = r & 31;
     const int ch = 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);      // LDS row 16 n + i of a phase holds channel 8 (i >> 2) + 4 n + (i & 3)
-    wt_src[k] = (ph * nchunk * Cout + n0 + ch) * 32 + q * 8;
-    wt_lds[k] = UB_OFF(r, q);
+    wt_src[0] = ((dy * 2 + dx) * nchunk * Cout + n0 + ch) * 32 + q * 8;
+    wt_lds[0] = UB_OFF(r, q);
   }
-  u32x4 rin[4], rwt[2];
+  u32x4 rin[4], rwt[1];
   auto load_chunk = [&](int cc) {
     const ET* s = in + (size_t)cc * H * W * 32;
 #pragma unroll
     for (int k = 0; k < 4; ++k) rin[k] = *(const u32x4*)(s + in_src[k]);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) rwt[k] = *(const u32x4*)(wgt + (size_t)wt_src[k] + (size_t)cc * Cout * 32);
+    rwt[0] = *(const u32x4*)(wgt + (size_t)wt_src[0] + (size_t)cc * Cout * 32);
   };
 
-  f32x4 acc[4][4][2];
+  f32x4 acc[4][2][2];
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     f32x4 bv;
@@ -303,22 +304,21 @@ k_upconv16(const u16* __restrict__ src_, int Cin, const u16* __restrict__ wgt_ /
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int ph = 0; ph < 4; ++ph) acc[m][ph][n] = bv;
+      for (int ph = 0; ph < 2; ++ph) acc[m][ph][n] = bv;
   }
   load_chunk(0);
   for (int cc = 0; cc < nchunk; ++cc) {
     __syncthreads();                  // every wave is done reading the previous chunk
 #pragma unroll
     for (int k = 0; k < 4; ++k) *(u32x4*)(s_in + in_lds[k]) = rin[k];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) *(u32x4*)(s_w + wt_lds[k]) = rwt[k];
+    *(u32x4*)(s_w + wt_lds[0]) = rwt[0];
     __syncthreads();
     if (cc + 1 < nchunk) load_chunk(cc + 1);      // in flight during the MFMAs below
     v8 xf[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) xf[m] = *(const v8*)(s_in + UB_OFF((wave * 4 + m) * 16 + li, lk));
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
+    for (int ph = 0; ph < 2; ++ph) {      // ph = dx
       v8 wf[2];
 #pragma unroll
       for (int n = 0; n < 2; ++n) wf[n] = *(const v8*)(s_w + UB_OFF(ph * 32 + n * 16 + li, lk));
@@ -333,8 +333,8 @@ k_upconv16(const u16* __restrict__ src_, int Cin, const u16* __restrict__ wgt_ /
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph) {
-      const int oy = 2 * (y0 + wave * 4 + m) + (ph >> 1), ox = 2 * (x0 + li) + (ph & 1);
+    for (int ph = 0; ph < 2; ++ph) {
+      const int oy = 2 * (y0 + wave * 4 + m) + dy, ox = 2 * (x0 + li) + ph;
       v8 o;
 #pragma unroll
       for (int r = 0; r < 8; ++r) o[r] = (ET)acc[m][ph][r >> 2][r & 3];

@@ -98,6 +98,9 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   const int per = (total + gridDim.x - 1) / gridDim.x;
   const int w_begin = blockIdx.x * per, w_end = min(total, w_begin + per);
   if (w_begin >= w_end) return;
+#ifdef SH_DMA_PRIO
+  __builtin_amdgcn_s_setprio(SH_DMA_PRIO);      // experiment: waves of another lane's kernels that share the SIMD lose the issue arbitration
+#endif
 
   float* s_bias = (float*)(smem + UD_BIAS_OFF);
   for (int i = tid; i < Cout; i += UD_THREADS) s_bias[i] = bias[i];

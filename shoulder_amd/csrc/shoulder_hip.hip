@@ -973,7 +973,7 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
   } else if (L.cout % 32 == 0 && C1 == 0 && C0 % 32 == 0 && !(getenv("SHOULDER_UNET_UPCONV") && getenv("SHOULDER_UNET_UPCONV")[0] == '0')) {
     // 2x2 transposed conv, all four phases per workgroup (k_unet16_l0.h)
-    LAUNCH(c, lname, (k_upconv16<EK>), dim3(tiles, L.cout / 32, nimg), dim3(UPC_THREADS), src0, C0, w, b, dst, H, W, L.cout);
+    LAUNCH(c, lname, (k_upconv16<EK>), dim3(tiles, L.cout / 32, nimg * 2), dim3(UPC_THREADS), src0, C0, w, b, dst, H, W, L.cout);
   } else if (L.cout % 64 == 0) {
     LAUNCH(c, lname, (k_conv_mfma16<EK, 1, 4, 0>), dim3(tiles, L.cout / 64, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
   } else {

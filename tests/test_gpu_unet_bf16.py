@@ -148,8 +148,8 @@ def test_level0_fused_matches_two_barrier_kernel(engine, monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", ["bf16", "f16"])
-def test_all_phase_upconv_matches_per_phase_kernel(engine, monkeypatch, name):
-    """k_upconv16 (16x16 source tile x 32 channels x all four phases per workgroup, input staged once, full output lines per
+def test_row_upconv_matches_per_phase_kernel(engine, monkeypatch, name):
+    """k_upconv16 (16x16 source tile x 32 channels x both column phases of a row parity per workgroup: full output lines per
     wave) sums every output in the order of the per-phase two-barrier kernel: logits and a decoder tensor are bit-identical."""
     rng = np.random.default_rng(11)
     img = rng.random((3, 256, 512), dtype=np.float32)

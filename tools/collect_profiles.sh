@@ -19,3 +19,11 @@ echo write done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --output-format csv -d $O/sq_$UNET -o sq -- python3 bench.py --unet $UNET --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs --lanes 1 > $O/sq_$UNET.log 2>&1
 echo sq done
 find $O -name "*.csv" | head -30
+# BASELINE configs[4]: the network alone, fp16 MFMA conv (tools/bench_unet.py --unet f16): kernel stats + HBM / SQ counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/unet_f16_stats -o stats -- python3 tools/bench_unet.py --unet f16 --reps 5 > $O/unet_f16_under_rocprof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/unet_f16_fetch -o fetch -- python3 tools/bench_unet.py --unet f16 --reps 2 > $O/unet_f16_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/unet_f16_write -o write -- python3 tools/bench_unet.py --unet f16 --reps 2 > $O/unet_f16_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE --output-format csv -d $O/unet_f16_sq -o sq -- python3 tools/bench_unet.py --unet f16 --reps 2 > $O/unet_f16_sq.log 2>&1
+python3 tools/bench_unet.py --unet f16 --layers > $O/unet_f16.log 2>&1
+python3 tools/bench_unet.py --unet bf16 --layers > $O/unet_bf16.log 2>&1
+echo unet f16 done
