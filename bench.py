@@ -388,6 +388,12 @@ def main():
             ach = g[dom32][1] / (g[dom32][0] * 1e-3) / 1e12
             extra["f32_unet"]["roofline"] = {"bound": "mfma", "kernel": dom32, "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s",
                                              "frac": round(ach / PEAK_MFMA_F32_TF, 4), "avg_ms": round(g[dom32][0] / g[dom32][2], 4), "launches": g[dom32][2]}
+        if args.unet == "bf16":      # the other 16-bit element type: same kernels and rate, 11 significant bits instead of 8
+            k16 = max(3, min(args.steps, 10))
+            el16, _, _ = run_leg(engs, "f16", k16, 1, pipelined)
+            extra["f16_unet"] = {"value": round(B * k16 / el16, 3), "unit": "meshes/s", "steps": k16, "warmup": 1, "ms_per_step": round(1e3 * el16 / k16, 3),
+                                 "dtype": "f64 geometry + f16 UNet", "lanes": lanes,
+                                 "parity": "mask-independent landmarks within 1e-4 mm of the oracle; anatomic-neck landmarks within the f16 bound of tests/test_gpu_end_to_end.py (plane point 0.06 mm, axes 0.4 mm)"}
         if lanes > 1:
             el1, _, _ = run_leg(engs[:1], args.unet, args.steps, 1, pipelined)
             extra["one_lane"] = {"value": round(B * args.steps / el1, 3), "unit": "meshes/s", "steps": args.steps, "warmup": 1,
