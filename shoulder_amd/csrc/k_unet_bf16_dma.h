@@ -159,6 +159,9 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     n_lbase = smem + buf * UD_BUF + wave * 1024;
   };
   auto piece = [&](int k) {      // k is a compile-time constant at every call site
+#ifdef SH_ABL_NODMA
+    if (k >= SH_ABL_NODMA) return;      // ablation build (wrong results): what the steady state costs without (some of) its DMA pieces
+#endif
     if (k < 5) {
       const ET* p = pixoff[k] >= 0 ? n_simg + (unsigned)((n_cb + pixoff[k]) * 32 + q8) : zero_page;
       __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + k * 8192), 16, 0, 0);

@@ -253,9 +253,21 @@ def unet_from_onnx(path_or_bytes):
             prod[nd["output"][0]] = {"kind": "cat", "parts": [prod[i] for i in nd["input"]]}
         elif op in ("Identity", "Dropout"):
             prod[nd["output"][0]] = prod[x]
+        elif op == "Sigmoid":
+            # Only as the tail of the network: the reference turns the model's output into a mask by a threshold
+            # (anatomic_neck.py:79-83: `mask > 0` for its logit-output models, `mask > 0.5` for the sigmoid-output "b loss"
+            # variant it keeps as a comment) and sigmoid(x) > 0.5 <=> x > 0, so the engine -- which thresholds the last
+            # convolution's output at 0 -- computes the mask of a sigmoid-tailed export by dropping the tail.
+            L = prod[x]
+            if L.get("kind") != "conv" or L["relu"] or nd["output"][0] != gout[0]:
+                raise UnsupportedOnnxModel(f"{_where(nd)}: Sigmoid is only accepted as the tail behind the last convolution")
+            import warnings
+            warnings.warn(f"{_where(nd)}: Sigmoid tail dropped -- the mask is sigmoid(x) > 0.5, i.e. logit > 0 "
+                          "(the reference's `mask > 0.5` variant, anatomic_neck.py:81-82)", stacklevel=2)
+            prod[nd["output"][0]] = L
         else:
             raise UnsupportedOnnxModel(f"{_where(nd)}: operator {op} is not part of the UNet family the engine executes "
-                                       "(Conv, ConvTranspose, BatchNormalization, Relu, MaxPool, Concat)")
+                                       "(Conv, ConvTranspose, BatchNormalization, Relu, MaxPool, Concat; Sigmoid / Identity as the tail)")
     if gout[0] not in prod or prod[gout[0]].get("kind") != "conv":
         raise UnsupportedOnnxModel("the graph output is not a convolution (the reference thresholds raw logits at 0)")
 

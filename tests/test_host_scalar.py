@@ -25,7 +25,7 @@ def dp(a):
 def hc():
     so = os.path.join(HC, "libhostcheck.so")
     src = os.path.join(HC, "hostcheck.cpp")
-    hdrs = [os.path.join(ROOT, "shoulder_amd", "csrc", h) for h in ("sh_scalar.h", "sh_common.h", "sh_hull.h")]
+    hdrs = [os.path.join(ROOT, "shoulder_amd", "csrc", h) for h in ("sh_scalar.h", "sh_common.h", "sh_hull.h")] + [os.path.join(HC, "hull_rounds_ref.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in [src] + hdrs):
         subprocess.check_call(["g++", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src])
     lib = ctypes.CDLL(so)
@@ -242,6 +242,35 @@ def test_hull_vs_qhull(hc):
         Q = P - c
         vol = np.einsum("ij,ij->i", Q[t[:, 0]], np.cross(Q[t[:, 1]], Q[t[:, 2]])).sum() / 6   # outward orientation -> positive
         assert abs(vol - ref.volume) <= 1e-9 * ref.volume
+
+
+def test_round_based_hull_reference(hc):
+    """tests/hostcheck/hull_rounds_ref.h -- the round-based (batched-insertion) quickhull studied for a device hull
+    (DESIGN.md 9): apexes whose visible regions share no vertex are inserted in the same round, no adjacency structure.
+    It must give the host quickhull's triangles exactly (the hull of points in general position is unique), and its trace
+    records WHY it is not the product: a humerus needs ~1000 dependent rounds because only 1-3 of the 10-40 faces that still
+    hold outside points can be served per round."""
+    from oracle.stl import load_stl
+    from conftest import BONES
+
+    def canon(t):
+        t = np.asarray(t).reshape(-1, 3)
+        r = np.argmin(t, axis=1)
+        return set(tuple(np.roll(row, -k)) for row, k in zip(t, r))
+    F = ctypes.POINTER(ctypes.c_float)
+    for name in ("humerus_left", "proximal_left_cut"):
+        v = np.ascontiguousarray(load_stl(os.path.join(BONES, name + ".stl"))[0], dtype=np.float32)
+        tris = np.zeros(3 * 20000, dtype=np.int32)
+        info = np.zeros(3, dtype=np.int32)
+        nf = hc.hc_hull_rounds(v.ctypes.data_as(F), len(v), 12, tris.ctypes.data_as(I), 20000, info.ctypes.data_as(I))
+        assert nf > 0, nf
+        P = np.ascontiguousarray(v, dtype=np.float64)
+        t2 = np.zeros(3 * 20000, dtype=np.int32)
+        nf2 = hc.hc_hull_tris_pts(dp(P), len(P), t2.ctypes.data_as(I), 20000)
+        assert nf2 == nf and canon(tris[:3 * nf]) == canon(t2[:3 * nf2])
+        nv, rounds, ins = (int(x) for x in info)
+        assert nf == 2 * nv - 4
+        assert rounds > 300 and ins / rounds < 5.0        # the measured parallel width of the insertion order (see docstring)
 
 
 def test_prox_canal_range(hc):

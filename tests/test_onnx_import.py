@@ -93,8 +93,8 @@ def test_imported_network_computes_what_the_graph_computes(weights, skip_first):
 
 def test_rejections_name_the_node(weights):
     ow_ = onnx_layout(weights, DEPTH)
-    with pytest.raises(UnsupportedOnnxModel, match="Sigmoid"):
-        unet_from_onnx(ow.unet_model(ow_, DEPTH, tail="Sigmoid"))
+    with pytest.raises(UnsupportedOnnxModel, match="Softmax"):
+        unet_from_onnx(ow.unet_model(ow_, DEPTH, tail="Softmax"))
     bad = dict(ow_)
     W, b = bad["enc0b"]
     bad["enc0b"] = (np.zeros((W.shape[0], W.shape[1], 5, 5), np.float32), b)
@@ -109,6 +109,19 @@ def test_rejections_name_the_node(weights):
         unet_from_onnx(b"\x08\x08")
     with pytest.raises(UnsupportedOnnxModel):
         unet_from_onnx(ow.unet_model(ow_, DEPTH)[:-40])
+
+
+def test_monotone_tails_are_dropped(weights):
+    """A Sigmoid (or Identity) behind the head is the reference's thresholded-output variant (anatomic_neck.py:79-83):
+    sigmoid(x) > 0.5 <=> x > 0, so the same parameters come out, with a warning that names the convention."""
+    ow_ = onnx_layout(weights, DEPTH)
+    plain, base, depth = unet_from_onnx(ow.unet_model(ow_, DEPTH))
+    with pytest.warns(UserWarning, match="Sigmoid tail dropped"):
+        sig, b2, d2 = unet_from_onnx(ow.unet_model(ow_, DEPTH, tail="Sigmoid"))
+    ident, b3, d3 = unet_from_onnx(ow.unet_model(ow_, DEPTH, tail="Identity"))
+    assert (base, depth) == (b2, d2) == (b3, d3)
+    for k in plain:
+        assert np.array_equal(plain[k], sig[k]) and np.array_equal(plain[k], ident[k]), k
 
 
 def test_reader_lists_nodes_and_initializers(weights):
