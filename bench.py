@@ -116,9 +116,11 @@ def sym_key(name, unet, cout, fused_net=True):
         fuse = 0
     if name == "unet.enc0b" and fused_net and os.environ.get("SHOULDER_UNET_L0") != "0" and os.environ.get("SHOULDER_UNET_FUSE_FIRST") != "0":
         return "k_enc0_fused16<%s>" % unet      # level-0 encoder as one persistent kernel (k_unet16_l0.h)
+    if up and os.environ.get("SHOULDER_UNET_UPCONV") != "0":
+        return "k_upconv16<%s>" % unet                           # 2x2 transposed conv, both column phases per workgroup (k_unet16_l0.h)
     dma = (not up and not (fuse & 1) and os.environ.get("SHOULDER_UNET_DMA") != "0" and (cout % 64 == 0 or os.environ.get("SHOULDER_UNET_DMA32") != "0"))
-    if dma:
-        return "k_conv3_dma16<%s,%d,%d>" % (unet, fuse, nt)      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h)
+    if dma:      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h); last argument = tap order (SCHED)
+        return "k_conv3_dma16<%s,%d,%d,%d>" % (unet, fuse, nt, 0 if os.environ.get("SHOULDER_DMA_SCHED") == "0" else 1)
     return "k_conv_mfma16<%s,%d,%d,%d>" % (unet, 1 if up else 9, nt, fuse)
 
 
