@@ -308,7 +308,21 @@ inline bool convex_hull_eps(const double* pts_in, int n, Hull& H, double eps_rel
       if (vmap[v] < 0) { vmap[v] = (int)H.vert_ids.size(); H.vert_ids.push_back(v); }
       H.tris.push_back(vmap[v]);
     }
-    for (int k = 0; k < 3; ++k) H.normals.push_back(B.F[f].n[k]);
+    // the record's normal: from the triangle rotated to its smallest point index first, coordinates centred on the
+    // bounding-box midpoint -- independent of the insertion history and of the summation order of a mean, so that the device
+    // hull (k_hull.h), which finds the same triangles by another route, hands k_obb_candidates the same bits
+    {
+      int r = 0;
+      for (int k = 1; k < 3; ++k) if (B.F[f].v[k] < B.F[f].v[r]) r = k;
+      double q[3][3];
+      for (int k = 0; k < 3; ++k)
+        for (int a = 0; a < 3; ++a) q[k][a] = pts_in[3 * (size_t)B.F[f].v[(r + k) % 3] + a] - 0.5 * (lo[a] + hi[a]);
+      const double u[3] = {q[1][0] - q[0][0], q[1][1] - q[0][1], q[1][2] - q[0][2]}, w[3] = {q[2][0] - q[0][0], q[2][1] - q[0][1], q[2][2] - q[0][2]};
+      const double nx = u[1] * w[2] - u[2] * w[1], ny = u[2] * w[0] - u[0] * w[2], nz = u[0] * w[1] - u[1] * w[0];
+      const double l = std::sqrt(nx * nx + ny * ny + nz * nz);
+      if (l == 0.0) { H.normals.push_back(0.0); H.normals.push_back(0.0); H.normals.push_back(1.0); }
+      else { H.normals.push_back(nx / l); H.normals.push_back(ny / l); H.normals.push_back(nz / l); }
+    }
   }
   for (size_t f = 0; f < B.F.size(); ++f) {
     if (!B.F[f].alive) continue;

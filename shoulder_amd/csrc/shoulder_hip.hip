@@ -25,6 +25,7 @@
 #include "k_hullpre.h"
 #include "k_te.h"
 #include "k_obb.h"
+#include "k_hull.h"
 #include "sh_hull.h"
 
 #include <atomic>
@@ -69,6 +70,11 @@ struct sh_ctx {
   std::map<std::string, ULayer> ulayers;
   size_t unet_floats = 0;
   bool obb_injected = false;
+  // hull of SH_STAGE_OBB: 1 = on the device (k_hull.h), 0 = host quickhull (sh_hull.h).  SHOULDER_HULL=host|device; default device.
+  // A humerus the device hull gives up (pinched horizon on nearly coplanar clouds, capacities) makes the whole batch go through
+  // the host quickhull (hull_host_gen == batch_gen) -- sh_run / sh_collect re-run it on their own.
+  int hull_mode = 1;
+  unsigned long long hull_host_gen = ~0ull;
   std::vector<float> h_verts;                // host copy of the vertices (hull stage)
   bool h_verts_valid = false;
   // device-generated batches: the hull's points come back through the prefilter (k_hullpre.h) into pinned memory
@@ -93,7 +99,8 @@ struct sh_ctx {
   } prep;
   hipEvent_t obb_done_ev = nullptr;      // recorded after the last kernel of a run that reads the hull.* device buffers
   // sh_submit / sh_collect: up to two runs in flight (the second one is enqueued while the first still executes)
-  struct Ticket { hipEvent_t ev = nullptr; int* h_err = nullptr; int cap = 0, B = 0; bool pending = false; sh_landmarks* host_out = nullptr; };
+  struct Ticket { hipEvent_t ev = nullptr; int* h_err = nullptr; int cap = 0, B = 0; bool pending = false; sh_landmarks* host_out = nullptr;
+                  uint32_t mask = 0; sh_landmarks* out_arg = nullptr; bool dev_hull = false; };
   Ticket tickets[2];
   int t_head = 0, t_tail = 0, n_pending = 0;
   hipStream_t out_stream = nullptr;      // sh_collect copies the records / status words of a finished run to the host on this stream
@@ -210,6 +217,7 @@ int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
   sh_ctx* c = new (std::nothrow) sh_ctx();
   if (!c) return SH_ERR_NOMEM;
   c->device = device;
+  if (const char* e = getenv("SHOULDER_HULL")) c->hull_mode = (e[0] == 'h' || e[0] == '0') ? 0 : 1;
   sh_default_params(&c->params);
   if (hip_stream) c->stream = (hipStream_t)hip_stream;
   else {
@@ -380,6 +388,18 @@ static int alloc_batch(sh_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&c->h_nkept, (size_t)B * 4));
     HIPCHK(c, hipHostMalloc((void**)&c->h_koff, (size_t)(B + 1) * 8));
     c->h_nkept_cap = B;
+  }
+  if (c->hull_mode == 1) {      // scratch of the device hull (k_hull.h), ~1.6 MB per humerus
+    ENS("hulld.fv", (size_t)B * HD_SLOTS * 3 * 4, 4);
+    ENS("hulld.vis", (size_t)B * HD_KC * HD_VMAX * 4, 4);
+    ENS("hulld.ev", (size_t)B * HD_KC * 3 * HD_VMAX * 2 * 4, 4);
+    ENS("hulld.hor", (size_t)B * HD_KC * (HD_VMAX + 2) * 2 * 4, 4);
+    ENS("hulld.newslot", (size_t)B * HD_SLOTS * 4, 4);
+    ENS("hulld.freestack", (size_t)B * HD_SLOTS * 4, 4);
+    ENS("hulld.tkeys", (size_t)B * HD_TBL * 8, 8);
+    ENS("hulld.tvals", (size_t)B * HD_TBL * 4, 4);
+    ENS("hulld.fail", (size_t)B * 4, 4);
+    ENS("hulld.rounds", (size_t)B * 4, 4);
   }
   ENS("obb.cand_vol", (size_t)B * SH_HF * 8, 8);
   ENS("obb.cand_edge", (size_t)B * SH_HF * 4, 4);
@@ -1162,6 +1182,17 @@ static HullPre hullpre_ptrs(sh_ctx* c) {      // calling thread only (buffer map
   return HullPre{(const float*)c->bufs["verts"].p, (const long long*)c->bufs["voff"].p, (int*)c->bufs["hullpre.ext"].p, (double*)c->bufs["hullpre.planes"].p,
                  (int*)c->bufs["hullpre.npl"].p, (float*)c->bufs["hullpre.kept"].p, (int*)c->bufs["hullpre.nkept"].p, (long long*)c->bufs["hullpre.koff"].p};
 }
+// the five launches of the device prefilter (k_hullpre.h): survivors of all B humeri compacted into hp.kept at hp.koff
+static void launch_prefilter(const HullPre& hp, int B, hipStream_t st) {
+  hipLaunchKernelGGL(k_hullpre_extremes, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, hp.ext);
+  hipLaunchKernelGGL(k_hullpre_polytope, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, (const int*)hp.ext, hp.planes, hp.npl);
+  hipLaunchKernelGGL(k_hullpre_filter<false>, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl,
+                     (const long long*)hp.koff, hp.kept, hp.nkept);
+  hipLaunchKernelGGL(k_hullpre_offsets, dim3(1), dim3(64), 0, st, (const int*)hp.nkept, hp.koff, B);
+  hipLaunchKernelGGL(k_hullpre_filter<true>, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl,
+                     (const long long*)hp.koff, hp.kept, hp.nkept);
+}
+
 static hipError_t fetch_hull_points(sh_ctx* c, const HullPre& hp, hipStream_t st) {
   const int B = c->B;
   c->hull_cnt.resize(B);
@@ -1182,13 +1213,7 @@ static hipError_t fetch_hull_points(sh_ctx* c, const HullPre& hp, hipStream_t st
     c->hull_src = c->h_verts.data();
     return hipSuccess;
   }
-  hipLaunchKernelGGL(k_hullpre_extremes, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, hp.ext);
-  hipLaunchKernelGGL(k_hullpre_polytope, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, (const int*)hp.ext, hp.planes, hp.npl);
-  hipLaunchKernelGGL(k_hullpre_filter<false>, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl,
-                     (const long long*)hp.koff, hp.kept, hp.nkept);
-  hipLaunchKernelGGL(k_hullpre_offsets, dim3(1), dim3(64), 0, st, (const int*)hp.nkept, hp.koff, B);
-  hipLaunchKernelGGL(k_hullpre_filter<true>, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl,
-                     (const long long*)hp.koff, hp.kept, hp.nkept);
+  launch_prefilter(hp, B, st);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(c->h_koff, hp.koff, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -1341,8 +1366,23 @@ static hipError_t hull_upload(sh_ctx* c, int slot, int B, void* const dst[6], hi
 
 // mesh.py:63-125.  Host: convex hulls (hull_host_phase; already done by the background thread when `prepared_slot`
 // >= 0).  Device: candidate boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
+static bool device_hull_now(const sh_ctx* c) { return c->hull_mode == 1 && c->hull_host_gen != c->batch_gen; }
+
 static int run_obb(sh_ctx* c, int prepared_slot) {
   const int B = c->Bwin, b0 = c->b0;
+  int nfmax = 1;
+  if (device_hull_now(c)) {
+    // hull on the device: prefilter -> round-based quickhull (k_hull.h), all on this context's stream; nothing comes to the host
+    launch_prefilter(hullpre_ptrs(c), B, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HullScratch hs{buf<int>(c, "hulld.fv"), buf<int>(c, "hulld.vis"), buf<int>(c, "hulld.ev"), buf<int>(c, "hulld.hor"), buf<int>(c, "hulld.newslot"),
+                   buf<int>(c, "hulld.freestack"), buf<unsigned long long>(c, "hulld.tkeys"), buf<unsigned>(c, "hulld.tvals")};
+    LAUNCH(c, "k_hull_rounds", k_hull_rounds, dim3(B), dim3(HD_THREADS), (const float*)c->bufs["hullpre.kept"].p, (const long long*)c->bufs["hullpre.koff"].p, hs,
+           buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), buf<int>(c, "hull.nv"), buf<int>(c, "hull.nf"), buf<int>(c, "hull.ne"),
+           buf<int>(c, "hulld.fail"), buf<int>(c, "hulld.rounds"));
+    LAUNCH(c, "k_hull_flag", k_hull_flag, dim3((B + 63) / 64), dim3(64), buf<int>(c, "hulld.fail"), buf<int>(c, "err"), B);
+    nfmax = HD_SLOTS;      // (the face counts stay on the device: the candidate kernel's tiles beyond a hull's faces return at once)
+  } else {
   int slot = prepared_slot;
   if (slot < 0) {
     slot = c->hslot; c->hslot ^= 1;
@@ -1353,11 +1393,11 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
     if (hrc != SH_OK) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", bad, hrc); return fail(c, hrc, m); }
   }
   const int* counts = c->hstage[slot].cnt;
-  int nfmax = 1;
   for (int b = 0; b < B; ++b) nfmax = std::max(nfmax, counts[B + b]);
   if (!(prepared_slot >= 0 && c->prep.uploaded)) {
     void* const dst[6] = {buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), buf<int>(c, "hull.nv"), buf<int>(c, "hull.nf"), buf<int>(c, "hull.ne")};
     HIPCHK(c, hull_upload(c, slot, B, dst, c->stream));
+  }
   }
   const int* cnt_nv = buf<int>(c, "hull.nv");
   const int* cnt_nf = buf<int>(c, "hull.nf");
@@ -1610,14 +1650,16 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   // a window is only enqueued, so the hulls of the next window are computed while it runs (off by default).
   int wsize = SH_WINDOW;
   if (const char* e = getenv("SHOULDER_WINDOW")) { int v = atoi(e); if (v > 0) wsize = v; }     // tests exercise small windows
-  const int win = ((mask & SH_STAGE_OBB) && B > wsize) ? wsize : B;
+  const bool dev_hull = (mask & SH_STAGE_OBB) && device_hull_now(c);
+  const int win = ((mask & SH_STAGE_OBB) && B > wsize && !dev_hull) ? wsize : B;      // (windows exist to overlap HOST hulls with device work)
   // hulls prepared by the background thread during the previous run (sh_set_overlap)?
   int prepared = -1;
   if (c->prep.active) {
     int prc = join_prepared(c);
     if ((mask & SH_STAGE_OBB) && win == B && prc == SH_OK && c->prep.gen == c->batch_gen && c->prep.B == B) { prepared = c->prep.slot; c->hslot = prepared ^ 1; }
   }
-  if ((mask & SH_STAGE_OBB) && prepared < 0) {
+  if (dev_hull) prepared = -1;
+  if ((mask & SH_STAGE_OBB) && prepared < 0 && !dev_hull) {
     // the host hull needs its points (a device-generated batch: every run, a new batch is new data)
     auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, fetch_hull_points(c, hullpre_ptrs(c), c->stream));
@@ -1629,7 +1671,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     rc = run_window(c, mask, widx == 0 ? prepared : -1);
   }
   // everything of this run is enqueued: the host is free until the device is done -> hulls of the next run
-  if (rc == SH_OK && c->overlap && (mask & SH_STAGE_OBB) && win == B) start_prepare(c);
+  if (rc == SH_OK && c->overlap && (mask & SH_STAGE_OBB) && win == B && !dev_hull) start_prepare(c);
   c->b0 = 0; c->Bwin = B;
   if (mask & SH_STAGE_OBB) c->obb_injected = true;
   if (rc != SH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
@@ -1655,7 +1697,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   }
   HIPCHK(c, hipMemcpyAsync(err_stage, buf<int>(c, "err"), (size_t)B * 4, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipEventRecord(tk.ev, c->stream));
-  tk.B = B; tk.pending = true;
+  tk.B = B; tk.pending = true; tk.mask = mask; tk.out_arg = out; tk.dev_hull = dev_hull;
   c->t_head ^= 1; ++c->n_pending;
   return SH_OK;
 }
@@ -1672,6 +1714,20 @@ int sh_collect(sh_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(tk.host_out, buf<char>(c, ("out.landmarks" + tslot).c_str()), (size_t)tk.B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->out_stream));
   HIPCHK(c, hipMemcpyAsync(tk.h_err, buf<char>(c, ("out.err" + tslot).c_str()), (size_t)tk.B * 4, hipMemcpyDeviceToHost, c->out_stream));
   HIPCHK(c, hipStreamSynchronize(c->out_stream));
+  if (tk.dev_hull) {
+    bool gave_up = false;
+    for (int b = 0; b < tk.B; ++b) gave_up |= tk.h_err[b] == SH_ERR_HULL_DEV;
+    if (gave_up) {
+      // The device hull gave a humerus up (a horizon pinched by the tolerance, a capacity): this batch goes through the host
+      // quickhull, which has the retry / joggle logic.  Done here, synchronously, when no other run is in flight.
+      c->hull_host_gen = c->batch_gen;
+      if (c->n_pending != 0) return fail(c, SH_ERR_GEOMETRY, "device hull gave a mesh up while another run is in flight: collect it, then run the batch again (it will use the host quickhull)");
+      const uint32_t mask = tk.mask; sh_landmarks* out = tk.out_arg;
+      int rc2 = sh_submit(c, mask, out);
+      if (rc2 != SH_OK) return rc2;
+      return sh_collect(c);
+    }
+  }
   for (int b = 0; b < tk.B; ++b)
     if (tk.h_err[b] != 0) {
       char m[128];

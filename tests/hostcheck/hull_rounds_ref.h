@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <unordered_map>
 #include <cstdio>
 #include <cstdlib>
 
@@ -78,49 +79,56 @@ inline int hull_rounds(const float* pts, int n, Out& out, int K = 128, int VMAX 
     if (conf[p] == -2) continue;
     for (int f = 0; f < 4; ++f) { double d = dist(F[f], p); if (d > eps) { conf[p] = f; F[f].apex = std::max(F[f].apex, key(d, p)); break; } }
   }
-  std::vector<int> owner(n, 0x7fffffff);
-  struct Cand { int face, pt, nvis, ok, nh, off; std::vector<int> vis; std::vector<int> ha, hb; };
+  // ---- rounds
+  auto hash32 = [](int x) { unsigned u = (unsigned)x * 2654435761u; u ^= u >> 15; u *= 2246822519u; u ^= u >> 13; return u; };
+  std::unordered_map<long long, unsigned> eowner;      // undirected edge (min * n + max) -> smallest priority that claims it
+  struct Cand { int face, pt, ok, nh, off; unsigned prio; std::vector<int> vis; std::vector<int> ha, hb; };
   std::vector<Cand> C;
-  std::vector<int> freelist;
-  for (int round = 0; round < 4096; ++round) {
-    // R0: candidates = per direction bucket (octahedral map of the face normal, G x G cells) the alive face whose farthest
-    // conflict point is farthest (ties: lower slot): spatially spread apexes rarely see the same faces, so most of them can
-    // be inserted in the same round.  Candidate order = bucket order.  Free slots = dead slots (slot order).
-    C.clear(); freelist.clear();
-    {
-      const int G = K;      // (K is the grid size here: G x G buckets)
-      std::vector<unsigned long long> bkey(G * G, 0);
-      std::vector<int> bface(G * G, -1);
-      for (int f = 0; f < nslots; ++f) {
-        if (!F[f].alive) { freelist.push_back(f); continue; }
-        if (F[f].apex == 0) continue;
-        const double* nn = F[f].n;
-        const double s1 = std::fabs(nn[0]) + std::fabs(nn[1]) + std::fabs(nn[2]);
-        double u = nn[0] / s1, v = nn[1] / s1;
-        if (nn[2] < 0) { const double uu = (1.0 - std::fabs(v)) * (u >= 0 ? 1.0 : -1.0), vv = (1.0 - std::fabs(u)) * (v >= 0 ? 1.0 : -1.0); u = uu; v = vv; }
-        int bu = (int)((u * 0.5 + 0.5) * G), bv = (int)((v * 0.5 + 0.5) * G);
-        bu = std::min(std::max(bu, 0), G - 1); bv = std::min(std::max(bv, 0), G - 1);
-        const int b = bv * G + bu;
-        const unsigned long long k2 = F[f].apex & ~0x1FFFFFull;      // distance part
-        if (bface[b] < 0 || k2 > bkey[b]) { bkey[b] = k2; bface[b] = f; }
-      }
-      for (int b = 0; b < G * G; ++b)
-        if (bface[b] >= 0) { const int f = bface[b]; Cand cd; cd.face = f; cd.pt = 0x1FFFFF - (int)(F[f].apex & 0x1FFFFF); cd.nvis = 0; cd.ok = 1; cd.nh = 0; cd.off = 0; C.push_back(cd); }
-    }
-    if (C.empty()) break;
+  std::vector<int> freeStack;                           // dead slots of EARLIER rounds, popped from the back
+  const int KC = K;                                     // candidates per round (device: 128)
+  for (int round = 0; round < 100000; ++round) {
+    // R0: candidates.  Every alive face that holds outside points offers its farthest one; priority = a hash of (the point's
+    // index, the round) (spatially incoherent, so that chains of neighbours do not all lose to one another).  When there are more than
+    // 64, those with priority <= 2^32 * 64 / ncand take part (about 64), plus the minimum; at most KC, in slot order.
+    C.clear();
+    int ncand = 0; unsigned minp = 0xFFFFFFFFu;
+    for (int f = 0; f < nslots; ++f)
+      if (F[f].alive && F[f].apex != 0) { ++ncand; minp = std::min(minp, hash32((0x1FFFFF - (int)(F[f].apex & 0x1FFFFF)) + round * 0x9E3779B)); }
+    if (ncand == 0) break;
     out.rounds = round + 1;
-    // R1: visible faces of every candidate (all alive slots, slot order) + vertex claims (smallest candidate id wins)
+    const unsigned T = ncand <= 64 ? 0xFFFFFFFFu : (unsigned)((64ull << 32) / (unsigned long long)ncand);
+    for (int f = 0; f < nslots && (int)C.size() < KC; ++f) {
+      if (!F[f].alive || F[f].apex == 0) continue;
+      const int pt = 0x1FFFFF - (int)(F[f].apex & 0x1FFFFF);
+      const unsigned h = hash32(pt + round * 0x9E3779B);      // (re-drawn every round: a face's apex stays the same until the face dies)
+      if (h > T && h != minp) continue;
+      Cand cd; cd.face = f; cd.pt = pt; cd.ok = 1; cd.nh = 0; cd.off = 0; cd.prio = (h & ~127u) | (unsigned)C.size();
+      C.push_back(cd);
+    }
+    // R1: visible faces of every candidate (all alive slots, slot order); every undirected edge of a visible face is claimed
+    // with the candidate's priority, the smallest claim wins
+    eowner.clear();
     for (size_t ci = 0; ci < C.size(); ++ci) {
       Cand& cd = C[ci];
       for (int f = 0; f < nslots; ++f)
         if (F[f].alive && dist(F[f], cd.pt) > eps) cd.vis.push_back(f);
-      cd.nvis = (int)cd.vis.size();
-      if (cd.nvis > VMAX) return out.fail = 20;
-      for (int f : cd.vis) for (int k = 0; k < 3; ++k) owner[F[f].v[k]] = std::min(owner[F[f].v[k]], (int)ci);
+      if ((int)cd.vis.size() > VMAX) return out.fail = 20;
+      if (cd.vis.empty()) return out.fail = 25;
+      for (int f : cd.vis) for (int k = 0; k < 3; ++k) {
+        const int a = F[f].v[k], b = F[f].v[(k + 1) % 3];
+        const long long ek = (long long)std::min(a, b) * n + std::max(a, b);
+        auto it = eowner.find(ek);
+        if (it == eowner.end()) eowner[ek] = cd.prio; else it->second = std::min(it->second, cd.prio);
+      }
     }
-    // R2: a candidate goes ahead when it owns every vertex of its visible faces
+    // R2: a candidate goes ahead when every edge of its visible faces is its own: its visible region then shares no face with
+    // another going candidate's and is not edge-adjacent to it (touching in a vertex is harmless: a cone's faces are only
+    // reachable through its ring)
     for (size_t ci = 0; ci < C.size(); ++ci)
-      for (int f : C[ci].vis) for (int k = 0; k < 3; ++k) if (owner[F[f].v[k]] != (int)ci) C[ci].ok = 0;
+      for (int f : C[ci].vis) for (int k = 0; k < 3; ++k) {
+        const int a = F[f].v[k], b = F[f].v[(k + 1) % 3];
+        if (eowner[(long long)std::min(a, b) * n + std::max(a, b)] != C[ci].prio) C[ci].ok = 0;
+      }
     // R3: horizon = directed edges of visible faces whose reverse is not an edge of a visible face; must be one simple loop
     for (size_t ci = 0; ci < C.size(); ++ci) {
       Cand& cd = C[ci];
@@ -133,7 +141,6 @@ inline int hull_rounds(const float* pts, int n, Out& out, int K = 128, int VMAX 
       }
       cd.nh = (int)cd.ha.size();
       if (cd.nh < 3) return out.fail = 21;
-      // simple loop: walking start -> end -> the edge starting there ... returns to edge 0 after exactly nh steps
       int cur = 0, steps = 0;
       do {
         int found = -1, cnt = 0;
@@ -143,63 +150,49 @@ inline int hull_rounds(const float* pts, int n, Out& out, int K = 128, int VMAX 
       } while (++steps < cd.nh && cur != 0);
       if (cur != 0 || steps != cd.nh) return out.fail = 23;
     }
-    if (getenv("HULLREF_TRACE")) { int nok = 0; for (auto& cd : C) nok += cd.ok; int nconf = 0; for (int f = 0; f < nslots; ++f) nconf += F[f].alive && F[f].apex != 0; fprintf(stderr, "round %d cand %zu ok %d faces_with_conflict %d nslots %d\n", round, C.size(), nok, nconf, nslots); }
-    // R4: slots of the new faces: free slots first (slot order), then the end of the array; candidates in order
-    {
-      size_t fl = 0;
-      std::vector<int> newslots;
-      for (size_t ci = 0; ci < C.size(); ++ci) {
-        Cand& cd = C[ci];
-        if (!cd.ok) continue;
-        cd.off = (int)newslots.size();
-        for (int k = 0; k < cd.nh; ++k) {
-          int s;
-          if (fl < freelist.size()) s = freelist[fl++];
-          else { if (nslots >= FCAP) return out.fail = 24; s = nslots++; }
-          newslots.push_back(s);
-        }
-      }
-      // R5: kill the visible faces, create the new ones, release the vertex claims
-      for (size_t ci = 0; ci < C.size(); ++ci) {
-        Cand& cd = C[ci];
-        for (int f : cd.vis) for (int k = 0; k < 3; ++k) owner[F[f].v[k]] = 0x7fffffff;
-        if (!cd.ok) continue;
-        ++out.insertions;
-        for (int f : cd.vis) { F[f].alive = false; F[f].kill = (int)ci; F[f].apex = 0; }
-      }
-      for (size_t ci = 0; ci < C.size(); ++ci) {
-        Cand& cd = C[ci];
-        if (!cd.ok) continue;
-        for (int k = 0; k < cd.nh; ++k) {
-          Face& g = F[newslots[cd.off + k]];
-          g.v[0] = cd.ha[k]; g.v[1] = cd.hb[k]; g.v[2] = cd.pt; plane(g); g.alive = true; g.apex = 0; g.kill = -1;
-        }
-      }
-      // R6: points of the killed faces go to the first new face (creation order) of their killer that sees them
-      for (int q = 0; q < n; ++q) {
-        const int f = conf[q];
-        if (f < 0 || F[f].kill < 0) continue;      // (a reused slot has kill == -1 again only after its old points moved: see below)
-        Cand& cd = C[F[f].kill];
-        if (q == cd.pt) { conf[q] = -2; continue; }
-        conf[q] = -1;
-        for (int k = 0; k < cd.nh; ++k) {
-          const int s = newslots[cd.off + k];
-          const double d = dist(F[s], q);
-          if (d > eps) { conf[q] = s; break; }
-        }
-      }
-      // (two passes on the device: the kill marks are cleared and the apex keys taken only after every point has moved)
-      for (int q = 0; q < n; ++q) if (conf[q] >= 0 && F[conf[q]].alive) { /* key refresh below */ }
-      for (size_t ci = 0; ci < C.size(); ++ci) if (C[ci].ok) for (int f : C[ci].vis) F[f].kill = -1;
-      for (int s : newslots) F[s].apex = 0;
-      for (int q = 0; q < n; ++q) {
-        const int f = conf[q];
-        if (f < 0) continue;
-        bool isnew = false;
-        for (int s : newslots) if (s == f) { isnew = true; break; }
-        if (isnew) F[f].apex = std::max(F[f].apex, key(dist(F[f], q), q));
+    if (getenv("HULLREF_TRACE")) { int nok = 0; for (auto& cd : C) nok += cd.ok; fprintf(stderr, "round %d ncand %d selected %zu ok %d nslots %d\n", round, ncand, C.size(), nok, nslots); }
+    // R4: slots of the new faces, candidates in order: free slots of earlier rounds first (stack), then the end of the array
+    std::vector<int> newslots;
+    for (size_t ci = 0; ci < C.size(); ++ci) {
+      Cand& cd = C[ci];
+      if (!cd.ok) continue;
+      cd.off = (int)newslots.size();
+      for (int k = 0; k < cd.nh; ++k) {
+        int sl;
+        if (!freeStack.empty()) { sl = freeStack.back(); freeStack.pop_back(); }
+        else { if (nslots >= FCAP) return out.fail = 24; sl = nslots++; }
+        newslots.push_back(sl);
       }
     }
+    // R5: kill the visible faces (their slots become free for LATER rounds), create the new ones
+    for (size_t ci = 0; ci < C.size(); ++ci) {
+      Cand& cd = C[ci];
+      if (!cd.ok) continue;
+      ++out.insertions;
+      for (int f : cd.vis) { F[f].alive = false; F[f].kill = (int)ci; F[f].apex = 0; freeStack.push_back(f); }
+    }
+    for (size_t ci = 0; ci < C.size(); ++ci) {
+      Cand& cd = C[ci];
+      if (!cd.ok) continue;
+      for (int k = 0; k < cd.nh; ++k) {
+        Face& g = F[newslots[cd.off + k]];
+        g.v[0] = cd.ha[k]; g.v[1] = cd.hb[k]; g.v[2] = cd.pt; plane(g); g.alive = true; g.apex = 0; g.kill = -1;
+      }
+    }
+    // R6: points of the killed faces go to the first new face (creation order) of their killer that sees them
+    for (int q = 0; q < n; ++q) {
+      const int f = conf[q];
+      if (f < 0 || F[f].kill < 0) continue;
+      Cand& cd = C[F[f].kill];
+      if (q == cd.pt) { conf[q] = -2; continue; }
+      conf[q] = -1;
+      for (int k = 0; k < cd.nh; ++k) {
+        const int sl = newslots[cd.off + k];
+        const double d = dist(F[sl], q);
+        if (d > eps) { conf[q] = sl; F[sl].apex = std::max(F[sl].apex, key(d, q)); break; }
+      }
+    }
+    for (size_t ci = 0; ci < C.size(); ++ci) if (C[ci].ok) for (int f : C[ci].vis) F[f].kill = -1;
   }
   // ---- emit: vertices ascending, faces in slot order with the smallest vertex first; closedness check
   std::vector<char> used(n, 0);
