@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not compute the host hulls of step k+1 during the device work of step k")
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     ap.add_argument("--from-stl", action="store_true", help="every step starts from the bytes of B binary STL files (device-side parse + vertex merge, sh_upload_stl)")
+    ap.add_argument("--hull", choices=["auto", "host", "device"], default="auto", help="where the convex hull of the OBB stage runs (sh_set_hull_mode); "
+                    "auto = host quickhull on hosts with >= 16 threads per rank, else the device hull")
     ap.add_argument("--check-gather", action="store_true", help="after the timed region rank 0 compares the records the last gather delivered for its own shard with a run of its own engine")
     args = ap.parse_args()
 
@@ -224,6 +226,7 @@ def main():
         for e in engs:
             e.param_block_commit()      # host mirrors follow the device block (a later sh_load_* re-uploads from them)
     for e in engs:
+        e.set_hull_mode(args.hull)
         e.set_unet_turns(lanes > 1 and os.environ.get("SH_BENCH_NO_TURNS") != "1")
 
     T = synth.similarity_transforms(B, verts, seed=1234, start=rank * B)
@@ -396,6 +399,26 @@ def main():
             extra["f16_unet"] = {"value": round(B * k16 / el16, 3), "unit": "meshes/s", "steps": k16, "warmup": 1, "ms_per_step": round(1e3 * el16 / k16, 3),
                                  "dtype": "f64 geometry + f16 UNet", "lanes": lanes,
                                  "parity": "mask-independent landmarks within 1e-4 mm of the oracle; anatomic-neck landmarks within the f16 bound of tests/test_gpu_end_to_end.py (plane point 0.06 mm, axes 0.4 mm)"}
+        if eng.hull_mode == "host" and pipelined:
+            # the same step with the hull on the device (k_hull.h): nothing goes to the host or comes back from it.  Its lanes are
+            # serial chains with a 6.5 ms hull kernel at the head, so three of them are needed to keep the chip busy.
+            dev_engs = [Engine(local) for _ in range(3)]
+            for e in dev_engs:
+                e.load_rfc()
+                e.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
+                e.set_hull_mode("device")
+                e.set_unet_turns(True)
+                e.upload([(verts, faces)])
+                e.synth_batch(T)
+            kd = max(6, min(args.steps, 12))
+            eld, regd, _ = run_leg(dev_engs, args.unet, kd, 1, pipelined)
+            lmd = dev_engs[0].run(_lib.STAGE_ALL)
+            same = all(np.array_equal(lmd[k], lm[k]) for k in ("obb_transform", "canal_axis", "te_axis", "groove_axis", "csys", "n_anp"))
+            extra["device_hull"] = {"value": round(B * kd / eld, 3), "unit": "meshes/s", "steps": kd, "warmup": 1, "ms_per_step": round(1e3 * eld / kd, 3),
+                                    "lanes": 3, "host_ms_per_step": {k: round(regd[k][0] * regd[k][1] / kd, 3) for k in ("host.verts_d2h", "host.hull")},
+                                    "records_equal_to_host_hull_run": bool(same)}
+            for e in dev_engs:
+                e.close()
         if lanes > 1:
             el1, _, _ = run_leg(engs[:1], args.unet, args.steps, 1, pipelined)
             extra["one_lane"] = {"value": round(B * args.steps / el1, 3), "unit": "meshes/s", "steps": args.steps, "warmup": 1,
@@ -486,7 +509,7 @@ def main():
                "config": {"workload": f"BASELINE configs[{2 if world == 1 else 3}]: batch {B} synthetic humeri per GPU, all stages (SH_STAGE_ALL incl. the batch's apply_csys)",
                           "batch_per_gpu": B, "global_batch": B * world, "vertices": V, "triangles": F, "unet": f"base{unet_spec.BASE} depth{unet_spec.DEPTH} 512x512",
                           "parallelism": f"dp{world}", "input": "binary STL bytes every step (device parse + merge, PCIe inclusive)" if args.from_stl else "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM",
-                          "lanes": lanes, "hull_threads_per_process": hull_threads(int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), "host": host_info(),
+                          "lanes": lanes, "hull": eng.hull_mode, "hull_threads_per_process": hull_threads(int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), "host": host_info(),
                           "schedule": ((f"{lanes} engine contexts per GPU, step s on lane s % {lanes}, their streams overlap on the device (sh_submit / sh_collect); " if lanes > 1 else "two steps in flight (sh_submit / sh_collect); ") if pipelined else "") + ("host hulls of step k+1 overlap the device work of step k; pipeline filled and drained inside the timed region" if overlap else "serial hulls"),
                           "meshes_with_error_status": n_bad},
                "roofline": roof, "cpu_baseline": cpu}

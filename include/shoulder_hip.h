@@ -220,6 +220,14 @@ int  sh_enable_timing(sh_ctx*, int level);
  * (any sh_upload_meshes / sh_synth_batch / sh_store("verts") voids them); sh_discard_prepared
  * drops them explicitly (the next run then does its host phase inline).  Results are identical
  * either way.  Off by default. */
+/* Where the convex hull of SH_STAGE_OBB (`Trimesh.apply_obb()` -> qhull, mesh.py:82) is computed: "host" (quickhull on a
+ * process-wide pool of worker threads, points read back through the device prefilter; hidden behind the previous run with
+ * sh_set_overlap), "device" (round-based quickhull, k_hull.h: nothing leaves the GPU; a humerus it gives up -- more than 8 192
+ * prefilter survivors, a horizon pinched by nearly coplanar points -- sends the batch through the host hull, from inside
+ * sh_run / sh_collect) or "auto" (default, also SHOULDER_HULL: host while the rank has >= 16 hardware threads).  Both give the
+ * same triangles and the same record bits, hence bit-identical frames.  sh_get_hull_mode: 0 host, 1 device. */
+int  sh_set_hull_mode(sh_ctx*, const char* mode);
+int  sh_get_hull_mode(const sh_ctx*);
 int  sh_set_overlap(sh_ctx*, int on);
 int  sh_discard_prepared(sh_ctx*);
 

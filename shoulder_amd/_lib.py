@@ -66,7 +66,7 @@ EXPORTS = ["sh_ctx_create", "sh_ctx_destroy", "sh_last_error", "sh_default_param
            "sh_load_unet", "sh_param_block", "sh_upload_meshes", "sh_synth_batch", "sh_batch_size", "sh_run",
            "sh_landmarks_device", "sh_affine_apply", "sh_mesh_transformed", "sh_transform_points", "sh_section_plane", "sh_buffer_info", "sh_fetch", "sh_store",
            "sh_kernel_time_ms", "sh_enable_timing", "sh_set_overlap", "sh_discard_prepared", "sh_unet_infer", "sh_host_alloc", "sh_host_free", "sh_upload_stl", "sh_submit", "sh_collect",
-           "sh_slice_mesh_planes", "sh_set_unet_turns", "sh_get_params", "sh_buffer_device", "sh_param_block_commit"]
+           "sh_slice_mesh_planes", "sh_set_unet_turns", "sh_get_params", "sh_buffer_device", "sh_param_block_commit", "sh_set_hull_mode", "sh_get_hull_mode"]
 
 _lib = None
 
@@ -106,6 +106,8 @@ def load(build_if_missing=True):
     L.sh_get_params.argtypes = [vp, ctypes.POINTER(Params)]
     L.sh_buffer_device.argtypes = [vp, cp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
     L.sh_param_block_commit.argtypes = [vp]
+    L.sh_set_hull_mode.argtypes = [vp, cp]
+    L.sh_get_hull_mode.argtypes = [vp]
     L.sh_load_rfc.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_int]
     L.sh_load_unet.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t]
     L.sh_param_block.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]

@@ -32,7 +32,10 @@ namespace sh {
 #define HD_NW (HD_THREADS / 64)
 #define HD_SLOTS 3072         // face slots (alive + not yet reused); a humerus ends with ~2 700 faces
 #define HD_NMAX 8192          // input points (survivors of the prefilter: ~6 300 of a humerus's 16 222 vertices)
-#define HD_KC 128             // candidates per round
+#define HD_KC 64              // candidates per round (4 per wave)
+#define HD_NJ (HD_KC / HD_NW)
+#define HD_VL 32              // visible faces of a candidate kept in LDS (more: global scratch)
+#define HD_NSL 1024           // new-face slots of a round kept in LDS (more: global scratch)
 #define HD_VMAX 256           // visible faces per candidate
 #define HD_TBL 32768          // entries of the edge table
 #define HD_MAXROUNDS 4096
@@ -128,6 +131,17 @@ __device__ inline bool hd_tbl_slot(unsigned long long* tkeys, unsigned long long
   return false;
 }
 
+// the record of the unit tetrahedron (0, e1, e2, e3): 4 vertices, 4 outward faces, 6 edges (va -> vb in the winding of face f)
+__device__ inline void hd_unit_tetrahedron(double* HV, double* NR, int* ED, int* nv, int* nf, int* ne) {
+  const double v[12] = {0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const double r3 = 0.57735026918962573;
+  const double nr[12] = {0, 0, -1, 0, -1, 0, -1, 0, 0, r3, r3, r3};      // faces (0,2,1) (0,1,3) (0,3,2) (1,2,3)
+  const int ed[24] = {0, 1, 1, 0, 0, 2, 0, 2, 0, 3, 2, 1, 1, 2, 3, 0, 1, 3, 1, 3, 2, 3, 3, 2};
+  for (int i = 0; i < 12; ++i) { HV[i] = v[i]; NR[i] = nr[i]; }
+  for (int i = 0; i < 24; ++i) ED[i] = ed[i];
+  *nv = 4; *nf = 4; *ne = 6;
+}
+
 __global__ void __launch_bounds__(HD_THREADS)
 k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff, HullScratch sc,
               double* __restrict__ hv, double* __restrict__ normals, int* __restrict__ edges,
@@ -136,9 +150,13 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
   __shared__ HdPlane s_pl[HD_SLOTS];                       // 98 304 B
   __shared__ unsigned long long s_key[HD_SLOTS];           // 24 576 B  apex keys; face ids at the end
   __shared__ short s_conf[HD_NMAX];                        // 16 384 B  conflict face of a point (-1 inside, -2 inserted); vertex ids at the end
-  __shared__ unsigned char s_alive[HD_SLOTS], s_kill[HD_SLOTS];
+  __shared__ unsigned char s_alive[HD_SLOTS];              // 0 dead, 1 alive, 2 + ci: killed in this round by candidate ci
   __shared__ int c_face[HD_KC], c_pt[HD_KC], c_ok[HD_KC], c_nvis[HD_KC], c_nh[HD_KC], c_off[HD_KC], c_koff[HD_KC];
   __shared__ unsigned c_prio[HD_KC];
+  __shared__ short s_visl[HD_KC][HD_VL];                   // visible faces of a candidate (the common case: <= 32)
+  __shared__ int2 s_hz[HD_NW][64];                         // per wave: horizon edges being compacted
+  __shared__ short s_newslot[HD_NSL];
+  __shared__ int s_ncand, s_tot[3];
   __shared__ int s_w[HD_NW + 1];
   __shared__ double s_rv[HD_NW];
   __shared__ int s_ri[HD_NW];
@@ -160,10 +178,10 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
   double* HV = hv + (size_t)b * SH_HV * 3;
   double* NR = normals + (size_t)b * SH_HF * 3;
   int* ED = edges + (size_t)b * SH_HE * 4;
-  // failure: reason for the host (which then runs its own quickhull for this batch) and an empty but well-formed record, so that
-  // the kernels queued behind this one read nothing uninitialised
-#define HD_FAIL(code) do { if (tid == 0) { fail_out[b] = (code); nv_out[b] = 0; nf_out[b] = 0; ne_out[b] = 0; if (rounds_out) rounds_out[b] = 0; \
-                                           for (int k_ = 0; k_ < 4; ++k_) ED[k_] = 0; for (int k_ = 0; k_ < 6; ++k_) HV[k_] = 0.0; NR[0] = 0.0; NR[1] = 0.0; NR[2] = 1.0; } return; } while (0)
+  // failure: the reason for the host (which then runs its own quickhull for this batch) and a small WELL-FORMED record -- the unit
+  // tetrahedron -- so that the kernels already queued behind this one (candidate boxes, frame, slices ...) work on finite, in-range
+  // data for this humerus; its status word says that its landmarks are void
+#define HD_FAIL(code) do { if (tid == 0) { fail_out[b] = (code); if (rounds_out) rounds_out[b] = 0; hd_unit_tetrahedron(HV, NR, ED, nv_out + b, nf_out + b, ne_out + b); } return; } while (0)
   if (n < 4) HD_FAIL(1);
   if (n > HD_NMAX) HD_FAIL(40);
   if (tid == 0) s_fail = 0;
@@ -217,7 +235,7 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
     double p3[3]; hd_point(P, i3, c, p3);
     if (hd_dist(tmp, p3) > 0) { const int t = i1; i1 = i2; i2 = t; }
   }
-  for (int f = tid; f < HD_SLOTS; f += HD_THREADS) { s_alive[f] = 0; s_kill[f] = 255; s_key[f] = 0ull; }
+  for (int f = tid; f < HD_SLOTS; f += HD_THREADS) { s_alive[f] = 0; s_key[f] = 0ull; }
   for (int i = tid; i < HD_TBL; i += HD_THREADS) { tkeys[i] = 0ull; tvals[i] = 0xFFFFFFFFu; }
   __syncthreads();
   if (tid < 4) {
@@ -242,34 +260,58 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
   unsigned long long stamp = 0;
   __syncthreads();
 
+  constexpr int RNG = HD_SLOTS / HD_NW;                     // slots a wave scans in R0 (192 = 3 x 64)
+#ifdef SH_HULL_PROF
+  unsigned long long pt0 = __builtin_amdgcn_s_memrealtime(), pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define HD_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); pacc[i] += t_ - pt0; pt0 = t_; } while (0)
+#else
+#define HD_STAMP(i) do { } while (0)
+#endif
   for (int round = 0; round < HD_MAXROUNDS; ++round) {
-    // ---- R0: candidates
-    int ncand = 0; unsigned minp = 0xFFFFFFFFu;
-    for (int f = tid; f < nslots; f += HD_THREADS)
-      if (s_alive[f] && s_key[f] != 0ull) { ++ncand; minp = min(minp, hd_hash32((unsigned)((0x1FFFFF - (int)(s_key[f] & 0x1FFFFF)) + round * 0x9E3779B))); }
-    if (tid == 0) s_minp = 0xFFFFFFFFu;
-    int tot;
-    (void)hd_block_scan(ncand, s_w, &tot);
-    ncand = tot;
-    if (ncand == 0) break;
-    atomicMin(&s_minp, minp);
+    // ---- R0: candidates.  Every wave scans its own slot range; counts and the smallest priority meet in LDS
+    if (tid == 0) { s_ncand = 0; s_minp = 0xFFFFFFFFu; }
     __syncthreads();
-    minp = s_minp;
+    int pt_[RNG / 64]; unsigned h_[RNG / 64]; bool cand_[RNG / 64];
+    {
+      int wc = 0; unsigned wmin = 0xFFFFFFFFu;
+#pragma unroll
+      for (int it = 0; it < RNG / 64; ++it) {
+        const int f = wave * RNG + it * 64 + lane;
+        cand_[it] = f < nslots && s_alive[f] == 1 && s_key[f] != 0ull;
+        pt_[it] = cand_[it] ? 0x1FFFFF - (int)(s_key[f] & 0x1FFFFF) : 0;
+        h_[it] = hd_hash32((unsigned)(pt_[it] + round * 0x9E3779B));
+        wc += __popcll(__ballot(cand_[it]));
+        if (cand_[it]) wmin = min(wmin, h_[it]);
+      }
+      for (int off = 32; off > 0; off >>= 1) wmin = min(wmin, (unsigned)__shfl_down((int)wmin, off));
+      if (lane == 0 && wc) { atomicAdd(&s_ncand, wc); atomicMin(&s_minp, wmin); }
+    }
+    __syncthreads();
+    const int ncand = s_ncand;
+    if (ncand == 0) break;
+    const unsigned minp = s_minp;
     rounds = round + 1;
     const unsigned T = ncand <= 64 ? 0xFFFFFFFFu : (unsigned)((64ull << 32) / (unsigned long long)ncand);
+    {
+      int sc_ = 0;
+#pragma unroll
+      for (int it = 0; it < RNG / 64; ++it) { cand_[it] = cand_[it] && (h_[it] <= T || h_[it] == minp); sc_ += __popcll(__ballot(cand_[it])); }
+      if (lane == 0) s_w[wave] = sc_;
+    }
+    __syncthreads();
     int nsel = 0;
-    for (int f0 = 0; f0 < nslots; f0 += HD_THREADS) {
-      const int f = f0 + tid;
-      int flag = 0, pt = 0; unsigned h = 0;
-      if (f < nslots && s_alive[f] && s_key[f] != 0ull) {
-        pt = 0x1FFFFF - (int)(s_key[f] & 0x1FFFFF);
-        h = hd_hash32((unsigned)(pt + round * 0x9E3779B));
-        flag = (h <= T || h == minp) ? 1 : 0;
+    {
+      int base = 0;
+      for (int w = 0; w < HD_NW; ++w) { const int t = s_w[w]; if (w < wave) base += t; nsel += t; }
+#pragma unroll
+      for (int it = 0; it < RNG / 64; ++it) {
+        const unsigned long long m = __ballot(cand_[it]);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (cand_[it] && pos < HD_KC) {
+          c_face[pos] = wave * RNG + it * 64 + lane; c_pt[pos] = pt_[it]; c_prio[pos] = (h_[it] & ~127u) | (unsigned)pos; c_ok[pos] = 0; c_nh[pos] = 0; c_nvis[pos] = 0;
+        }
+        base += __popcll(m);
       }
-      int t2;
-      const int pos = nsel + hd_block_scan(flag, s_w, &t2);
-      if (flag && pos < HD_KC) { c_face[pos] = f; c_pt[pos] = pt; c_prio[pos] = (h & ~127u) | (unsigned)pos; c_ok[pos] = 1; c_nh[pos] = 0; }
-      nsel += t2;
     }
     if (nsel > HD_KC) nsel = HD_KC;
     if (tbl_used > HD_TBL / 4) {      // stale keys of earlier rounds (other stamps) only lengthen the probes: sweep them out now and then
@@ -278,149 +320,207 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
     }
     stamp = (unsigned long long)(round + 1) << 26;
     __syncthreads();
-    // ---- R1: visible faces + edge claims, one wave per candidate
-    for (int ci = wave; ci < nsel; ci += HD_NW) {
+    HD_STAMP(0);
+    // ---- R1: visible faces + edge claims; wave w serves candidates w, w + 16, ... (the same wave in every phase).  A candidate
+    // that sees at most 21 faces (63 directed edges: the rule, a later round's apex sees ~6) keeps one edge per lane in
+    // registers from here to R5; larger ones go through the global scratch.
+    int ea[HD_NJ], eb[HD_NJ], ha[HD_NJ], hb[HD_NJ];
+#pragma unroll
+    for (int j = 0; j < HD_NJ; ++j) {
+      const int ci = wave + j * HD_NW;
+      ea[j] = eb[j] = ha[j] = hb[j] = -1;
+      if (ci >= nsel) continue;
       double pq[3]; hd_point(P, c_pt[ci], c, pq);
       int base = 0;
       for (int f0 = 0; f0 < nslots; f0 += 64) {
         const int f = f0 + lane;
-        const bool vis = f < nslots && s_alive[f] && hd_dist(s_pl[f], pq) > eps;
+        const bool vis = f < nslots && s_alive[f] == 1 && hd_dist(s_pl[f], pq) > eps;
         const unsigned long long m = __ballot(vis);
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (vis && pos < HD_VMAX) visg[ci * HD_VMAX + pos] = f;
+        if (vis) { if (pos < HD_VL) s_visl[ci][pos] = (short)f; if (pos < HD_VMAX) visg[ci * HD_VMAX + pos] = f; }
         base += __popcll(m);
       }
       if (lane == 0) { c_nvis[ci] = base; if (base > HD_VMAX) atomicMax(&s_fail, 20); if (base == 0) atomicMax(&s_fail, 25); }
-      __threadfence_block();      // the list is read back by other lanes of this wave
+      __threadfence_block();      // the lists are read back by other lanes of this wave
       const int nvis = min(base, HD_VMAX);
       const unsigned prio = c_prio[ci];
+      const bool fast = 3 * nvis <= 64;
       for (int e = lane; e < 3 * nvis; e += 64) {
-        const int f = visg[ci * HD_VMAX + e / 3], k = e % 3;
+        const int f = nvis <= HD_VL ? (int)s_visl[ci][e / 3] : visg[ci * HD_VMAX + e / 3], k = e % 3;
         const int a = fv[3 * f + k], bq = fv[3 * f + (k + 1) % 3];
-        evg[(ci * 3 * HD_VMAX + e) * 2] = a; evg[(ci * 3 * HD_VMAX + e) * 2 + 1] = bq;
+        if (fast) { ea[j] = a; eb[j] = bq; }
+        else { evg[(ci * 3 * HD_VMAX + e) * 2] = a; evg[(ci * 3 * HD_VMAX + e) * 2 + 1] = bq; }
         const unsigned long long key = stamp | ((unsigned long long)min(a, bq) << 13) | (unsigned long long)max(a, bq);
         int sl;
         if (hd_tbl_slot(tkeys, key, true, &sl)) atomicMin(&tvals[sl], prio); else atomicMax(&s_fail, 26);
       }
     }
     __syncthreads();
+    HD_STAMP(1);
     if (s_fail) break;
     // ---- R2 + R3: ownership, horizon
-    for (int ci = wave; ci < nsel; ci += HD_NW) {
+#pragma unroll
+    for (int j = 0; j < HD_NJ; ++j) {
+      const int ci = wave + j * HD_NW;
+      if (ci >= nsel) continue;
       const int nvis = c_nvis[ci], ne3 = 3 * nvis;
       const unsigned prio = c_prio[ci];
+      const bool fast = ne3 <= 64;
       bool mine = true;
       for (int e = lane; e < ne3; e += 64) {
-        const int a = evg[(ci * 3 * HD_VMAX + e) * 2], bq = evg[(ci * 3 * HD_VMAX + e) * 2 + 1];
+        const int a = fast ? ea[j] : evg[(ci * 3 * HD_VMAX + e) * 2], bq = fast ? eb[j] : evg[(ci * 3 * HD_VMAX + e) * 2 + 1];
         const unsigned long long key = stamp | ((unsigned long long)min(a, bq) << 13) | (unsigned long long)max(a, bq);
         int sl;
         if (!hd_tbl_slot(tkeys, key, false, &sl)) { atomicMax(&s_fail, 27); mine = false; }
         else if (__hip_atomic_load(&tvals[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != prio) mine = false;
       }
       const bool ok = __all(mine);
-      if (lane == 0) c_ok[ci] = ok ? 1 : 0;
       if (!ok) continue;
-      // horizon edges in (face, edge) order
       int nh = 0;
-      for (int e0 = 0; e0 < ne3; e0 += 64) {
-        const int e = e0 + lane;
-        bool hz = false; int a = 0, bq = 0;
-        if (e < ne3) {
-          a = evg[(ci * 3 * HD_VMAX + e) * 2]; bq = evg[(ci * 3 * HD_VMAX + e) * 2 + 1];
-          bool twin = false;
-          for (int e2 = 0; e2 < ne3; ++e2)
-            if (evg[(ci * 3 * HD_VMAX + e2) * 2] == bq && evg[(ci * 3 * HD_VMAX + e2) * 2 + 1] == a) { twin = true; break; }
-          hz = !twin;
-        }
+      if (fast) {
+        // every lane holds one directed edge: its reverse is searched among the others by shuffles
+        const int a = ea[j], bq = eb[j];
+        bool twin = false;
+        for (int e2 = 0; e2 < ne3; ++e2) { const int a2 = __shfl(a, e2), b2 = __shfl(bq, e2); twin |= (a2 == bq && b2 == a); }
+        const bool hz = lane < ne3 && !twin;
         const unsigned long long m = __ballot(hz);
-        const int pos = nh + __popcll(m & ((1ull << lane) - 1ull));
-        if (hz && pos < HD_VMAX + 2) { horg[(ci * (HD_VMAX + 2) + pos) * 2] = a; horg[(ci * (HD_VMAX + 2) + pos) * 2 + 1] = bq; }
-        nh += __popcll(m);
-      }
-      __threadfence_block();
-      if (nh < 3 || nh > HD_VMAX + 2) { if (lane == 0) atomicMax(&s_fail, 21); continue; }
-      // one simple loop: from edge 0 follow end -> the unique edge starting there; back at edge 0 after exactly nh steps
-      int cur = 0, steps = 0, bad = 0;
-      do {
-        const int target = horg[(ci * (HD_VMAX + 2) + cur) * 2 + 1];
-        int found = -1, cnt = 0;
-        for (int k0 = 0; k0 < nh; k0 += 64) {
-          const int k = k0 + lane;
-          const bool hit = k < nh && horg[(ci * (HD_VMAX + 2) + k) * 2] == target;
-          const unsigned long long m = __ballot(hit);
-          if (m && found < 0) found = k0 + __ffsll((long long)m) - 1;
-          cnt += __popcll(m);
+        nh = __popcll(m);
+        if (hz) s_hz[wave][__popcll(m & ((1ull << lane) - 1ull))] = make_int2(a, bq);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (nh < 3) { if (lane == 0) atomicMax(&s_fail, 21); continue; }
+        const int2 he = lane < nh ? s_hz[wave][lane] : make_int2(-1, -2);
+        ha[j] = he.x; hb[j] = he.y;
+        // one simple loop: from edge 0 follow end -> the unique edge starting there; back at edge 0 after exactly nh steps
+        int cur = 0, steps = 0, bad = 0;
+        do {
+          const int target = __shfl(hb[j], cur);
+          const unsigned long long mm = __ballot(lane < nh && ha[j] == target);
+          if (__popcll(mm) != 1) { bad = 22; break; }
+          cur = __ffsll((long long)mm) - 1;
+        } while (++steps < nh && cur != 0);
+        if (!bad && (cur != 0 || steps != nh)) bad = 23;
+        if (bad) { if (lane == 0) atomicMax(&s_fail, bad); continue; }
+      } else {
+        for (int e0 = 0; e0 < ne3; e0 += 64) {
+          const int e = e0 + lane;
+          bool hz = false; int a = 0, bq = 0;
+          if (e < ne3) {
+            a = evg[(ci * 3 * HD_VMAX + e) * 2]; bq = evg[(ci * 3 * HD_VMAX + e) * 2 + 1];
+            bool twin = false;
+            for (int e2 = 0; e2 < ne3; ++e2)
+              if (evg[(ci * 3 * HD_VMAX + e2) * 2] == bq && evg[(ci * 3 * HD_VMAX + e2) * 2 + 1] == a) { twin = true; break; }
+            hz = !twin;
+          }
+          const unsigned long long m = __ballot(hz);
+          const int pos = nh + __popcll(m & ((1ull << lane) - 1ull));
+          if (hz && pos < HD_VMAX + 2) { horg[(ci * (HD_VMAX + 2) + pos) * 2] = a; horg[(ci * (HD_VMAX + 2) + pos) * 2 + 1] = bq; }
+          nh += __popcll(m);
         }
-        if (cnt != 1) { bad = 22; break; }
-        cur = found;
-      } while (++steps < nh && cur != 0);
-      if (!bad && (cur != 0 || steps != nh)) bad = 23;
-      if (bad) { if (lane == 0) atomicMax(&s_fail, bad); continue; }
-      if (lane == 0) c_nh[ci] = nh;
+        __threadfence_block();
+        if (nh < 3 || nh > HD_VMAX + 2) { if (lane == 0) atomicMax(&s_fail, 21); continue; }
+        int cur = 0, steps = 0, bad = 0;
+        do {
+          const int target = horg[(ci * (HD_VMAX + 2) + cur) * 2 + 1];
+          int found = -1, cnt = 0;
+          for (int k0 = 0; k0 < nh; k0 += 64) {
+            const int k = k0 + lane;
+            const bool hit = k < nh && horg[(ci * (HD_VMAX + 2) + k) * 2] == target;
+            const unsigned long long mm = __ballot(hit);
+            if (mm && found < 0) found = k0 + __ffsll((long long)mm) - 1;
+            cnt += __popcll(mm);
+          }
+          if (cnt != 1) { bad = 22; break; }
+          cur = found;
+        } while (++steps < nh && cur != 0);
+        if (!bad && (cur != 0 || steps != nh)) bad = 23;
+        if (bad) { if (lane == 0) atomicMax(&s_fail, bad); continue; }
+      }
+      if (lane == 0) { c_nh[ci] = nh; c_ok[ci] = 1; }
     }
     __syncthreads();
+    HD_STAMP(2);
     if (s_fail) break;
-    // ---- R4: slots.  Offsets of the new faces / of the dead faces per candidate (candidate order), then the slot numbers
-    int total_new, total_dead;
-    {
-      const int v1 = (tid < nsel && c_ok[tid]) ? c_nh[tid] : 0, v2 = (tid < nsel && c_ok[tid]) ? c_nvis[tid] : 0;
-      const int o1 = hd_block_scan(v1, s_w, &total_new);
-      const int o2 = hd_block_scan(v2, s_w, &total_dead);
-      int claims;
-      (void)hd_block_scan(tid < nsel ? 3 * min(c_nvis[tid], HD_VMAX) : 0, s_w, &claims);
-      tbl_used += claims;
-      if (tid < nsel) { c_off[tid] = o1; c_koff[tid] = o2; }
+    // ---- R4: slots.  Wave 0: offsets of the new faces / of the dead faces per candidate (candidate order: one per lane)
+    if (wave == 0) {
+      const bool okc = lane < nsel && c_ok[lane];
+      int v1 = okc ? c_nh[lane] : 0, v2 = okc ? c_nvis[lane] : 0, v3 = lane < nsel ? 3 * min(c_nvis[lane], HD_VMAX) : 0;
+      int i1 = v1, i2 = v2, i3 = v3;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t1 = __shfl_up(i1, off), t2 = __shfl_up(i2, off), t3 = __shfl_up(i3, off);
+        if (lane >= off) { i1 += t1; i2 += t2; i3 += t3; }
+      }
+      if (lane < nsel) { c_off[lane] = i1 - v1; c_koff[lane] = i2 - v2; }
+      if (lane == 63) { s_tot[0] = i1; s_tot[1] = i2; s_tot[2] = i3; }
     }
+    __syncthreads();
+    const int total_new = s_tot[0], total_dead = s_tot[1];
+    tbl_used += s_tot[2];
     const int pops = min(total_new, nfree), nslots_new = nslots + (total_new - pops), nfree_mid = nfree - pops;
     if (nslots_new > HD_SLOTS) { if (tid == 0) s_fail = 24; __syncthreads(); break; }
-    for (int j = tid; j < total_new; j += HD_THREADS) newslot[j] = j < nfree ? freestack[nfree - 1 - j] : nslots + (j - nfree);
+    for (int jn = tid; jn < total_new; jn += HD_THREADS) {
+      const int sl = jn < nfree ? freestack[nfree - 1 - jn] : nslots + (jn - nfree);
+      if (jn < HD_NSL) s_newslot[jn] = (short)sl;
+      if (total_new > HD_NSL) newslot[jn] = sl;
+    }
     __syncthreads();
+    HD_STAMP(3);
     // ---- R5: kill, create
-    for (int ci = wave; ci < nsel; ci += HD_NW) {
-      if (!c_ok[ci]) continue;
+#pragma unroll
+    for (int j = 0; j < HD_NJ; ++j) {
+      const int ci = wave + j * HD_NW;
+      if (ci >= nsel || !c_ok[ci]) continue;
       const int nvis = c_nvis[ci], nh = c_nh[ci], off = c_off[ci], koffc = c_koff[ci], pt = c_pt[ci];
+      const bool fast = 3 * nvis <= 64;
       for (int i = lane; i < nvis; i += 64) {
-        const int f = visg[ci * HD_VMAX + i];
-        s_alive[f] = 0; s_kill[f] = (unsigned char)ci; s_key[f] = 0ull;
+        const int f = nvis <= HD_VL ? (int)s_visl[ci][i] : visg[ci * HD_VMAX + i];
+        s_alive[f] = (unsigned char)(2 + ci); s_key[f] = 0ull;
         freestack[nfree_mid + koffc + i] = f;
       }
       double pp[3]; hd_point(P, pt, c, pp);
       for (int k = lane; k < nh; k += 64) {
-        const int sl = newslot[off + k];
-        const int a = horg[(ci * (HD_VMAX + 2) + k) * 2], bq = horg[(ci * (HD_VMAX + 2) + k) * 2 + 1];
+        const int sl = total_new > HD_NSL ? newslot[off + k] : (int)s_newslot[off + k];
+        const int a = fast ? ha[j] : horg[(ci * (HD_VMAX + 2) + k) * 2], bq = fast ? hb[j] : horg[(ci * (HD_VMAX + 2) + k) * 2 + 1];
         double pa[3], pb[3];
         hd_point(P, a, c, pa); hd_point(P, bq, c, pb);
         s_pl[sl] = hd_plane(pa, pb, pp);
         fv[3 * sl] = a; fv[3 * sl + 1] = bq; fv[3 * sl + 2] = pt;
-        s_alive[sl] = 1; s_kill[sl] = 255; s_key[sl] = 0ull;
+        s_alive[sl] = 1; s_key[sl] = 0ull;
       }
     }
     __syncthreads();
+    HD_STAMP(4);
     // ---- R6: the points of the dead faces move
     for (int q = tid; q < n; q += HD_THREADS) {
       const int f = s_conf[q];
       if (f < 0) continue;
-      const int ci = s_kill[f];
-      if (ci == 255) continue;
+      const int st = s_alive[f];
+      if (st < 2) continue;
+      const int ci = st - 2;
       if (q == c_pt[ci]) { s_conf[q] = -2; continue; }
       double pq[3]; hd_point(P, q, c, pq);
       short cf = -1;
       const int nh = c_nh[ci], off = c_off[ci];
       for (int k = 0; k < nh; ++k) {
-        const int sl = newslot[off + k];
+        const int sl = total_new > HD_NSL ? newslot[off + k] : (int)s_newslot[off + k];
         const double d = hd_dist(s_pl[sl], pq);
         if (d > eps) { cf = (short)sl; atomicMax(&s_key[sl], hd_key(d, q)); break; }
       }
       s_conf[q] = cf;
     }
     __syncthreads();
-    for (int ci = wave; ci < nsel; ci += HD_NW) {
-      if (!c_ok[ci]) continue;
-      for (int i = lane; i < c_nvis[ci]; i += 64) s_kill[visg[ci * HD_VMAX + i]] = 255;
+#pragma unroll
+    for (int j = 0; j < HD_NJ; ++j) {
+      const int ci = wave + j * HD_NW;
+      if (ci >= nsel || !c_ok[ci]) continue;
+      const int nvis = c_nvis[ci];
+      for (int i = lane; i < nvis; i += 64) s_alive[nvis <= HD_VL ? (int)s_visl[ci][i] : visg[ci * HD_VMAX + i]] = 0;
     }
     nslots = nslots_new; nfree = nfree_mid + total_dead;
-    __syncthreads();
+    HD_STAMP(5);
   }
+#ifdef SH_HULL_PROF
+  if (tid == 0 && b == 0) printf("hull prof (100 MHz ticks): R0 %llu R1 %llu R2R3 %llu R4 %llu R5 %llu R6+ %llu rounds %d\n", pacc[0], pacc[1], pacc[2], pacc[3], pacc[4], pacc[5], rounds);
+#endif
   __syncthreads();
   if (s_fail) HD_FAIL(s_fail);
   if (rounds >= HD_MAXROUNDS) HD_FAIL(28);
@@ -431,7 +531,7 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
   __syncthreads();
   for (int f0 = 0; f0 < nslots; f0 += HD_THREADS) {
     const int f = f0 + tid;
-    const int flag = (f < nslots && s_alive[f]) ? 1 : 0;
+    const int flag = (f < nslots && s_alive[f] == 1) ? 1 : 0;
     int t2;
     const int pos = nf + hd_block_scan(flag, s_w, &t2);
     if (flag) { s_key[f] = (unsigned long long)pos; for (int k = 0; k < 3; ++k) s_conf[fv[3 * f + k]] = 1; }
@@ -452,7 +552,7 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
   if (nvh > SH_HV || nf > SH_HF) HD_FAIL(41);
   // normals: triangle rotated to its smallest vertex first, centred coordinates (sh_hull.h writes the same)
   for (int f = tid; f < nslots; f += HD_THREADS) {
-    if (!s_alive[f]) continue;
+    if (s_alive[f] != 1) continue;
     int v[3] = {fv[3 * f], fv[3 * f + 1], fv[3 * f + 2]};
     int r = 0;
     if (v[1] < v[r]) r = 1;
@@ -468,7 +568,7 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
   __syncthreads();
   for (int e = tid; e < 3 * nslots; e += HD_THREADS) {
     const int f = e / 3, k = e % 3;
-    if (!s_alive[f]) continue;
+    if (s_alive[f] != 1) continue;
     const int a = fv[3 * f + k], bq = fv[3 * f + (k + 1) % 3];
     const unsigned long long key = (1ull << 40) | ((unsigned long long)a << 13) | (unsigned long long)bq;
     int sl;
@@ -479,7 +579,7 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
   for (int e0 = 0; e0 < 3 * nslots; e0 += HD_THREADS) {
     const int e = e0 + tid, f = e / 3, k = e % 3;
     int flag = 0, a = 0, bq = 0;
-    if (e < 3 * nslots && s_alive[f]) { a = fv[3 * f + k]; bq = fv[3 * f + (k + 1) % 3]; flag = a < bq ? 1 : 0; }
+    if (e < 3 * nslots && s_alive[f] == 1) { a = fv[3 * f + k]; bq = fv[3 * f + (k + 1) % 3]; flag = a < bq ? 1 : 0; }
     int t2;
     const int pos = neh + hd_block_scan(flag, s_w, &t2);
     if (flag) {

@@ -280,8 +280,8 @@ k_obb_pick(const double* __restrict__ hv, const double* __restrict__ normals, co
     obb_basis(n, u, v);
     int e = cand_edge[(size_t)b * SH_HF + bf];
     const int* E = edges + ((size_t)b * SH_HE + (e < 0 || e >= SH_HE ? 0 : e)) * 4;
-    const double* pa = hv + ((size_t)b * SH_HV + E[0]) * 3;
-    const double* pc = hv + ((size_t)b * SH_HV + E[1]) * 3;
+    const double* pa = hv + ((size_t)b * SH_HV + min(max(E[0], 0), SH_HV - 1)) * 3;      // (clamped: a void record must not turn into a wild read)
+    const double* pc = hv + ((size_t)b * SH_HV + min(max(E[1], 0), SH_HV - 1)) * 3;
     double d[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
     double ex = dot3(d, u), ey = dot3(d, v);
     double l = sqrt(ex * ex + ey * ey);

@@ -70,7 +70,7 @@ struct sh_ctx {
   std::map<std::string, ULayer> ulayers;
   size_t unet_floats = 0;
   bool obb_injected = false;
-  // hull of SH_STAGE_OBB: 1 = on the device (k_hull.h), 0 = host quickhull (sh_hull.h).  SHOULDER_HULL=host|device; default device.
+  // hull of SH_STAGE_OBB: 1 = on the device (k_hull.h), 0 = host quickhull (sh_hull.h).  sh_set_hull_mode / SHOULDER_HULL=host|device|auto.
   // A humerus the device hull gives up (pinched horizon on nearly coplanar clouds, capacities) makes the whole batch go through
   // the host quickhull (hull_host_gen == batch_gen) -- sh_run / sh_collect re-run it on their own.
   int hull_mode = 1;
@@ -208,6 +208,28 @@ int sh_default_params(sh_params* p) {
   return SH_OK;
 }
 
+// "host" | "device" | "auto" (default).  auto: the host quickhull while this rank has at least 16 hardware threads for its pool
+// (it is free for the GPU and hidden behind the previous step), the device hull on thin hosts -- DESIGN.md 9.2 has the numbers.
+static int hull_mode_from(const char* e) {
+  if (e && (e[0] == 'h' || e[0] == '0')) return 0;
+  if (e && (e[0] == 'd' || e[0] == '1')) return 1;
+  unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+  if (const char* w = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(w); if (v > 1) nt = std::max(1u, nt / (unsigned)v); }
+  return nt >= 16 ? 0 : 1;
+}
+
+int sh_set_hull_mode(sh_ctx* c, const char* mode) {
+  if (!c || !mode) return SH_ERR_ARG;
+  if (strcmp(mode, "host") && strcmp(mode, "device") && strcmp(mode, "auto")) return fail(c, SH_ERR_ARG, "sh_set_hull_mode: host | device | auto");
+  if (c->n_pending != 0) return fail(c, SH_ERR_STATE, "sh_set_hull_mode: runs are in flight");
+  if (c->prep.active) { if (c->prep.th.joinable()) c->prep.th.join(); c->prep.active = false; c->prep.gen = ~0ull; }
+  c->hull_mode = hull_mode_from(strcmp(mode, "auto") ? mode : nullptr);
+  c->hull_host_gen = ~0ull;
+  return SH_OK;
+}
+
+int sh_get_hull_mode(const sh_ctx* c) { return c ? c->hull_mode : SH_ERR_ARG; }
+
 int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
   if (!out) return SH_ERR_ARG;
   *out = nullptr;
@@ -217,7 +239,7 @@ int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
   sh_ctx* c = new (std::nothrow) sh_ctx();
   if (!c) return SH_ERR_NOMEM;
   c->device = device;
-  if (const char* e = getenv("SHOULDER_HULL")) c->hull_mode = (e[0] == 'h' || e[0] == '0') ? 0 : 1;
+  c->hull_mode = hull_mode_from(getenv("SHOULDER_HULL"));
   sh_default_params(&c->params);
   if (hip_stream) c->stream = (hipStream_t)hip_stream;
   else {
@@ -389,18 +411,6 @@ static int alloc_batch(sh_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&c->h_koff, (size_t)(B + 1) * 8));
     c->h_nkept_cap = B;
   }
-  if (c->hull_mode == 1) {      // scratch of the device hull (k_hull.h), ~1.6 MB per humerus
-    ENS("hulld.fv", (size_t)B * HD_SLOTS * 3 * 4, 4);
-    ENS("hulld.vis", (size_t)B * HD_KC * HD_VMAX * 4, 4);
-    ENS("hulld.ev", (size_t)B * HD_KC * 3 * HD_VMAX * 2 * 4, 4);
-    ENS("hulld.hor", (size_t)B * HD_KC * (HD_VMAX + 2) * 2 * 4, 4);
-    ENS("hulld.newslot", (size_t)B * HD_SLOTS * 4, 4);
-    ENS("hulld.freestack", (size_t)B * HD_SLOTS * 4, 4);
-    ENS("hulld.tkeys", (size_t)B * HD_TBL * 8, 8);
-    ENS("hulld.tvals", (size_t)B * HD_TBL * 4, 4);
-    ENS("hulld.fail", (size_t)B * 4, 4);
-    ENS("hulld.rounds", (size_t)B * 4, 4);
-  }
   ENS("obb.cand_vol", (size_t)B * SH_HF * 8, 8);
   ENS("obb.cand_edge", (size_t)B * SH_HF * 4, 4);
   ENS("obb.best_enc", (size_t)B * 8, 8);
@@ -411,6 +421,29 @@ static int alloc_batch(sh_ctx* c) {
   ENS("obb.resid", (size_t)B * 2 * 8, 8);
 #undef ENS
   c->obb_injected = false;
+  return SH_OK;
+}
+
+// Scratch of the device hull (k_hull.h), ~1.6 MB per humerus, allocated on the first run that uses it.
+static int alloc_hulld(sh_ctx* c) {
+  const int B = c->B;
+  int rc;
+#define ENS(name, bytes, elem)                                              \
+  do {                                                                      \
+    if ((rc = ensure(c, name, (size_t)(bytes), elem)) != SH_OK) return rc;  \
+    c->bufs[name].per_mesh = (size_t)(bytes) / (size_t)B;                   \
+  } while (0)
+  ENS("hulld.fv", (size_t)B * HD_SLOTS * 3 * 4, 4);
+  ENS("hulld.vis", (size_t)B * HD_KC * HD_VMAX * 4, 4);
+  ENS("hulld.ev", (size_t)B * HD_KC * 3 * HD_VMAX * 2 * 4, 4);
+  ENS("hulld.hor", (size_t)B * HD_KC * (HD_VMAX + 2) * 2 * 4, 4);
+  ENS("hulld.newslot", (size_t)B * HD_SLOTS * 4, 4);
+  ENS("hulld.freestack", (size_t)B * HD_SLOTS * 4, 4);
+  ENS("hulld.tkeys", (size_t)B * HD_TBL * 8, 8);
+  ENS("hulld.tvals", (size_t)B * HD_TBL * 4, 4);
+  ENS("hulld.fail", (size_t)B * 4, 4);
+  ENS("hulld.rounds", (size_t)B * 4, 4);
+#undef ENS
   return SH_OK;
 }
 
@@ -1373,6 +1406,7 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   int nfmax = 1;
   if (device_hull_now(c)) {
     // hull on the device: prefilter -> round-based quickhull (k_hull.h), all on this context's stream; nothing comes to the host
+    { int arc = alloc_hulld(c); if (arc != SH_OK) return arc; }
     launch_prefilter(hullpre_ptrs(c), B, c->stream);
     HIPCHK(c, hipGetLastError());
     HullScratch hs{buf<int>(c, "hulld.fv"), buf<int>(c, "hulld.vis"), buf<int>(c, "hulld.ev"), buf<int>(c, "hulld.hor"), buf<int>(c, "hulld.newslot"),

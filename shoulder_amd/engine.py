@@ -324,6 +324,14 @@ class Engine:
     def enable_timing(self, on=True):
         self._chk(self.L.sh_enable_timing(self.h, int(on)))      # 0 off, 1 every launch, 2 UNet layers only
 
+    def set_hull_mode(self, mode):
+        """"host" | "device" | "auto": where the convex hull of the OBB stage is computed (sh_set_hull_mode); same results."""
+        self._chk(self.L.sh_set_hull_mode(self.h, str(mode).encode()))
+
+    @property
+    def hull_mode(self):
+        return "device" if self.L.sh_get_hull_mode(self.h) == 1 else "host"
+
     def set_overlap(self, on=True):
         """Streaming runs on the resident batch: compute the host hulls of the next run while the device works on this one."""
         self._chk(self.L.sh_set_overlap(self.h, 1 if on else 0))

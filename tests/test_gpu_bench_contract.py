@@ -35,6 +35,9 @@ def test_bench_line():
     assert f["value"] > 0 and "f32" in f["dtype"] and abs(f["value"] - 8 * 1e3 / f["ms_per_step"]) < 1e-2 * f["value"]
     assert f["roofline"]["peak"] == 157.3 and 0 < f["roofline"]["frac"] < 1
     assert d["one_lane"]["lanes"] == 1 and d["one_lane"]["value"] > 0
+    dh = d["device_hull"]      # the same step with the hull on the device: no host work, the same records
+    assert dh["value"] > 0 and dh["host_ms_per_step"] == {"host.verts_d2h": 0.0, "host.hull": 0.0} and dh["records_equal_to_host_hull_run"] is True
+    assert d["config"]["hull"] in ("host", "device")
     assert d["config"]["hull_threads_per_process"] >= 1 and d["config"]["host"]["os_cpu_count"] >= 1
     assert "k_slice_link" in d["geometry_kernels"] and d["geometry_kernels"]["k_slice_link"]["frac_of_hbm_peak"] > 0
 

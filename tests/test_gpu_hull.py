@@ -17,15 +17,9 @@ OBB_ONLY = _lib.STAGE_OBB
 def _engine(mode, weights):
     from shoulder_amd import unet_spec
     from shoulder_amd.engine import Engine
-    old = os.environ.get("SHOULDER_HULL")
-    os.environ["SHOULDER_HULL"] = mode          # read when the context is created
-    try:
-        e = Engine(0)
-    finally:
-        if old is None:
-            del os.environ["SHOULDER_HULL"]
-        else:
-            os.environ["SHOULDER_HULL"] = old
+    e = Engine(0)
+    e.set_hull_mode(mode)
+    assert e.hull_mode == mode
     e.load_rfc()
     e.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
     return e
