@@ -410,7 +410,7 @@ def main():
                 e.set_unet_turns(True)
                 e.upload([(verts, faces)])
                 e.synth_batch(T)
-            kd = max(6, min(args.steps, 12))
+            kd = 3 * max(8, min(args.steps, 20))      # (three lanes fill and drain inside the timed region: more steps than the other legs)
             eld, regd, _ = run_leg(dev_engs, args.unet, kd, 1, pipelined)
             lmd = dev_engs[0].run(_lib.STAGE_ALL)
             same = all(np.array_equal(lmd[k], lm[k]) for k in ("obb_transform", "canal_axis", "te_axis", "groove_axis", "csys", "n_anp"))

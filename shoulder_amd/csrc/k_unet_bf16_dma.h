@@ -66,7 +66,11 @@ template <int N> __device__ inline void ud_wait_vm() {      // s_waitcnt takes a
 // NN = 4).  1: column (dx) major -- the 6 pixel-row fragments of a dx serve its three dy taps (rows m + dy), so a step reads
 // 18 pixel + 9 NN weight fragments (54 at NN = 4): a quarter less LDS traffic per MFMA (what the chip spends per MFMA
 // decides the clock it holds, cdna_hip_programming.md 5.4 rule 28).
-template <int EK, int FUSE, int NN = 4, int SCHED = 1>
+// WRES: weights resident.  A layer with ONE cout group whose packed weights fit beside two input buffers (nchunk * 16 NN <= 128
+// rows per tap set: 32->64, 64->64, 64->32, 32->32 -- the 64- and 32-channel levels, where a weight set is shared by 8 192 /
+// 32 768 tiles) loads them into LDS once per workgroup; a step then stages only its 41 KB input tile: 6 DMA pieces instead of
+// 10 / 8 (the ablation builds price the weight pieces at 10-14 % of such a layer).
+template <int EK, int FUSE, int NN = 4, int SCHED = 1, int WRES = 0>
 __global__ void __launch_bounds__(UD_THREADS)
 k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int C0, int C1,
               const u16* __restrict__ wgt_, const float* __restrict__ bias, u16* __restrict__ dst_,
@@ -86,8 +90,10 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   static_assert(!(FUSE & UF_HEAD) || NN == 2, "the head reads all 32 channels of a pixel from one item");
   constexpr int WR = 16 * NN;                        // weight rows per tap
   constexpr int WSH = NN == 4 ? 6 : 5;               // log2(WR)
-  constexpr int SLOTS = (UD_INROWS + 9 * WR) * 4;    // 16-byte slots of a step: 4896 / 3744
-  constexpr int NPIECE = (SLOTS + UD_THREADS - 1) / UD_THREADS;      // 10 / 8
+  constexpr int SLOTS = WRES ? UD_INROWS * 4 : (UD_INROWS + 9 * WR) * 4;    // 16-byte slots of a step: 4896 / 3744; 2592 with resident weights
+  constexpr int NPIECE = (SLOTS + UD_THREADS - 1) / UD_THREADS;      // 10 / 8; 6
+  constexpr int BUFB = WRES ? UD_INROWS * 64 : UD_BUF;               // bytes of a staging buffer
+  constexpr int WRES_OFF = 2 * UD_INROWS * 64;                       // resident weights: [chunk][tap][WR rows] of 64 B behind the two input buffers
   constexpr int NSTORE = (FUSE & UF_HEAD) ? 4 : 2 * NN + ((FUSE & UF_POOL) ? NN : 0);      // dwordx4 stores per wave and item
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -105,6 +111,16 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   float* s_bias = (float*)(smem + UD_BIAS_OFF);
   for (int i = tid; i < Cout; i += UD_THREADS) s_bias[i] = bias[i];
   if (FUSE & UF_HEAD) for (int i = tid; i < 32; i += UD_THREADS) s_bias[256 + i] = head_w[i];
+  if constexpr (WRES != 0) {
+    // LDS row (chunk, tap, 16 n + i) <- packed row (tap, chunk, channel of that MFMA row); the 16-byte slot swizzle on the source
+    const int nrows = (Cin >> 5) * 9 * WR;
+    for (int e = tid; e < nrows * 4; e += UD_THREADS) {
+      const int row = e >> 2, q = e & 3;
+      const int cc = row / (9 * WR), rem = row - cc * 9 * WR, tap = rem >> WSH, j = rem & (WR - 1);
+      const int ch = 4 * NN * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);
+      *(u32x4*)(smem + WRES_OFF + e * 16) = *(const u32x4*)(wgt + (size_t)((tap * (Cin >> 5) + cc) * Cout + ch) * 32 + ((q ^ ((row >> 1) & 2)) << 3));
+    }
+  }
   __syncthreads();       // every ordinary load is retired before the first LDS-DMA is issued
 
   // staging plan: slot e_k = tid + 512 k -> row r_k = (tid >> 2) + 128 k; k = 0..4 halo rows, k = 5 mixed, k = 6..9 weight rows.
@@ -156,7 +172,7 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     n_cb = ((first ? c0 : c0 - C0) >> 5) * (H * W);      // pixel offset of this chunk's 32-channel plane (channel-blocked activations)
     n_simg = (first ? src0 : src1) + (size_t)i_img * H * W * n_Cs;
     n_wbase = wgt + ((size_t)cc * Cout + i_g * WR) * 32;
-    n_lbase = smem + buf * UD_BUF + wave * 1024;
+    n_lbase = smem + buf * BUFB + wave * 1024;
   };
   auto piece = [&](int k) {      // k is a compile-time constant at every call site
 #ifdef SH_ABL_NODMA
@@ -167,8 +183,12 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
       __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + k * 8192), 16, 0, 0);
     } else if (k == 5) {
       const ET* pi = pixoff[5] >= 0 ? n_simg + (unsigned)((n_cb + pixoff[5]) * 32 + q8) : zero_page;
-      const ET* p = in5 ? pi : n_wbase + wrel5;
-      __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + 5 * 8192), 16, 0, 0);
+      if constexpr (WRES != 0) {      // the last 8 halo rows: the first 32 lanes of wave 0
+        if (in5) __builtin_amdgcn_global_load_lds((ud_gptr)pi, (ud_lptr)(n_lbase + 5 * 8192), 16, 0, 0);
+      } else {
+        const ET* p = in5 ? pi : n_wbase + wrel5;
+        __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(n_lbase + 5 * 8192), 16, 0, 0);
+      }
     } else if (k < NPIECE - 1) {
       __builtin_amdgcn_global_load_lds((ud_gptr)(n_wbase + (wrel5 + (k - 5) * wstep)), (ud_lptr)(n_lbase + k * 8192), 16, 0, 0);
     } else if (k == NPIECE - 1) {
@@ -205,13 +225,13 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
         item_lane_setup();
         describe(0, buf ^ 1);
       } else has_next = false;
-      const unsigned char* sb = smem + buf * UD_BUF;
+      const unsigned char* sb = smem + buf * BUFB;
       const unsigned char* xb[2][3];
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) xb[sp][dx] = sb + xoff[sp][dx];
-      const unsigned char* wbp = sb + woff;
+      const unsigned char* wbp = WRES ? smem + WRES_OFF + cc * 9 * WR * 64 + (woff - UD_INROWS * 64) : sb + woff;
       if constexpr (SCHED == 0) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {

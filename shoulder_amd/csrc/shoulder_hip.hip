@@ -1000,10 +1000,14 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     const u16* zp = (const u16*)c->bufs["unet16.zero"].p;
     const float* nof = nullptr;
     static const int sched = (getenv("SHOULDER_DMA_SCHED") && getenv("SHOULDER_DMA_SCHED")[0] == '0') ? 0 : 1;      // tap order inside a step (k_unet_bf16_dma.h)
+    // weights resident in LDS (k_unet_bf16_dma.h, WRES): one cout group and nchunk * rows-per-tap <= 128
+    const bool wres_on = !(getenv("SHOULDER_DMA_WRES") && getenv("SHOULDER_DMA_WRES")[0] == '0');
+    const bool wres = wres_on && sched == 1 && L.cout == (dma64 ? 64 : 32) && ((C0 + C1) / 32) * (dma64 ? 64 : 32) <= 128;
 #define DMA_LAUNCH(F, N, ...)                                                                                                     \
   do {                                                                                                                            \
-    if (sched == 0) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                          \
-    else { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1>), g, dim3(UD_THREADS), __VA_ARGS__); }                                     \
+    if (wres) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1, 1>), g, dim3(UD_THREADS), __VA_ARGS__); }                            \
+    else if (sched == 0) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 0, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                 \
+    else { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                                 \
   } while (0)
     if (dma64) {
       if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr);

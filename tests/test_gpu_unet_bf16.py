@@ -148,6 +148,26 @@ def test_level0_fused_matches_two_barrier_kernel(engine, monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_resident_weights_match_staged_weights(engine, monkeypatch, name):
+    """k_conv3_dma16<..., WRES = 1> keeps the weights of the one-group layers (32->64, 64->64, 64->32, 32->32) in LDS for the
+    whole launch instead of staging them with every step: same operations in the same order, bit-identical logits and tensors."""
+    rng = np.random.default_rng(13)
+    img = rng.random((3, 256, 512), dtype=np.float32)
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        monkeypatch.setenv("SHOULDER_DMA_WRES", "1")
+        a = engine.unet_infer(img)
+        sa = [engine.fetch(f"unet16.skip{i}", np.uint16).copy() for i in (0, 1)]
+        monkeypatch.setenv("SHOULDER_DMA_WRES", "0")
+        b = engine.unet_infer(img)
+        sb = [engine.fetch(f"unet16.skip{i}", np.uint16).copy() for i in (0, 1)]
+        assert np.array_equal(a, b) and all(np.array_equal(x, y) for x, y in zip(sa, sb))
+    finally:
+        monkeypatch.delenv("SHOULDER_DMA_WRES", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
 def test_row_upconv_matches_per_phase_kernel(engine, monkeypatch, name):
     """k_upconv16 (16x16 source tile x 32 channels x both column phases of a row parity per workgroup: full output lines per
     wave) sums every output in the order of the per-phase two-barrier kernel: logits and a decoder tensor are bit-identical."""
