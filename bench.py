@@ -80,6 +80,18 @@ def unet_couts(base, depth):
     return out
 
 
+def unet_cins(base, depth):
+    ch = [base << i for i in range(depth + 1)]
+    out = {}
+    for i in range(depth):
+        out[f"unet.enc{i}a"] = ch[i - 1] if i else 1
+        out[f"unet.enc{i}b"] = out[f"unet.dec{i}b"] = ch[i]
+        out[f"unet.up{i}"] = ch[i + 1]
+        out[f"unet.dec{i}a"] = 2 * ch[i]
+    out["unet.bota"], out["unet.botb"] = ch[depth - 1], ch[depth]
+    return out
+
+
 def geom_bytes(B, V, F):
     """Algorithmic HBM bytes per launch of the geometry kernels (one launch = whole batch)."""
     seg = 32
@@ -119,8 +131,12 @@ def sym_key(name, unet, cout, fused_net=True):
     if up and os.environ.get("SHOULDER_UNET_UPCONV") != "0":
         return "k_upconv16<%s>" % unet                           # 2x2 transposed conv, both column phases per workgroup (k_unet16_l0.h)
     dma = (not up and not (fuse & 1) and os.environ.get("SHOULDER_UNET_DMA") != "0" and (cout % 64 == 0 or os.environ.get("SHOULDER_UNET_DMA32") != "0"))
-    if dma:      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h); last argument = tap order (SCHED)
-        return "k_conv3_dma16<%s,%d,%d,%d>" % (unet, fuse, nt, 0 if os.environ.get("SHOULDER_DMA_SCHED") == "0" else 1)
+    if dma:      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h); last arguments = tap order (SCHED), weights resident (WRES)
+        sched = 0 if os.environ.get("SHOULDER_DMA_SCHED") == "0" else 1
+        grp = 64 if cout % 64 == 0 else 32
+        cin = unet_cins(unet_spec.BASE, unet_spec.DEPTH)[name]
+        wres = int(sched == 1 and os.environ.get("SHOULDER_DMA_WRES") != "0" and cout == grp and (cin // 32) * grp <= 128)
+        return "k_conv3_dma16<%s,%d,%d,%d,%d>" % (unet, fuse, nt, sched, wres)
     return "k_conv_mfma16<%s,%d,%d,%d>" % (unet, 1 if up else 9, nt, fuse)
 
 

@@ -324,41 +324,100 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
     // ---- R1: visible faces + edge claims; wave w serves candidates w, w + 16, ... (the same wave in every phase).  A candidate
     // that sees at most 21 faces (63 directed edges: the rule, a later round's apex sees ~6) keeps one edge per lane in
     // registers from here to R5; larger ones go through the global scratch.
-    int ea[HD_NJ], eb[HD_NJ], ha[HD_NJ], hb[HD_NJ];
+    int ea[HD_NJ], eb[HD_NJ], ha[HD_NJ], hb[HD_NJ], nvis_[HD_NJ], tsl[HD_NJ];
+    {
+      // one pass over the planes serves the wave's four candidates (a plane is read from LDS once)
+      double pq[HD_NJ][3];
+      bool valid[HD_NJ];
 #pragma unroll
-    for (int j = 0; j < HD_NJ; ++j) {
-      const int ci = wave + j * HD_NW;
-      ea[j] = eb[j] = ha[j] = hb[j] = -1;
-      if (ci >= nsel) continue;
-      double pq[3]; hd_point(P, c_pt[ci], c, pq);
-      int base = 0;
+      for (int j = 0; j < HD_NJ; ++j) {
+        const int ci = wave + j * HD_NW;
+        ea[j] = eb[j] = ha[j] = hb[j] = -1; nvis_[j] = 0; tsl[j] = -1;
+        valid[j] = ci < nsel;
+        hd_point(P, c_pt[valid[j] ? ci : 0], c, pq[j]);
+      }
       for (int f0 = 0; f0 < nslots; f0 += 64) {
         const int f = f0 + lane;
-        const bool vis = f < nslots && s_alive[f] == 1 && hd_dist(s_pl[f], pq) > eps;
-        const unsigned long long m = __ballot(vis);
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (vis) { if (pos < HD_VL) s_visl[ci][pos] = (short)f; if (pos < HD_VMAX) visg[ci * HD_VMAX + pos] = f; }
-        base += __popcll(m);
+        const bool inb = f < nslots && s_alive[f] == 1;
+        const HdPlane pl = s_pl[inb ? f : 0];
+#pragma unroll
+        for (int j = 0; j < HD_NJ; ++j) {
+          const int ci = wave + j * HD_NW;
+          const bool vis = inb && valid[j] && hd_dist(pl, pq[j]) > eps;
+          const unsigned long long m = __ballot(vis);
+          if (m) {
+            const int pos = nvis_[j] + __popcll(m & ((1ull << lane) - 1ull));
+            if (vis) { if (pos < HD_VL) s_visl[ci][pos] = (short)f; else if (pos < HD_VMAX) visg[ci * HD_VMAX + pos] = f; }
+            nvis_[j] += __popcll(m);
+          }
+        }
       }
-      if (lane == 0) { c_nvis[ci] = base; if (base > HD_VMAX) atomicMax(&s_fail, 20); if (base == 0) atomicMax(&s_fail, 25); }
-      __threadfence_block();      // the lists are read back by other lanes of this wave
-      const int nvis = min(base, HD_VMAX);
-      const unsigned prio = c_prio[ci];
-      const bool fast = 3 * nvis <= 64;
-      for (int e = lane; e < 3 * nvis; e += 64) {
-        const int f = nvis <= HD_VL ? (int)s_visl[ci][e / 3] : visg[ci * HD_VMAX + e / 3], k = e % 3;
-        const int a = fv[3 * f + k], bq = fv[3 * f + (k + 1) % 3];
-        if (fast) { ea[j] = a; eb[j] = bq; }
-        else { evg[(ci * 3 * HD_VMAX + e) * 2] = a; evg[(ci * 3 * HD_VMAX + e) * 2 + 1] = bq; }
-        const unsigned long long key = stamp | ((unsigned long long)min(a, bq) << 13) | (unsigned long long)max(a, bq);
-        int sl;
-        if (hd_tbl_slot(tkeys, key, true, &sl)) atomicMin(&tvals[sl], prio); else atomicMax(&s_fail, 26);
+      bool any_big = false;
+#pragma unroll
+      for (int j = 0; j < HD_NJ; ++j) {
+        const int ci = wave + j * HD_NW;
+        if (!valid[j]) continue;
+        if (lane == 0) { c_nvis[ci] = nvis_[j]; if (nvis_[j] > HD_VMAX) atomicMax(&s_fail, 20); if (nvis_[j] == 0) atomicMax(&s_fail, 25); }
+        any_big |= nvis_[j] > HD_VL;
+        nvis_[j] = min(nvis_[j], HD_VMAX);
+      }
+      if (any_big) __threadfence_block();      // (the part of a long list that went to global scratch is read back by other lanes)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // edges of the short lists (<= 21 faces): one per lane; the loads / atomics of the four candidates are issued together
+      unsigned long long key_[HD_NJ];
+#pragma unroll
+      for (int j = 0; j < HD_NJ; ++j) {
+        const int ci = wave + j * HD_NW;
+        key_[j] = 0ull;
+        if (valid[j] && 3 * nvis_[j] <= 64 && lane < 3 * nvis_[j]) {
+          const int f = (int)s_visl[ci][lane / 3], k = lane % 3;
+          ea[j] = fv[3 * f + k]; eb[j] = fv[3 * f + (k + 1) % 3];
+        }
+      }
+      unsigned long long got[HD_NJ]; unsigned hh[HD_NJ];
+#pragma unroll
+      for (int j = 0; j < HD_NJ; ++j) {
+        got[j] = ~0ull; hh[j] = 0;
+        if (ea[j] >= 0) {
+          key_[j] = stamp | ((unsigned long long)min(ea[j], eb[j]) << 13) | (unsigned long long)max(ea[j], eb[j]);
+          hh[j] = hd_hash_key(key_[j]) & (HD_TBL - 1);
+          got[j] = atomicCAS(&tkeys[hh[j]], 0ull, key_[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < HD_NJ; ++j) {
+        if (ea[j] < 0) continue;
+        int sl = (int)hh[j];
+        if (got[j] != 0ull && got[j] != key_[j]) {      // first probe taken by another edge: walk on
+          if (!hd_tbl_slot(tkeys, key_[j], true, &sl)) { atomicMax(&s_fail, 26); sl = -1; }
+        }
+        tsl[j] = sl;
+        if (sl >= 0) atomicMin(&tvals[sl], c_prio[wave + j * HD_NW]);
+      }
+      // long lists: the sequential form through global scratch
+#pragma unroll
+      for (int j = 0; j < HD_NJ; ++j) {
+        const int ci = wave + j * HD_NW;
+        if (!valid[j] || 3 * nvis_[j] <= 64) continue;
+        const int nvis = nvis_[j];
+        const unsigned prio = c_prio[ci];
+        for (int e = lane; e < 3 * nvis; e += 64) {
+          const int f = e / 3 < HD_VL ? (int)s_visl[ci][e / 3] : visg[ci * HD_VMAX + e / 3], k = e % 3;
+          const int a = fv[3 * f + k], bq = fv[3 * f + (k + 1) % 3];
+          evg[(ci * 3 * HD_VMAX + e) * 2] = a; evg[(ci * 3 * HD_VMAX + e) * 2 + 1] = bq;
+          const unsigned long long key = stamp | ((unsigned long long)min(a, bq) << 13) | (unsigned long long)max(a, bq);
+          int sl;
+          if (hd_tbl_slot(tkeys, key, true, &sl)) atomicMin(&tvals[sl], prio); else atomicMax(&s_fail, 26);
+        }
       }
     }
     __syncthreads();
     HD_STAMP(1);
     if (s_fail) break;
     // ---- R2 + R3: ownership, horizon
+    unsigned tv[HD_NJ];
+#pragma unroll
+    for (int j = 0; j < HD_NJ; ++j) tv[j] = tsl[j] >= 0 ? __hip_atomic_load(&tvals[tsl[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
     for (int j = 0; j < HD_NJ; ++j) {
       const int ci = wave + j * HD_NW;
@@ -367,8 +426,11 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
       const unsigned prio = c_prio[ci];
       const bool fast = ne3 <= 64;
       bool mine = true;
+      if (fast) {      // the claim remembered its table slot
+        if (lane < ne3) mine = tsl[j] >= 0 && tv[j] == prio;
+      } else
       for (int e = lane; e < ne3; e += 64) {
-        const int a = fast ? ea[j] : evg[(ci * 3 * HD_VMAX + e) * 2], bq = fast ? eb[j] : evg[(ci * 3 * HD_VMAX + e) * 2 + 1];
+        const int a = evg[(ci * 3 * HD_VMAX + e) * 2], bq = evg[(ci * 3 * HD_VMAX + e) * 2 + 1];
         const unsigned long long key = stamp | ((unsigned long long)min(a, bq) << 13) | (unsigned long long)max(a, bq);
         int sl;
         if (!hd_tbl_slot(tkeys, key, false, &sl)) { atomicMax(&s_fail, 27); mine = false; }
@@ -472,7 +534,7 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
       const int nvis = c_nvis[ci], nh = c_nh[ci], off = c_off[ci], koffc = c_koff[ci], pt = c_pt[ci];
       const bool fast = 3 * nvis <= 64;
       for (int i = lane; i < nvis; i += 64) {
-        const int f = nvis <= HD_VL ? (int)s_visl[ci][i] : visg[ci * HD_VMAX + i];
+        const int f = i < HD_VL ? (int)s_visl[ci][i] : visg[ci * HD_VMAX + i];
         s_alive[f] = (unsigned char)(2 + ci); s_key[f] = 0ull;
         freestack[nfree_mid + koffc + i] = f;
       }
@@ -513,7 +575,7 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
       const int ci = wave + j * HD_NW;
       if (ci >= nsel || !c_ok[ci]) continue;
       const int nvis = c_nvis[ci];
-      for (int i = lane; i < nvis; i += 64) s_alive[nvis <= HD_VL ? (int)s_visl[ci][i] : visg[ci * HD_VMAX + i]] = 0;
+      for (int i = lane; i < nvis; i += 64) s_alive[i < HD_VL ? (int)s_visl[ci][i] : visg[ci * HD_VMAX + i]] = 0;
     }
     nslots = nslots_new; nfree = nfree_mid + total_dead;
     HD_STAMP(5);

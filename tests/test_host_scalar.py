@@ -245,11 +245,11 @@ def test_hull_vs_qhull(hc):
 
 
 def test_round_based_hull_reference(hc):
-    """tests/hostcheck/hull_rounds_ref.h -- the round-based (batched-insertion) quickhull studied for a device hull
-    (DESIGN.md 9): apexes whose visible regions share no vertex are inserted in the same round, no adjacency structure.
-    It must give the host quickhull's triangles exactly (the hull of points in general position is unique), and its trace
-    records WHY it is not the product: a humerus needs ~1000 dependent rounds because only 1-3 of the 10-40 faces that still
-    hold outside points can be served per round."""
+    """tests/hostcheck/hull_rounds_ref.h -- the CPU statement of the round-based (batched-insertion) quickhull that
+    k_hull_rounds runs on the device: ~64 candidate apexes per round drawn by a per-round hash, the ones
+    whose visible regions share no edge with a higher-priority candidate are inserted together, no adjacency structure.
+    It must give the host quickhull's triangles exactly (the hull of points in general position is unique); the trace
+    pins the round count the device kernel's cost model rests on (~100 dependent rounds per humerus)."""
     from oracle.stl import load_stl
     from conftest import BONES
 
@@ -262,7 +262,7 @@ def test_round_based_hull_reference(hc):
         v = np.ascontiguousarray(load_stl(os.path.join(BONES, name + ".stl"))[0], dtype=np.float32)
         tris = np.zeros(3 * 20000, dtype=np.int32)
         info = np.zeros(3, dtype=np.int32)
-        nf = hc.hc_hull_rounds(v.ctypes.data_as(F), len(v), 12, tris.ctypes.data_as(I), 20000, info.ctypes.data_as(I))
+        nf = hc.hc_hull_rounds(v.ctypes.data_as(F), len(v), 64, tris.ctypes.data_as(I), 20000, info.ctypes.data_as(I))
         assert nf > 0, nf
         P = np.ascontiguousarray(v, dtype=np.float64)
         t2 = np.zeros(3 * 20000, dtype=np.int32)
@@ -270,7 +270,8 @@ def test_round_based_hull_reference(hc):
         assert nf2 == nf and canon(tris[:3 * nf]) == canon(t2[:3 * nf2])
         nv, rounds, ins = (int(x) for x in info)
         assert nf == 2 * nv - 4
-        assert rounds > 300 and ins / rounds < 5.0        # the measured parallel width of the insertion order (see docstring)
+        print(name, 'rounds', rounds, 'insertions', ins)
+        assert 40 < rounds < 200 and ins / rounds > 3.0        # the parallel width the device kernel relies on
 
 
 def test_prox_canal_range(hc):
