@@ -134,6 +134,7 @@ def sym_key(name, unet, cout, fused_net=True):
     if dma:      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h); last arguments = tap order (SCHED), weights resident (WRES)
         sched = 0 if os.environ.get("SHOULDER_DMA_SCHED") == "0" else 1
         grp = 64 if cout % 64 == 0 else 32
+        from shoulder_amd import unet_spec
         cin = unet_cins(unet_spec.BASE, unet_spec.DEPTH)[name]
         wres = int(sched == 1 and os.environ.get("SHOULDER_DMA_WRES") != "0" and cout == grp and (cin // 32) * grp <= 128)
         return "k_conv3_dma16<%s,%d,%d,%d,%d>" % (unet, fuse, nt, sched, wres)
