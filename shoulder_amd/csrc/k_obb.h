@@ -4,6 +4,9 @@
 //   k_obb_candidates  one workgroup per (16 hull faces, humerus): for every face normal find the silhouette
 //                     edges of the hull (= edges of the 2-D hull of its projection on the face plane) and
 //                     for each take the enclosing rectangle -> min area x height = candidate volume
+//   k_obb_face_area2 / k_obb_bounds / k_obb_select   lower bound of every direction's box volume (Cauchy: projected area =
+//                     1/2 sum_f A_f |n . n_f|, times the height) -> only the directions whose bound does not exceed the best
+//                     exact volume found so far are handed to k_obb_candidates (two passes: seed, survivors)
 //   k_obb_pick        argmin volume -> axes ordered by ascending extent, signs fixed by vertex 0,
 //                     box centred at the origin  -> T_pre (CT -> raw OBB)
 //   k_obb_end_points  sections at 0.95*zmin / 0.95*zmax (mesh.py:91-99), crossing points only
@@ -27,6 +30,161 @@ __device__ inline void obb_basis(const double* n, double* u, double* v) { plane_
 #define SH_OBB_GROUP 4           // faces whose rectangle scans run together (2 would fit three workgroups per CU: measured slower)
 #define SH_SIL_MAX 512           // silhouette edges per direction
 
+// ---- pruning bounds.  The box of direction n has volume height(n) x min-area rectangle(n), and the rectangle is at least as
+// large as the projection of the hull on the plane normal to n, whose area is 1/2 sum_f A_f |n . n_f| (Cauchy).  The bound is
+// cheap and regular (one dot product per (direction, vertex) and (direction, face)); a direction whose bound exceeds an exact
+// candidate volume by more than rounding (1e-9 relative, the sums carry ~1e-13) cannot be the minimum and is never evaluated.
+// Which directions survive never changes the minimum k_obb_pick takes: an equal or smaller volume is never dropped.
+
+// 2 x area of every hull face from the edge records: the directed edges (a -> b) of face f sum a x b to 2 A_f n_f
+__global__ void __launch_bounds__(256)
+k_obb_face_area2(const double* __restrict__ hv, const double* __restrict__ normals, const int* __restrict__ edges, const int* __restrict__ ne_,
+                 double* __restrict__ area2 /*[B][SH_HF], zero*/) {
+  const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= ne_[b]) return;
+  const double* P = hv + (size_t)b * SH_HV * 3;
+  const double* NN = normals + (size_t)b * SH_HF * 3;
+  const int4 ed = *(const int4*)(edges + ((size_t)b * SH_HE + e) * 4);
+  const double a[3] = {P[3 * ed.x] - P[0], P[3 * ed.x + 1] - P[1], P[3 * ed.x + 2] - P[2]};
+  const double q[3] = {P[3 * ed.y] - P[0], P[3 * ed.y + 1] - P[1], P[3 * ed.y + 2] - P[2]};
+  const double cr[3] = {a[1] * q[2] - a[2] * q[1], a[2] * q[0] - a[0] * q[2], a[0] * q[1] - a[1] * q[0]};
+  atomicAdd(&area2[(size_t)b * SH_HF + ed.z], dot3(cr, NN + 3 * (size_t)ed.z));
+  atomicAdd(&area2[(size_t)b * SH_HF + ed.w], -dot3(cr, NN + 3 * (size_t)ed.w));
+}
+
+// 128 directions per workgroup, two per lane (a record read serves both); the SH_OBB_BND_SPLIT waves share the vertices and
+// faces (a contiguous slice each, combined in LDS in wave order), read through wave-uniform addresses: scalar loads, eight
+// records per trip so that a trip pays the scalar-cache latency once; many short waves hide the rest.  Also resets the
+// directions' candidate records ("not evaluated") and folds the smallest bound of the humerus.
+#define SH_OBB_BND_SPLIT 4
+#define SH_OBB_BND_DIRS 128
+#define SH_OBB_BND_THREADS (64 * SH_OBB_BND_SPLIT)
+__global__ void __launch_bounds__(SH_OBB_BND_THREADS)
+k_obb_bounds(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
+             const double* __restrict__ area2, double* __restrict__ lb_out /*[B][SH_HF]*/, unsigned long long* __restrict__ lbmin_enc /*[B], ~0*/,
+             double* __restrict__ cand_vol, int* __restrict__ cand_edge) {
+  constexpr int S = SH_OBB_BND_SPLIT;
+  __shared__ double s_mn[S][2][64], s_mx[S][2][64], s_s[S][2][64];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nv = nv_[b], nf = nf_[b];
+  if (blockIdx.x * SH_OBB_BND_DIRS >= nf) return;
+  const double* P = hv + (size_t)b * SH_HV * 3;
+  const double* NN = normals + (size_t)b * SH_HF * 3;
+  const double* A2 = area2 + (size_t)b * SH_HF;
+  int jd[2];
+  double n[2][3];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    jd[d] = blockIdx.x * SH_OBB_BND_DIRS + d * 64 + lane;
+    const int jc = jd[d] < nf ? jd[d] : nf - 1;
+    n[d][0] = NN[3 * jc]; n[d][1] = NN[3 * jc + 1]; n[d][2] = NN[3 * jc + 2];
+  }
+  const int vper = ((nv + S - 1) / S + 7) & ~7, fper = ((nf + S - 1) / S + 7) & ~7;      // slices start on multiples of 8 records (64-byte aligned runs)
+  double mn[2] = {1e300, 1e300}, mx[2] = {-1e300, -1e300}, s[2] = {0.0, 0.0};
+  auto vert = [&](double x, double y, double z) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) { const double h = fma(n[d][0], x, fma(n[d][1], y, n[d][2] * z)); mn[d] = fmin(mn[d], h); mx[d] = fmax(mx[d], h); }
+  };
+  auto face = [&](double x, double y, double z, double a) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) s[d] = fma(fabs(fma(n[d][0], x, fma(n[d][1], y, n[d][2] * z))), fabs(a), s[d]);
+  };
+  {
+    int i0 = wave * vper;
+    const int i1 = min(nv, i0 + vper);
+    for (; i0 + 8 <= i1; i0 += 8) {
+      double p[24];
+#pragma unroll
+      for (int u = 0; u < 24; ++u) p[u] = P[3 * i0 + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vert(p[3 * u], p[3 * u + 1], p[3 * u + 2]);
+    }
+    for (; i0 < i1; ++i0) vert(P[3 * i0], P[3 * i0 + 1], P[3 * i0 + 2]);
+  }
+  {
+    int f0 = wave * fper;
+    const int f1 = min(nf, f0 + fper);
+    for (; f0 + 8 <= f1; f0 += 8) {
+      double q[24], a[8];
+#pragma unroll
+      for (int u = 0; u < 24; ++u) q[u] = NN[3 * f0 + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = A2[f0 + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) face(q[3 * u], q[3 * u + 1], q[3 * u + 2], a[u]);
+    }
+    for (; f0 < f1; ++f0) face(NN[3 * f0], NN[3 * f0 + 1], NN[3 * f0 + 2], A2[f0]);
+  }
+#pragma unroll
+  for (int d = 0; d < 2; ++d) { s_mn[wave][d][lane] = mn[d]; s_mx[wave][d][lane] = mx[d]; s_s[wave][d][lane] = s[d]; }
+  __syncthreads();
+  if (wave >= 2) return;
+  const int d = wave, j = blockIdx.x * SH_OBB_BND_DIRS + d * 64 + lane;      // waves 0 and 1 finish one direction set each
+  double fmn = s_mn[0][d][lane], fmx = s_mx[0][d][lane], fs = s_s[0][d][lane];
+#pragma unroll
+  for (int w = 1; w < S; ++w) { fmn = fmin(fmn, s_mn[w][d][lane]); fmx = fmax(fmx, s_mx[w][d][lane]); fs += s_s[w][d][lane]; }
+  const double lb = 0.25 * fs * (fmx - fmn);
+  unsigned long long enc = ~0ull;
+  if (j < nf) {
+    lb_out[(size_t)b * SH_HF + j] = lb;
+    cand_vol[(size_t)b * SH_HF + j] = 1e300;
+    cand_edge[(size_t)b * SH_HF + j] = 0x7fffffff;
+    if (lb >= 0.0) enc = (unsigned long long)__double_as_longlong(lb);      // (a NaN bound takes no part; its direction survives below)
+  }
+  for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(enc, off); enc = o < enc ? o : enc; }
+  if (lane == 0 && enc != ~0ull) atomicMin(&lbmin_enc[b], enc);
+}
+
+// one workgroup per humerus: the directions of the next k_obb_candidates pass, in face order.
+//   pass 0 (seed)      the first 16 directions whose bound is within 5 % of the humerus's smallest bound (never empty): their
+//                      exact volumes give the first best_enc
+//   pass 1 (survivors) every other direction whose bound does not exceed best_enc
+__global__ void __launch_bounds__(256)
+k_obb_select(const double* __restrict__ lb_, const int* __restrict__ nf_, const unsigned long long* __restrict__ lbmin_enc,
+             const unsigned long long* __restrict__ best_enc, int pass, int* __restrict__ dir_list, int* __restrict__ dir_count,
+             unsigned char* __restrict__ seeded /*[B][SH_HF]*/) {
+  __shared__ int s_w[4];
+  __shared__ int s_base;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nf = nf_[b];
+  const double* lb = lb_ + (size_t)b * SH_HF;
+  int* out = dir_list + (size_t)b * SH_HF;
+  unsigned char* sd = seeded + (size_t)b * SH_HF;
+  double thr;
+  if (pass == 0) {
+    const unsigned long long m = lbmin_enc[b];
+    thr = m == ~0ull ? 1e300 : __longlong_as_double((long long)m) * 1.05;
+  } else {
+    const unsigned long long ub = best_enc[b];
+    thr = ub == ~0ull ? 1e300 : __longlong_as_double((long long)ub);
+  }
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < nf; j0 += 256) {
+    const int j = j0 + tid;
+    bool keep = false;
+    if (j < nf) {
+      const double v = lb[j];
+      if (pass == 0) keep = !(v > thr);
+      else keep = !sd[j] && !(v * (1.0 - 1e-9) > thr);
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int pos = s_base + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pos += s_w[w];
+    if (pass == 0) {
+      if (keep && pos >= SH_OBB_TILE) keep = false;      // the seed pass is one tile
+      if (j < nf) sd[j] = keep ? 1 : 0;
+    }
+    if (keep) out[pos] = j;
+    __syncthreads();
+    if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+  }
+  if (tid == 0) dir_count[b] = pass == 0 ? min(s_base, SH_OBB_TILE) : s_base;
+}
+
 // One workgroup per (tile of 16 hull faces, humerus).  The hull record (vertices, normals, edges: ~160 KB) is read
 // from L2 once per tile instead of once per face -- with one face per workgroup the kernel was bound by those
 // re-reads (11 TB/s of L2 traffic), not by arithmetic:
@@ -39,6 +197,7 @@ __global__ void __launch_bounds__(SH_OBB_THREADS)
 k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
                  const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge,
                  int* __restrict__ err, unsigned long long* __restrict__ best_enc /*[B]: bits of the smallest candidate volume so far, ~0 = none*/,
+                 const int* __restrict__ dir_list /*[B][SH_HF]: the directions (hull faces) to evaluate*/, const int* __restrict__ dir_count /*[B]*/,
                  int ntiles, int B) {
   constexpr int T = SH_OBB_TILE, G = SH_OBB_GROUP, NW = SH_OBB_THREADS / 64;
   __shared__ double tn[T][3], tu[T][3], tv[T][3];
@@ -52,6 +211,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
   __shared__ int g_edge[G];
   __shared__ double g_hull2[NW][G];  // per wave: twice the signed area of the projected hull (shoelace over the directed silhouette edges)
   __shared__ int g_skip[G];
+  __shared__ int s_dir[T];
   // XCD-aware order: consecutive workgroups go to the 8 XCDs in turn, each with its own L2.  Linear id L -> humerus
   // 8 * chunk + L % 8, so every tile of a humerus runs on one XCD and its hull record (160 KB, re-read by all 171 tiles)
   // stays in that XCD's L2: 8 records at a time per XCD instead of all B of them.
@@ -60,13 +220,16 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
   if (b >= B) return;
   const int f0 = (rr >> 3) * T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = nv_[b], nf = nf_[b], ne = ne_[b];
-  if (f0 >= nf) return;
-  const int nt = min(T, nf - f0);                      // directions in this tile
+  const int ndir = dir_count[b];
+  if (f0 >= ndir) return;
+  const int nt = min(T, ndir - f0);                    // directions in this tile: entries f0 .. f0 + nt - 1 of the humerus's list
   const double* P = hv + (size_t)b * SH_HV * 3;
   const double* NN = normals + (size_t)b * SH_HF * 3;
   const int* E = edges + (size_t)b * SH_HE * 4;
   if (tid < T) {
-    const double* N = NN + 3 * (size_t)(f0 + (tid < nt ? tid : 0));
+    const int dir = dir_list[(size_t)b * SH_HF + f0 + (tid < nt ? tid : 0)];
+    s_dir[tid] = dir;
+    const double* N = NN + 3 * (size_t)dir;
     double n[3] = {N[0], N[1], N[2]}, u[3], v[3];
     obb_basis(n, u, v);
     for (int k = 0; k < 3; ++k) { tn[tid][k] = n[k]; tu[tid][k] = u[k]; tv[tid][k] = v[k]; }
@@ -193,6 +356,11 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
       for (int w = 0; w < NW; ++w) hull2 += g_hull2[w][tid];
       const double lb = 0.5 * fabs(hull2) * (hhi[g0 + tid] - hlo[g0 + tid]);
       if (ub != ~0ull && lb * (1.0 - 1e-9) > __longlong_as_double((long long)ub)) g_skip[tid] = 1;
+#if defined(SH_ABL_OBB) && SH_ABL_OBB == 1
+      g_skip[tid] = 0;      // ablation: no pruning
+#elif defined(SH_ABL_OBB) && SH_ABL_OBB == 2
+      g_skip[tid] = 1;      // ablation (wrong results): no rectangle scan at all -> the cost of the sweeps
+#endif
     }
     __syncthreads();
     // every lane takes item tid of each pass of 256 (edge s of direction jj) and remembers (area, edge, direction);
@@ -240,8 +408,8 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     if (tid < G && g0 + tid < nt) {
       const int j = g0 + tid;
       const double vol = g_skip[tid] ? 1e300 : __longlong_as_double((long long)g_area[tid]) * (hhi[j] - hlo[j]);
-      cand_vol[(size_t)b * SH_HF + f0 + j] = vol;
-      cand_edge[(size_t)b * SH_HF + f0 + j] = g_edge[tid];
+      cand_vol[(size_t)b * SH_HF + s_dir[j]] = vol;
+      cand_edge[(size_t)b * SH_HF + s_dir[j]] = g_edge[tid];
       if (vol < 1e299) atomicMin(&best_enc[b], (unsigned long long)__double_as_longlong(vol));
     }
     __syncthreads();

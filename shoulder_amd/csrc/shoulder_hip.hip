@@ -414,6 +414,12 @@ static int alloc_batch(sh_ctx* c) {
   ENS("obb.cand_vol", (size_t)B * SH_HF * 8, 8);
   ENS("obb.cand_edge", (size_t)B * SH_HF * 4, 4);
   ENS("obb.best_enc", (size_t)B * 8, 8);
+  ENS("obb.lbmin_enc", (size_t)B * 8, 8);
+  ENS("obb.area2", (size_t)B * SH_HF * 8, 8);
+  ENS("obb.lb", (size_t)B * SH_HF * 8, 8);
+  ENS("obb.dir_list", (size_t)B * SH_HF * 4, 4);
+  ENS("obb.dir_count", (size_t)B * 4, 4);
+  ENS("obb.seeded", (size_t)B * SH_HF, 1);
   ENS("obb.T_pre", (size_t)B * 16 * 8, 8);
   ENS("obb.zb_pre", (size_t)B * 2 * 8, 8);
   ENS("obb.endpts", (size_t)B * 2 * SH_ENDCAP * 2 * 8, 8);
@@ -1441,15 +1447,25 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   const int* cnt_nf = buf<int>(c, "hull.nf");
   const int* cnt_ne = buf<int>(c, "hull.ne");
   {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(c, hipMemsetAsync(buf<unsigned long long>(c, "obb.best_enc"), 0xFF, (size_t)B * 8, c->stream));      // "no candidate volume yet"
-    if (c->timing == 1) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
+    HIPCHK(c, hipMemsetAsync(buf<unsigned long long>(c, "obb.lbmin_enc"), 0xFF, (size_t)B * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(buf<double>(c, "obb.area2"), 0, (size_t)B * SH_HF * 8, c->stream));
+    const int nemax = 3 * nfmax / 2 + 3;      // (a closed triangulated surface: 2 E = 3 F)
+    LAUNCH(c, "k_obb_face_area2", k_obb_face_area2, dim3((unsigned)((std::min(nemax, SH_HE) + 255) / 256), (unsigned)B), dim3(256), buf<double>(c, "hull.hv"),
+           buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.area2"));
+    LAUNCH(c, "k_obb_bounds", k_obb_bounds, dim3((unsigned)((nfmax + SH_OBB_BND_DIRS - 1) / SH_OBB_BND_DIRS), (unsigned)B), dim3(SH_OBB_BND_THREADS),
+           buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<double>(c, "obb.area2"), buf<double>(c, "obb.lb"),
+           buf<unsigned long long>(c, "obb.lbmin_enc"), buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"));
     const int ntiles = (nfmax + SH_OBB_TILE - 1) / SH_OBB_TILE;
-    hipLaunchKernelGGL(k_obb_candidates, dim3((unsigned)(ntiles * ((B + 7) / 8) * 8)), dim3(SH_OBB_THREADS), 0, c->stream, buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"),
-                       cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"),
-                       buf<unsigned long long>(c, "obb.best_enc"), ntiles, B);
-    if (c->timing == 1) { (void)hipEventRecord(e1, c->stream); c->pending.emplace_back("k_obb_candidates", e0, e1); }
-    HIPCHK(c, hipGetLastError());
+    for (int pass = 0; pass < 2; ++pass) {      // seed tile, then the directions its best volume cannot exclude
+      LAUNCH(c, "k_obb_select", k_obb_select, dim3(B), dim3(256), buf<double>(c, "obb.lb"), cnt_nf, buf<unsigned long long>(c, "obb.lbmin_enc"),
+             buf<unsigned long long>(c, "obb.best_enc"), pass, buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"), buf<unsigned char>(c, "obb.seeded"));
+      const int nt_pass = pass == 0 ? 1 : ntiles;
+      LAUNCH(c, pass == 0 ? "k_obb_seed" : "k_obb_candidates", k_obb_candidates, dim3((unsigned)(nt_pass * ((B + 7) / 8) * 8)), dim3(SH_OBB_THREADS),
+             buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"),
+             buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"), buf<unsigned long long>(c, "obb.best_enc"), buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"),
+             nt_pass, B);
+    }
   }
   LAUNCH(c, "k_obb_pick", k_obb_pick, dim3(B), dim3(256), buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"),
          buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<float>(c, "verts"), buf<long long>(c, "voff"), buf<double>(c, "obb.T_pre"),
