@@ -23,7 +23,11 @@ __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][51
   // (sh_scalar.h, host-tested): NumPy's pairwise mean is reproduced with lanes as the 8 x 4 partial
   // accumulators, every filter tap sum / plateau walk / prominence scan is the sequential routine
   // applied per sample or per peak.
-  __shared__ double s_r[SH_MPROX], s_neg[SH_MPROX], s_filt[SH_MPROX], s_roll[SH_MPROX];
+  // two row buffers serve the four stages (LDS per wave decides how many rows a CU works on at once): r, then the filtered
+  // row in A; r - mean (negated), then the rolled filtered row in B
+  __shared__ double s_bufA[SH_MPROX], s_bufB[SH_MPROX];
+  double* const s_r = s_bufA; double* const s_filt = s_bufA;
+  double* const s_neg = s_bufB; double* const s_roll = s_bufB;
   __shared__ int s_cand[SH_PEAK_CAP];
   __shared__ Peak s_pk[SH_PEAK_CAP];
   __shared__ int s_pass[SH_PEAK_CAP];
@@ -64,9 +68,10 @@ __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][51
     if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
   const int amin = __shfl(bi, 0);
-  for (int k = lane; k < M; k += 64) { int src = k + amin; if (src >= M) src -= M; s_roll[k] = s_filt[src]; }
   double* r0row = r0 + (size_t)gid * M;
   for (int k = lane; k < M; k += 64) r0row[k] = -s_neg[k];      // polar_0 radius = r - mean(r)
+  __syncthreads();      // (the rolled row takes s_neg's place)
+  for (int k = lane; k < M; k += 64) { int src = k + amin; if (src >= M) src -= M; s_roll[k] = s_filt[src]; }
   __syncthreads();
   // local maxima: every rising edge is examined independently (equivalent to the sequential scan)
   for (int k = 1 + lane; k < M - 1; k += 64)
@@ -206,7 +211,7 @@ __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][51
     const double n = norm3(cu);
     cu[0] /= n; cu[1] /= n; cu[2] /= n;
     const double z = zs[i], th = s_th[k];
-    const double rad = s_r[s_pidx[k]];
+    const double rad = row[M + s_pidx[k]];
     const double px = rad * cos(th), py = rad * sin(th);
     const double dx = px - cu[0] * z, dy = py - cu[1] * z;
     double* X = xraw + ((size_t)b * SH_GSLOTS + (size_t)i * SH_MAXPEAK + k) * 9;
