@@ -95,77 +95,80 @@ k_anp_scale(const double* __restrict__ raw, const unsigned long long* __restrict
   for (int i = blockIdx.x * 256 + tid; i < SH_IMG; i += gridDim.x * 256) o[i] = (float)(x[i] * sc + mn);
 }
 
-// one block of 512 lanes per humerus; a wave takes whole image rows (coalesced 64-pixel reads, edges by ballot)
+// Edge pixels of the mask in two launches over (8 image rows, humerus) workgroups, one wave per row (coalesced 64-pixel reads,
+// edges by ballot): counts per row first, then every row finds its place in the row-major point list from the counts of the
+// rows before it (one block per humerus kept 192 CUs idle for 0.3 ms on the critical path behind the network).
+__global__ void __launch_bounds__(512)
+k_anp_edge_count(const float* __restrict__ logits, int* __restrict__ rowcnt /*[B][SH_ANP_ROWS][2]: mask changes, mask pixels*/) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 8 + (threadIdx.x >> 6);
+  const int M = SH_MPROX;
+  const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
+  float v[SH_MPROX / 64];
+#pragma unroll
+  for (int c = 0; c < SH_MPROX / 64; ++c) v[c] = lg[c * 64 + lane];      // the whole row in flight at once
+  int ne = 0, nm = 0, carry = 0;
+#pragma unroll
+  for (int c = 0; c < SH_MPROX / 64; ++c) {
+    const int m = v[c] > 0.0f ? 1 : 0;
+    int prev = __shfl_up(m, 1);
+    if (lane == 0) prev = carry;
+    ne += __popcll(__ballot(m != prev));      // np.diff(mask, prepend=0) != 0
+    nm += __popcll(__ballot(m));
+    carry = __shfl(m, 63);
+  }
+  if (lane == 0) { rowcnt[2 * ((size_t)b * SH_ANP_ROWS + i)] = ne; rowcnt[2 * ((size_t)b * SH_ANP_ROWS + i) + 1] = nm; }
+}
+
 __global__ void __launch_bounds__(512)
 k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, const double* __restrict__ shft_theta,
-            const double* __restrict__ prox_zs, double* __restrict__ pts_obb, int* __restrict__ counts, int* __restrict__ err) {
-  __shared__ int cnt[SH_ANP_ROWS];
-  __shared__ int offs[SH_ANP_ROWS];
-  __shared__ int tot_mask[8];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+            const double* __restrict__ prox_zs, const int* __restrict__ rowcnt, double* __restrict__ pts_obb, int* __restrict__ counts,
+            int* __restrict__ err) {
+  static_assert(SH_ANP_ROWS == 512, "8 row counts per lane");
+  const int b = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 8 + (threadIdx.x >> 6);
   const int M = SH_MPROX;
-  // pass 1: per row, number of mask changes along theta (np.diff(mask, prepend=0) != 0) and mask pixels
-  int nm_w = 0;
-  for (int i = wave; i < SH_ANP_ROWS; i += 8) {
-    const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
-    float v[SH_MPROX / 64];
+  // this row's first slot = edges of the rows before it; the whole image's totals for the first row's wave
+  const int2* rc = (const int2*)(rowcnt + 2 * (size_t)b * SH_ANP_ROWS);
+  int before = 0, tot = 0, totm = 0;
 #pragma unroll
-    for (int c = 0; c < SH_MPROX / 64; ++c) v[c] = lg[c * 64 + lane];      // the whole row in flight at once
-    int ne = 0, carry = 0;
-#pragma unroll
-    for (int c = 0; c < SH_MPROX / 64; ++c) {
-      const int m = v[c] > 0.0f ? 1 : 0;
-      int prev = __shfl_up(m, 1);
-      if (lane == 0) prev = carry;
-      ne += __popcll(__ballot(m != prev));
-      nm_w += __popcll(__ballot(m));
-      carry = __shfl(m, 63);
-    }
-    if (lane == 0) cnt[i] = ne;
+  for (int q = 0; q < SH_ANP_ROWS / 64; ++q) {
+    const int r = q * 64 + lane;
+    const int2 c2 = rc[r];
+    before += r < i ? c2.x : 0; tot += c2.x; totm += c2.y;
   }
-  if (lane == 0) tot_mask[wave] = nm_w;
-  __syncthreads();
-  // exclusive scan of the per-row edge counts (row-major boolean gather order)
-  if (tid == 0) {
-    int acc = 0;
-    for (int r = 0; r < SH_ANP_ROWS; ++r) { offs[r] = acc; acc += cnt[r]; }
-    int tm = 0;
-    for (int w = 0; w < 8; ++w) tm += tot_mask[w];
-    counts[2 * b] = acc;
-    counts[2 * b + 1] = tm;
-    if (acc > SH_ANP_CAP) atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
-    if (acc < 6) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
+  for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off); tot += __shfl_xor(tot, off); totm += __shfl_xor(totm, off); }
+  if (i == 0 && lane == 0) {
+    counts[2 * b] = tot;
+    counts[2 * b + 1] = totm;
+    if (tot > SH_ANP_CAP) atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
+    if (tot < 6) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
   }
-  __syncthreads();
-  // pass 2: the edge pixels as points (r cos t, r sin t, z), in row-major order
-  for (int i = wave; i < SH_ANP_ROWS; i += 8) {
-    const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
-    const double* t = shft_theta + ((size_t)b * SH_ANP_ROWS + i) * M;
-    const double* r = raw + ((size_t)b * SH_ANP_ROWS + i) * M;
-    const double z = prox_zs[(size_t)b * SH_NPROX + SH_ANP_ROW0 + i];
-    int o = offs[i], carry = 0;
-    float v[SH_MPROX / 64];
+  // the edge pixels as points (r cos t, r sin t, z), in row-major order
+  const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
+  const double* t = shft_theta + ((size_t)b * SH_ANP_ROWS + i) * M;
+  const double* r = raw + ((size_t)b * SH_ANP_ROWS + i) * M;
+  const double z = prox_zs[(size_t)b * SH_NPROX + SH_ANP_ROW0 + i];
+  int o = before, carry = 0;
+  float v[SH_MPROX / 64];
 #pragma unroll
-    for (int c = 0; c < SH_MPROX / 64; ++c) v[c] = lg[c * 64 + lane];
+  for (int c = 0; c < SH_MPROX / 64; ++c) v[c] = lg[c * 64 + lane];
 #pragma unroll
-    for (int c = 0; c < SH_MPROX / 64; ++c) {
-      const int j = c * 64 + lane;
-      const int m = v[c] > 0.0f ? 1 : 0;
-      int prev = __shfl_up(m, 1);
-      if (lane == 0) prev = carry;
-      const unsigned long long eb = __ballot(m != prev);
-      if (m != prev) {
-        const int pos = o + __popcll(eb & ((1ull << lane) - 1ull));
-        if (pos < SH_ANP_CAP) {
-          double* p = pts_obb + ((size_t)b * SH_ANP_CAP + pos) * 3;
-          p[0] = r[j] * cos(t[j]);
-          p[1] = r[j] * sin(t[j]);
-          p[2] = z;
-        }
+  for (int c = 0; c < SH_MPROX / 64; ++c) {
+    const int j = c * 64 + lane;
+    const int m = v[c] > 0.0f ? 1 : 0;
+    int prev = __shfl_up(m, 1);
+    if (lane == 0) prev = carry;
+    const unsigned long long eb = __ballot(m != prev);
+    if (m != prev) {
+      const int pos = o + __popcll(eb & ((1ull << lane) - 1ull));
+      if (pos < SH_ANP_CAP) {
+        double* p = pts_obb + ((size_t)b * SH_ANP_CAP + pos) * 3;
+        p[0] = r[j] * cos(t[j]);
+        p[1] = r[j] * sin(t[j]);
+        p[2] = z;
       }
-      o += __popcll(eb);
-      carry = __shfl(m, 63);
     }
+    o += __popcll(eb);
+    carry = __shfl(m, 63);
   }
 }
 

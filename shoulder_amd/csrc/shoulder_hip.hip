@@ -375,6 +375,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("anp.logits", (size_t)B * SH_IMG * 4, 4);
   ENS("anp.points_obb", (size_t)B * SH_ANP_CAP * 3 * 8, 8);
   ENS("anp.counts", (size_t)B * 2 * 4, 4);
+  ENS("anp.rowcnt", (size_t)B * SH_ANP_ROWS * 2 * 4, 4);
   ENS("anp.plane", (size_t)B * 6 * 8, 8);
   ENS("anp.axes_obb", (size_t)B * 12 * 8, 8);
   // trans-epicondylar
@@ -1573,8 +1574,10 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     rc = unet_dispatch(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
     (void)unet_turn_leave(c);      // also after a failed pass: whatever was enqueued is what the next context waits for
     if (rc != SH_OK) return rc;
-    LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(B), dim3(512), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
-           buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"), buf<int>(c, "err"));
+    LAUNCH(c, "k_anp_edge_count", k_anp_edge_count, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<float>(c, "anp.logits"), buf<int>(c, "anp.rowcnt"));
+    LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
+           buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<int>(c, "anp.rowcnt"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
+           buf<int>(c, "err"));
     LAUNCH(c, "k_anp_plane", k_anp_plane, dim3(B), dim3(256), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
            buf<double>(c, "anp.plane"), buf<int>(c, "err"));
     LAUNCH(c, "k_rays", k_rays, dim3(B, 4), dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
