@@ -240,51 +240,70 @@ k_anp_plane(const double* __restrict__ pts_obb, const int* __restrict__ counts, 
 }
 
 // K23: rays from the plane point: 0 = +normal, 1 = -normal, 2 = +central, 3 = -central
-// (central = normal with z zeroed, renormalised).  One block per (humerus, ray), all triangles,
-// Moller-Trumbore in fp64, nearest forward hit.
-__global__ void __launch_bounds__(256)
-k_rays(const double* __restrict__ vobb, const int* __restrict__ faces, const long long* __restrict__ voff,
-       const long long* __restrict__ foff, const double* __restrict__ plane, double* __restrict__ axes_obb, int* __restrict__ err) {
-  __shared__ double wt[4];
-  int b = blockIdx.x, ray = blockIdx.y, tid = threadIdx.x;
-  const double* pl = plane + 6 * b;
-  double o[3] = {pl[0], pl[1], pl[2]};
-  double d[3] = {pl[3], pl[4], pl[5]};
+// (central = normal with z zeroed, renormalised); Moller-Trumbore in fp64 against all triangles, nearest forward hit.
+// k_rays_hit: (chunk of triangles, humerus) workgroups, every triangle fetched once for the four rays, nearest t per ray by
+// atomicMin on its bit pattern (t > 0: patterns order like values; ~0 = no hit).  k_rays: the four end points per humerus.
+#define SH_RAY_CHUNKS 16
+__device__ inline void ray_dir(const double* pl, int ray, double* d) {
+  d[0] = pl[3]; d[1] = pl[4]; d[2] = pl[5];
   if (d[2] < 0) { d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
   if (ray >= 2) { d[2] = 0.0; double n = norm3(d); d[0] /= n; d[1] /= n; d[2] /= n; }
   if (ray & 1) { d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2]; }
+}
+__global__ void __launch_bounds__(256)
+k_rays_hit(const double* __restrict__ vobb, const int* __restrict__ faces, const long long* __restrict__ voff,
+           const long long* __restrict__ foff, const double* __restrict__ plane, unsigned long long* __restrict__ tmin /*[B][4], ~0*/) {
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const double* pl = plane + 6 * b;
+  const double o[3] = {pl[0], pl[1], pl[2]};
+  double d[4][3];
+#pragma unroll
+  for (int ray = 0; ray < 4; ++ray) ray_dir(pl, ray, d[ray]);
   const double* vb = vobb + 3 * voff[b];
   const int* fb = faces + 3 * foff[b];
-  long long nf = foff[b + 1] - foff[b];
-  double tbest = 1e300;
-  for (long long f = tid; f < nf; f += 256) {
+  const long long nf = foff[b + 1] - foff[b];
+  double tbest[4] = {1e300, 1e300, 1e300, 1e300};
+  for (long long f = blockIdx.x * 256 + tid; f < nf; f += (long long)gridDim.x * 256) {
     const double* A = vb + 3 * (size_t)fb[3 * f];
     const double* Bv = vb + 3 * (size_t)fb[3 * f + 1];
     const double* Cv = vb + 3 * (size_t)fb[3 * f + 2];
-    double e1[3] = {Bv[0] - A[0], Bv[1] - A[1], Bv[2] - A[2]};
-    double e2[3] = {Cv[0] - A[0], Cv[1] - A[1], Cv[2] - A[2]};
-    double pv[3];
-    cross3(d, e2, pv);
-    double det = dot3(e1, pv);
-    if (!(fabs(det) > 1e-12)) continue;
-    double inv = 1.0 / det;
-    double tv[3] = {o[0] - A[0], o[1] - A[1], o[2] - A[2]};
-    double uu = dot3(tv, pv) * inv;
+    const double e1[3] = {Bv[0] - A[0], Bv[1] - A[1], Bv[2] - A[2]};
+    const double e2[3] = {Cv[0] - A[0], Cv[1] - A[1], Cv[2] - A[2]};
+    const double tv[3] = {o[0] - A[0], o[1] - A[1], o[2] - A[2]};
     double qv[3];
     cross3(tv, e1, qv);
-    double ww = dot3(d, qv) * inv;
-    double t = dot3(e2, qv) * inv;
-    if (uu >= 0 && ww >= 0 && uu + ww <= 1 && t > 1e-9 && t < tbest) tbest = t;
+#pragma unroll
+    for (int ray = 0; ray < 4; ++ray) {
+      double pv[3];
+      cross3(d[ray], e2, pv);
+      const double det = dot3(e1, pv);
+      if (!(fabs(det) > 1e-12)) continue;
+      const double inv = 1.0 / det;
+      const double uu = dot3(tv, pv) * inv;
+      const double ww = dot3(d[ray], qv) * inv;
+      const double t = dot3(e2, qv) * inv;
+      if (uu >= 0 && ww >= 0 && uu + ww <= 1 && t > 1e-9 && t < tbest[ray]) tbest[ray] = t;
+    }
   }
-  for (int off = 32; off > 0; off >>= 1) tbest = fmin(tbest, __shfl_down(tbest, off));
-  if ((tid & 63) == 0) wt[tid >> 6] = tbest;
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < 4; ++w) tbest = fmin(tbest, wt[w]);
-    double* a = axes_obb + ((size_t)b * 4 + ray) * 3;
-    if (tbest > 1e299) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); a[0] = a[1] = a[2] = 0.0; }
-    else for (int k = 0; k < 3; ++k) a[k] = o[k] + d[k] * tbest;
+#pragma unroll
+  for (int ray = 0; ray < 4; ++ray) {
+    double t = tbest[ray];
+    for (int off = 32; off > 0; off >>= 1) t = fmin(t, __shfl_down(t, off));
+    if ((tid & 63) == 0 && t < 1e299) atomicMin(&tmin[4 * b + ray], (unsigned long long)__double_as_longlong(t));
   }
+}
+__global__ void k_rays(const double* __restrict__ plane, const unsigned long long* __restrict__ tmin, double* __restrict__ axes_obb,
+                       int* __restrict__ err, int B) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= 4 * B) return;
+  const int b = g >> 2, ray = g & 3;
+  const double* pl = plane + 6 * b;
+  double d[3];
+  ray_dir(pl, ray, d);
+  double* a = axes_obb + (size_t)g * 3;
+  const unsigned long long e = tmin[g];
+  if (e == ~0ull) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); a[0] = a[1] = a[2] = 0.0; }
+  else { const double t = __longlong_as_double((long long)e); for (int k = 0; k < 3; ++k) a[k] = pl[k] + d[k] * t; }
 }
 
 }  // namespace sh

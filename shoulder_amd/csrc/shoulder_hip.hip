@@ -376,6 +376,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("anp.points_obb", (size_t)B * SH_ANP_CAP * 3 * 8, 8);
   ENS("anp.counts", (size_t)B * 2 * 4, 4);
   ENS("anp.rowcnt", (size_t)B * SH_ANP_ROWS * 2 * 4, 4);
+  ENS("anp.ray_t", (size_t)B * 4 * 8, 8);
   ENS("anp.plane", (size_t)B * 6 * 8, 8);
   ENS("anp.axes_obb", (size_t)B * 12 * 8, 8);
   // trans-epicondylar
@@ -1580,8 +1581,11 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<int>(c, "err"));
     LAUNCH(c, "k_anp_plane", k_anp_plane, dim3(B), dim3(256), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
            buf<double>(c, "anp.plane"), buf<int>(c, "err"));
-    LAUNCH(c, "k_rays", k_rays, dim3(B, 4), dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
-           buf<long long>(c, "foff"), buf<double>(c, "anp.plane"), buf<double>(c, "anp.axes_obb"), buf<int>(c, "err"));
+    HIPCHK(c, hipMemsetAsync(buf<unsigned long long>(c, "anp.ray_t"), 0xFF, (size_t)B * 4 * 8, c->stream));
+    LAUNCH(c, "k_rays_hit", k_rays_hit, dim3(SH_RAY_CHUNKS, B), dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
+           buf<long long>(c, "foff"), buf<double>(c, "anp.plane"), buf<unsigned long long>(c, "anp.ray_t"));
+    LAUNCH(c, "k_rays", k_rays, dim3((4 * B + 63) / 64), dim3(64), buf<double>(c, "anp.plane"), buf<unsigned long long>(c, "anp.ray_t"),
+           buf<double>(c, "anp.axes_obb"), buf<int>(c, "err"), B);
   }
   if (mask & SH_STAGE_TE) {
     LAUNCH(c, "k_te_rows", k_te_rows<SH_SMALLSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
