@@ -217,20 +217,24 @@ __device__ inline uint32_t hash_key64(unsigned long long k) {
 
 // select: 0 = largest loop (slice.py:53-59), 1 = loop whose closed-ring vertex mean is nearest
 // the origin in L1 (surgical_neck.py:40-48)
-// Two instantiations share the grid: CAP = SH_SMALLSEG (27 KB of LDS, 5 workgroups per CU) takes the planes with up to
-// 384 segments -- every section of a humerus at the fixture resolution -- and CAP = SH_MAXSEG (70 KB, 2 per CU) the rest; the other tier's planes exit at once.
+// Two instantiations share the grid: CAP = SH_SMALLSEG (14.5 KB of LDS, 8 workgroups = every wave slot of a CU) takes the planes
+// with up to 384 segments -- every section of a humerus at the fixture resolution -- and CAP = SH_MAXSEG (38 KB) the rest; the
+// other tier's planes exit at once.
 template <int CAP>
 __device__ inline void slice_link_plane(const int pl, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops,
              int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err,
              double* __restrict__ areas_total /*nullable: |sum of the signed loop areas| = Path2D.area*/) {
-  constexpr int HASH = CAP <= 256 ? 512 : (CAP <= 512 ? 1024 : 2048);
+  // LDS per plane decides how many planes a CU joins at once (the join is a chain of short dependent steps): 36 bytes per
+  // segment.  bufB holds the hash table until the label ping-pong starts; the rank arrays take the label buffer the
+  // ping-pong leaves free, the start-node -> loop map the other one; the crossing points stay in HBM (read twice, L2 hits).
+  constexpr int HASH = CAP <= 384 ? 512 : 2048;
+  static_assert(HASH * 4 <= CAP * 8 && HASH > CAP, "the hash table lives in bufB");
   __shared__ unsigned long long skey[CAP];
-  __shared__ unsigned long long bufA[CAP];   // ekey, then label ping, then ring x
-  __shared__ unsigned long long bufB[CAP];   // label pong, then ring y
-  __shared__ double px[CAP], py[CAP];
-  __shared__ int nxt[CAP], jmpA[CAP], jmpB[CAP], rnkA[CAP], rnkB[CAP];
-  __shared__ int table[HASH];
+  __shared__ unsigned long long bufA[CAP];   // ekey, then label ping, then rank arrays or loop map, then ring x
+  __shared__ unsigned long long bufB[CAP];   // hash table, then label pong, then rank arrays or loop map, then ring y
+  __shared__ int nxt[CAP], jmpA[CAP], jmpB[CAP];
+  int* const table = (int*)bufB;
   __shared__ int l_start[SH_MAXLOOPS], l_len[SH_MAXLOOPS], l_off[SH_MAXLOOPS];
   __shared__ double l_area[SH_MAXLOOPS], l_sel[SH_MAXLOOPS];
   __shared__ int n_loops, bad, best_loop;
@@ -248,7 +252,6 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     Seg s = sp[i];
     skey[i] = ((unsigned long long)s.s_lo << 32) | s.s_hi;
     bufA[i] = ((unsigned long long)s.e_lo << 32) | s.e_hi;
-    px[i] = s.px; py[i] = s.py;
   }
   __syncthreads();
   if (n < 3) {
@@ -293,8 +296,9 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     unsigned long long* tl = labA; labA = labB; labB = tl;
     int* tj = ja; ja = jb; jb = tj;
   }
-  // (b) forward distance to the loop's start node (absorbing)
-  int* ra = rnkA; int* rb = rnkB;
+  // (b) forward distance to the loop's start node (absorbing).  labA holds the labels; labB's buffer is free for the ranks
+  int* ra = (int*)labB; int* rb = ra + CAP;
+  int* const loop_of = (int*)labA;      // start node -> loop id, written once the labels have been consumed (below)
   for (int i = tid; i < n; i += SH_LINK_THREADS) {
     bool st = skey[i] == labA[i];
     ja[i] = st ? i : nxt[i];
@@ -330,7 +334,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
       int s = l_start[l];
       int L = ra[nxt[s]] + 1;
       l_len[l] = L; l_off[l] = off; off += L;
-      table[s] = l;               // start node -> loop id (table no longer needed as a hash)
+      loop_of[s] = l;
     }
     if (off != n) bad = 1;        // some segments are on no closed loop
   }
@@ -344,7 +348,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     int c = 0;
     for (int i = tid; i < n; i += SH_LINK_THREADS, ++c) {
       int s = ja[i];
-      int l = table[s];
+      int l = loop_of[s];
       int L = l_len[l];
       int r = ra[i];
       int pos = r == 0 ? 0 : L - r;
@@ -355,14 +359,15 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
   {
     int c = 0;
     for (int i = tid; i < n; i += SH_LINK_THREADS, ++c)
-      if (my_pos[c] >= 0 && my_pos[c] < n) { rx[my_pos[c]] = px[i]; ry[my_pos[c]] = py[i]; }
+      if (my_pos[c] >= 0 && my_pos[c] < n) { rx[my_pos[c]] = sp[i].px; ry[my_pos[c]] = sp[i].py; }
   }
   __syncthreads();
   // AABB over every loop vertex (trimesh Path2D.centroid, slice.py:38)
   {
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
     for (int i = tid; i < n; i += SH_LINK_THREADS) {
-      x0 = fmin(x0, px[i]); x1 = fmax(x1, px[i]); y0 = fmin(y0, py[i]); y1 = fmax(y1, py[i]);
+      const double qx = sp[i].px, qy = sp[i].py;
+      x0 = fmin(x0, qx); x1 = fmax(x1, qx); y0 = fmin(y0, qy); y1 = fmax(y1, qy);
     }
     for (int off = 32; off > 0; off >>= 1) {
       x0 = fmin(x0, __shfl_down(x0, off)); x1 = fmax(x1, __shfl_down(x1, off));
