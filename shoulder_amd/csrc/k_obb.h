@@ -139,6 +139,8 @@ k_obb_bounds(const double* __restrict__ hv, const int* __restrict__ nv_, const d
 //   pass 0 (seed)      the first 16 directions whose bound is within 5 % of the humerus's smallest bound (never empty): their
 //                      exact volumes give the first best_enc
 //   pass 1 (survivors) every other direction whose bound does not exceed best_enc
+//   pass 2             every direction not seeded, whatever its bound (SHOULDER_OBB_PRUNE=0, the A/B of the pruning: seed
+//                      tile, then all the rest)
 __global__ void __launch_bounds__(256)
 k_obb_select(const double* __restrict__ lb_, const int* __restrict__ nf_, const unsigned long long* __restrict__ lbmin_enc,
              const unsigned long long* __restrict__ best_enc, int pass, int* __restrict__ dir_list, int* __restrict__ dir_count,
@@ -154,10 +156,10 @@ k_obb_select(const double* __restrict__ lb_, const int* __restrict__ nf_, const 
   if (pass == 0) {
     const unsigned long long m = lbmin_enc[b];
     thr = m == ~0ull ? 1e300 : __longlong_as_double((long long)m) * 1.05;
-  } else {
+  } else if (pass == 1) {
     const unsigned long long ub = best_enc[b];
     thr = ub == ~0ull ? 1e300 : __longlong_as_double((long long)ub);
-  }
+  } else thr = 1e300;
   if (tid == 0) s_base = 0;
   __syncthreads();
   for (int j0 = 0; j0 < nf; j0 += 256) {
@@ -198,7 +200,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
                  const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge,
                  int* __restrict__ err, unsigned long long* __restrict__ best_enc /*[B]: bits of the smallest candidate volume so far, ~0 = none*/,
                  const int* __restrict__ dir_list /*[B][SH_HF]: the directions (hull faces) to evaluate*/, const int* __restrict__ dir_count /*[B]*/,
-                 int ntiles, int B) {
+                 int ntiles, int B, int skip_on /*0: no in-kernel skip either (A/B of the pruning)*/) {
   constexpr int T = SH_OBB_TILE, G = SH_OBB_GROUP, NW = SH_OBB_THREADS / 64;
   __shared__ double tn[T][3], tu[T][3], tv[T][3];
   __shared__ double red[NW][2 * T];
@@ -355,7 +357,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
       double hull2 = 0.0;
       for (int w = 0; w < NW; ++w) hull2 += g_hull2[w][tid];
       const double lb = 0.5 * fabs(hull2) * (hhi[g0 + tid] - hlo[g0 + tid]);
-      if (ub != ~0ull && lb * (1.0 - 1e-9) > __longlong_as_double((long long)ub)) g_skip[tid] = 1;
+      if (skip_on && ub != ~0ull && lb * (1.0 - 1e-9) > __longlong_as_double((long long)ub)) g_skip[tid] = 1;
 #if defined(SH_ABL_OBB) && SH_ABL_OBB == 1
       g_skip[tid] = 0;      // ablation: no pruning
 #elif defined(SH_ABL_OBB) && SH_ABL_OBB == 2

@@ -1459,14 +1459,16 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
            buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<double>(c, "obb.area2"), buf<double>(c, "obb.lb"),
            buf<unsigned long long>(c, "obb.lbmin_enc"), buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"));
     const int ntiles = (nfmax + SH_OBB_TILE - 1) / SH_OBB_TILE;
+    // SHOULDER_OBB_PRUNE=0: every direction is evaluated (the A/B of the pruning bound: same frames, tests/test_gpu_hull.py)
+    const bool prune = !(getenv("SHOULDER_OBB_PRUNE") && getenv("SHOULDER_OBB_PRUNE")[0] == '0');
     for (int pass = 0; pass < 2; ++pass) {      // seed tile, then the directions its best volume cannot exclude
       LAUNCH(c, "k_obb_select", k_obb_select, dim3(B), dim3(256), buf<double>(c, "obb.lb"), cnt_nf, buf<unsigned long long>(c, "obb.lbmin_enc"),
-             buf<unsigned long long>(c, "obb.best_enc"), pass, buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"), buf<unsigned char>(c, "obb.seeded"));
+             buf<unsigned long long>(c, "obb.best_enc"), (prune || pass == 0) ? pass : 2, buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"), buf<unsigned char>(c, "obb.seeded"));
       const int nt_pass = pass == 0 ? 1 : ntiles;
       LAUNCH(c, pass == 0 ? "k_obb_seed" : "k_obb_candidates", k_obb_candidates, dim3((unsigned)(nt_pass * ((B + 7) / 8) * 8)), dim3(SH_OBB_THREADS),
              buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"),
              buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"), buf<unsigned long long>(c, "obb.best_enc"), buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"),
-             nt_pass, B);
+             nt_pass, B, prune ? 1 : 0);
     }
   }
   LAUNCH(c, "k_obb_pick", k_obb_pick, dim3(B), dim3(256), buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"),
