@@ -75,7 +75,8 @@ __global__ void __launch_bounds__(UD_THREADS)
 k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int C0, int C1,
               const u16* __restrict__ wgt_, const float* __restrict__ bias, u16* __restrict__ dst_,
               int H, int W, int Cout, int relu, int nimg, const u16* __restrict__ zero_page_, u16* __restrict__ pooled_,
-              const float* __restrict__ head_w, const float* __restrict__ head_b, float* __restrict__ logits) {
+              const float* __restrict__ head_w, const float* __restrict__ head_b, float* __restrict__ logits,
+              unsigned* __restrict__ ticket /*zero at launch; nullptr: fixed equal shares*/, const int* __restrict__ tk_tab /*[ntk + 1] item bounds*/, int ntk) {
   using ET = typename EKT<EK>::type;
   const ET* src0 = (const ET*)src0_;
   const ET* src1 = (const ET*)src1_;
@@ -101,9 +102,15 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   const int Cin = C0 + C1, nchunk = Cin >> 5;
   const int tiles_x = W / 32, tiles_y = H / 16, ngroups = Cout / WR;
   const int total = nimg * tiles_x * tiles_y * ngroups;
-  const int per = (total + gridDim.x - 1) / gridDim.x;
-  const int w_begin = blockIdx.x * per, w_end = min(total, w_begin + per);
-  if (w_begin >= w_end) return;
+  // Work distribution.  Fixed: workgroup g walks items [g per, (g + 1) per).  Tickets (the default beside another lane): runs
+  // of items of DECREASING length (tk_tab, built on the host: every ticket is half of what would be a fair share of the
+  // remaining items) are handed out by a global counter, so a workgroup that starts late -- its CU was still held by a
+  // kernel of the engine's other lane -- takes less and the layer ends when the chip runs out of work; long first tickets
+  // keep the counter traffic at ~5 atomics per workgroup, short last ones the tail.  The id of the ticket after the
+  // current one is always already in LDS (fetched one ticket ahead by lane 0 of wave 0): no step waits for the counter.
+  __shared__ int s_q[2];
+  const bool dyn = ticket != nullptr;
+  if (dyn && tid == 0) { s_q[0] = (int)atomicAdd(ticket, 1u); s_q[1] = (int)atomicAdd(ticket, 1u); }
 #ifdef SH_DMA_PRIO
   __builtin_amdgcn_s_setprio(SH_DMA_PRIO);      // experiment: waves of another lane's kernels that share the SIMD lose the issue arbitration
 #endif
@@ -122,6 +129,17 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     }
   }
   __syncthreads();       // every ordinary load is retired before the first LDS-DMA is issued
+  int qk = 1;                                                  // s_q slot of the ticket after the current one
+  int w_begin, w_end;
+  if (dyn) {
+    const int t0 = __builtin_amdgcn_readfirstlane(s_q[0]);
+    if (t0 >= ntk) return;
+    w_begin = tk_tab[t0]; w_end = tk_tab[t0 + 1];
+  } else {
+    const int per = (total + gridDim.x - 1) / gridDim.x;
+    w_begin = blockIdx.x * per; w_end = min(total, w_begin + per);
+    if (w_begin >= w_end) return;
+  }
 
   // staging plan: slot e_k = tid + 512 k -> row r_k = (tid >> 2) + 128 k; k = 0..4 halo rows, k = 5 mixed, k = 6..9 weight rows.
   // The swizzle bit (bit 2 of the row) is the same for every k, weight rows advance by two taps per k.
@@ -147,12 +165,12 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   }
 
   int i_g, i_tx, i_ty, i_img;      // item being staged
-  {
-    int w = w_begin;
+  auto decode = [&](int w) {
     i_g = w % ngroups; w /= ngroups;
     i_tx = w % tiles_x; w /= tiles_x;
     i_ty = w % tiles_y; i_img = w / tiles_y;
-  }
+  };
+  decode(w_begin);
   int pixoff[6];
   auto item_lane_setup = [&]() {
 #pragma unroll
@@ -202,7 +220,8 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   for (int k = 0; k < NPIECE; ++k) piece(k);
   int buf = 0;
   bool stores_in_flight = false;
-  for (int w = w_begin; w < w_end; ++w) {
+  for (int w = w_begin;;) {
+    bool more = true;
     const int c_x0 = i_tx * 32, c_y0 = i_ty * 16, c_img = i_img, c_n0 = i_g * WR;
     f32x4 acc[4][NN];
 #pragma unroll
@@ -221,10 +240,21 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
       if (cc + 1 < nchunk) {
         describe(cc + 1, buf ^ 1);
       } else if (w + 1 < w_end) {
+        ++w;
         if (++i_g == ngroups) { i_g = 0; if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; ++i_img; } } }
         item_lane_setup();
         describe(0, buf ^ 1);
-      } else has_next = false;
+      } else if (dyn) {      // next ticket: its id was written before this step's barrier; the slot it frees is refilled for the one after
+        const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);
+        if (nt < ntk) {
+          if (tid == 0) s_q[qk ^ 1] = (int)atomicAdd(ticket, 1u);
+          qk ^= 1;
+          w = tk_tab[nt]; w_end = tk_tab[nt + 1];
+          decode(w);
+          item_lane_setup();
+          describe(0, buf ^ 1);
+        } else { has_next = false; more = false; }
+      } else { has_next = false; more = false; }
       const unsigned char* sb = smem + buf * BUFB;
       const unsigned char* xb[2][3];
 #pragma unroll
@@ -322,6 +352,7 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     }
     (void)NSTORE;
     stores_in_flight = true;
+    if (!more) break;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

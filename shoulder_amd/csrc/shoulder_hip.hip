@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -111,6 +112,9 @@ struct sh_ctx {
   hipStream_t copy_stream = nullptr;
   // timing
   bool zero_page_ready = false;
+  int ticket_next = 0;              // next free work counter of "unet16.tickets" (one per persistent conv launch of a forward pass)
+  std::map<std::tuple<int, int, int>, std::pair<int, int>> tk_tabs;      // (items, workgroups, cout groups) -> (offset, tickets) in "unet16.tk_tab"
+  int tk_tab_used = 0;
   bool packtab_ready = false;      // layer table of k_pack_w_bf16_all uploaded (reset by sh_load_unet)
   int num_cus = 0;
   int timing = 0;      // 0 off, 1 every launch, 2 UNet layers only
@@ -980,6 +984,8 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
 }  // extern "C" (the templates below need C++ linkage)
 
 // ---- UNet forward (16-bit MFMA paths: EK = 0 __bf16, 1 _Float16; tensors as raw u16) -----------------------------------------
+#define SH_UNET_TICKETS 64
+#define SH_UNET_TKTAB (1 << 18)
 template <int EK>
 static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const u16* src0, const u16* src1, int C0, int C1,
                            u16* dst, int H, int W, int nimg, int relu, int fuse = 0, ConvFuse fz = ConvFuse{}) {
@@ -1005,6 +1011,35 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     // launch over the CUs another lane's kernels leave free (a workgroup takes a whole CU's LDS, so it waits for a free CU)
     static const int gridmul = getenv("SHOULDER_DMA_GRIDMUL") ? std::max(1, atoi(getenv("SHOULDER_DMA_GRIDMUL"))) : 1;
     const dim3 g((unsigned)std::min(total, c->num_cus * gridmul));
+    // work tickets (k_unet_bf16_dma.h; SHOULDER_DMA_TICKETS=0: fixed equal shares): item bounds of decreasing runs, built once per shape
+    static const bool tickets_on = !(getenv("SHOULDER_DMA_TICKETS") && getenv("SHOULDER_DMA_TICKETS")[0] == '0');
+    unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
+    if (tickets_on) {
+      const int ngrp = L.cout / (dma64 ? 64 : 32);
+      const auto key = std::make_tuple(total, (int)g.x, ngrp);
+      auto it = c->tk_tabs.find(key);
+      if (it == c->tk_tabs.end()) {
+        std::vector<int> tab;
+        int pos = 0;
+        while (pos < total) {
+          static const double tkdiv = getenv("SHOULDER_DMA_TKDIV") ? std::max(1.0, atof(getenv("SHOULDER_DMA_TKDIV"))) : 3.0;
+          int sz = std::max(1, (int)std::ceil((total - pos) / (tkdiv * (double)g.x)));
+          if (sz >= ngrp) sz = sz / ngrp * ngrp;      // whole cout-group sets of a tile: its input tile comes from HBM once
+          tab.push_back(pos);
+          pos += std::min(sz, total - pos);
+        }
+        tab.push_back(total);
+        if (c->tk_tab_used + (int)tab.size() > SH_UNET_TKTAB) return fail(c, SH_ERR_CAPACITY, "unet: ticket table full");
+        HIPCHK(c, hipMemcpyAsync(buf<int>(c, "unet16.tk_tab") + c->tk_tab_used, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));      // `tab` is a local
+        it = c->tk_tabs.emplace(key, std::make_pair(c->tk_tab_used, (int)tab.size() - 1)).first;
+        c->tk_tab_used += (int)tab.size();
+      }
+      if (c->ticket_next >= SH_UNET_TICKETS) return fail(c, SH_ERR_CAPACITY, "unet: out of work counters");
+      tk = buf<unsigned>(c, "unet16.tickets") + c->ticket_next++;
+      tk_tab = buf<int>(c, "unet16.tk_tab") + it->second.first;
+      ntk = it->second.second;
+    }
     const u16* zp = (const u16*)c->bufs["unet16.zero"].p;
     const float* nof = nullptr;
     static const int sched = (getenv("SHOULDER_DMA_SCHED") && getenv("SHOULDER_DMA_SCHED")[0] == '0') ? 0 : 1;      // tap order inside a step (k_unet_bf16_dma.h)
@@ -1018,11 +1053,11 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     else { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                                 \
   } while (0)
     if (dma64) {
-      if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr);
-      else DMA_LAUNCH(0, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr);
-    } else if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr);
-    else if (fuse == UF_HEAD) DMA_LAUNCH(UF_HEAD, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits);
-    else DMA_LAUNCH(0, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr);
+      if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
+      else DMA_LAUNCH(0, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
+    } else if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
+    else if (fuse == UF_HEAD) DMA_LAUNCH(UF_HEAD, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits, tk, tk_tab, ntk);
+    else DMA_LAUNCH(0, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
 #undef DMA_LAUNCH
   } else if (L.taps == 9 && L.cout % 64 == 0) {
     const dim3 g(tiles, L.cout / 64, nimg);
@@ -1075,6 +1110,10 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
     }
     LAUNCH(c, "k_pack_w_bf16", k_pack_w16_all<EK>, dim3(2048), dim3(256), P, PW, (const PackEntry*)c->bufs["unet16.packtab"].p, (int)tab.size(), total);
   }
+  if ((rc = ensure(c, "unet16.tickets", SH_UNET_TICKETS * 4, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "unet16.tk_tab", SH_UNET_TKTAB * 4, 4)) != SH_OK) return rc;
+  HIPCHK(c, hipMemsetAsync(buf<unsigned>(c, "unet16.tickets"), 0, SH_UNET_TICKETS * 4, c->stream));
+  c->ticket_next = 0;
   const char* unf = getenv("SHOULDER_UNET_UNFUSED");
   const bool fused = base == 32 && !(unf && unf[0] == '1');
   const size_t full = (size_t)nimg * H * W * base * 2;
