@@ -224,7 +224,7 @@ template <int CAP>
 __device__ inline void slice_link_plane(const int pl, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops,
              int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err,
-             double* __restrict__ areas_total /*nullable: |sum of the signed loop areas| = Path2D.area*/) {
+             double* __restrict__ areas_total /*nullable: |sum of the signed loop areas| = Path2D.area*/, int* __restrict__ nlarge = nullptr) {
   // LDS per plane decides how many planes a CU joins at once (the join is a chain of short dependent steps): 36 bytes per
   // segment.  bufB holds the hash table until the label ping-pong starts; the rank arrays take the label buffer the
   // ping-pong leaves free, the start-node -> loop map the other one; the crossing points stay in HBM (read twice, L2 hits).
@@ -243,7 +243,10 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
   const int b = pl / N;                // pl = b*N + k
   const int tid = threadIdx.x;
   int cnt = seg_count[pl];
-  if (CAP == SH_SMALLSEG ? cnt > SH_SMALLSEG : cnt <= SH_SMALLSEG) return;      // the other tier's plane
+  if (CAP == SH_SMALLSEG ? cnt > SH_SMALLSEG : cnt <= SH_SMALLSEG) {      // the other tier's plane
+    if (CAP == SH_SMALLSEG && nlarge && tid == 0) atomicAdd(nlarge, 1);        // (tells the large-tier sweeps that they have work)
+    return;
+  }
   const int n = cnt > SH_MAXSEG ? SH_MAXSEG : cnt;
   if (tid == 0) { n_loops = 0; bad = 0; best_loop = 0; bb[0] = bb[2] = ~0ull; bb[1] = bb[3] = 0ull; }
   for (int i = tid; i < HASH; i += SH_LINK_THREADS) table[i] = -1;
@@ -440,12 +443,15 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
 // with more than SH_SMALLSEG segments -- a workgroup per plane would pay its 70 KB LDS allocation 40 000 times for nothing.
 __global__ void __launch_bounds__(SH_LINK_THREADS)
 k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs, double* __restrict__ centroids, double* __restrict__ areas,
-             int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total) {
-  slice_link_plane<SH_SMALLSEG>(blockIdx.x, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total);
+             int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total,
+             int* __restrict__ nlarge /*zero at launch: planes left to the large tier*/) {
+  slice_link_plane<SH_SMALLSEG>(blockIdx.x, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total, nlarge);
 }
 __global__ void __launch_bounds__(SH_LINK_THREADS)
 k_slice_link_large(int nplanes, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs, double* __restrict__ centroids, double* __restrict__ areas,
-                   int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total) {
+                   int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total,
+                   const int* __restrict__ nlarge) {
+  if (*nlarge == 0) return;      // (the usual case: the sweep below is ~75 dependent loads per workgroup for nothing)
   for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
     if (seg_count[pl] <= SH_SMALLSEG) continue;
     slice_link_plane<SH_MAXSEG>(pl, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total);
@@ -457,13 +463,15 @@ k_slice_link_large(int nplanes, int N, const int* __restrict__ seg_count, const 
 // One workgroup per (mesh, plane).  cumsum is sequential (np.cumsum order); each sample is one
 // np.interp evaluation; theta = atan2(y,x), r = sqrt(x^2+y^2); rows rolled to argmin(theta).
 #define SH_RS_THREADS 256
+// Round 2: the samples stay in registers (two per lane; M = 512, 256 lanes) -- 9 KB of LDS per plane instead of 25 KB, so a CU
+// works on eight planes at once; np.cumsum's running sum (one lane, order kept) loads eight lengths at a time instead of
+// paying an LDS round trip per element (it was half of a plane's latency); x and y share one search per sample.
 template <int CAP>
 __device__ inline void resample_polar_plane(const int pl, int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring,
                  const double* __restrict__ centroids, double* __restrict__ ixy,
                  double* __restrict__ itr_start, double* __restrict__ itr_cs) {
+  static_assert(SH_MPROX == 2 * SH_RS_THREADS, "two samples per lane");
   __shared__ double rx[CAP + 1], ry[CAP + 1], d[CAP + 1];
-  __shared__ double sx[SH_MPROX], sy[SH_MPROX], th[SH_MPROX], rr[SH_MPROX];
-  __shared__ unsigned long long amin_enc;   // (enc(theta) high bits | index) is not exact; use 2-step
   __shared__ int amin_idx;
   __shared__ double wmin[SH_RS_THREADS / 64];
   __shared__ int widx[SH_RS_THREADS / 64];
@@ -482,29 +490,62 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
   if (tid == 0) {
     double acc = 0.0;
     d[0] = 0.0;
-    for (int q = 1; q <= L; ++q) { acc += d[q]; d[q] = acc; }
+    int q = 1;
+    for (; q + 8 <= L + 1; q += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = d[q + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc += v[u]; v[u] = acc; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d[q + u] = v[u];
+    }
+    for (; q <= L; ++q) { acc += d[q]; d[q] = acc; }
   }
   __syncthreads();
   const double dmax = d[L];
-  for (int j = tid; j < M; j += SH_RS_THREADS) {
-    double t = linspace_at(0.0, dmax, M, j);
-    sx[j] = interp1(t, d, rx, L + 1);
-    sy[j] = interp1(t, d, ry, L + 1);
+  double sx[2], sy[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = tid + u * SH_RS_THREADS;
+    const double t = linspace_at(0.0, dmax, M, j);
+    // interp1 (sh_common.h) for x and y with one search: same comparisons, same arithmetic per coordinate
+    const int n = L + 1;
+    if (t < d[0]) { sx[u] = rx[0]; sy[u] = ry[0]; }
+    else if (!(t < d[n - 1])) { sx[u] = rx[n - 1]; sy[u] = ry[n - 1]; }
+    else {
+      int lo = 0, hi = n - 1;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t >= d[mid]) lo = mid; else hi = mid; }
+      const double x0 = d[lo], fx = rx[lo], fy = ry[lo];
+      if (x0 == t) { sx[u] = fx; sy[u] = fy; }
+      else {
+        const double den = d[lo + 1] - x0;
+        sx[u] = (rx[lo + 1] - fx) / den * (t - x0) + fx;
+        sy[u] = (ry[lo + 1] - fy) / den * (t - x0) + fy;
+      }
+    }
   }
-  __syncthreads();
   double* oxy = ixy + (size_t)pl * 2 * M;
-  for (int j = tid; j < M; j += SH_RS_THREADS) { oxy[j] = sx[j]; oxy[M + j] = sy[j]; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) { const int j = tid + u * SH_RS_THREADS; oxy[j] = sx[u]; oxy[M + j] = sy[u]; }
   const double cx = centroids[2 * (size_t)pl], cy = centroids[2 * (size_t)pl + 1];
   for (int pass = 0; pass < 2; ++pass) {
-    double ox = pass ? cx : 0.0, oy = pass ? cy : 0.0;
+    const double ox = pass ? cx : 0.0, oy = pass ? cy : 0.0;
     double best = 1e300;
     int bi = 0x7fffffff;
-    for (int j = tid; j < M; j += SH_RS_THREADS) {
-      double x = sx[j] - ox, y = sy[j] - oy;
-      double t = atan2(y, x);
-      th[j] = t;
-      rr[j] = sqrt(x * x + y * y);
-      if (t < best || (t == best && j < bi)) { best = t; bi = j; }
+    double th[2], rr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = tid + u * SH_RS_THREADS;
+      const double x = sx[u] - ox, y = sy[u] - oy;
+#if defined(SH_ABL_RS) && SH_ABL_RS == 1
+      th[u] = y + x;      // ablation (wrong results): what the kernel costs without its atan2 / sqrt
+      rr[u] = x * x + y * y;
+#else
+      th[u] = atan2(y, x);
+      rr[u] = sqrt(x * x + y * y);
+#endif
+      if (th[u] < best || (th[u] == best && j < bi)) { best = th[u]; bi = j; }
     }
     for (int off = 32; off > 0; off >>= 1) {
       double ob = __shfl_down(best, off);
@@ -520,16 +561,16 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
       amin_idx = bx;
     }
     __syncthreads();
-    const int k0 = amin_idx;
+    const int k0 = amin_idx;      // row rolled so that sample k0 comes first: out[j] = in[(j + k0) % M]
     double* o = (pass ? itr_cs : itr_start) + (size_t)pl * 2 * M;
-    for (int j = tid; j < M; j += SH_RS_THREADS) {
-      int src = j + k0; if (src >= M) src -= M;
-      o[j] = th[src];
-      o[M + j] = rr[src];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int dst = tid + u * SH_RS_THREADS - k0; if (dst < 0) dst += M;
+      o[dst] = th[u];
+      o[M + dst] = rr[u];
     }
-    __syncthreads();
+    __syncthreads();      // wmin / widx / amin_idx are reused by the next pass
   }
-  (void)amin_enc;
 }
 
 __global__ void __launch_bounds__(SH_RS_THREADS)
@@ -539,7 +580,8 @@ k_resample_polar(int N, int M, const int* __restrict__ ring_n, const double* __r
 }
 __global__ void __launch_bounds__(SH_RS_THREADS)
 k_resample_polar_large(int nplanes, int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring, const double* __restrict__ centroids,
-                       double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs) {
+                       double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs, const int* __restrict__ nlarge) {
+  if (*nlarge == 0) return;      // no plane with more than SH_SMALLSEG segments, hence no ring that long
   for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
     if (ring_n[pl] <= SH_SMALLSEG) continue;
     resample_polar_plane<SH_MAXSEG>(pl, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs);

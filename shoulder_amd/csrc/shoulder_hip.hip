@@ -353,6 +353,8 @@ static int alloc_batch(sh_ctx* c) {
     ENS((p + ".ring_n").c_str(), (size_t)B * s.N * 4, 4);
     if (s.ring) ENS((p + ".ring").c_str(), (size_t)B * s.N * (SH_MAXSEG + 1) * 2 * 8, 8);
   }
+  ENS("slices.nlarge", 64, 4);
+  c->bufs["slices.nlarge"].per_mesh = 0;
   ENS("prox.ixy", (size_t)B * SH_NPROX * 2 * SH_MPROX * 8, 8);
   ENS("prox.itr_start", (size_t)B * SH_NPROX * 2 * SH_MPROX * 8, 8);
   ENS("prox.itr_centered_start", (size_t)B * SH_NPROX * 2 * SH_MPROX * 8, 8);
@@ -1238,6 +1240,8 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   LAUNCH(c, "k_make_planes", k_make_planes, dim3(B), dim3(256), kind, N, buf<double>(c, kind == 4 ? "obb.zb_pre" : "z_bounds"), buf<double>(c, "neck_z"), zs, zeff, B);
   double* atot = total_area ? buf<double>(c, (p + ".area_total").c_str()) : (double*)nullptr;
   HIPCHK(c, hipMemsetAsync(cnt, 0, (size_t)B * N * 4, c->stream));
+  int* nlarge = (int*)c->bufs["slices.nlarge"].p;
+  HIPCHK(c, hipMemsetAsync(nlarge, 0, 4, c->stream));
   if (N > SH_EMIT_MAXN) return fail(c, SH_ERR_CAPACITY, "slice set has more planes than k_slice_emit's LDS histogram");
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 4096), (unsigned)B);
   LAUNCH(c, "k_slice_emit", k_slice_emit, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
@@ -1246,14 +1250,14 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   int* rn = buf<int>(c, (p + ".ring_n").c_str());
   double* rg = ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr;
   LAUNCH(c, "k_slice_link", k_slice_link, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
-         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot);
+         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, nlarge);
   LAUNCH(c, "k_slice_link", k_slice_link_large, dim3(std::min(B * N, 512)), dim3(SH_LINK_THREADS), B * N, N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
-         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot);
+         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, (const int*)nlarge);
   if (resample) {
     LAUNCH(c, "k_resample_polar", k_resample_polar, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
            buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
     LAUNCH(c, "k_resample_polar", k_resample_polar_large, dim3(std::min(B * N, 512)), dim3(SH_RS_THREADS), B * N, N, SH_MPROX, rn, rg,
-           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
+           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const int*)nlarge);
   }
   return SH_OK;
 }
