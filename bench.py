@@ -181,8 +181,9 @@ def main():
     ap.add_argument("--cpu-meshes", type=int, default=4, help="humeri of the batch the single-core oracle leg processes")
     ap.add_argument("--cpu-pool", type=int, default=-1, help="worker processes of the pooled oracle leg (one humerus each); -1 = host cores of this process, at most 16; 0 = skip")
     ap.add_argument("--no-pipeline", action="store_true", help="wait for every step before enqueueing the next one (sh_run instead of sh_submit / sh_collect)")
-    ap.add_argument("--lanes", type=int, default=2, help="engine contexts per GPU; steps alternate between them and their streams overlap on the device "
-                    "(the small geometry kernels of one step fill the gaps of the other step's UNet); 1 = a single context")
+    ap.add_argument("--lanes", type=int, default=0, help="engine contexts per GPU; steps alternate between them and their streams overlap on the device "
+                    "(the small geometry kernels of one step fill the gaps of the other step's UNet); 1 = a single context; "
+                    "0 (default) = 2 with the hull on the host, 3 with the hull on the device (its lanes start with a 5.6 ms hull kernel on 64 CUs)")
     ap.add_argument("--no-overlap", action="store_true", help="do not compute the host hulls of step k+1 during the device work of step k")
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     ap.add_argument("--from-stl", action="store_true", help="every step starts from the bytes of B binary STL files (device-side parse + vertex merge, sh_upload_stl)")
@@ -198,7 +199,7 @@ def main():
     # HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); two streams on one queue run in
     # order.  The lanes below need their streams on different queues next to torch's and RCCL's streams, so: more queues,
     # and the engine contexts are created before anything else makes streams.  (Must be set before HIP initialises.)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     # SH_BENCH_FORCE_DIST=1 exercises the collective code path with a single rank (1-GPU rehearsal)
     use_dist = world > 1 or os.environ.get("SH_BENCH_FORCE_DIST") == "1"
@@ -219,9 +220,11 @@ def main():
         cpu = cpu_baseline(verts, faces, synth.similarity_transforms(B, verts, seed=1234), weights, args.cpu_meshes, args.cpu_pool)
     # Lanes: independent engine contexts (own stream, own scratch) on this GPU.  Step s runs on lane s % lanes, so the launch-
     # and latency-bound geometry kernels of one step execute beside the chip-filling UNet kernels of the previous step.
-    lanes = max(1, args.lanes) if not args.no_pipeline else 1
-    engs = [Engine(local) for _ in range(lanes)]
-    eng = engs[0]
+    eng = Engine(local)
+    if args.hull != "auto":      # (auto: what the engine chose at creation -- SHOULDER_HULL, else by the host's threads per rank)
+        eng.set_hull_mode(args.hull)
+    lanes = (args.lanes if args.lanes > 0 else (3 if eng.hull_mode == "device" else 2)) if not args.no_pipeline else 1
+    engs = [eng] + [Engine(local) for _ in range(lanes - 1)]
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -244,7 +247,7 @@ def main():
         for e in engs:
             e.param_block_commit()      # host mirrors follow the device block (a later sh_load_* re-uploads from them)
     for e in engs:
-        e.set_hull_mode(args.hull)
+        e.set_hull_mode(eng.hull_mode)
         e.set_unet_turns(lanes > 1 and os.environ.get("SH_BENCH_NO_TURNS") != "1")
 
     T = synth.similarity_transforms(B, verts, seed=1234, start=rank * B)

@@ -238,7 +238,7 @@ int  sh_discard_prepared(sh_ctx*);
  * turn this on chain their UNet passes with events in the order the host enqueued them, so a UNet pass only ever
  * shares the device with geometry.  Results are identical either way.  Off by default.
  * The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams on
- * one queue run in order: a process that also runs torch / RCCL streams should export GPU_MAX_HW_QUEUES=8 before HIP
+ * one queue run in order: a process that also runs torch / RCCL streams should export GPU_MAX_HW_QUEUES=16 before HIP
  * initialises (bench.py does). */
 int  sh_set_unet_turns(sh_ctx*, int on);
 
