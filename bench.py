@@ -129,6 +129,8 @@ def sym_key(name, unet, cout, fused_net=True):
         fuse = 0
     if name == "unet.enc0b" and fused_net and os.environ.get("SHOULDER_UNET_L0") != "0" and os.environ.get("SHOULDER_UNET_FUSE_FIRST") != "0":
         return "k_enc0_fused16<%s>" % unet      # level-0 encoder as one persistent kernel (k_unet16_l0.h)
+    if name == "unet.dec0a" and fused_net and os.environ.get("SHOULDER_UNET_DEC0") != "0":
+        return "k_dec0a_up16<%s>" % unet      # dec0a with up0 computed inside (k_unet16_dec0.h); no unet.up0 launch then
     if up and os.environ.get("SHOULDER_UNET_UPCONV") != "0":
         return "k_upconv16<%s>" % unet                           # 2x2 transposed conv, both column phases per workgroup (k_unet16_l0.h)
     dma = (not up and not (fuse & 1) and os.environ.get("SHOULDER_UNET_DMA") != "0" and (cout % 64 == 0 or os.environ.get("SHOULDER_UNET_DMA32") != "0"))

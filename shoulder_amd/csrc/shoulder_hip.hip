@@ -21,6 +21,7 @@
 #include "k_unet_bf16.h"
 #include "k_unet_bf16_dma.h"
 #include "k_unet16_l0.h"
+#include "k_unet16_dec0.h"
 #include "k_stl.h"
 #include "k_clip.h"
 #include "k_hullpre.h"
@@ -988,6 +989,38 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
 // ---- UNet forward (16-bit MFMA paths: EK = 0 __bf16, 1 _Float16; tensors as raw u16) -----------------------------------------
 #define SH_UNET_TICKETS 64
 #define SH_UNET_TKTAB (1 << 18)
+// work tickets of the persistent convs (k_unet_bf16_dma.h; SHOULDER_DMA_TICKETS=0: fixed equal shares): the next free counter
+// of this forward pass and the table of item bounds of decreasing runs for (items, workgroups, cout groups), built once per shape
+static int dma_tickets(sh_ctx* c, int total, int nwg, int ngrp, unsigned** tk, const int** tk_tab, int* ntk) {
+  *tk = nullptr; *tk_tab = nullptr; *ntk = 0;
+  const bool tickets_on = !(getenv("SHOULDER_DMA_TICKETS") && getenv("SHOULDER_DMA_TICKETS")[0] == '0');      // (read per launch: the tests switch it in-process)
+  if (!tickets_on) return SH_OK;
+  const auto key = std::make_tuple(total, nwg, ngrp);
+  auto it = c->tk_tabs.find(key);
+  if (it == c->tk_tabs.end()) {
+    std::vector<int> tab;
+    int pos = 0;
+    while (pos < total) {
+      static const double tkdiv = getenv("SHOULDER_DMA_TKDIV") ? std::max(1.0, atof(getenv("SHOULDER_DMA_TKDIV"))) : 3.0;
+      int sz = std::max(1, (int)std::ceil((total - pos) / (tkdiv * (double)nwg)));
+      if (sz >= ngrp) sz = sz / ngrp * ngrp;      // whole cout-group sets of a tile: its input tile comes from HBM once
+      tab.push_back(pos);
+      pos += std::min(sz, total - pos);
+    }
+    tab.push_back(total);
+    if (c->tk_tab_used + (int)tab.size() > SH_UNET_TKTAB) return fail(c, SH_ERR_CAPACITY, "unet: ticket table full");
+    HIPCHK(c, hipMemcpyAsync(buf<int>(c, "unet16.tk_tab") + c->tk_tab_used, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // `tab` is a local
+    it = c->tk_tabs.emplace(key, std::make_pair(c->tk_tab_used, (int)tab.size() - 1)).first;
+    c->tk_tab_used += (int)tab.size();
+  }
+  if (c->ticket_next >= SH_UNET_TICKETS) return fail(c, SH_ERR_CAPACITY, "unet: out of work counters");
+  *tk = buf<unsigned>(c, "unet16.tickets") + c->ticket_next++;
+  *tk_tab = buf<int>(c, "unet16.tk_tab") + it->second.first;
+  *ntk = it->second.second;
+  return SH_OK;
+}
+
 template <int EK>
 static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const u16* src0, const u16* src1, int C0, int C1,
                            u16* dst, int H, int W, int nimg, int relu, int fuse = 0, ConvFuse fz = ConvFuse{}) {
@@ -1013,35 +1046,8 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     // launch over the CUs another lane's kernels leave free (a workgroup takes a whole CU's LDS, so it waits for a free CU)
     static const int gridmul = getenv("SHOULDER_DMA_GRIDMUL") ? std::max(1, atoi(getenv("SHOULDER_DMA_GRIDMUL"))) : 1;
     const dim3 g((unsigned)std::min(total, c->num_cus * gridmul));
-    // work tickets (k_unet_bf16_dma.h; SHOULDER_DMA_TICKETS=0: fixed equal shares): item bounds of decreasing runs, built once per shape
-    static const bool tickets_on = !(getenv("SHOULDER_DMA_TICKETS") && getenv("SHOULDER_DMA_TICKETS")[0] == '0');
     unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
-    if (tickets_on) {
-      const int ngrp = L.cout / (dma64 ? 64 : 32);
-      const auto key = std::make_tuple(total, (int)g.x, ngrp);
-      auto it = c->tk_tabs.find(key);
-      if (it == c->tk_tabs.end()) {
-        std::vector<int> tab;
-        int pos = 0;
-        while (pos < total) {
-          static const double tkdiv = getenv("SHOULDER_DMA_TKDIV") ? std::max(1.0, atof(getenv("SHOULDER_DMA_TKDIV"))) : 3.0;
-          int sz = std::max(1, (int)std::ceil((total - pos) / (tkdiv * (double)g.x)));
-          if (sz >= ngrp) sz = sz / ngrp * ngrp;      // whole cout-group sets of a tile: its input tile comes from HBM once
-          tab.push_back(pos);
-          pos += std::min(sz, total - pos);
-        }
-        tab.push_back(total);
-        if (c->tk_tab_used + (int)tab.size() > SH_UNET_TKTAB) return fail(c, SH_ERR_CAPACITY, "unet: ticket table full");
-        HIPCHK(c, hipMemcpyAsync(buf<int>(c, "unet16.tk_tab") + c->tk_tab_used, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));      // `tab` is a local
-        it = c->tk_tabs.emplace(key, std::make_pair(c->tk_tab_used, (int)tab.size() - 1)).first;
-        c->tk_tab_used += (int)tab.size();
-      }
-      if (c->ticket_next >= SH_UNET_TICKETS) return fail(c, SH_ERR_CAPACITY, "unet: out of work counters");
-      tk = buf<unsigned>(c, "unet16.tickets") + c->ticket_next++;
-      tk_tab = buf<int>(c, "unet16.tk_tab") + it->second.first;
-      ntk = it->second.second;
-    }
+    { int rct; if ((rct = dma_tickets(c, total, (int)g.x, L.cout / (dma64 ? 64 : 32), &tk, &tk_tab, &ntk)) != SH_OK) return rct; }
     const u16* zp = (const u16*)c->bufs["unet16.zero"].p;
     const float* nof = nullptr;
     static const int sched = (getenv("SHOULDER_DMA_SCHED") && getenv("SHOULDER_DMA_SCHED")[0] == '0') ? 0 : 1;      // tap order inside a step (k_unet_bf16_dma.h)
@@ -1178,6 +1184,27 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
   u16* x = A; u16* y = Bq;
   for (int i = D - 1; i >= 0; --i) {
     std::string nu = "up" + std::to_string(i), na = "dec" + std::to_string(i) + "a", nb = "dec" + std::to_string(i) + "b";
+    const char* d0env = getenv("SHOULDER_UNET_DEC0");
+    if (fused && i == 0 && ch == 64 && (2 * w) % 32 == 0 && (2 * h) % 16 == 0 && !(d0env && d0env[0] == '0')) {
+      // level 0: the up-convolution computed inside dec0a (k_unet16_dec0.h); x = low-resolution input, y = dec0a's output
+      h *= 2; w *= 2; ch /= 2;
+      const sh_ctx::ULayer& lu = L(nu);
+      const sh_ctx::ULayer& la = L(na);
+      if ((rc = ensure(c, "unet16.zero", 256, 2)) != SH_OK) return rc;
+      if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
+      if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
+      const int total = nimg * (w / 32) * (h / 16);
+      const dim3 g((unsigned)std::min(total, c->num_cus));
+      unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
+      if ((rc = dma_tickets(c, total, (int)g.x, 1, &tk, &tk_tab, &ntk)) != SH_OK) return rc;
+      LAUNCH(c, "unet.dec0a", (k_dec0a_up16<EK>), g, dim3(UD_THREADS), skip[0], x, PW + la.w_off, P + la.b_off, PW + lu.w_off, P + lu.b_off, y, h, w, nimg,
+             (const u16*)c->bufs["unet16.zero"].p, tk, tk_tab, ntk);
+      const sh_ctx::ULayer& l = L("head");
+      ConvFuse fz{};
+      fz.head_w = P + l.w_off; fz.head_b = P + l.b_off; fz.logits = logits;
+      if ((rc = conv_layer16<EK>(c, ("unet." + nb).c_str(), L(nb), y, nullptr, ch, 0, x, h, w, nimg, 1, UF_HEAD, fz)) != SH_OK) return rc;
+      return SH_OK;
+    }
     if ((rc = conv_layer16<EK>(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
     h *= 2; w *= 2; ch /= 2;
     if ((rc = conv_layer16<EK>(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;

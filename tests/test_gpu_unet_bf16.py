@@ -168,6 +168,49 @@ def test_resident_weights_match_staged_weights(engine, monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_fused_upconv_dec0a_matches_two_launches(engine, monkeypatch, name):
+    """k_dec0a_up16 computes up0's half of dec0a's input tile on the matrix cores inside the conv (k_unet16_dec0.h) instead of
+    reading it from HBM: the values are rounded exactly as k_upconv16 rounds them, so the logits are the same bit for bit
+    (image borders included: 256 x 512 and 512 x 512, several images)."""
+    rng = np.random.default_rng(19)
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        for H, W, n in ((256, 512, 3), (512, 512, 2)):
+            img = rng.random((n, H, W), dtype=np.float32)
+            monkeypatch.setenv("SHOULDER_UNET_DEC0", "0")
+            a = engine.unet_infer(img)
+            monkeypatch.setenv("SHOULDER_UNET_DEC0", "1")
+            b = engine.unet_infer(img)
+            assert np.isfinite(b).all()
+            assert np.array_equal(a, b), (H, W, float(np.abs(a - b).max()), int((a != b).sum()))
+    finally:
+        monkeypatch.delenv("SHOULDER_UNET_DEC0", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_work_tickets_match_fixed_shares(engine, monkeypatch, name):
+    """k_conv3_dma16 hands its items out in tickets from a global counter (which workgroup computes an item depends on the run);
+    the fixed equal shares of SHOULDER_DMA_TICKETS=0 give the same tensors bit for bit, at both image sizes, run after run."""
+    rng = np.random.default_rng(17)
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        for H, W, n in ((256, 512, 3), (512, 512, 5)):
+            img = rng.random((n, H, W), dtype=np.float32)
+            monkeypatch.setenv("SHOULDER_DMA_TICKETS", "0")
+            a = engine.unet_infer(img)
+            sa = [engine.fetch(f"unet16.skip{i}", np.uint16).copy() for i in (0, 1, 2, 3)]
+            monkeypatch.setenv("SHOULDER_DMA_TICKETS", "1")
+            for _ in range(2):
+                b = engine.unet_infer(img)
+                sb = [engine.fetch(f"unet16.skip{i}", np.uint16).copy() for i in (0, 1, 2, 3)]
+                assert np.array_equal(a, b) and all(np.array_equal(x, y) for x, y in zip(sa, sb))
+    finally:
+        monkeypatch.delenv("SHOULDER_DMA_TICKETS", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
 def test_row_upconv_matches_per_phase_kernel(engine, monkeypatch, name):
     """k_upconv16 (16x16 source tile x 32 channels x both column phases of a row parity per workgroup: full output lines per
     wave) sums every output in the order of the per-phase two-barrier kernel: logits and a decoder tensor are bit-identical."""
