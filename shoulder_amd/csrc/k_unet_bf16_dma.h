@@ -72,6 +72,9 @@ template <int N> __device__ inline void ud_wait_vm() {      // s_waitcnt takes a
 // rows per tap set: 32->64, 64->64, 64->32, 32->32 -- the 64- and 32-channel levels, where a weight set is shared by 8 192 /
 // 32 768 tiles) loads them into LDS once per workgroup; a step then stages only its 41 KB input tile: 6 DMA pieces instead of
 // 10 / 8 (the ablation builds price the weight pieces at 10-14 % of such a layer).
+// WRES = 2 (32 -> 32 channels: one chunk, NN = 2): the 18 weight fragments of a lane additionally stay in REGISTERS (72 VGPRs) for the
+// whole launch.  A 32-cout item reads one LDS fragment per two MFMAs, i.e. 256 B per cycle and CU at full matrix rate -- twice what
+// the LDS delivers; without the weight reads a step needs 18 fragment reads for its 72 MFMAs instead of 36.
 template <int EK, int FUSE, int NN = 4, int SCHED = 1, int WRES = 0>
 __global__ void __launch_bounds__(UD_THREADS)
 k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int C0, int C1,
@@ -131,6 +134,14 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     }
   }
   __syncthreads();       // every ordinary load is retired before the first LDS-DMA is issued
+  static_assert(WRES != 2 || (NN == 2 && SCHED == 1), "register-resident weights: the 32 -> 32 layers");
+  v8 wreg[WRES == 2 ? 9 : 1][2];
+  if constexpr (WRES == 2) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) wreg[tap][n] = *(const v8*)(smem + WRES_OFF + (tap * WR + n * 16) * 64 + UB_OFF(lane & 15, lane >> 4) * 2);
+  }
   int qk = 1;                                                  // s_q slot of the ticket after the current one
   int w_begin, w_end;
   if (dyn) {
@@ -290,7 +301,10 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
           const int tap = dy * 3 + dx, slot = dx * 3 + dy;
           v8 wf[NN];
 #pragma unroll
-          for (int n = 0; n < NN; ++n) wf[n] = *(const v8*)(wbp + (tap * WR + n * 16) * 64);
+          for (int n = 0; n < NN; ++n) {
+            if constexpr (WRES == 2) wf[n] = wreg[tap][n & 1];
+            else wf[n] = *(const v8*)(wbp + (tap * WR + n * 16) * 64);
+          }
           if (has_next) { if (slot < NPIECE) piece(slot); if (slot == 8 && NPIECE == 10) piece(9); }
 #pragma unroll
           for (int m = 0; m < 4; ++m)

@@ -1054,9 +1054,12 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     // weights resident in LDS (k_unet_bf16_dma.h, WRES): one cout group and nchunk * rows-per-tap <= 128
     const bool wres_on = !(getenv("SHOULDER_DMA_WRES") && getenv("SHOULDER_DMA_WRES")[0] == '0');
     const bool wres = wres_on && sched == 1 && L.cout == (dma64 ? 64 : 32) && ((C0 + C1) / 32) * (dma64 ? 64 : 32) <= 128;
+    // 32 -> 32 layers: the weight fragments also stay in registers (SHOULDER_DMA_WREG=0: LDS reads as in the other layers)
+    const bool wreg = wres && !dma64 && C0 + C1 == 32 && !(getenv("SHOULDER_DMA_WREG") && getenv("SHOULDER_DMA_WREG")[0] == '0');
 #define DMA_LAUNCH(F, N, ...)                                                                                                     \
   do {                                                                                                                            \
-    if (wres) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1, 1>), g, dim3(UD_THREADS), __VA_ARGS__); }                            \
+    if (wres && wreg && N == 2) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, 2, 1, 2>), g, dim3(UD_THREADS), __VA_ARGS__); }              \
+    else if (wres) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1, 1>), g, dim3(UD_THREADS), __VA_ARGS__); }                       \
     else if (sched == 0) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 0, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                 \
     else { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                                 \
   } while (0)
