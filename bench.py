@@ -190,7 +190,7 @@ def main():
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     ap.add_argument("--from-stl", action="store_true", help="every step starts from the bytes of B binary STL files (device-side parse + vertex merge, sh_upload_stl)")
     ap.add_argument("--hull", choices=["auto", "host", "device"], default="auto", help="where the convex hull of the OBB stage runs (sh_set_hull_mode); "
-                    "auto = host quickhull on hosts with >= 16 threads per rank, else the device hull")
+                    "auto = host quickhull on hosts with >= 48 hardware threads per rank, else the device hull")
     ap.add_argument("--check-gather", action="store_true", help="after the timed region rank 0 compares the records the last gather delivered for its own shard with a run of its own engine")
     args = ap.parse_args()
 

@@ -213,14 +213,15 @@ int sh_default_params(sh_params* p) {
   return SH_OK;
 }
 
-// "host" | "device" | "auto" (default).  auto: the host quickhull while this rank has at least 16 hardware threads for its pool
-// (it is free for the GPU and hidden behind the previous step), the device hull on thin hosts -- DESIGN.md 9.2 has the numbers.
+// "host" | "device" | "auto" (default).  auto: the host quickhull while this rank has at least 48 hardware threads to itself (it
+// is free for the GPU and hidden behind the previous step: at ~7 000 humeri/s a rank keeps ~14 cores busy with hulls), the device
+// hull otherwise -- 8 ranks on a 256-thread host, a thin host, a CPU quota.  DESIGN.md 9.2 has the numbers.
 static int hull_mode_from(const char* e) {
   if (e && (e[0] == 'h' || e[0] == '0')) return 0;
   if (e && (e[0] == 'd' || e[0] == '1')) return 1;
   unsigned nt = std::max(1u, std::thread::hardware_concurrency());
   if (const char* w = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(w); if (v > 1) nt = std::max(1u, nt / (unsigned)v); }
-  return nt >= 16 ? 0 : 1;
+  return nt >= 48 ? 0 : 1;
 }
 
 int sh_set_hull_mode(sh_ctx* c, const char* mode) {
