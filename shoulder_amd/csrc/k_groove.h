@@ -237,11 +237,17 @@ k_groove_scale(const double* __restrict__ xraw, const int* __restrict__ npk, dou
   const int b = blockIdx.x, tid = threadIdx.x;
   const double* X = xraw + (size_t)b * SH_GSLOTS * 9;
   const int* np_ = npk + (size_t)b * SH_GROOVE_NROWS;
-  if (tid == 0) {
-    int P = 0;
-    for (int i = 0; i < SH_GROOVE_NROWS; ++i)
-      for (int k = 0; k < np_[i]; ++k) slot[P++] = i * SH_MAXPEAK + k;
-    P_s = P;
+  // slot table in row order: every row finds its first position from the counts of the rows before it (one lane walking
+  // 330 dependent global loads was a third of the kernel)
+  __shared__ int s_cnt[SH_GROOVE_NROWS];
+  for (int i = tid; i < SH_GROOVE_NROWS; i += 256) s_cnt[i] = np_[i];
+  __syncthreads();
+  for (int i = tid; i < SH_GROOVE_NROWS; i += 256) {
+    int off = 0;
+    for (int j = 0; j < i; ++j) off += s_cnt[j];
+    const int n = s_cnt[i];
+    for (int k = 0; k < n; ++k) slot[off + k] = i * SH_MAXPEAK + k;
+    if (i == SH_GROOVE_NROWS - 1) P_s = off + n;
   }
   __syncthreads();
   const int P = P_s;
@@ -251,11 +257,29 @@ k_groove_scale(const double* __restrict__ xraw, const int* __restrict__ npk, dou
     __syncthreads();
     if (tid < nf) {
       const double* c = col[tid];
+      // (the order of the additions is the oracle's; the operands are fetched eight at a time so that the chain of adds does
+      //  not wait for an LDS round trip per term)
       double s = 0.0;
-      for (int p = 0; p < P; ++p) s += c[p];
+      int p = 0;
+      for (; p + 8 <= P; p += 8) {
+        double t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = c[p + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t8[u];
+      }
+      for (; p < P; ++p) s += c[p];
       const double mean = P ? s / (double)P : 0.0;
       double v = 0.0;
-      for (int p = 0; p < P; ++p) { double d = c[p] - mean; v += d * d; }
+      p = 0;
+      for (; p + 8 <= P; p += 8) {
+        double t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = c[p + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const double d = t8[u] - mean; v += d * d; }
+      }
+      for (; p < P; ++p) { double d = c[p] - mean; v += d * d; }
       const double var = P ? v / (double)P : 0.0;
       // sklearn StandardScaler (1.6): a feature is "constant" -- scale 1 -- when its variance is within the error bound of the
       // two-pass algorithm, var <= n eps var + (n mean eps)^2 (`_is_constant_feature`), not only when it is exactly zero.
@@ -325,13 +349,25 @@ __global__ void k_groove_kde(const double* __restrict__ ptheta, const float* __r
   __shared__ double wv[4];
   __shared__ int wi[4];
   int b = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) {
-    int n = 0;
-    for (int s = 0; s < SH_GSLOTS; ++s)
-      if (proba[(size_t)b * SH_GSLOTS + s] > 0.4f) sel[n++] = ptheta[(size_t)b * SH_GSLOTS + s];
-    nsel = n;
-  }
+  // the selected peaks in slot order (ordered compaction by ballots; one lane walking 2 310 dependent global loads was most
+  // of the kernel)
+  __shared__ int s_wc[4];
+  if (tid == 0) nsel = 0;
   __syncthreads();
+  for (int s0 = 0; s0 < SH_GSLOTS; s0 += 256) {
+    const int s = s0 + tid;
+    const bool keep = s < SH_GSLOTS && proba[(size_t)b * SH_GSLOTS + s] > 0.4f;
+    const double val = keep ? ptheta[(size_t)b * SH_GSLOTS + s] : 0.0;
+    const unsigned long long m = __ballot(keep);
+    if ((tid & 63) == 0) s_wc[tid >> 6] = __popcll(m);
+    __syncthreads();
+    int pos = nsel + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+    for (int w = 0; w < (tid >> 6); ++w) pos += s_wc[w];
+    if (keep) sel[pos] = val;
+    __syncthreads();
+    if (tid == 0) nsel += s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    __syncthreads();
+  }
   const int n = nsel;
   if (n == 0) { if (tid == 0) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); bg_theta[b] = 0.0; } return; }
   double best = -1.0;
