@@ -217,24 +217,24 @@ __device__ inline uint32_t hash_key64(unsigned long long k) {
 
 // select: 0 = largest loop (slice.py:53-59), 1 = loop whose closed-ring vertex mean is nearest
 // the origin in L1 (surgical_neck.py:40-48)
-// Two instantiations share the grid: CAP = SH_SMALLSEG (14.5 KB of LDS, 8 workgroups = every wave slot of a CU) takes the planes
-// with up to 384 segments -- every section of a humerus at the fixture resolution -- and CAP = SH_MAXSEG (38 KB) the rest; the
+// Two instantiations share the grid: CAP = SH_SMALLSEG (17.5 KB of LDS, 8 workgroups = every wave slot of a CU) takes the planes
+// with up to 384 segments -- every section of a humerus at the fixture resolution -- and CAP = SH_MAXSEG (46 KB) the rest; the
 // other tier's planes exit at once.
 template <int CAP>
 __device__ inline void slice_link_plane(const int pl, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops,
              int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err,
              double* __restrict__ areas_total /*nullable: |sum of the signed loop areas| = Path2D.area*/, int* __restrict__ nlarge = nullptr) {
-  // LDS per plane decides how many planes a CU joins at once (the join is a chain of short dependent steps): 36 bytes per
-  // segment.  bufB holds the hash table until the label ping-pong starts; the rank arrays take the label buffer the
-  // ping-pong leaves free, the start-node -> loop map the other one; the crossing points stay in HBM (read twice, L2 hits).
+  // LDS per plane decides how many planes a CU joins at once (the join is a chain of short dependent steps): 44 bytes per
+  // segment.  bufB holds the hash table until the label ping-pong starts; the crossing points stay in HBM (read twice, L2 hits).
   constexpr int HASH = CAP <= 384 ? 512 : 2048;
   static_assert(HASH * 4 <= CAP * 8 && HASH > CAP, "the hash table lives in bufB");
   __shared__ unsigned long long skey[CAP];
   __shared__ unsigned long long bufA[CAP];   // ekey, then label ping, then rank arrays or loop map, then ring x
   __shared__ unsigned long long bufB[CAP];   // hash table, then label pong, then rank arrays or loop map, then ring y
-  __shared__ int nxt[CAP], jmpA[CAP], jmpB[CAP];
+  __shared__ int nxt[CAP], jmpA[CAP], jmpB[CAP], offA[CAP], offB[CAP];
   int* const table = (int*)bufB;
+  __shared__ unsigned long long l_key[SH_MAXLOOPS];
   __shared__ int l_start[SH_MAXLOOPS], l_len[SH_MAXLOOPS], l_off[SH_MAXLOOPS];
   __shared__ double l_area[SH_MAXLOOPS], l_sel[SH_MAXLOOPS];
   __shared__ int n_loops, bad, best_loop;
@@ -282,47 +282,38 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     nxt[i] = found;
   }
   __syncthreads();
-  // (a) loop label = min start key over the loop
+  // One pointer-jumping pass gives both what the walk needs (round 2; two passes before: labels, then ranks): every node carries,
+  // for the stretch of 2^k successors starting at itself, the smallest start key on it and the distance to that key's node.
+  // Joining a stretch with the one behind it keeps the smaller key (its own on a tie: a stretch longer than the loop meets
+  // the same node again), so once the stretches cover the loop every node knows the loop's canonical start (B-1: the
+  // minimum edge key) and its forward distance to it.
   unsigned long long* labA = bufA;
   unsigned long long* labB = bufB;
-  for (int i = tid; i < n; i += SH_LINK_THREADS) { labA[i] = skey[i]; jmpA[i] = nxt[i]; }
-  __syncthreads();
   int* ja = jmpA; int* jb = jmpB;
+  int* ra = offA; int* rb = offB;
+  for (int i = tid; i < n; i += SH_LINK_THREADS) { labA[i] = skey[i]; ja[i] = nxt[i]; ra[i] = 0; }
+  __syncthreads();
   for (int span = 1; span < n; span <<= 1) {
     for (int i = tid; i < n; i += SH_LINK_THREADS) {
-      int j = ja[i];
-      unsigned long long a = labA[i], c = labA[j];
-      labB[i] = a < c ? a : c;
+      const int j = ja[i];
+      const unsigned long long a = labA[i], c = labA[j];
+      const bool own = a <= c;
+      labB[i] = own ? a : c;
+      rb[i] = own ? ra[i] : span + ra[j];
       jb[i] = ja[j];
     }
     __syncthreads();
     unsigned long long* tl = labA; labA = labB; labB = tl;
     int* tj = ja; ja = jb; jb = tj;
+    int* tr = ra; ra = rb; rb = tr;
   }
-  // (b) forward distance to the loop's start node (absorbing).  labA holds the labels; labB's buffer is free for the ranks
-  int* ra = (int*)labB; int* rb = ra + CAP;
-  int* const loop_of = (int*)labA;      // start node -> loop id, written once the labels have been consumed (below)
-  for (int i = tid; i < n; i += SH_LINK_THREADS) {
-    bool st = skey[i] == labA[i];
-    ja[i] = st ? i : nxt[i];
-    ra[i] = st ? 0 : 1;
-    if (st) {
+  // labA[i] = start key of i's loop, ra[i] = forward steps from i to the start node (0: i is a start node)
+  for (int i = tid; i < n; i += SH_LINK_THREADS)
+    if (ra[i] == 0) {
       int l = atomicAdd(&n_loops, 1);
       if (l < SH_MAXLOOPS) l_start[l] = i;
     }
-  }
   __syncthreads();
-  for (int span = 1; span < n; span <<= 1) {
-    for (int i = tid; i < n; i += SH_LINK_THREADS) {
-      int j = ja[i];
-      rb[i] = ra[i] + ra[j];
-      jb[i] = ja[j];
-    }
-    __syncthreads();
-    int* t1 = ra; ra = rb; rb = t1;
-    int* t2 = ja; ja = jb; jb = t2;
-  }
-  // now ja[i] = start node of i's loop, ra[i] = forward steps from i to it
   const int nl = n_loops > SH_MAXLOOPS ? SH_MAXLOOPS : n_loops;
   if (tid == 0) {
     if (n_loops > SH_MAXLOOPS) atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
@@ -337,7 +328,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
       int s = l_start[l];
       int L = ra[nxt[s]] + 1;
       l_len[l] = L; l_off[l] = off; off += L;
-      loop_of[s] = l;
+      l_key[l] = skey[s];
     }
     if (off != n) bad = 1;        // some segments are on no closed loop
   }
@@ -350,12 +341,13 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
   {
     int c = 0;
     for (int i = tid; i < n; i += SH_LINK_THREADS, ++c) {
-      int s = ja[i];
-      int l = loop_of[s];
-      int L = l_len[l];
-      int r = ra[i];
-      int pos = r == 0 ? 0 : L - r;
-      my_pos[c] = (l < 0 || l >= nl) ? -1 : l_off[l] + pos;
+      const unsigned long long key = labA[i];
+      int l = -1;
+      for (int q = 0; q < nl; ++q) if (l_key[q] == key) { l = q; break; }      // (one or two loops per section)
+      const int L = l >= 0 ? l_len[l] : 1;
+      const int r = ra[i];
+      const int pos = r == 0 ? 0 : L - r;
+      my_pos[c] = l < 0 ? -1 : l_off[l] + pos;
     }
   }
   __syncthreads();
