@@ -238,7 +238,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
   __shared__ int l_start[SH_MAXLOOPS], l_len[SH_MAXLOOPS], l_off[SH_MAXLOOPS];
   __shared__ double l_area[SH_MAXLOOPS], l_sel[SH_MAXLOOPS];
   __shared__ int n_loops, bad, best_loop;
-  __shared__ unsigned long long bb[4];
+  __shared__ double bbv[4];
 
   const int b = pl / N;                // pl = b*N + k
   const int tid = threadIdx.x;
@@ -248,7 +248,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     return;
   }
   const int n = cnt > SH_MAXSEG ? SH_MAXSEG : cnt;
-  if (tid == 0) { n_loops = 0; bad = 0; best_loop = 0; bb[0] = bb[2] = ~0ull; bb[1] = bb[3] = 0ull; }
+  if (tid == 0) { n_loops = 0; bad = 0; best_loop = 0; }
   for (int i = tid; i < HASH; i += SH_LINK_THREADS) table[i] = -1;
   const Seg* sp = segs + (size_t)pl * SH_MAXSEG;
   for (int i = tid; i < n; i += SH_LINK_THREADS) {
@@ -257,6 +257,9 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     bufA[i] = ((unsigned long long)s.e_lo << 32) | s.e_hi;
   }
   __syncthreads();
+#if defined(SH_ABL_LINK) && SH_ABL_LINK == 1
+  return;
+#endif
   if (n < 3) {
     if (tid == 0) {
       centroids[2 * (size_t)pl] = 0; centroids[2 * (size_t)pl + 1] = 0; areas[pl] = 0; nloops[pl] = 0; ring_n[pl] = 0;
@@ -282,6 +285,9 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     nxt[i] = found;
   }
   __syncthreads();
+#if defined(SH_ABL_LINK) && SH_ABL_LINK == 2
+  return;
+#endif
   // One pointer-jumping pass gives both what the walk needs (round 2; two passes before: labels, then ranks): every node carries,
   // for the stretch of 2^k successors starting at itself, the smallest start key on it and the distance to that key's node.
   // Joining a stretch with the one behind it keeps the smaller key (its own on a tie: a stretch longer than the loop meets
@@ -307,6 +313,9 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     int* tj = ja; ja = jb; jb = tj;
     int* tr = ra; ra = rb; rb = tr;
   }
+#if defined(SH_ABL_LINK) && SH_ABL_LINK == 3
+  return;
+#endif
   // labA[i] = start key of i's loop, ra[i] = forward steps from i to the start node (0: i is a start node)
   for (int i = tid; i < n; i += SH_LINK_THREADS)
     if (ra[i] == 0) {
@@ -357,27 +366,29 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
       if (my_pos[c] >= 0 && my_pos[c] < n) { rx[my_pos[c]] = sp[i].px; ry[my_pos[c]] = sp[i].py; }
   }
   __syncthreads();
-  // AABB over every loop vertex (trimesh Path2D.centroid, slice.py:38)
-  {
+#if defined(SH_ABL_LINK) && SH_ABL_LINK == 4
+  return;
+#endif
+  // AABB over every loop vertex (trimesh Path2D.centroid, slice.py:38) by the last wave, while the other three take the loops
+  // (all four waves reducing four doubles each through the LDS crossbar, then 64-bit LDS atomics, was a quarter of the kernel).
+  // The ordered ring in LDS holds every crossing point once -- min / max do not care about the order; a section with
+  // segments on no closed loop is flagged above and its numbers are void anyway.
+  const int lane = tid & 63, wave = tid >> 6;
+  if (wave == SH_LINK_THREADS / 64 - 1) {
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
-    for (int i = tid; i < n; i += SH_LINK_THREADS) {
-      const double qx = sp[i].px, qy = sp[i].py;
+    for (int i = lane; i < n; i += 64) {
+      const double qx = rx[i], qy = ry[i];
       x0 = fmin(x0, qx); x1 = fmax(x1, qx); y0 = fmin(y0, qy); y1 = fmax(y1, qy);
     }
     for (int off = 32; off > 0; off >>= 1) {
       x0 = fmin(x0, __shfl_down(x0, off)); x1 = fmax(x1, __shfl_down(x1, off));
       y0 = fmin(y0, __shfl_down(y0, off)); y1 = fmax(y1, __shfl_down(y1, off));
     }
-    if ((tid & 63) == 0) {
-      atomicMin(&bb[0], enc_f64(x0)); atomicMax(&bb[1], enc_f64(x1));
-      atomicMin(&bb[2], enc_f64(y0)); atomicMax(&bb[3], enc_f64(y1));
-    }
-  }
-  // per-loop shoelace area and the selection score: one wave per loop, lane-strided terms in ring order, fixed shuffle
-  // tree (deterministic; one lane walking the ring alone cost as much as the whole join)
-  {
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int l = wave; l < nl; l += SH_LINK_THREADS / 64) {
+    if (lane == 0) { bbv[0] = x0; bbv[1] = x1; bbv[2] = y0; bbv[3] = y1; }
+  } else {
+    // per-loop shoelace area and the selection score: one wave per loop, lane-strided terms in ring order, fixed shuffle
+    // tree (deterministic; one lane walking the ring alone cost as much as the whole join)
+    for (int l = wave; l < nl; l += SH_LINK_THREADS / 64 - 1) {
       const int o = l_off[l], L = l_len[l];
       double a2 = 0.0, mx = 0.0, my = 0.0;
       for (int q = lane; q < L; q += 64) {
@@ -394,6 +405,9 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
       }
     }
   }
+#if defined(SH_ABL_LINK) && SH_ABL_LINK == 7
+  return;
+#endif
   __syncthreads();
   if (tid == 0) {
     int best = 0;
@@ -402,7 +416,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
       else { if (l_sel[l] < l_sel[best]) best = l; }
     }
     best_loop = best;
-    double x0 = dec_f64(bb[0]), x1 = dec_f64(bb[1]), y0 = dec_f64(bb[2]), y1 = dec_f64(bb[3]);
+    double x0 = bbv[0], x1 = bbv[1], y0 = bbv[2], y1 = bbv[3];
     centroids[2 * (size_t)pl] = 0.5 * (x0 + x1);
     centroids[2 * (size_t)pl + 1] = 0.5 * (y0 + y1);
     int amax = 0;
@@ -418,6 +432,9 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     if (bad) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
   }
   __syncthreads();
+#if defined(SH_ABL_LINK) && SH_ABL_LINK == 5
+  return;
+#endif
   if (ring) {
     int l = best_loop, o = l_off[l], L = l_len[l];
     bool rev = l_area[l] < 0;           // clockwise loop: traverse backwards from the same start

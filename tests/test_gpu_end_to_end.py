@@ -14,6 +14,7 @@ MM = 1e-4      # north-star tolerance, mm
 
 @pytest.fixture(scope="module")
 def ran(engine, oracle_bones):
+    engine.reset_params()      # (whatever an earlier test file left: bone kind, UNet element type, cut-offs)
     hs = [oracle_bones(n) for n in NAMES]
     engine.upload([(h.verts, h.faces) for h in hs])
     lm = engine.run(_lib.STAGE_ALL)

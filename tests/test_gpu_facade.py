@@ -15,6 +15,7 @@ MM = 1e-4
 
 @pytest.fixture(scope="module")
 def hum(engine):
+    engine.reset_params()      # (whatever an earlier test file left: bone kind, UNet element type, cut-offs)
     import shoulder_amd as shoulder
     return shoulder.Humerus(os.path.join(BONES, "humerus_left.stl"), engine=engine)
 

@@ -15,6 +15,7 @@ STAGES = _lib.STAGE_ALL & ~_lib.STAGE_OBB
 
 @pytest.fixture(scope="module")
 def ran(engine, oracle_bones):
+    engine.reset_params()      # (whatever an earlier test file left: bone kind, UNet element type, cut-offs)
     hs = [oracle_bones(n) for n in NAMES]
     engine.upload([(h.verts, h.faces) for h in hs])
     engine.store("obb_transform", np.stack([h.T_obb for h in hs]))
