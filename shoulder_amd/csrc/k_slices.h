@@ -237,7 +237,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
   __shared__ unsigned long long l_key[SH_MAXLOOPS];
   __shared__ int l_start[SH_MAXLOOPS], l_len[SH_MAXLOOPS], l_off[SH_MAXLOOPS];
   __shared__ double l_area[SH_MAXLOOPS], l_sel[SH_MAXLOOPS];
-  __shared__ int n_loops, bad, best_loop;
+  __shared__ int n_loops, bad;
   __shared__ double bbv[4];
 
   const int b = pl / N;                // pl = b*N + k
@@ -248,7 +248,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     return;
   }
   const int n = cnt > SH_MAXSEG ? SH_MAXSEG : cnt;
-  if (tid == 0) { n_loops = 0; bad = 0; best_loop = 0; }
+  if (tid == 0) { n_loops = 0; bad = 0; }
   for (int i = tid; i < HASH; i += SH_LINK_THREADS) table[i] = -1;
   const Seg* sp = segs + (size_t)pl * SH_MAXSEG;
   for (int i = tid; i < n; i += SH_LINK_THREADS) {
@@ -409,13 +409,14 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
   return;
 #endif
   __syncthreads();
+  // the chosen loop: every lane picks it for itself (at most a handful of broadcast reads) -- one lane choosing it for all,
+  // between two barriers and in front of its scalar stores, was a quarter of the kernel
+  int best = 0;
+  for (int l = 1; l < nl; ++l) {
+    if (select == 0) { if (fabs(l_area[l]) > fabs(l_area[best])) best = l; }
+    else { if (l_sel[l] < l_sel[best]) best = l; }
+  }
   if (tid == 0) {
-    int best = 0;
-    for (int l = 1; l < nl; ++l) {
-      if (select == 0) { if (fabs(l_area[l]) > fabs(l_area[best])) best = l; }
-      else { if (l_sel[l] < l_sel[best]) best = l; }
-    }
-    best_loop = best;
     double x0 = bbv[0], x1 = bbv[1], y0 = bbv[2], y1 = bbv[3];
     centroids[2 * (size_t)pl] = 0.5 * (x0 + x1);
     centroids[2 * (size_t)pl + 1] = 0.5 * (y0 + y1);
@@ -431,12 +432,11 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     ring_n[pl] = l_len[best];
     if (bad) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
   }
-  __syncthreads();
 #if defined(SH_ABL_LINK) && SH_ABL_LINK == 5
   return;
 #endif
   if (ring) {
-    int l = best_loop, o = l_off[l], L = l_len[l];
+    int l = best, o = l_off[l], L = l_len[l];
     bool rev = l_area[l] < 0;           // clockwise loop: traverse backwards from the same start
     double* out = ring + (size_t)pl * (SH_MAXSEG + 1) * 2;
     for (int q = tid; q <= L; q += SH_LINK_THREADS) {
