@@ -471,15 +471,16 @@ k_slice_link_large(int nplanes, int N, const int* __restrict__ seg_count, const 
 // ---- K8/K9: arclength resampling + polar images (slice.py:65-147, :166-206) -------------------
 // One workgroup per (mesh, plane).  cumsum is sequential (np.cumsum order); each sample is one
 // np.interp evaluation; theta = atan2(y,x), r = sqrt(x^2+y^2); rows rolled to argmin(theta).
-#define SH_RS_THREADS 256
-// Round 2: the samples stay in registers (two per lane; M = 512, 256 lanes) -- 9 KB of LDS per plane instead of 25 KB, so a CU
+#define SH_RS_THREADS 128      // two waves per plane: 16 planes per CU hide each other's serial stretches (ring load, running sum)
+// Round 2: the samples stay in registers (four per lane; M = 512, 128 lanes) -- 9 KB of LDS per plane instead of 25 KB, so a CU
 // works on eight planes at once; np.cumsum's running sum (one lane, order kept) loads eight lengths at a time instead of
 // paying an LDS round trip per element (it was half of a plane's latency); x and y share one search per sample.
 template <int CAP>
 __device__ inline void resample_polar_plane(const int pl, int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring,
                  const double* __restrict__ centroids, double* __restrict__ ixy,
                  double* __restrict__ itr_start, double* __restrict__ itr_cs) {
-  static_assert(SH_MPROX == 2 * SH_RS_THREADS, "two samples per lane");
+  static_assert(SH_MPROX % SH_RS_THREADS == 0, "whole samples per lane");
+  constexpr int NS = SH_MPROX / SH_RS_THREADS;      // samples per lane
   __shared__ double rx[CAP + 1], ry[CAP + 1], d[CAP + 1];
   __shared__ int amin_idx;
   __shared__ double wmin[SH_RS_THREADS / 64];
@@ -512,10 +513,13 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
     for (; q <= L; ++q) { acc += d[q]; d[q] = acc; }
   }
   __syncthreads();
+#if defined(SH_ABL_RS) && SH_ABL_RS == 2
+  return;
+#endif
   const double dmax = d[L];
-  double sx[2], sy[2];
+  double sx[NS], sy[NS];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NS; ++u) {
     const int j = tid + u * SH_RS_THREADS;
     const double t = linspace_at(0.0, dmax, M, j);
     // interp1 (sh_common.h) for x and y with one search: same comparisons, same arithmetic per coordinate
@@ -536,15 +540,21 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
   }
   double* oxy = ixy + (size_t)pl * 2 * M;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) { const int j = tid + u * SH_RS_THREADS; oxy[j] = sx[u]; oxy[M + j] = sy[u]; }
+  for (int u = 0; u < NS; ++u) { const int j = tid + u * SH_RS_THREADS; oxy[j] = sx[u]; oxy[M + j] = sy[u]; }
+#if defined(SH_ABL_RS) && SH_ABL_RS == 3
+  return;
+#endif
   const double cx = centroids[2 * (size_t)pl], cy = centroids[2 * (size_t)pl + 1];
   for (int pass = 0; pass < 2; ++pass) {
+#if defined(SH_ABL_RS) && SH_ABL_RS == 4
+    if (pass == 1) return;
+#endif
     const double ox = pass ? cx : 0.0, oy = pass ? cy : 0.0;
     double best = 1e300;
     int bi = 0x7fffffff;
-    double th[2], rr[2];
+    double th[NS], rr[NS];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NS; ++u) {
       const int j = tid + u * SH_RS_THREADS;
       const double x = sx[u] - ox, y = sy[u] - oy;
 #if defined(SH_ABL_RS) && SH_ABL_RS == 1
@@ -573,7 +583,7 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
     const int k0 = amin_idx;      // row rolled so that sample k0 comes first: out[j] = in[(j + k0) % M]
     double* o = (pass ? itr_cs : itr_start) + (size_t)pl * 2 * M;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NS; ++u) {
       int dst = tid + u * SH_RS_THREADS - k0; if (dst < 0) dst += M;
       o[dst] = th[u];
       o[M + dst] = rr[u];
