@@ -1009,7 +1009,12 @@ static int dma_tickets(sh_ctx* c, int total, int nwg, int ngrp, unsigned** tk, c
       pos += std::min(sz, total - pos);
     }
     tab.push_back(total);
-    if (c->tk_tab_used + (int)tab.size() > SH_UNET_TKTAB) return fail(c, SH_ERR_CAPACITY, "unet: ticket table full");
+    if ((int)tab.size() > SH_UNET_TKTAB) return fail(c, SH_ERR_CAPACITY, "unet: ticket table larger than its buffer");
+    if (c->tk_tab_used + (int)tab.size() > SH_UNET_TKTAB) {      // many different shapes (sh_unet_infer with varying n): start the cache over
+      HIPCHK(c, hipStreamSynchronize(c->stream));                  // (launches that read the old tables are done)
+      c->tk_tabs.clear();
+      c->tk_tab_used = 0;
+    }
     HIPCHK(c, hipMemcpyAsync(buf<int>(c, "unet16.tk_tab") + c->tk_tab_used, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));      // `tab` is a local
     it = c->tk_tabs.emplace(key, std::make_pair(c->tk_tab_used, (int)tab.size() - 1)).first;
