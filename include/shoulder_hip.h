@@ -133,6 +133,9 @@ int  sh_param_block(sh_ctx*, void** dev_ptr, size_t* nbytes);
  * mirrors from it, so that a later sh_load_rfc / sh_load_unet -- which re-uploads the whole block from the mirrors --
  * does not put stale values back.  The forest's topology (child indices, roots) is validated like in sh_load_rfc. */
 int  sh_param_block_commit(sh_ctx*);
+/* (The 16-bit UNet paths pack their weights from this block once and keep the packed copy until the block can have
+ * changed: sh_load_*, sh_param_block / sh_buffer_device("params") handing the pointer out, sh_param_block_commit, sh_store.
+ * A caller that keeps the pointer and writes the block again later must call sh_param_block_commit again.) */
 
 /* ---- meshes (replace MeshLoader, mesh.py:14-41; vertices already merged) ------------- */
 int  sh_upload_meshes(sh_ctx*, const float* verts /* sumV x 3 */, const int32_t* faces /* sumF x 3, per-mesh local ids */,

@@ -117,6 +117,8 @@ struct sh_ctx {
   std::map<std::tuple<int, int, int>, std::pair<int, int>> tk_tabs;      // (items, workgroups, cout groups) -> (offset, tickets) in "unet16.tk_tab"
   int tk_tab_used = 0;
   bool packtab_ready = false;      // layer table of k_pack_w_bf16_all uploaded (reset by sh_load_unet)
+  int packed_kind = -1;            // element kind (0 bf16, 1 f16) "params_bf16" was packed for from the CURRENT parameter block; -1: repack.
+                                   // Reset wherever the block can change: sh_load_*, sh_param_block (the pointer goes to the caller), sh_param_block_commit
   int num_cus = 0;
   int timing = 0;      // 0 off, 1 every launch, 2 UNet layers only
   std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t>> pending;
@@ -663,6 +665,7 @@ int sh_buffer_device(sh_ctx* c, const char* name, void** dev_ptr, size_t* nbytes
   if (it == c->bufs.end() || !it->second.p) return fail(c, SH_ERR_ARG, std::string("no buffer named ") + name);
   *dev_ptr = it->second.p;
   if (nbytes) *nbytes = it->second.bytes;
+  if (std::string(name) == "params") c->packed_kind = -1;      // (the caller may write it)
   return SH_OK;
 }
 
@@ -684,6 +687,7 @@ int sh_store(sh_ctx* c, const char* name, const void* host, size_t nbytes) {
   if (nbytes > it->second.bytes) return fail(c, SH_ERR_ARG, std::string("sh_store: size exceeds buffer ") + name);
   HIPCHK(c, hipSetDevice(c->device));
   if (std::string(name) == "verts") { (void)join_prepared(c); ++c->batch_gen; c->h_verts_valid = false; }
+  if (std::string(name) == "params") c->packed_kind = -1;
   HIPCHK(c, hipMemcpyAsync(it->second.p, host, nbytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (std::string(name) == "obb_transform") c->obb_injected = true;
@@ -1110,7 +1114,8 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
   if ((rc = ensure(c, "params_bf16", c->unet_floats * 2, 2)) != SH_OK) return rc;
   const float* P = buf<float>(c, "params");
   u16* PW = buf<u16>(c, "params_bf16");
-  {     // repack the MFMA layers' weights (cheap; stays correct after a parameter broadcast): one launch for all layers
+  static const bool repack_always = getenv("SHOULDER_UNET_REPACK") && getenv("SHOULDER_UNET_REPACK")[0] == '1';
+  if (c->packed_kind != EK || repack_always) {     // pack the MFMA layers' weights for this element type: one launch for all layers, once per parameter block
     std::vector<PackEntry> tab;
     long long total = 0;
     for (auto& kv : c->ulayers) {
@@ -1126,6 +1131,7 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
       c->packtab_ready = true;
     }
     LAUNCH(c, "k_pack_w_bf16", k_pack_w16_all<EK>, dim3(2048), dim3(256), P, PW, (const PackEntry*)c->bufs["unet16.packtab"].p, (int)tab.size(), total);
+    c->packed_kind = EK;
   }
   if ((rc = ensure(c, "unet16.tickets", SH_UNET_TICKETS * 4, 4)) != SH_OK) return rc;
   if ((rc = ensure(c, "unet16.tk_tab", SH_UNET_TKTAB * 4, 4)) != SH_OK) return rc;
@@ -1913,6 +1919,7 @@ int sh_landmarks_device(sh_ctx* c, void** p, size_t* n) {
 
 // ---- parameters ------------------------------------------------------------------------------------
 static int upload_params(sh_ctx* c) {
+  c->packed_kind = -1;
   const size_t N = c->h_feat.size(), T = c->h_roots.size();
   const size_t bytes = c->unet_floats * 4 + N * 4 * 5 + T * 4;
   int rc = ensure(c, "params", bytes ? bytes : 16, 4);
@@ -2013,6 +2020,7 @@ int sh_load_unet(sh_ctx* c, int base, int depth, const float* packed, size_t n_f
 
 int sh_param_block_commit(sh_ctx* c) {
   if (!c) return SH_ERR_ARG;
+  c->packed_kind = -1;
   auto it = c->bufs.find("params");
   if (it == c->bufs.end()) return fail(c, SH_ERR_STATE, "sh_param_block_commit: no parameters loaded");
   HIPCHK(c, hipSetDevice(c->device));
@@ -2059,6 +2067,7 @@ int sh_param_block_commit(sh_ctx* c) {
 
 int sh_param_block(sh_ctx* c, void** p, size_t* n) {
   if (!c || !p || !n) return SH_ERR_ARG;
+  c->packed_kind = -1;      // the caller may write the block from here on (and confirms with sh_param_block_commit)
   auto it = c->bufs.find("params");
   if (it == c->bufs.end()) return fail(c, SH_ERR_STATE, "sh_param_block: no parameters loaded");
   *p = it->second.p;

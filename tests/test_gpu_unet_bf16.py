@@ -188,6 +188,45 @@ def test_fused_upconv_dec0a_matches_two_launches(engine, monkeypatch, name):
         engine.set_params(unet_dtype=_lib.UNET_F32)
 
 
+def test_packed_weights_follow_the_parameter_block(unet_weights):
+    """The 16-bit paths pack their conv weights once per parameter block: a second sh_load_unet, and a block written through
+    the device pointer + sh_param_block_commit, must both be seen by the next pass (no stale packed copy)."""
+    from shoulder_amd import unet_spec
+    from shoulder_amd.engine import Engine
+    rng = np.random.default_rng(23)
+    img = rng.random((2, 256, 512), dtype=np.float32)
+    e = Engine(0)
+    try:
+        e.load_rfc()
+        e.load_unet(unet_weights, unet_spec.BASE, unet_spec.DEPTH)
+        e.set_params(unet_dtype=_lib.UNET_BF16)
+        a = e.unet_infer(img)
+        w2 = {k: v.copy() for k, v in unet_weights.items()}
+        w2["dec0b_w"] = w2["dec0b_w"] * np.float32(0.5)      # an MFMA layer's weights: only the packed copy carries them
+        e.load_unet(w2, unet_spec.BASE, unet_spec.DEPTH)
+        b = e.unet_infer(img)
+        assert not np.array_equal(a, b)
+        f = Engine(0)
+        try:
+            f.load_rfc()
+            f.load_unet(w2, unet_spec.BASE, unet_spec.DEPTH)
+            f.set_params(unet_dtype=_lib.UNET_BF16)
+            np.testing.assert_array_equal(b, f.unet_infer(img))
+            # the first engine's block written over the second one's (what a broadcast does), then committed
+            f.load_unet(unet_weights, unet_spec.BASE, unet_spec.DEPTH)
+            f.unet_infer(img)
+            _, n = e.param_block()
+            _, n2 = f.param_block()
+            assert n == n2
+            f.store("params", e.fetch("params", np.uint8, (n,)))
+            f.param_block_commit()
+            np.testing.assert_array_equal(b, f.unet_infer(img))
+        finally:
+            f.close()
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("name", ["bf16", "f16"])
 def test_work_tickets_match_fixed_shares(engine, monkeypatch, name):
     """k_conv3_dma16 hands its items out in tickets from a global counter (which workgroup computes an item depends on the run);
