@@ -57,3 +57,22 @@ def test_rccl_leg_single_rank():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["meshes_with_error_status"] == 0
     assert d["gather_check"] == {"records": 8, "own_shard_equal_to_local_run": True}
     assert "f32_unet" not in d            # extra legs belong to the plain N=1 run
+
+
+def test_rccl_leg_as_one_of_eight_ranks():
+    """The same leg configured as a rank of an 8-GPU node sees itself (LOCAL_WORLD_SIZE=8: fewer than 48 hardware threads
+    per rank even on a 256-thread host): hull mode `auto` resolves to the device hull, bench.py then runs three lanes, nothing
+    goes through the host (`host_ms_per_step` = 0), stdout carries exactly one line, and the gathered records equal the
+    rank's own run."""
+    env = dict(os.environ, SH_BENCH_FORCE_DIST="1", LOCAL_WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578")
+    env.pop("SHOULDER_HULL", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "1", "--batch", "8",
+                          "--no-cpu-baseline", "--check-gather"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len([ln for ln in out.stdout.splitlines() if ln.strip()]) == 1, out.stdout[:500]
+    d = json.loads(out.stdout)
+    if (os.cpu_count() or 1) // 8 < 48:
+        assert d["config"]["hull"] == "device" and d["config"]["lanes"] == 3
+        assert d["host_ms_per_step"] == {"host.verts_d2h": 0.0, "host.hull": 0.0}
+    assert d["value"] > 0 and d["config"]["meshes_with_error_status"] == 0
+    assert d["gather_check"] == {"records": 8, "own_shard_equal_to_local_run": True}
