@@ -116,6 +116,9 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   __shared__ int s_q[2];
   const bool dyn = ticket != nullptr;
   if (dyn && tid == 0) { s_q[0] = (int)atomicAdd(ticket, 1u); s_q[1] = (int)atomicAdd(ticket, 1u); }
+#ifdef SH_DMA_PRIO_HALF
+  if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);      // experiment: static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
 #ifdef SH_DMA_PRIO
   __builtin_amdgcn_s_setprio(SH_DMA_PRIO);      // experiment: waves of another lane's kernels that share the SIMD lose the issue arbitration
 #endif
@@ -268,6 +271,14 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
           describe(0, buf ^ 1);
         } else { has_next = false; more = false; }
       } else { has_next = false; more = false; }
+#ifdef SH_DMA_UNCOND
+      // experiment: the pieces are issued unconditionally (no branch around each of them in the step body); without a next
+      // step they re-stage the current step's sources into the other buffer, which nobody reads
+      if (!has_next) n_lbase = smem + (buf ^ 1) * BUFB + wave * 1024;
+#define UD_HAS_NEXT true
+#else
+#define UD_HAS_NEXT has_next
+#endif
       const unsigned char* sb = smem + buf * BUFB;
       const unsigned char* xb[2][3];
 #pragma unroll
@@ -284,7 +295,7 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
         for (int m = 0; m < 4; ++m) { const int s = m + dy; xf[m] = *(const v8*)(xb[s & 1][dx] + (s & ~1) * UD_PW * 64); }
 #pragma unroll
         for (int n = 0; n < NN; ++n) wf[n] = *(const v8*)(wbp + (tap * WR + n * 16) * 64);
-        if (has_next) { if (tap < NPIECE) piece(tap); if (tap == 8 && NPIECE == 10) piece(9); }
+        if (UD_HAS_NEXT) { if (tap < NPIECE) piece(tap); if (tap == 8 && NPIECE == 10) piece(9); }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -305,7 +316,12 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
             if constexpr (WRES == 2) wf[n] = wreg[tap][n & 1];
             else wf[n] = *(const v8*)(wbp + (tap * WR + n * 16) * 64);
           }
-          if (has_next) { if (slot < NPIECE) piece(slot); if (slot == 8 && NPIECE == 10) piece(9); }
+#ifdef SH_DMA_EARLY
+          // experiment: two pieces per tap in the first taps of the step, so the last piece has half a step to land
+          if (UD_HAS_NEXT) { if (2 * slot < NPIECE) piece(2 * slot); if (2 * slot + 1 < NPIECE) piece(2 * slot + 1); }
+#else
+          if (UD_HAS_NEXT) { if (slot < NPIECE) piece(slot); if (slot == 8 && NPIECE == 10) piece(9); }
+#endif
 #pragma unroll
           for (int m = 0; m < 4; ++m)
 #pragma unroll
