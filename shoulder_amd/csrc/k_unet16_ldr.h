@@ -1,0 +1,308 @@
+// k_unet16_ldr.h -- 3x3 conv, 16-bit, 64-cout items: the persistent LDS-DMA conv of k_unet_bf16_dma.h with the two jobs of a
+// workgroup given to different waves.
+//
+// k_conv3_dma16 lets each of its 8 waves do both: 144 MFMAs of a step and 10 of the step's 80 LDS-DMA pieces, issued between
+// its MFMA groups.  Its counters (profiles/r02_pmc_sq_b64_bf16.json) say the matrix pipe idles 40 % of the cycles, and its
+// ablation builds price the pieces at 24-37 % of a layer: a `global_load_lds_dwordx4` holds the issuing wave for 100-185
+// cycles (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), 20 of them per SIMD and step beside 4 608 cycles of MFMA, and
+// the two waves of a SIMD run the same program in lockstep, so they issue their pieces -- and read their fragments -- at
+// the same moments.  Moving the pieces around inside the step changes nothing (round 3: SH_DMA_EARLY / _UNCOND / _PRIO_HALF).
+//
+// Here a workgroup is 4 COMPUTE waves + 4 LOADER waves (one of each per SIMD):
+//   compute wave (cw = 0..3): 8 rows x 16 pixels x 64 couts of the 32 x 16 tile = 128 accumulator registers, 288 MFMAs per
+//     step and nothing else but the fragment reads -- 66 `ds_read_b128` per step (per column offset dx: 10 pixel-row
+//     fragments that serve its three dy taps + 12 weight fragments) where the 8-wave form reads 2 x 54 for the same MFMAs;
+//     no vector-memory instruction except the epilogue stores, no vmcnt wait, no address arithmetic per step;
+//   loader wave (lw = 0..3): decodes the next step, issues ALL its LDS-DMA pieces (20, or 11 with resident weights) right
+//     after the step barrier, waits for them (vmcnt(0)) and joins the next barrier: a step's data has a whole step to land,
+//     and the wave is parked -- it takes no issue slot from the compute wave of its SIMD -- for most of it.
+// One raw s_barrier per step for the whole workgroup, as before.  Same LDS image (two 78 KB buffers: 18 x 36 halo rows +
+// 576 weight rows of 64 B, XOR slot swizzle on the DMA's source and on the read), same work items and tickets, same
+// channel dealing, same tap order (dx major) and chunk order per output element: results are bit-identical to
+// k_conv3_dma16 (tests/test_gpu_unet_bf16.py::test_loader_wave_conv_bit_identical).
+#pragma once
+#include "k_unet_bf16_dma.h"
+
+namespace sh {
+
+#define UL_NCW 4                          // compute waves; waves UL_NCW .. 7 load
+#define UL_LTHREADS 256                   // lanes of the loader half
+
+// FUSE: 0 or UF_POOL.  WRES: 0 = weights staged with every step; 1 = one cout group whose packed weights fit behind the two
+// input buffers (nchunk <= 2): loaded once per workgroup.
+template <int EK, int FUSE, int WRES>
+__global__ void __launch_bounds__(UD_THREADS)
+k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int C0, int C1,
+              const u16* __restrict__ wgt_, const float* __restrict__ bias, u16* __restrict__ dst_,
+              int H, int W, int Cout, int relu, int nimg, const u16* __restrict__ zero_page_, u16* __restrict__ pooled_,
+              unsigned* __restrict__ ticket /*zero at launch; nullptr: fixed equal shares*/, const int* __restrict__ tk_tab /*[ntk + 1] item bounds*/, int ntk) {
+  using ET = typename EKT<EK>::type;
+  const ET* src0 = (const ET*)src0_;
+  const ET* src1 = (const ET*)src1_;
+  const ET* wgt = (const ET*)wgt_;
+  ET* dst = (ET*)dst_;
+  const ET* zero_page = (const ET*)zero_page_;
+  ET* pooled = (ET*)pooled_;
+  using v8 = typename E16<ET>::v8;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[UD_SMEM];
+  __shared__ int s_q[2];
+  constexpr int WR = 64;                                               // weight rows per tap
+  constexpr int SLOTS = WRES ? UD_INROWS * 4 : UD_SLOTS;               // 16-byte slots of a step: 2592 / 4896
+  constexpr int NPIECE = (SLOTS + UL_LTHREADS - 1) / UL_LTHREADS;      // 11 / 20 pieces per loader wave and step
+  constexpr int NHALO = (UD_INROWS * 4 + UL_LTHREADS - 1) / UL_LTHREADS;      // 11: pieces 0..10 carry halo rows (10: the last 8 rows)
+  constexpr int BUFB = WRES ? UD_INROWS * 64 : UD_BUF;
+  constexpr int WRES_OFF = 2 * UD_INROWS * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loader = wave >= UL_NCW;
+  const int li = lane & 15, lk = lane >> 4;
+  const int Cin = C0 + C1, nchunk = Cin >> 5;
+  const int tiles_x = W / 32, tiles_y = H / 16, ngroups = Cout / WR;
+  const int total = nimg * tiles_x * tiles_y * ngroups;
+  const bool dyn = ticket != nullptr;
+  if (dyn && tid == UL_LTHREADS) { s_q[0] = (int)atomicAdd(ticket, 1u); s_q[1] = (int)atomicAdd(ticket, 1u); }
+
+  float* s_bias = (float*)(smem + UD_BIAS_OFF);
+  for (int i = tid; i < Cout; i += UD_THREADS) s_bias[i] = bias[i];
+  if constexpr (WRES != 0) {
+    // LDS row (chunk, tap, 16 n + i) <- packed row (tap, chunk, channel 16 (i >> 2) + 4 n + (i & 3)); the 16-byte slot swizzle on the source
+    const int nrows = nchunk * 9 * WR;
+    for (int e = tid; e < nrows * 4; e += UD_THREADS) {
+      const int row = e >> 2, q = e & 3;
+      const int cc = row / (9 * WR), rem = row - cc * 9 * WR, tap = rem >> 6, j = rem & (WR - 1);
+      const int ch = 16 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);
+      *(u32x4*)(smem + WRES_OFF + e * 16) = *(const u32x4*)(wgt + (size_t)((tap * nchunk + cc) * Cout + ch) * 32 + ((q ^ ((row >> 1) & 2)) << 3));
+    }
+  }
+  __syncthreads();       // every ordinary load is retired before the first LDS-DMA is issued
+  int qk = 1;
+  int w_begin, w_end;
+  if (dyn) {
+    const int t0 = __builtin_amdgcn_readfirstlane(s_q[0]);
+    if (t0 >= ntk) return;
+    w_begin = tk_tab[t0]; w_end = tk_tab[t0 + 1];
+  } else {
+    const int per = (total + gridDim.x - 1) / gridDim.x;
+    w_begin = blockIdx.x * per; w_end = min(total, w_begin + per);
+    if (w_begin >= w_end) return;
+  }
+
+  // ---- loader lanes: staging plan.  Slot e_k = ltid + 256 k -> LDS row r_k = (ltid >> 2) + 64 k; rows < 648 are halo pixels
+  // (row = py * 36 + px), rows 648 + 64 tap + j weight row j of tap `tap`.  The swizzle bit (bit 2 of the row) is the same
+  // for every k.
+  const int ltid = tid - UL_LTHREADS, lw = wave - UL_NCW;
+  const int r0 = (ltid >> 2) & 63;
+  const int q8 = ((ltid & 3) ^ ((r0 >> 1) & 2)) * 8;
+  int hpy[NHALO], hpx[NHALO];                                       // halo pixel of piece k (px >= 34: padding column)
+#pragma unroll
+  for (int k = 0; k < NHALO; ++k) { const int r = r0 + 64 * k; hpy[k] = r / UD_PW; hpx[k] = r - hpy[k] * UD_PW; }
+  // weight rows: lanes r0 >= 8 hold row j = r0 - 8 of tap k - 10 in piece k, lanes r0 < 8 row j = r0 + 56 of tap k - 11
+  const bool wlow = r0 < 8;                                          // (these lanes carry the last 8 halo rows in piece 10)
+  const int wj = wlow ? r0 + 56 : r0 - 8;
+  const int wch = 16 * ((wj & 15) >> 2) + 4 * (wj >> 4) + (wj & 3);
+  const int wtap_stride = nchunk * Cout * 32;                        // elements between two taps of the packed weights
+  const int wlane = (wlow ? -11 : -10) * wtap_stride + wch * 32 + q8;
+
+  int i_g, i_tx, i_ty, i_img;      // item being staged
+  auto decode = [&](int w) {
+    i_g = w % ngroups; w /= ngroups;
+    i_tx = w % tiles_x; w /= tiles_x;
+    i_ty = w % tiles_y; i_img = w / tiles_y;
+  };
+  decode(w_begin);
+  int pixoff[NHALO];
+  auto item_lane_setup = [&]() {
+#pragma unroll
+    for (int k = 0; k < NHALO; ++k) {
+      const int gx = i_tx * 32 + hpx[k] - 1, gy = i_ty * 16 + hpy[k] - 1;
+      const bool ok = hpx[k] < 34 && gx >= 0 && gx < W && gy >= 0 && gy < H;
+      pixoff[k] = ok ? gy * W + gx : -1;
+    }
+  };
+  auto stage = [&](int cc, int buf) {      // all pieces of step (current item, chunk cc) -> buffer buf; loader waves only
+    const int c0 = cc * 32;
+    const bool first = c0 < C0;
+    const int Cs = first ? C0 : C1;
+    const int cb = ((first ? c0 : c0 - C0) >> 5) * (H * W);      // pixel offset of this chunk's 32-channel plane (channel-blocked activations)
+    const ET* simg = (first ? src0 : src1) + (size_t)i_img * H * W * Cs;
+    const ET* wbase = wgt + ((size_t)cc * Cout + i_g * WR) * 32;
+    unsigned char* lbase = smem + buf * BUFB + lw * 1024;
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) {
+      if (k < NHALO - 1) {
+        const ET* p = pixoff[k] >= 0 ? simg + (unsigned)((cb + pixoff[k]) * 32 + q8) : zero_page;
+        __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(lbase + k * 4096), 16, 0, 0);
+      } else if (k == NHALO - 1) {      // rows 640..703: 8 halo rows, then the first 56 weight rows
+        const ET* pi = pixoff[k] >= 0 ? simg + (unsigned)((cb + pixoff[k]) * 32 + q8) : zero_page;
+        if constexpr (WRES != 0) {
+          if (wlow) __builtin_amdgcn_global_load_lds((ud_gptr)pi, (ud_lptr)(lbase + k * 4096), 16, 0, 0);
+        } else {
+          const ET* p = wlow ? pi : wbase + (wlane + k * wtap_stride);
+          __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(lbase + k * 4096), 16, 0, 0);
+        }
+      } else if (k < NPIECE - 1) {
+        __builtin_amdgcn_global_load_lds((ud_gptr)(wbase + (wlane + k * wtap_stride)), (ud_lptr)(lbase + k * 4096), 16, 0, 0);
+      } else {                          // the last piece: rows 1216..1223 only (tap 8, rows 56..63)
+        if (wlow) __builtin_amdgcn_global_load_lds((ud_gptr)(wbase + (wlane + k * wtap_stride)), (ud_lptr)(lbase + k * 4096), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- compute lanes: fragment read offsets (bytes inside a buffer)
+  const int xh = wave & 1, rg8 = (wave >> 1) & 1;
+  int xoff[2][3], woff;
+  {
+    const int rowbase = rg8 * 8 * UD_PW + xh * 16 + li;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) xoff[sp][dx] = UB_OFF(rowbase + sp * UD_PW + dx, lk) * 2;
+    woff = UB_OFF(UD_INROWS + li, lk) * 2;
+  }
+
+  if (loader) {
+    item_lane_setup();
+    stage(0, 0);
+  }
+#ifdef UL_PRIO
+  else __builtin_amdgcn_s_setprio(UL_PRIO);      // experiment: the compute wave wins the issue arbitration against its SIMD's loader wave
+#endif
+  int buf = 0;
+  for (int w = w_begin;;) {
+    bool more = true;
+    const int c_x0 = i_tx * 32, c_y0 = i_ty * 16, c_img = i_img, c_n0 = i_g * WR;
+    f32x4 acc[8][4];
+    if (!loader) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const f32x4 bv = *(const f32x4*)(s_bias + c_n0 + 16 * lk + 4 * n);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m][n] = bv;
+      }
+    }
+    for (int cc = 0; cc < nchunk; ++cc) {
+      if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the step have landed
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();      // every loader's pieces have landed; every compute wave is done reading the other buffer
+      // the step after this one (every wave keeps the walk: the compute waves need the item's coordinates for their epilogue)
+      int n_cc = cc + 1;
+      bool has_next = true, new_item = false;
+      if (n_cc < nchunk) {
+      } else if (w + 1 < w_end) {
+        ++w;
+        if (++i_g == ngroups) { i_g = 0; if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; ++i_img; } } }
+        n_cc = 0; new_item = true;
+      } else if (dyn) {      // next ticket: its id was written before this step's barrier; the slot it frees is refilled for the one after
+        const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);
+        if (nt < ntk) {
+          if (tid == UL_LTHREADS) s_q[qk ^ 1] = (int)atomicAdd(ticket, 1u);
+          qk ^= 1;
+          w = tk_tab[nt]; w_end = tk_tab[nt + 1];
+          decode(w);
+          n_cc = 0; new_item = true;
+        } else { has_next = false; more = false; }
+      } else { has_next = false; more = false; }
+      if (loader) {
+#if !(defined(UL_ABL) && (UL_ABL == 1 || UL_ABL == 4))      // ablation 1 (wrong results): no DMA at all -> what the compute waves need on their own
+        if (has_next) {
+          if (new_item) item_lane_setup();
+          stage(n_cc, buf ^ 1);
+        }
+#endif
+      } else {
+#if defined(UL_ABL) && UL_ABL == 2      // ablation 2 (wrong results): no fragment reads, no MFMAs -> what staging alone takes
+        asm volatile("" :: "v"(acc[0][0]));
+        if (false)
+#endif
+        {
+        const unsigned char* sb = smem + buf * BUFB;
+        const unsigned char* wbp = WRES ? smem + WRES_OFF + cc * 9 * WR * 64 + (woff - UD_INROWS * 64) : sb + woff;
+#if defined(UL_ABL) && (UL_ABL == 3 || UL_ABL == 4)      // ablation 3 (wrong results): the 288 MFMAs of a step on fragments read once -> the bare matrix stream + barrier
+        {
+          v8 xq[10], wf[4];
+#pragma unroll
+          for (int s = 0; s < 10; ++s) xq[s] = *(const v8*)(sb + xoff[s & 1][0] + (s & ~1) * UD_PW * 64);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) wf[n] = *(const v8*)(wbp + (n * 16) * 64);
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+              for (int n = 0; n < 4; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xq[m + t % 3], acc[m][n]);
+        }
+#else
+        // compiler-scheduled form: per column offset the 10 pixel rows, per tap the 4 weight fragments
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          v8 xq[10];
+#pragma unroll
+          for (int s = 0; s < 10; ++s) xq[s] = *(const v8*)(sb + xoff[s & 1][dx] + (s & ~1) * UD_PW * 64);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int tap = dy * 3 + dx;
+            v8 wf[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) wf[n] = *(const v8*)(wbp + (tap * WR + n * 16) * 64);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+              for (int n = 0; n < 4; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xq[m + dy], acc[m][n]);
+          }
+        }
+#endif
+        }
+      }
+      buf ^= 1;
+    }
+    if (!loader) {
+      // channel-blocked output: channel c_n0 + 16 lk + 8 h of pixel (gy, gx) is element ((c >> 5) HW + pix) 32 + (c & 31); one
+      // uniform 64-bit base per item and one 32-bit lane offset, the rest of every address is a constant
+      const unsigned HW = (unsigned)(H * W);
+      ET* ob = dst + ((size_t)c_img * Cout + c_n0) * HW;
+      const unsigned lo = (((unsigned)(lk >> 1) * HW + (unsigned)((c_y0 + rg8 * 8) * W + c_x0 + xh * 16 + li)) << 5) + 16u * (lk & 1);
+      ET* pb = pooled;
+      unsigned plo = 0;
+      if (FUSE & UF_POOL) {
+        pb = pooled + ((size_t)c_img * Cout + c_n0) * (HW >> 2);
+        plo = (((unsigned)(lk >> 1) * (HW >> 2) + (unsigned)(((c_y0 + rg8 * 8) >> 1) * (W >> 1) + ((c_x0 + xh * 16 + li) >> 1))) << 5) + 16u * (lk & 1);
+      }
+#pragma unroll
+      for (int mp = 0; mp < 4; ++mp)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          v8 oa, ob8, op;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            float va = acc[2 * mp][2 * h + (r >> 2)][r & 3], vb = acc[2 * mp + 1][2 * h + (r >> 2)][r & 3];
+            if (relu) { va = fmaxf(va, 0.0f); vb = fmaxf(vb, 0.0f); }
+            oa[r] = (ET)va; ob8[r] = (ET)vb;
+            if (FUSE & UF_POOL) {      // (rounding to ET and the ReLU are monotonic: the same value as pooling first)
+              float vp = fmaxf(va, vb);
+              vp = fmaxf(vp, __shfl_xor(vp, 1));
+              op[r] = (ET)vp;
+            }
+          }
+          *(v8*)(ob + (lo + (unsigned)((2 * mp) * W * 32 + 8 * h))) = oa;
+          *(v8*)(ob + (lo + (unsigned)((2 * mp + 1) * W * 32 + 8 * h))) = ob8;
+          if (FUSE & UF_POOL) {
+            if (!(li & 1)) *(v8*)(pb + (plo + (unsigned)(mp * (W >> 1) * 32 + 8 * h))) = op;
+          }
+        }
+    }
+    if (!more) break;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// NOT kept (round 3, measured at B = 64, 512 x 512, bf16; layer dec0b + head = k_conv3_dma16<.., UF_HEAD, 2, 1, 2>, 0.46 ms):
+// the same role split for the 32 -> 32 layer with the fused head, in three forms, each bit-identical to the 8-wave kernel:
+//   two halo buffers, epilogue in the compute wave                                      0.45 ms (without its MFMAs: 0.25)
+//   epilogue handed to the loader waves through a 64 KB LDS exchange area               0.48 ms (one tile's staging in flight)
+//   three halo buffers + weights in LDS, the epilogue of tile i - 1 spread behind the
+//   taps of tile i in the compute wave (two accumulator sets)                           0.48 ms (without epilogue 0.30,
+//                                                                                        without MFMAs 0.23 = the HBM time)
+// A tile of this layer is 144 MFMAs per compute wave and an epilogue of ~200 vector instructions; one wave per SIMD cannot
+// overlap the two, and the 8-wave kernel's second wave per SIMD does exactly that.  The layer stays on k_conv3_dma16.
+
+}  // namespace sh

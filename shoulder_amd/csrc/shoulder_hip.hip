@@ -20,6 +20,7 @@
 #include "k_unet.h"
 #include "k_unet_bf16.h"
 #include "k_unet_bf16_dma.h"
+#include "k_unet16_ldr.h"
 #include "k_unet16_l0.h"
 #include "k_unet16_dec0.h"
 #include "k_stl.h"
@@ -1073,7 +1074,15 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     else if (sched == 0) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 0, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                 \
     else { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                                 \
   } while (0)
-    if (dma64) {
+    // 64-cout items: compute waves + loader waves (k_unet16_ldr.h); SHOULDER_DMA_LDR=0 keeps the form where every wave does both
+    const bool ldr = dma64 && sched == 1 && !(getenv("SHOULDER_DMA_LDR") && getenv("SHOULDER_DMA_LDR")[0] == '0');
+    if (ldr) {
+      u16* pl = fuse == UF_POOL ? (u16*)fz.pooled : (u16*)nullptr;
+      if (fuse == UF_POOL && wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
+      else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
+      else if (wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
+      else { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
+    } else if (dma64) {
       if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
       else DMA_LAUNCH(0, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
     } else if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk);

@@ -250,6 +250,31 @@ def test_work_tickets_match_fixed_shares(engine, monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_loader_wave_conv_bit_identical(engine, monkeypatch, name):
+    """k_conv3_ldr16 (k_unet16_ldr.h: 4 compute waves + 4 loader waves per workgroup) against k_conv3_dma16 (every wave stages
+    and multiplies): same chunk and tap order per output element -> the same tensors bit for bit, with tickets and with fixed
+    shares, at both image sizes, run after run (the hand-off is one barrier per step: a race would show as a changing result)."""
+    rng = np.random.default_rng(23)
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        for H, W, n in ((256, 512, 3), (512, 512, 5)):
+            img = rng.random((n, H, W), dtype=np.float32)
+            monkeypatch.setenv("SHOULDER_DMA_LDR", "0")
+            a = engine.unet_infer(img)
+            sa = [engine.fetch(f"unet16.skip{i}", np.uint16).copy() for i in (0, 1, 2, 3)]
+            monkeypatch.setenv("SHOULDER_DMA_LDR", "1")
+            for tickets in ("1", "0", "1"):
+                monkeypatch.setenv("SHOULDER_DMA_TICKETS", tickets)
+                b = engine.unet_infer(img)
+                sb = [engine.fetch(f"unet16.skip{i}", np.uint16).copy() for i in (0, 1, 2, 3)]
+                assert np.array_equal(a, b) and all(np.array_equal(x, y) for x, y in zip(sa, sb))
+    finally:
+        monkeypatch.delenv("SHOULDER_DMA_LDR", raising=False)
+        monkeypatch.delenv("SHOULDER_DMA_TICKETS", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
 def test_row_upconv_matches_per_phase_kernel(engine, monkeypatch, name):
     """k_upconv16 (16x16 source tile x 32 channels x both column phases of a row parity per workgroup: full output lines per
     wave) sums every output in the order of the per-phase two-barrier kernel: logits and a decoder tensor are bit-identical."""
