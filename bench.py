@@ -36,7 +36,7 @@ PEAK_MFMA_F32_TF = 157.3       # dense f32 MFMA (= vector rate)
 PEAK_MFMA_BF16_TF = 2500.0
 
 GEOM_KERNELS = ["k_hull_rounds", "k_hull_flag", "k_apply_csys", "k_obb_face_area2", "k_obb_bounds", "k_obb_select", "k_obb_seed", "k_obb_candidates", "k_obb_pick", "k_obb_end_points", "k_obb_ends", "k_transform_verts", "k_make_planes",
-                "k_slice_emit", "k_slice_link", "k_resample_polar", "k_neck", "k_canal", "k_groove_rows", "k_groove_scale",
+                "k_slice_emit", "k_slice_link", "k_slice_link_large", "k_resample_polar", "k_resample_polar_large", "k_te_rows_large", "k_rfc_pack", "k_obb_seed", "k_neck", "k_canal", "k_groove_rows", "k_groove_scale",
                 "k_groove_rfc", "k_groove_kde", "k_groove_localmin", "k_groove_axis", "k_anp_rows", "k_anp_minmax", "k_anp_edge_count", "k_anp_edges",
                 "k_anp_plane", "k_rays_hit", "k_rays", "k_te_rows", "k_te_final", "k_pack", "k_metrics", "k_sphere_partial", "k_anp_scale", "k_init_bounds",
                 "k_decode_bounds", "k_section_points"]
@@ -93,24 +93,64 @@ def unet_cins(base, depth):
 
 
 def geom_bytes(B, V, F):
-    """Algorithmic HBM bytes per launch of the geometry kernels (one launch = whole batch)."""
+    """Per STEP (all launches of a kernel name in one SH_STAGE_ALL pass over B humeri): name -> (algorithmic bytes in this
+    implementation's layout -- f64 geometry, 32-byte segments --, SURVEY 8(d) bytes for the same work in the survey's f32
+    layout or None where the survey names no figure).  Plane sets per step: full 200, distal 200, proximal 600, neck contour 1;
+    ~145 crossing segments per plane (28.5 k + 28.5 k + 88 k segments per humerus)."""
+    s_full, s_dist, s_prox, s_neck = 28471.0, 28500.0, 88100.0, 150.0
+    S = s_full + s_dist + s_prox + s_neck
     seg = 32
-    n_planes = {"full": 200, "distal": 200, "prox": 600}
-    s_per_plane = 145.0     # mean crossing triangles per plane (SURVEY App. D)
     return {
-        "k_transform_verts": B * V * (12 + 24),
-        "k_slice_emit": B * (24 * V + 12 * F) ,          # + segments, accounted on the link side
-        "k_slice_link": B * 600 * s_per_plane * seg + B * 600 * (s_per_plane * 16),
-        "k_resample_polar": B * 600 * (s_per_plane * 16 + 3 * 2 * 512 * 8),
-        "k_groove_rows": B * 330 * (2 * 512 * 8 + 512 * 8),
-        "k_anp_rows": B * 512 * (2 * 512 * 8 + 2 * 512 * 8),
-        "k_anp_minmax": B * 512 * 512 * (8 + 4),
-        "k_anp_edges": B * 512 * 512 * 4,
-        "k_rays_hit": B * (24 * V + 12 * F),      # every triangle once for the four rays
-        "k_obb_bounds": B * (1368 * 24 + 2732 * 32),                     # the hull record once (vertices, normals, areas): compute bound, listed for completeness
-        "k_obb_candidates": B * (1368 * 24 + 2732 * 24 + 4098 * 16),
+        "k_transform_verts": (B * V * (12 + 24), B * 2 * 12 * V),
+        # four passes over the mesh (one per plane set) + the segments written (read back by the link kernels)
+        "k_slice_emit": (B * (4 * (24 * V + 12 * F) + seg * S), B * (3 * (12 * V + 12 * F) + 16 * S)),
+        # segments read; closed rings written for the distal / proximal / neck sets
+        "k_slice_link": (B * (seg * S + 16 * (s_dist + s_prox + s_neck)), B * 16 * S),
+        "k_slice_link_large": (0, None),
+        # proximal rings read, resampled contour + two polar images written (3 x 2 x 512 f64 per plane)
+        "k_resample_polar": (B * (16 * s_prox + 600 * 3 * 2 * 512 * 8), B * (600 * 512 * 2 * 4 * 3)),
+        "k_resample_polar_large": (0, None),
+        "k_groove_rows": (B * 330 * (2 * 512 * 8 + 512 * 8), B * 330 * 2 * 512 * 4),
+        "k_anp_rows": (B * 512 * (2 * 512 * 8 + 2 * 512 * 8), B * 512 * 2 * 512 * 4 * 2),
+        "k_anp_minmax": (B * 512 * 512 * 8, None),
+        "k_anp_scale": (B * 512 * 512 * (8 + 4), B * 512 * 512 * 4),
+        "k_anp_edge_count": (B * 512 * 512 * 4, None),
+        "k_anp_edges": (B * 512 * 512 * 4, B * 512 * 512 * 4),
+        "k_sphere_partial": (B * 512 * 512 * 4, None),
+        "k_rays_hit": (B * (24 * V + 12 * F), B * (12 * V + 12 * F)),      # every triangle once for the four rays
+        "k_apply_csys": (B * V * (12 + 24), B * 2 * 12 * V),
+        "k_obb_end_points": (B * (12 * V + 12 * F), None),
+        "k_obb_bounds": (B * (1368 * 24 + 2732 * 32), None),            # the hull record once: compute bound, listed for completeness
+        "k_obb_candidates": (B * (1368 * 24 + 2732 * 24 + 4098 * 16), None),
+        "k_te_rows": (B * 37 * 300 * 16, None),
+        "k_te_rows_large": (0, None),
     }
 
+
+# kernel (timer) name -> stage of the hot path (DESIGN.md 1), for the per-stage device times of the single-humerus leg
+def stage_of(name):
+    if name.startswith("unet.") or name in ("k_pack_w_bf16",):
+        return "anatomic_neck.unet"
+    for pfx, st in (("k_hull", "obb"), ("k_obb", "obb"), ("host.", "obb.host"), ("k_transform_verts", "slices"), ("k_make_planes", "slices"),
+                    ("k_init_bounds", "slices"), ("k_decode_bounds", "slices"), ("k_slice", "slices"), ("k_resample", "slices"),
+                    ("k_neck", "surgical_neck"), ("k_canal", "canal"), ("k_groove", "bicipital_groove"), ("k_rfc", "bicipital_groove"),
+                    ("k_anp", "anatomic_neck.geometry"), ("k_rays", "anatomic_neck.geometry"), ("k_te", "trans_epicondylar"),
+                    ("k_pack", "csys"), ("k_metrics", "csys"), ("k_sphere", "csys"), ("k_apply", "csys"), ("k_section", "csys")):
+        if name.startswith(pfx):
+            return st
+    return "other"
+
+
+# what the test suite asserts for the UNet arithmetic of a leg (tests/test_gpu_end_to_end.py::test_full_size_batch_equivariance
+# on this bench's own batch, test_gpu_landmarks.py on the fixtures): every landmark that does not read the mask is within
+# 1e-4 mm of the oracle in all three; the anatomic-neck landmarks move by single mask pixels on the 16-bit paths
+PARITY_NOTE = {
+    "f32": "every landmark within 1e-4 mm of the oracle, integer decisions equal, f32 logits bit-exact (north-star tolerance met)",
+    "bf16": "mask-independent landmarks (OBB, canal, groove, TE, csys) within 1e-4 mm of the oracle; anatomic-neck landmarks within the bf16 "
+            "bound asserted on this batch: plane point 0.3 mm, axis ends 1.5 mm, edge-point count +-60 (1e-4 mm is met by the f32_unet leg)",
+    "f16": "mask-independent landmarks within 1e-4 mm of the oracle; anatomic-neck landmarks within the f16 bound asserted on this batch: "
+           "plane point 0.06 mm, axis ends 0.4 mm, edge-point count +-12",
+}
 
 UNET_ENUM = {"f32": 0, "bf16": 1, "f16": 2}
 
@@ -170,7 +210,59 @@ def hull_threads(world_local):
     """The worker pool of the host hull phase (HullPool, shoulder_hip.hip), one per process shared by its lanes: hardware threads / LOCAL_WORLD_SIZE, at most 32."""
     if os.environ.get("SHOULDER_HULL_THREADS"):
         return int(os.environ["SHOULDER_HULL_THREADS"])
-    return max(1, min(32, (os.cpu_count() or 1) // max(1, world_local)))
+    return max(1, min(32, len(os.sched_getaffinity(0)) // max(1, world_local)))
+
+
+def launch_ranks(n, argv, worker=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N rank processes of one node
+    ourselves -- fresh children, one per GPU, with the environment torch.distributed.run would give them (RANK, LOCAL_RANK,
+    WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT) -- BEFORE anything in this process touches
+    the GPU (this process never does: it only waits).  Rank 0's stdout is forwarded as it is (the one JSON line); the other
+    ranks' stdout goes to stderr.  Returns the exit code: 0 if every rank ended with 0, else the first non-zero one (the
+    remaining ranks are terminated, so a failed rank does not leave the others waiting in a collective)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "SH_BENCH_SELF_LAUNCHED": "1"})
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    rc = 0
+    t_end = None if timeout is None else time.time() + timeout
+    out0 = None
+    import threading
+    buf = []
+    th = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)      # (a full pipe must not block rank 0)
+    th.start()
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c
+                    print(f"bench.py: rank {r} ended with exit code {c}; stopping the other ranks", file=sys.stderr)
+                    for q in live:
+                        procs[q].terminate()
+        if t_end is not None and time.time() > t_end and live:
+            rc = rc or 124
+            for q in live:
+                procs[q].kill()
+        time.sleep(0.05)
+    th.join(timeout=10)
+    out0 = buf[0] if buf else b""
+    if rc == 0:
+        sys.stdout.write(out0.decode(errors="replace"))
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(out0.decode(errors="replace"))
+    return rc
 
 
 def main():
@@ -198,6 +290,10 @@ def main():
     ap.add_argument("--check-gather", action="store_true", help="after the timed region rank 0 compares the records the last gather delivered for its own shard with a run of its own engine")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torch.distributed.run: this process becomes the launcher of its own N ranks and never initialises the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,8 +305,8 @@ def main():
     import torch
     # SH_BENCH_FORCE_DIST=1 exercises the collective code path with a single rank (1-GPU rehearsal)
     use_dist = world > 1 or os.environ.get("SH_BENCH_FORCE_DIST") == "1"
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}: measuring {world} rank(s)", file=sys.stderr)
 
     from shoulder_amd import _lib, synth, unet_spec
     from shoulder_amd import dist as shd
@@ -457,6 +553,7 @@ def main():
                                     "records_equal_to_host_hull_run": bool(same)}
             for e in dev_engs:
                 e.close()
+        extra["single_humerus_f32"] = single_humerus_leg(local, weights, verts, faces)
         if lanes > 1:
             el1, _, _ = run_leg(engs[:1], args.unet, args.steps, 1, pipelined)
             extra["one_lane"] = {"value": round(B * args.steps / el1, 3), "unit": "meshes/s", "steps": args.steps, "warmup": 1,
@@ -487,7 +584,7 @@ def main():
                 g["flops"] += ul[name][0] * B * n
                 g["bytes"] += ul[name][1] * B * n
             else:
-                g["bytes"] += gb.get(name, 0) * n
+                g["bytes"] += gb.get(name, (0, None))[0] * (n / max(1, extra_times.get(name, (0, 1))[1]))      # (per-step bytes x steps)
         dom = max(sym, key=lambda k: sym[k]["ms"]) if sym else None
         roof = None
         if dom:
@@ -532,13 +629,30 @@ def main():
         unet_ms = sum(times[k][0] for k in times if k.startswith("unet."))
         unet_tf = sum(v[0] for v in ul.values()) * B / (unet_ms * 1e-3) / 1e12 if unet_ms else None
         top = sorted(((k, round(v["ms"] / args.steps, 3)) for k, v in sym.items()), key=lambda kv: -kv[1])[:10]
-        # per-kernel table of the geometry stage: algorithmic bytes (geom_bytes) / average duration vs the 8 TB/s roof
+        # Per-kernel table of the geometry stage, per STEP: every launch of a kernel name in one step (the four plane sets go
+        # through k_slice_emit / k_slice_link, the large-capacity instantiations have names of their own) -> time per step,
+        # this implementation's algorithmic bytes for exactly those launches, SURVEY 8(d)'s bytes where it names them, and the
+        # memory-side bytes rocprofv3 counted for the same kernel (profiles/, null without a matching profile).
+        pmc_geom = {}
+        for rnd in ("r03", "r02"):
+            pth = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b{B}_{args.unet}.json")
+            if os.path.exists(pth):
+                pmc_geom = json.load(open(pth))["kernels"]
+                break
         geom_tab = {}
         for name, (ms, n) in extra_times.items():
-            if n and name in gb and ms > 0:
-                gbs = gb[name] / (ms * 1e-3) / 1e9
-                geom_tab[name] = {"avg_ms": round(ms, 4), "algorithmic_mb": round(gb[name] / 1e6, 2), "gb_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4)}
-
+            if n and ms > 0 and name in gb and gb[name][0] > 0:
+                per_step = ms * n
+                gbs = gb[name][0] / (per_step * 1e-3) / 1e9
+                row = {"ms_per_step": round(per_step, 4), "launches_per_step": n, "algorithmic_mb_per_step": round(gb[name][0] / 1e6, 2),
+                       "gb_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4)}
+                if gb[name][1]:
+                    row["survey_mb_per_step"] = round(gb[name][1] / 1e6, 2)
+                    row["frac_of_hbm_peak_survey_bytes"] = round(gb[name][1] / (per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                pk = pmc_geom.get("sh::" + name)
+                row["pmc_mb_per_step"] = round(pk["hbm_bytes_per_launch"] * pk.get("launches_per_step", n) / 1e6, 2) if pk and "hbm_bytes_per_launch" in pk else None
+                geom_tab[name] = row
+        geom_ms = sum(ms * n for name, (ms, n) in extra_times.items() if n and not name.startswith("unet.") and name not in ("k_synth_batch", "k_pack_w_bf16"))
         value = world * B * args.steps / el
         out = {"metric": "humerus meshes/s end-to-end (all 4 landmarks)", "value": round(value, 3), "unit": "meshes/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True,
@@ -550,18 +664,75 @@ def main():
                           "lanes": lanes, "hull": eng.hull_mode, "hull_threads_per_process": hull_threads(int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), "host": host_info(),
                           "schedule": ((f"{lanes} engine contexts per GPU, step s on lane s % {lanes}, their streams overlap on the device (sh_submit / sh_collect); " if lanes > 1 else "two steps in flight (sh_submit / sh_collect); ") if pipelined else "") + ("host hulls of step k+1 overlap the device work of step k; pipeline filled and drained inside the timed region" if overlap else "serial hulls"),
                           "meshes_with_error_status": n_bad},
+               "parity": PARITY_NOTE[args.unet],
                "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)
         if gather_check is not None:
             out["gather_check"] = gather_check
         out.update({"unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top,
                     "device_ms_per_step_total": round(total_dev / args.steps, 3), "host_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()},
-                    "geometry_kernels": geom_tab})
+                    "geometry_ms_per_step_one_lane": round(geom_ms, 3), "geometry_kernels": geom_tab})
         print(json.dumps(out))
     for e in engs:
         e.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def single_humerus_leg(device, weights, verts, faces, reps=10):
+    """BASELINE configs[1]: ONE humerus (tests/golden/bones/humerus_left.stl), full landmark set, f32 UNet -- latency, not
+    throughput.  (a) `Engine.run(STAGE_ALL)` on the resident mesh: wall ms per humerus (median of `reps`, each run waited for),
+    with the device time per stage from HIP events around every launch of one extra run; (b) the reference README's flow through
+    the facade (bone.py:110-157): `Humerus(stl)` -> `apply_csys_canal_transepiconylar()` -> the four accessors, from the file on
+    disk, wall ms (median)."""
+    from shoulder_amd import _lib, bone, unet_spec
+    from shoulder_amd.engine import Engine
+    e = Engine(device)
+    e.load_rfc()
+    e.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
+    e.set_params(unet_dtype=_lib.UNET_F32)
+    e.upload([(verts, faces)])
+    for _ in range(2):
+        e.run(_lib.STAGE_ALL)
+    walls = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        lm = e.run(_lib.STAGE_ALL)
+        walls.append(1e3 * (time.perf_counter() - t0))
+    e.enable_timing(1)
+    e.reset_timers()
+    e.run(_lib.STAGE_ALL)
+    stages = {}
+    for name in GEOM_KERNELS + list(unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512)) + ["unet.pool", "host.hull", "host.verts_d2h"]:
+        ms, n = e.kernel_time_ms(name)
+        if n:
+            st = stage_of(name)
+            stages[st] = stages.get(st, 0.0) + ms * n
+    e.enable_timing(0)
+    ok = int(lm["status"][0]) == 0
+    e.close()
+    # the facade on its process-wide default engine (created here with the same parameters)
+    import warnings
+    stl = os.path.join(ROOT, "tests", "golden", "bones", "humerus_left.stl")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        de = bone.default_engine(device, unet_weights=weights)
+    de.set_params(unet_dtype=_lib.UNET_F32)
+    fw = []
+    for i in range(1 + max(3, reps // 2)):
+        t0 = time.perf_counter()
+        h = bone.Humerus(stl)
+        h.apply_csys_canal_transepiconylar()
+        got = (h.canal.axis(), h.trans_epiconylar.axis(), h.anatomic_neck.points(), h.bicipital_groove.axis())
+        if i:                                               # (the first pass allocates the engine's scratch)
+            fw.append(1e3 * (time.perf_counter() - t0))
+    med = lambda a: float(sorted(a)[len(a) // 2])
+    return {"workload": "BASELINE configs[1]: single humerus (humerus_left.stl, 16 222 vertices), full landmark set, f32 UNet, 1 GPU",
+            "engine_run_ms": round(med(walls), 3), "engine_run_ms_min": round(min(walls), 3), "reps": reps, "status_ok": ok,
+            "device_ms_by_stage": {k: round(v, 3) for k, v in sorted(stages.items())}, "device_ms_total": round(sum(v for k, v in stages.items() if not k.endswith(".host")), 3),
+            "facade_readme_flow_ms": round(med(fw), 3), "facade_readme_flow_ms_min": round(min(fw), 3),
+            "facade_flow": "Humerus(stl) -> apply_csys_canal_transepiconylar() -> canal.axis(), trans_epiconylar.axis(), anatomic_neck.points(), bicipital_groove.axis(); file read + parse included",
+            "landmarks_checked": int(len(got)), "parity": PARITY_NOTE["f32"]}
 
 
 def stl_bytes(verts, faces):
@@ -621,7 +792,8 @@ def cpu_baseline(verts, faces, T, weights, n_meshes, pool):
         # oracle time alone (all workers run side by side), which is what a long-running pool would sustain
         out["pool"] = {"value": round(pool / elp, 4), "unit": "meshes/s", "cores": pool, "value_compute_only": round(pool / max(per), 4),
                        "per_worker_s": [round(x, 2) for x in per],
-                       "sample": f"{pool} humeri, one per worker process (spawn), wall {elp:.1f} s incl. start-up and imports; slowest worker's oracle time {max(per):.1f} s"}
+                       "host_cores": os.cpu_count(),
+                       "sample": f"{pool} humeri, one per worker process (spawn) on {pool} of the host's {os.cpu_count()} hardware threads, wall {elp:.1f} s incl. start-up and imports; slowest worker's oracle time {max(per):.1f} s"}
     return out
 
 

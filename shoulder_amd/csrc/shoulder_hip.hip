@@ -1302,12 +1302,12 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   double* rg = ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr;
   LAUNCH(c, "k_slice_link", k_slice_link, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, nlarge);
-  LAUNCH(c, "k_slice_link", k_slice_link_large, dim3(std::min(B * N, 512)), dim3(SH_LINK_THREADS), B * N, N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
+  LAUNCH(c, "k_slice_link_large", k_slice_link_large, dim3(std::min(B * N, 512)), dim3(SH_LINK_THREADS), B * N, N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, (const int*)nlarge);
   if (resample) {
     LAUNCH(c, "k_resample_polar", k_resample_polar, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
            buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
-    LAUNCH(c, "k_resample_polar", k_resample_polar_large, dim3(std::min(B * N, 512)), dim3(SH_RS_THREADS), B * N, N, SH_MPROX, rn, rg,
+    LAUNCH(c, "k_resample_polar_large", k_resample_polar_large, dim3(std::min(B * N, 512)), dim3(SH_RS_THREADS), B * N, N, SH_MPROX, rn, rg,
            buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const int*)nlarge);
   }
   return SH_OK;
@@ -1686,7 +1686,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   if (mask & SH_STAGE_TE) {
     LAUNCH(c, "k_te_rows", k_te_rows<SH_SMALLSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), B);
-    LAUNCH(c, "k_te_rows", k_te_rows<SH_MAXSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
+    LAUNCH(c, "k_te_rows_large", k_te_rows<SH_MAXSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), B);
     LAUNCH(c, "k_te_final", k_te_final, dim3(B), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),

@@ -39,7 +39,20 @@ def test_bench_line():
     assert dh["value"] > 0 and dh["host_ms_per_step"] == {"host.verts_d2h": 0.0, "host.hull": 0.0} and dh["records_equal_to_host_hull_run"] is True
     assert d["config"]["hull"] in ("host", "device")
     assert d["config"]["hull_threads_per_process"] >= 1 and d["config"]["host"]["os_cpu_count"] >= 1
-    assert "k_slice_link" in d["geometry_kernels"] and d["geometry_kernels"]["k_slice_link"]["frac_of_hbm_peak"] > 0
+    # geometry table: per STEP (every launch of a kernel name in one step), algorithmic and SURVEY bytes, PMC bytes or null
+    gk = d["geometry_kernels"]
+    row = gk["k_slice_link"]
+    assert row["launches_per_step"] == 4 and row["ms_per_step"] > 0 and row["algorithmic_mb_per_step"] > 0 and "pmc_mb_per_step" in row
+    assert abs(row["frac_of_hbm_peak"] - row["algorithmic_mb_per_step"] / row["ms_per_step"] / 8000.0) < 2e-3
+    assert "k_slice_link_large" not in gk or gk["k_slice_link_large"]["algorithmic_mb_per_step"] == 0      # (own timer name: not averaged into the row above)
+    assert gk["k_resample_polar"]["launches_per_step"] == 1 and gk["k_resample_polar"]["survey_mb_per_step"] > 0
+    assert d["geometry_ms_per_step_one_lane"] > 0
+    assert "1e-4 mm" in d["parity"] and "bf16" in d["parity"]
+    # BASELINE configs[1]: one humerus, f32 UNet: latency through the engine and through the facade's README flow
+    sh = d["single_humerus_f32"]
+    assert sh["status_ok"] is True and 0 < sh["engine_run_ms_min"] <= sh["engine_run_ms"] and sh["facade_readme_flow_ms"] > 0
+    assert {"obb", "slices", "bicipital_groove", "anatomic_neck.unet", "trans_epicondylar", "csys"} <= set(sh["device_ms_by_stage"])
+    assert sh["device_ms_total"] <= sh["engine_run_ms"] * 1.05
 
 
 def test_rccl_leg_single_rank():
