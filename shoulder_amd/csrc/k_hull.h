@@ -146,7 +146,8 @@ __global__ void __launch_bounds__(HD_THREADS)
 k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff, HullScratch sc,
               double* __restrict__ hv, double* __restrict__ normals, int* __restrict__ edges,
               int* __restrict__ nv_out, int* __restrict__ nf_out, int* __restrict__ ne_out,
-              int* __restrict__ fail_out /*[B]: 0 or a positive reason*/, int* __restrict__ rounds_out /*[B] (nullable)*/) {
+              int* __restrict__ fail_out /*[B]: 0 or a positive reason*/, int* __restrict__ rounds_out /*[B] (nullable)*/,
+              const int* __restrict__ skip /*[B] (nullable): 1 = this humerus' record is already in place (host quickhull), leave it*/) {
   __shared__ HdPlane s_pl[HD_SLOTS];                       // 98 304 B
   __shared__ unsigned long long s_key[HD_SLOTS];           // 24 576 B  apex keys; face ids at the end
   __shared__ short s_conf[HD_NMAX];                        // 16 384 B  conflict face of a point (-1 inside, -2 inserted); vertex ids at the end
@@ -165,6 +166,7 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
   __shared__ unsigned s_minp;
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (skip != nullptr && skip[b] != 0) { if (tid == 0) { fail_out[b] = 0; if (rounds_out) rounds_out[b] = 0; } return; }
   const float* P = kept + 3 * koff[b];
   const int n = (int)(koff[b + 1] - koff[b]);
   int* fv = sc.fv + (size_t)b * HD_SLOTS * 3;

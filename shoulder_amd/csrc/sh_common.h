@@ -31,7 +31,7 @@
 // status should name the cause, not the consequence.
 #define SH_ERR_CAPACITY_DEV (-4)
 #define SH_ERR_GEOMETRY_DEV (-5)
-#define SH_ERR_HULL_DEV (-7)      // internal: the device hull gave this humerus up (k_hull.h); the batch is re-run with the host quickhull
+#define SH_ERR_HULL_DEV (-7)      // internal: the device hull gave this humerus up (k_hull.h); sh_collect re-does that humerus with the host quickhull
 
 namespace sh {
 

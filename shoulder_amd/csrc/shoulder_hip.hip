@@ -37,6 +37,7 @@
 #include <deque>
 #include <functional>
 #include <thread>
+#include <sched.h>
 
 using namespace sh;
 
@@ -74,10 +75,14 @@ struct sh_ctx {
   size_t unet_floats = 0;
   bool obb_injected = false;
   // hull of SH_STAGE_OBB: 1 = on the device (k_hull.h), 0 = host quickhull (sh_hull.h).  sh_set_hull_mode / SHOULDER_HULL=host|device|auto.
-  // A humerus the device hull gives up (pinched horizon on nearly coplanar clouds, capacities) makes the whole batch go through
-  // the host quickhull (hull_host_gen == batch_gen) -- sh_run / sh_collect re-run it on their own.
+  // A humerus the device hull gives up (pinched horizon on nearly coplanar clouds, capacities) is re-done ALONE by sh_collect:
+  // host quickhull for that humerus, its record patched into the device buffers, its stages re-run as a window of one behind
+  // whatever else is in flight on the stream (redo_given_up).  `hulld.skip[b]` then keeps the device hull off that humerus for
+  // as long as the batch stays resident (skip_gen == batch_gen).
   int hull_mode = 1;
-  unsigned long long hull_host_gen = ~0ull;
+  unsigned long long skip_gen = ~0ull;
+  bool redo_records = false;               // run_obb: the hull records of the window are in place already (redo_given_up)
+  int redo_nf = 0;
   std::vector<float> h_verts;                // host copy of the vertices (hull stage)
   bool h_verts_valid = false;
   // device-generated batches: the hull's points come back through the prefilter (k_hullpre.h) into pinned memory
@@ -102,7 +107,7 @@ struct sh_ctx {
   } prep;
   hipEvent_t obb_done_ev = nullptr;      // recorded after the last kernel of a run that reads the hull.* device buffers
   // sh_submit / sh_collect: up to two runs in flight (the second one is enqueued while the first still executes)
-  struct Ticket { hipEvent_t ev = nullptr; int* h_err = nullptr; int cap = 0, B = 0; bool pending = false; sh_landmarks* host_out = nullptr;
+  struct Ticket { hipEvent_t ev = nullptr; int* h_err = nullptr; int* h_fail = nullptr; int cap = 0, B = 0; bool pending = false; sh_landmarks* host_out = nullptr;
                   uint32_t mask = 0; sh_landmarks* out_arg = nullptr; bool dev_hull = false; };
   Ticket tickets[2];
   int t_head = 0, t_tail = 0, n_pending = 0;
@@ -218,13 +223,34 @@ int sh_default_params(sh_params* p) {
 
 // "host" | "device" | "auto" (default).  auto: the host quickhull while this rank has at least 48 hardware threads to itself (it
 // is free for the GPU and hidden behind the previous step: at ~7 000 humeri/s a rank keeps ~14 cores busy with hulls), the device
-// hull otherwise -- 8 ranks on a 256-thread host, a thin host, a CPU quota.  DESIGN.md 9.2 has the numbers.
+// hull otherwise -- 8 ranks on a 256-thread host, a thin host, a rank pinned to a few cores (affinity mask), a cgroup CPU quota.
+// Hardware threads this process may actually use: its affinity mask (taskset, a pinned rank, a container's cpuset) capped by a
+// cgroup-v2 CPU quota where one is set (cpu.max "<quota> <period>") -- std::thread::hardware_concurrency() sees neither.
+static unsigned usable_threads() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) { const int k = CPU_COUNT(&set); if (k > 0) n = (unsigned)k; }
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = {0}; long long period = 0;
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const long long quota = atoll(q);
+      if (quota > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    }
+    fclose(f);
+  }
+  return n;
+}
+
+static unsigned threads_per_local_rank() {
+  unsigned hw = usable_threads();
+  if (const char* w = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(w); if (v > 1) hw = std::max(1u, hw / (unsigned)v); }
+  return hw;
+}
+
 static int hull_mode_from(const char* e) {
   if (e && (e[0] == 'h' || e[0] == '0')) return 0;
   if (e && (e[0] == 'd' || e[0] == '1')) return 1;
-  unsigned nt = std::max(1u, std::thread::hardware_concurrency());
-  if (const char* w = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(w); if (v > 1) nt = std::max(1u, nt / (unsigned)v); }
-  return nt >= 48 ? 0 : 1;
+  return threads_per_local_rank() >= 48 ? 0 : 1;
 }
 
 int sh_set_hull_mode(sh_ctx* c, const char* mode) {
@@ -233,7 +259,6 @@ int sh_set_hull_mode(sh_ctx* c, const char* mode) {
   if (c->n_pending != 0) return fail(c, SH_ERR_STATE, "sh_set_hull_mode: runs are in flight");
   if (c->prep.active) { if (c->prep.th.joinable()) c->prep.th.join(); c->prep.active = false; c->prep.gen = ~0ull; }
   c->hull_mode = hull_mode_from(strcmp(mode, "auto") ? mode : nullptr);
-  c->hull_host_gen = ~0ull;
   return SH_OK;
 }
 
@@ -274,7 +299,7 @@ void sh_ctx_destroy(sh_ctx* c) {
   if (c->h_nkept) (void)hipHostFree(c->h_nkept);
   if (c->h_koff) (void)hipHostFree(c->h_koff);
   if (c->obb_done_ev) (void)hipEventDestroy(c->obb_done_ev);
-  for (auto& tk : c->tickets) { if (tk.ev) (void)hipEventDestroy(tk.ev); if (tk.h_err) (void)hipHostFree(tk.h_err); }
+  for (auto& tk : c->tickets) { if (tk.ev) (void)hipEventDestroy(tk.ev); if (tk.h_err) (void)hipHostFree(tk.h_err); if (tk.h_fail) (void)hipHostFree(tk.h_fail); }
   if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
   for (auto& kv : c->bufs)
     if (kv.second.p) (void)hipFree(kv.second.p);
@@ -462,7 +487,12 @@ static int alloc_hulld(sh_ctx* c) {
   ENS("hulld.tvals", (size_t)B * HD_TBL * 4, 4);
   ENS("hulld.fail", (size_t)B * 4, 4);
   ENS("hulld.rounds", (size_t)B * 4, 4);
+  ENS("hulld.skip", (size_t)B * 4, 4);
 #undef ENS
+  if (c->skip_gen != c->batch_gen) {      // a new batch: the device hull takes every humerus again
+    HIPCHK(c, hipMemsetAsync(c->bufs["hulld.skip"].p, 0, (size_t)B * 4, c->stream));
+    c->skip_gen = c->batch_gen;
+  }
   return SH_OK;
 }
 
@@ -1373,9 +1403,7 @@ class HullPool {
  public:
   static HullPool& instance() { static HullPool p; return p; }
   static unsigned thread_count() {
-    unsigned nt = std::max(1u, std::thread::hardware_concurrency());
-    if (const char* e = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(e); if (v > 1) nt = std::max(1u, nt / (unsigned)v); }
-    nt = std::min(nt, 32u);
+    unsigned nt = std::min(threads_per_local_rank(), 32u);      // (affinity mask / CPU quota / LOCAL_WORLD_SIZE aware)
     if (const char* e = getenv("SHOULDER_HULL_THREADS")) { int v = atoi(e); if (v > 0) nt = (unsigned)v; }
     return nt;
   }
@@ -1505,12 +1533,14 @@ static hipError_t hull_upload(sh_ctx* c, int slot, int B, void* const dst[6], hi
 
 // mesh.py:63-125.  Host: convex hulls (hull_host_phase; already done by the background thread when `prepared_slot`
 // >= 0).  Device: candidate boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
-static bool device_hull_now(const sh_ctx* c) { return c->hull_mode == 1 && c->hull_host_gen != c->batch_gen; }
+static bool device_hull_now(const sh_ctx* c) { return c->hull_mode == 1; }
 
 static int run_obb(sh_ctx* c, int prepared_slot) {
   const int B = c->Bwin, b0 = c->b0;
   int nfmax = 1;
-  if (device_hull_now(c)) {
+  if (c->redo_records) {
+    nfmax = std::max(1, c->redo_nf);      // (redo_given_up put the host quickhull's records of this window into hull.*)
+  } else if (device_hull_now(c)) {
     // hull on the device: prefilter -> round-based quickhull (k_hull.h), all on this context's stream; nothing comes to the host
     { int arc = alloc_hulld(c); if (arc != SH_OK) return arc; }
     launch_prefilter(hullpre_ptrs(c), B, c->stream);
@@ -1519,7 +1549,7 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
                    buf<int>(c, "hulld.freestack"), buf<unsigned long long>(c, "hulld.tkeys"), buf<unsigned>(c, "hulld.tvals")};
     LAUNCH(c, "k_hull_rounds", k_hull_rounds, dim3(B), dim3(HD_THREADS), (const float*)c->bufs["hullpre.kept"].p, (const long long*)c->bufs["hullpre.koff"].p, hs,
            buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), buf<int>(c, "hull.nv"), buf<int>(c, "hull.nf"), buf<int>(c, "hull.ne"),
-           buf<int>(c, "hulld.fail"), buf<int>(c, "hulld.rounds"));
+           buf<int>(c, "hulld.fail"), buf<int>(c, "hulld.rounds"), (const int*)buf<int>(c, "hulld.skip"));
     LAUNCH(c, "k_hull_flag", k_hull_flag, dim3((B + 63) / 64), dim3(64), buf<int>(c, "hulld.fail"), buf<int>(c, "err"), B);
     nfmax = HD_SLOTS;      // (the face counts stay on the device: the candidate kernel's tiles beyond a hull's faces return at once)
   } else {
@@ -1778,6 +1808,65 @@ int sh_discard_prepared(sh_ctx* c) {
   return SH_OK;
 }
 
+// The device hull gave the humeri in `list` up during the run of ticket `tk` (k_hull.h writes a unit tetrahedron for them, so
+// everything queued behind ran on finite data and their records are void).  Each of them gets the host quickhull -- which
+// has the retry / joggle logic -- its record goes into the device buffers where the device hull would have put it, and its
+// stages run again as a window of one humerus.  All of it is enqueued on the context's stream: behind a second run that may
+// be in flight (which finished with this batch's scratch buffers by then, and has parked its own results per ticket).
+// hulld.skip[b] is set, so later runs of the resident batch get these humeri right the first time.
+static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot, const std::vector<int>& list) {
+  const int B = tk.B;
+  std::vector<float> hv32;
+  std::vector<double> P;
+  shhull::Hull H;
+  int rc = SH_OK;
+  for (int b : list) {
+    const long long v0 = c->h_voff[b], nv = c->h_voff[b + 1] - v0;
+    hv32.resize(3 * (size_t)nv);
+    HIPCHK(c, hipMemcpyAsync(hv32.data(), (const float*)c->bufs["verts"].p + 3 * v0, (size_t)nv * 12, hipMemcpyDeviceToHost, c->out_stream));
+    HIPCHK(c, hipStreamSynchronize(c->out_stream));
+    P.assign(hv32.begin(), hv32.end());
+    int status = 0, hn = 0, fn = 0, en = 0;
+    if (!shhull::convex_hull(P.data(), (int)nv, H)) status = SH_ERR_GEOMETRY;
+    else {
+      hn = (int)H.vert_ids.size(); fn = (int)H.tris.size() / 3; en = (int)H.edges.size() / 4;
+      if (hn > SH_HV || fn > SH_HF || en > SH_HE) status = SH_ERR_CAPACITY;
+    }
+    if (status != 0) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", b, status); return fail(c, status, m); }
+    std::vector<double> hvd(3 * (size_t)hn);
+    for (int i = 0; i < hn; ++i)
+      for (int k = 0; k < 3; ++k) hvd[3 * (size_t)i + k] = P[3 * (size_t)H.vert_ids[i] + k];
+    c->b0 = 0; c->Bwin = B;
+    const int counts[3] = {hn, fn, en}, one = 1;
+    // (pageable sources: hipMemcpyAsync stages them before it returns)
+    HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.hv") + (size_t)b * SH_HV * 3, hvd.data(), hvd.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.normals") + (size_t)b * SH_HF * 3, H.normals.data(), (size_t)fn * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.edges") + (size_t)b * SH_HE * 4, H.edges.data(), (size_t)en * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.nv") + b, &counts[0], 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.nf") + b, &counts[1], 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.ne") + b, &counts[2], 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hulld.skip") + b, &one, 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(buf<int>(c, "err") + b, 0, 4, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // the sources above are locals
+    c->b0 = b; c->Bwin = 1; c->redo_records = true; c->redo_nf = fn;
+    rc = run_window(c, tk.mask, -1);
+    c->redo_records = false;
+    c->b0 = 0; c->Bwin = B;
+    if (rc != SH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+    // the record and the status word of this humerus -> where the run's results were parked (or the caller's device buffer)
+    const sh_landmarks* src = buf<sh_landmarks>(c, "landmarks") + b;
+    if (tk.host_out) HIPCHK(c, hipMemcpyAsync((sh_landmarks*)c->bufs["out.landmarks" + tslot].p + b, src, sizeof(sh_landmarks), hipMemcpyDeviceToDevice, c->stream));
+    else if (tk.out_arg) HIPCHK(c, hipMemcpyAsync(tk.out_arg + b, src, sizeof(sh_landmarks), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((int*)c->bufs["out.err" + tslot].p + b, buf<int>(c, "err") + b, 4, hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (tk.host_out)
+    HIPCHK(c, hipMemcpyAsync(tk.host_out, c->bufs["out.landmarks" + tslot].p, (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->out_stream));
+  HIPCHK(c, hipMemcpyAsync(tk.h_err, c->bufs["out.err" + tslot].p, (size_t)B * 4, hipMemcpyDeviceToHost, c->out_stream));
+  HIPCHK(c, hipStreamSynchronize(c->out_stream));
+  return SH_OK;
+}
+
 int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   if (!c) return SH_ERR_ARG;
   if (c->B < 1) return fail(c, SH_ERR_STATE, "sh_run: no meshes uploaded");
@@ -1787,8 +1876,10 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   sh_ctx::Ticket& tk = c->tickets[c->t_head];
   if (tk.cap < B) {
     if (tk.h_err) (void)hipHostFree(tk.h_err);
-    tk.h_err = nullptr; tk.cap = 0;
+    if (tk.h_fail) (void)hipHostFree(tk.h_fail);
+    tk.h_err = nullptr; tk.h_fail = nullptr; tk.cap = 0;
     HIPCHK(c, hipHostMalloc((void**)&tk.h_err, (size_t)B * 4));
+    HIPCHK(c, hipHostMalloc((void**)&tk.h_fail, (size_t)B * 4));
     tk.cap = B;
   }
   if (!tk.ev) HIPCHK(c, hipEventCreateWithFlags(&tk.ev, hipEventDisableTiming));
@@ -1801,6 +1892,9 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   }
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "err"), 0, B * 4, c->stream));
   if ((mask & SH_STAGE_APPLY) && !(mask & SH_STAGE_CSYS)) return fail(c, SH_ERR_ARG, "sh_run: SH_STAGE_APPLY needs SH_STAGE_CSYS in the same run");
+  // a proximal humerus' frame is canal / articular (bone.py:53-62): k_pack builds it from the anatomic-neck axes of THIS run
+  if (c->params.bone_kind == SH_BONE_PROXIMAL && (mask & SH_STAGE_CSYS) && !(mask & SH_STAGE_ANP))
+    return fail(c, SH_ERR_ARG, "sh_run: SH_STAGE_CSYS of a proximal humerus needs SH_STAGE_ANP in the same run (canal / articular frame)");
   if (!(mask & SH_STAGE_OBB) && !c->obb_injected)
     return fail(c, SH_ERR_STATE, "sh_run: no OBB transform (run SH_STAGE_OBB or sh_store(\"obb_transform\"))");
   // Windows: with the host hull in play the batch can be walked in windows of SHOULDER_WINDOW humeri; all device work of
@@ -1853,6 +1947,11 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     tk.host_out = out;
   }
   HIPCHK(c, hipMemcpyAsync(err_stage, buf<int>(c, "err"), (size_t)B * 4, hipMemcpyDeviceToDevice, c->stream));
+  if (dev_hull) {      // which humeri the device hull gave up: its own word per humerus (the status word can be overwritten by a later stage)
+    void* fail_stage = nullptr;
+    if (int e = ensure(c, ("out.hfail" + tslot).c_str(), (size_t)B * 4, 4, &fail_stage)) return e;
+    HIPCHK(c, hipMemcpyAsync(fail_stage, buf<int>(c, "hulld.fail"), (size_t)B * 4, hipMemcpyDeviceToDevice, c->stream));
+  }
   HIPCHK(c, hipEventRecord(tk.ev, c->stream));
   tk.B = B; tk.pending = true; tk.mask = mask; tk.out_arg = out; tk.dev_hull = dev_hull;
   c->t_head ^= 1; ++c->n_pending;
@@ -1872,17 +1971,13 @@ int sh_collect(sh_ctx* c) {
   HIPCHK(c, hipMemcpyAsync(tk.h_err, buf<char>(c, ("out.err" + tslot).c_str()), (size_t)tk.B * 4, hipMemcpyDeviceToHost, c->out_stream));
   HIPCHK(c, hipStreamSynchronize(c->out_stream));
   if (tk.dev_hull) {
-    bool gave_up = false;
-    for (int b = 0; b < tk.B; ++b) gave_up |= tk.h_err[b] == SH_ERR_HULL_DEV;
-    if (gave_up) {
-      // The device hull gave a humerus up (a horizon pinched by the tolerance, a capacity): this batch goes through the host
-      // quickhull, which has the retry / joggle logic.  Done here, synchronously, when no other run is in flight.
-      c->hull_host_gen = c->batch_gen;
-      if (c->n_pending != 0) return fail(c, SH_ERR_GEOMETRY, "device hull gave a mesh up while another run is in flight: collect it, then run the batch again (it will use the host quickhull)");
-      const uint32_t mask = tk.mask; sh_landmarks* out = tk.out_arg;
-      int rc2 = sh_submit(c, mask, out);
+    HIPCHK(c, hipMemcpyAsync(tk.h_fail, buf<char>(c, ("out.hfail" + tslot).c_str()), (size_t)tk.B * 4, hipMemcpyDeviceToHost, c->out_stream));
+    HIPCHK(c, hipStreamSynchronize(c->out_stream));
+    std::vector<int> gave_up;
+    for (int b = 0; b < tk.B; ++b) if (tk.h_fail[b] != 0) gave_up.push_back(b);
+    if (!gave_up.empty()) {
+      int rc2 = redo_given_up(c, tk, tslot, gave_up);
       if (rc2 != SH_OK) return rc2;
-      return sh_collect(c);
     }
   }
   for (int b = 0; b < tk.B; ++b)

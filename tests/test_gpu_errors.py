@@ -232,3 +232,19 @@ def test_rejected_unet_load_keeps_the_loaded_network(oracle_bones):
             np.testing.assert_array_equal(after[key], before[key], err_msg=key)
     finally:
         e.close()
+
+
+def test_proximal_csys_needs_the_anatomic_neck_stage(engine, oracle_bones):
+    """a proximal humerus' frame is canal / articular; SH_STAGE_CSYS without SH_STAGE_ANP in the same run would pack a
+    stale matrix (and SH_STAGE_APPLY would move the mesh with it) -- refused as an argument error."""
+    h = oracle_bones("humerus_left")
+    engine.upload([(h.verts, h.faces)])
+    engine.set_params(bone_kind=_lib.BONE_PROXIMAL)
+    try:
+        early = _lib.STAGE_OBB | _lib.STAGE_FULL | _lib.STAGE_NECK | _lib.STAGE_CANAL
+        engine.run(early)
+        with pytest.raises(ShoulderHipError) as err:
+            engine.run(_lib.STAGE_PROXIMAL | _lib.STAGE_GROOVE | _lib.STAGE_CSYS | _lib.STAGE_APPLY)
+        assert err.value.code == -1 and "SH_STAGE_ANP" in str(err.value)
+    finally:
+        engine.set_params(bone_kind=_lib.BONE_HUMERUS)

@@ -118,8 +118,8 @@ def test_proximal_and_streaming(engines, oracle_bones):
 def test_gives_up_cleanly_and_falls_back(engines):
     """An input the device hull does not take -- the midpoint-subdivided humerus: 65 k vertices of which far more than the
     kernel's 8 192 survive the prefilter, thousands of them coplanar with hull facets -- is reported per humerus (reason 40)
-    and the batch is re-run through the host quickhull by sh_run itself: same result as the host-hull engine, the other humerus
-    of the batch included; the next batch is back on the device hull."""
+    and THAT humerus is re-done by sh_run itself with the host quickhull (redo_given_up): same result as the host-hull engine,
+    the other humerus of the batch included; the next batch is back on the device hull."""
     dev, host = engines
     from oracle.stl import load_stl
     from test_gpu_highres import subdivide
@@ -137,3 +137,35 @@ def test_gives_up_cleanly_and_falls_back(engines):
     dev.upload([(hv, hf)])
     dev.run(OBB_ONLY, fetch=False)
     assert int(dev.fetch("hulld.fail", np.int32, (1,))[0]) == 0 and int(dev.fetch("hulld.rounds", np.int32, (1,))[0]) > 20
+
+
+def test_given_up_humerus_is_redone_alone_also_with_a_run_in_flight(engines):
+    """SH_STAGE_ALL, streaming: two submits in flight on the device-hull engine over a ragged batch whose middle humerus the
+    device hull gives up (the midpoint-subdivided mesh).  Each collect re-does only that humerus -- host quickhull, its record
+    patched into hull.*, its stages re-run as a window of one behind the other run -- and hands back records that equal the
+    host-hull engine's for EVERY humerus; `hulld.skip` then keeps the device hull off it (a third run needs no redo and the
+    device hull still ran for the others).  ADVICE r2: the decision comes from the hull's own per-humerus word, not from the
+    status word later stages may overwrite."""
+    dev, host = engines
+    from oracle.stl import load_stl
+    from test_gpu_highres import subdivide
+    a = load_stl(os.path.join(BONES, "humerus_right.stl"))
+    bad = subdivide(*load_stl(os.path.join(BONES, "humerus_left.stl")))
+    c = load_stl(os.path.join(BONES, "humerus_left_trab.stl"))
+    batch = [a, bad, c]
+    for e in (dev, host):
+        e.set_params(unet_dtype=_lib.UNET_F32)
+        e.upload(batch)
+    ref = host.run(_lib.STAGE_ALL).copy()
+    assert (ref["status"] == 0).all()
+    dev.submit(_lib.STAGE_ALL); dev.submit(_lib.STAGE_ALL)
+    r1 = dev.collect().copy(); r2 = dev.collect().copy()
+    assert dev.fetch("hulld.skip", np.int32, (3,)).tolist() == [0, 1, 0]
+    for r in (r1, r2):
+        assert (r["status"] == 0).all()
+        assert r.tobytes() == ref.tobytes()
+    r3 = dev.run(_lib.STAGE_ALL).copy()                      # skip in force: right the first time
+    assert r3.tobytes() == ref.tobytes()
+    assert dev.fetch("hulld.fail", np.int32, (3,)).tolist() == [0, 0, 0] and (dev.fetch("hulld.rounds", np.int32, (3,))[[0, 2]] > 20).all()
+    dev.upload([a])                                          # a new batch clears the skips
+    assert dev.run(_lib.STAGE_ALL)["status"][0] == 0 and dev.fetch("hulld.skip", np.int32, (1,))[0] == 0
