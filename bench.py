@@ -203,14 +203,26 @@ def host_info():
                 break
     except OSError:
         pass
-    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "affinity_cores": len(os.sched_getaffinity(0))}
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "affinity_cores": len(os.sched_getaffinity(0)), "usable_cores": usable_cores()}
+
+
+def usable_cores():
+    """Hardware threads this process may use: affinity mask, capped by a cgroup-v2 CPU quota (as usable_threads() in shoulder_hip.hip)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max" and int(period) > 0:
+            n = min(n, max(1, -(-int(q) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def hull_threads(world_local):
     """The worker pool of the host hull phase (HullPool, shoulder_hip.hip), one per process shared by its lanes: hardware threads / LOCAL_WORLD_SIZE, at most 32."""
     if os.environ.get("SHOULDER_HULL_THREADS"):
         return int(os.environ["SHOULDER_HULL_THREADS"])
-    return max(1, min(32, len(os.sched_getaffinity(0)) // max(1, world_local)))
+    return max(1, min(32, usable_cores() // max(1, world_local)))
 
 
 def launch_ranks(n, argv, worker=None, timeout=None):
@@ -553,6 +565,28 @@ def main():
                                     "records_equal_to_host_hull_run": bool(same)}
             for e in dev_engs:
                 e.close()
+        elif eng.hull_mode == "device" and pipelined:
+            # the headline ran with the hull on the device (what `auto` picks when this rank has fewer than 48 usable hardware
+            # threads, e.g. under a CPU quota): the same step with the host quickhull (two lanes, hulls of step k+1 computed by the
+            # host's worker threads behind the device work of step k), and whether both modes give the same records
+            host_engs = [Engine(local) for _ in range(2)]
+            for e in host_engs:
+                e.load_rfc()
+                e.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
+                e.set_hull_mode("host")
+                e.set_unet_turns(True)
+                e.upload([(verts, faces)])
+                e.synth_batch(T)
+            kh = max(8, min(args.steps, 20))
+            elh, regh, _ = run_leg(host_engs, args.unet, kh, 1, pipelined)
+            lmh = host_engs[0].run(_lib.STAGE_ALL)
+            same = all(np.array_equal(lmh[k], lm[k]) for k in ("obb_transform", "canal_axis", "te_axis", "groove_axis", "csys", "n_anp"))
+            extra["host_hull"] = {"value": round(B * kh / elh, 3), "unit": "meshes/s", "steps": kh, "warmup": 1, "ms_per_step": round(1e3 * elh / kh, 3),
+                                  "lanes": 2, "hull_threads_per_process": hull_threads(int(os.environ.get("LOCAL_WORLD_SIZE", "1"))),
+                                  "host_ms_per_step": {k: round(regh[k][0] * regh[k][1] / kh, 3) for k in ("host.verts_d2h", "host.hull")},
+                                  "records_equal_to_device_hull_run": bool(same)}
+            for e in host_engs:
+                e.close()
         extra["single_humerus_f32"] = single_humerus_leg(local, weights, verts, faces)
         if lanes > 1:
             el1, _, _ = run_leg(engs[:1], args.unet, args.steps, 1, pipelined)
@@ -779,7 +813,7 @@ def cpu_baseline(verts, faces, T, weights, n_meshes, pool):
            "sample": f"{n_meshes} of the batch's synthetic humeri, all stages, NumPy/SciPy oracle, BLAS limited to 1 thread, {el:.1f} s"}
     out.update(host_info())
     if pool < 0:
-        pool = min(16, len(os.sched_getaffinity(0)))
+        pool = min(16, usable_cores())
     pool = min(pool, len(T))
     if pool > 1:
         import multiprocessing as mp

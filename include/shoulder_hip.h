@@ -175,6 +175,12 @@ int  sh_mesh_transformed(sh_ctx*, int b, const double* T /* 16 */, double* out_v
  * anatomic_neck.py:120): upload n xyz float64, transform on the device, download. */
 int  sh_transform_points(sh_ctx*, const double* T /* 16 */, const double* in_pts /* host, n x 3 */, int n, double* out_pts /* host */);
 
+/* The closed largest loop of plane k of slice set `set` ("distal", "prox", "neckc") of humerus b after a run -- what
+ * `Slices.slices[k].polygons_closed[...]` exterior holds in the reference (slice.py:53-59, surgical_neck.py:37-54): n + 1
+ * points (x, y) in the box frame, counter-clockwise, canonical start (rule B-1), first = last.  Read from the fixed slot range
+ * or, for a plane with more crossing segments than slots, from the overflow pool.  out == NULL or cap < n + 1: only
+ * *n_out = n + 1 is set. */
+int  sh_ring(sh_ctx*, const char* set, int b, int k, double* out, int cap, int* n_out);
 /* `mesh_ct.section(plane_origin, plane_normal).vertices` for mesh b (AnatomicNeck.plane_points,
  * anatomic_neck.py:155-172): unique crossing points of one general plane, CT coordinates, unordered. */
 int  sh_section_plane(sh_ctx*, int b, const double* origin /* 3 */, const double* normal /* 3 */, double* out_pts /* cap x 3 */,

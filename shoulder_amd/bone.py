@@ -136,8 +136,7 @@ class SurgicalNeck(_Lm):
         super().__init__(bone)
         e = bone._engine
         self.neck_z = float(bone._early["neck_z"])
-        n = int(e.fetch("neckc.ring_n", np.int32, (1,))[0])
-        ring = e.fetch("neckc.ring", np.float64, (1025, 2))[:n + 1]
+        ring = e.ring("neckc", 0, 0)
         pts_obb = np.c_[ring, np.full(len(ring), self.neck_z)]
         self.points_ct = e.transform_points(pts_obb, _inv(bone._obb_transform))
         self.points = self.points_ct.copy()

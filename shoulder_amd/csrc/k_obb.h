@@ -14,14 +14,17 @@
 // Hull record per humerus (host quickhull, sh_hull.h): hv [HV][3] f64 CT coords, normals [HF][3],
 // edges [HE][4] = (va, vb, face f, face g).
 #pragma once
+#include <type_traits>
 #include "k_te.h"
 
 namespace sh {
 
-#define SH_HV 4096
-#define SH_HF 8192
-#define SH_HE 12288
-#define SH_ENDCAP 1024
+// hull record capacities (HBM): vertices / faces / edges per humerus.  The fixtures' hulls have 1 368 / 2 732 / 4 098; the hull of
+// a 519 k-triangle humerus 4 209 / 8 414 / 12 621; a convex region sampled more densely keeps more of its vertices on the hull.
+#define SH_HV 16384
+#define SH_HF 32768
+#define SH_HE 49152
+#define SH_ENDCAP 8192      // crossing points of an end section (mesh.py:91-107); ~330 at the fixture resolution, ~1 300 on a 519 k-triangle mesh
 
 __device__ inline void obb_basis(const double* n, double* u, double* v) { plane_basis(n, u, v); }
 
@@ -195,20 +198,27 @@ k_obb_select(const double* __restrict__ lb_, const int* __restrict__ nf_, const 
 //   edges     mask[f] ^ mask[g] = directions for which the edge is on the silhouette -> per-direction lists
 //   scans     four directions at a time: project the silhouette start vertices (LDS), then every silhouette
 //             edge takes the extents of all of them (ns x ns, fp64) -> min-area rectangle
+// Two capacity tiers (the hull record in HBM is sized for the large one, SH_HV / SH_HF / SH_HE; only this kernel keeps per-face
+// and per-silhouette state in LDS):  <16, 4, 512, 8192, unsigned short>  hulls of up to 8 192 faces -- every fixture (2 732) and
+// everything the device hull produces (3 072 slots) -- two workgroups per CU;  <8, 1, 2048, 32768, unsigned> the hull of a dense
+// mesh (a 519 k-triangle humerus: 8 414 faces), one workgroup per CU, chosen by the host when a hull of the launch needs it.
+template <int T, int G, int SIL, int HFCAP, typename LT>
 __global__ void __launch_bounds__(SH_OBB_THREADS)
 k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
                  const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge,
                  int* __restrict__ err, unsigned long long* __restrict__ best_enc /*[B]: bits of the smallest candidate volume so far, ~0 = none*/,
                  const int* __restrict__ dir_list /*[B][SH_HF]: the directions (hull faces) to evaluate*/, const int* __restrict__ dir_count /*[B]*/,
                  int ntiles, int B, int skip_on /*0: no in-kernel skip either (A/B of the pruning)*/) {
-  constexpr int T = SH_OBB_TILE, G = SH_OBB_GROUP, NW = SH_OBB_THREADS / 64;
+  constexpr int NW = SH_OBB_THREADS / 64;
+  constexpr int FB = (int)sizeof(LT) * 8 - 1;      // flag bit of a list entry: the edge's first face is the front face
+  typedef typename std::conditional<(T > 8), unsigned short, unsigned char>::type MT;
   __shared__ double tn[T][3], tu[T][3], tv[T][3];
   __shared__ double red[NW][2 * T];
   __shared__ double hlo[T], hhi[T];
-  __shared__ unsigned short fmask[SH_HF];
-  __shared__ unsigned short lists[T][SH_SIL_MAX];      // edge id | (first face is the front face) << 15
+  __shared__ MT fmask[HFCAP];
+  __shared__ LT lists[T][SIL];      // edge id | (first face is the front face) << FB
   __shared__ int cnt[T];
-  __shared__ double2 sxy[G][SH_SIL_MAX];
+  __shared__ double2 sxy[G][SIL];
   __shared__ unsigned long long g_area[G];
   __shared__ int g_edge[G];
   __shared__ double g_hull2[NW][G];  // per wave: twice the signed area of the projected hull (shoelace over the directed silhouette edges)
@@ -222,6 +232,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
   if (b >= B) return;
   const int f0 = (rr >> 3) * T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = nv_[b], nf = nf_[b], ne = ne_[b];
+  if (nf > HFCAP) { if (tid == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); return; }
   const int ndir = dir_count[b];
   if (f0 >= ndir) return;
   const int nt = min(T, ndir - f0);                    // directions in this tile: entries f0 .. f0 + nt - 1 of the humerus's list
@@ -277,7 +288,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
       unsigned m = 0;
 #pragma unroll
       for (int j = 0; j < T; ++j) m |= (dot3(q[u], tn[j]) > 0 ? 1u : 0u) << j;
-      if (f2 < nf) fmask[f2] = (unsigned short)m;
+      if (f2 < nf && f2 < HFCAP) fmask[f2] = (MT)m;
     }
   }
   __syncthreads();
@@ -302,7 +313,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
         const int j = __ffs(x) - 1;
         x &= x - 1;
         const int s = atomicAdd(&cnt[j], 1);
-        if (s < SH_SIL_MAX) lists[j][s] = (unsigned short)(e | (((m1 >> j) & 1u) << 15));
+        if (s < SIL) lists[j][s] = (LT)((unsigned)e | (((m1 >> j) & 1u) << FB));
       }
     }
   }
@@ -315,7 +326,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     for (int jj = 0; jj < G; ++jj) {
       const int j = g0 + jj;
       int c = j < nt ? cnt[j] : 0;
-      if (c > SH_SIL_MAX) { if (tid == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); c = SH_SIL_MAX; }
+      if (c > SIL) { if (tid == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); c = SIL; }
       ns[jj] = c; pre[jj + 1] = pre[jj] + c;
     }
     if (tid < G) { g_area[tid] = (unsigned long long)__double_as_longlong(1e300); g_edge[tid] = 0x7fffffff; g_skip[tid] = 0; }
@@ -330,9 +341,9 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
 #pragma unroll
       for (int k = 1; k < G; ++k) jj += it >= pre[k] ? 1 : 0;
       const int s = it - pre[jj], j = g0 + jj;
-      const unsigned short rec = lists[j][s];
-      const int e = rec & 0x7fff;
-      const bool fwd = (rec >> 15) != 0;
+      const unsigned rec = lists[j][s];
+      const int e = (int)(rec & ((1u << FB) - 1u));
+      const bool fwd = (rec >> FB) != 0;
       const double* p = P + 3 * (size_t)(fwd ? E[4 * e] : E[4 * e + 1]);
       const double* q = P + 3 * (size_t)(fwd ? E[4 * e + 1] : E[4 * e]);
       const double2 a = make_double2(dot3(p, tu[j]), dot3(p, tv[j]));
@@ -368,7 +379,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     // every lane takes item tid of each pass of 256 (edge s of direction jj) and remembers (area, edge, direction);
     // lexicographic (area, edge) minimum per direction in two steps: areas are non-negative doubles, so their bit
     // patterns order like the values
-    constexpr int NP = G * SH_SIL_MAX / SH_OBB_THREADS;
+    constexpr int NP = G * SIL / SH_OBB_THREADS;
     double a_[NP];
     int e_[NP], j_[NP];
 #pragma unroll
@@ -380,7 +391,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
 #pragma unroll
         for (int k = 1; k < G; ++k) jj += it >= pre[k] ? 1 : 0;
         const int s = it - pre[jj], j = g0 + jj, n2 = g_skip[jj] ? 0 : ns[jj];
-        const int e = lists[j][s] & 0x7fff;
+        const int e = (int)((unsigned)lists[j][s] & ((1u << FB) - 1u));
         double ex = 0.0, ey = 0.0, l = 0.0;
         if (n2 > 0) {      // (a skipped direction costs no gathers here)
           const double* pa3 = P + 3 * (size_t)E[4 * e]; const double* pc3 = P + 3 * (size_t)E[4 * e + 1];

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256)
 k_slice_emit(const double* __restrict__ vobb, const int* __restrict__ faces,
              const long long* __restrict__ voff, const long long* __restrict__ foff,
              const double* __restrict__ zeff, int N, int* __restrict__ seg_count,
-             Seg* __restrict__ segs, int* __restrict__ err) {
+             Seg* __restrict__ segs) {
   __shared__ int hist[SH_EMIT_MAXN];
   int b = blockIdx.y;
   long long f0 = foff[b], nf = foff[b + 1] - f0;
@@ -195,8 +195,8 @@ k_slice_emit(const double* __restrict__ vobb, const int* __restrict__ faces,
         int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
         sg.e_lo = (uint32_t)id[l]; sg.e_hi = (uint32_t)id[h];
       }
+      // a plane with more crossings than slots is an overflow plane: seg_count keeps counting, k_ovf.h sections it again into the pool
       if (slot < SH_MAXSEG) segs[((size_t)b * N + k) * SH_MAXSEG + slot] = sg;
-      else atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
     }
     __syncthreads();      // hist is zeroed again at the top of the next chunk
   }
@@ -247,7 +247,8 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
     if (CAP == SH_SMALLSEG && nlarge && tid == 0) atomicAdd(nlarge, 1);        // (tells the large-tier sweeps that they have work)
     return;
   }
-  const int n = cnt > SH_MAXSEG ? SH_MAXSEG : cnt;
+  if (cnt > SH_MAXSEG) return;      // an overflow plane: k_slice_link_huge (k_ovf.h)
+  const int n = cnt;
   if (tid == 0) { n_loops = 0; bad = 0; }
   for (int i = tid; i < HASH; i += SH_LINK_THREADS) table[i] = -1;
   const Seg* sp = segs + (size_t)pl * SH_MAXSEG;
@@ -462,7 +463,7 @@ k_slice_link_large(int nplanes, int N, const int* __restrict__ seg_count, const 
                    const int* __restrict__ nlarge) {
   if (*nlarge == 0) return;      // (the usual case: the sweep below is ~75 dependent loads per workgroup for nothing)
   for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
-    if (seg_count[pl] <= SH_SMALLSEG) continue;
+    if (seg_count[pl] <= SH_SMALLSEG || seg_count[pl] > SH_MAXSEG) continue;
     slice_link_plane<SH_MAXSEG>(pl, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total);
     __syncthreads();
   }
@@ -478,7 +479,7 @@ k_slice_link_large(int nplanes, int N, const int* __restrict__ seg_count, const 
 template <int CAP>
 __device__ inline void resample_polar_plane(const int pl, int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring,
                  const double* __restrict__ centroids, double* __restrict__ ixy,
-                 double* __restrict__ itr_start, double* __restrict__ itr_cs) {
+                 double* __restrict__ itr_start, double* __restrict__ itr_cs, const long long* __restrict__ ovf_roff) {
   static_assert(SH_MPROX % SH_RS_THREADS == 0, "whole samples per lane");
   constexpr int NS = SH_MPROX / SH_RS_THREADS;      // samples per lane
   __shared__ double rx[CAP + 1], ry[CAP + 1], d[CAP + 1];
@@ -488,6 +489,7 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
   const int tid = threadIdx.x;
   const int L = ring_n[pl];
   if (CAP == SH_SMALLSEG ? L > SH_SMALLSEG : L <= SH_SMALLSEG) return;      // the other tier's plane
+  if (ovf_roff[pl] >= 0) return;                                           // ring in the overflow pool: k_resample_polar_huge (k_ovf.h)
   const double* rp = ring + (size_t)pl * (SH_MAXSEG + 1) * 2;
   for (int q = tid; q <= L; q += SH_RS_THREADS) { rx[q] = rp[2 * q]; ry[q] = rp[2 * q + 1]; }
   __syncthreads();
@@ -594,16 +596,17 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
 
 __global__ void __launch_bounds__(SH_RS_THREADS)
 k_resample_polar(int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring, const double* __restrict__ centroids,
-                 double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs) {
-  resample_polar_plane<SH_SMALLSEG>(blockIdx.x, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs);
+                 double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs, const long long* __restrict__ ovf_roff) {
+  resample_polar_plane<SH_SMALLSEG>(blockIdx.x, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs, ovf_roff);
 }
 __global__ void __launch_bounds__(SH_RS_THREADS)
 k_resample_polar_large(int nplanes, int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring, const double* __restrict__ centroids,
-                       double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs, const int* __restrict__ nlarge) {
+                       double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs, const int* __restrict__ nlarge,
+                       const long long* __restrict__ ovf_roff) {
   if (*nlarge == 0) return;      // no plane with more than SH_SMALLSEG segments, hence no ring that long
   for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
-    if (ring_n[pl] <= SH_SMALLSEG) continue;
-    resample_polar_plane<SH_MAXSEG>(pl, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs);
+    if (ring_n[pl] <= SH_SMALLSEG || ovf_roff[pl] >= 0) continue;
+    resample_polar_plane<SH_MAXSEG>(pl, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs, ovf_roff);
     __syncthreads();
   }
 }

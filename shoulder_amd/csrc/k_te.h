@@ -6,6 +6,7 @@
 #pragma once
 #include "../../include/shoulder_hip.h"
 #include "k_unet.h"
+#include "k_ovf.h"
 
 namespace sh {
 
@@ -19,7 +20,8 @@ namespace sh {
 // lane 0's hull walk is latency-bound when every point comes from global memory).
 template <int CAP>
 __global__ void __launch_bounds__(64)
-k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, double* __restrict__ rects /*[B][37][7]*/, int B) {
+k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, double* __restrict__ rects /*[B][37][7]*/, int B,
+          const long long* __restrict__ ovf_roff /*distal set: >= 0 = the slice's ring is in the overflow pool (k_te_rows_huge takes it)*/) {
   __shared__ int dq[2 * CAP + 8];
   __shared__ int hull[2 * CAP + 8];
   __shared__ double hx[CAP], hy[CAP];
@@ -31,6 +33,7 @@ k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, doubl
   const double* gxy = ring + pl * (SH_MAXSEG + 1) * 2;
   const int n = ring_n[pl];
   if (CAP == SH_SMALLSEG ? n > SH_SMALLSEG : n <= SH_SMALLSEG) return;      // the other tier's slice
+  if (ovf_roff[pl] >= 0) return;
   double* o = rects + (size_t)gid * 7;
   if (n < 3) { if (lane < 7) o[lane] = 0.0; return; }
   for (int q = lane; q < 2 * (n + 1); q += 64) s_xy[q] = gxy[q];
@@ -81,11 +84,73 @@ k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, doubl
   (void)B;
 }
 
+// the same for a distal slice whose ring lives in the overflow pool (k_ovf.h): hull deque and hull points in the slice's workspace
+__global__ void __launch_bounds__(64)
+k_te_rows_huge(OvfPools P, OvfSet S, const int* __restrict__ ring_n, double* __restrict__ rects /*[B][37][7]*/) {
+  __shared__ int nh_s;
+  const int nlist = *S.nlist, lane = threadIdx.x;
+  for (int it = blockIdx.x; it < nlist; it += gridDim.x) {
+    const int pl = S.list[it];
+    const int b = pl / SH_NDIST, j = pl % SH_NDIST - SH_TE_ROW0;
+    if (j < 0 || j >= SH_TE_NROWS) continue;
+    const double* xy = P.ring + 2 * S.roff[pl];
+    const int n = ring_n[pl];
+    double* o = rects + ((size_t)b * SH_TE_NROWS + j) * 7;
+    if (n < 3) { if (lane < 7) o[lane] = 0.0; continue; }
+    double* hx = (double*)(P.work + S.woff[pl]);
+    double* hy = hx + n;
+    int* dq = (int*)(hy + n);
+    int* hull = dq + 2 * n + 8;
+    if (lane == 0) nh_s = convex_hull_simple_polygon(xy, n, dq, hull);
+    __syncthreads();
+    const int nh = nh_s;
+    for (int k = lane; k < nh; k += 64) { hx[k] = xy[2 * hull[k]]; hy[k] = xy[2 * hull[k] + 1]; }
+    __syncthreads();
+    double best = 1e300;
+    int bi = 0x7fffffff;
+    Rect2 r;
+    r.cx = r.cy = r.mx = r.my = r.L = r.W = r.area = 0.0;
+    for (int i = lane; i < nh; i += 64) {
+      const int i2 = i + 1 == nh ? 0 : i + 1;
+      double ex = hx[i2] - hx[i], ey = hy[i2] - hy[i];
+      const double ln = hypot(ex, ey);
+      if (ln == 0) continue;
+      ex /= ln; ey /= ln;
+      const double nx = -ey, ny = ex;
+      double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
+      for (int k = 0; k < nh; ++k) {
+        const double a = hx[k] * ex + hy[k] * ey, bb = hx[k] * nx + hy[k] * ny;
+        amin = a < amin ? a : amin; amax = a > amax ? a : amax;
+        bmin = bb < bmin ? bb : bmin; bmax = bb > bmax ? bb : bmax;
+      }
+      const double ea = amax - amin, eb = bmax - bmin, area = ea * eb;
+      if (area < best) {
+        best = area; bi = i;
+        const double ca = 0.5 * (amax + amin), cb = 0.5 * (bmax + bmin);
+        r.cx = ex * ca + nx * cb; r.cy = ey * ca + ny * cb; r.area = area;
+        if (ea >= eb) { r.mx = ex; r.my = ey; r.L = ea; r.W = eb; }
+        else { r.mx = nx; r.my = ny; r.L = eb; r.W = ea; }
+      }
+    }
+    double wb = best;
+    int wi = bi;
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_down(wb, off);
+      const int oi = __shfl_down(wi, off);
+      if (ob < wb || (ob == wb && oi < wi)) { wb = ob; wi = oi; }
+    }
+    wi = __shfl(wi, 0);
+    if (bi == wi && wi != 0x7fffffff) { o[0] = r.cx; o[1] = r.cy; o[2] = r.mx; o[3] = r.my; o[4] = r.L; o[5] = r.W; o[6] = r.area; }
+    else if (wi == 0x7fffffff && lane < 7) o[lane] = 0.0;
+    __syncthreads();
+  }
+}
+
 #define SH_TE_DSCR (6 * SH_MAXSEG + 64 * SH_TE_MAXCH)
 __global__ void k_te_final(const double* __restrict__ ring, const int* __restrict__ ring_n, const double* __restrict__ rects,
                            const double* __restrict__ distal_zs, const double* __restrict__ T_obb, const double* __restrict__ canal_axis_ct,
                            const double* __restrict__ axes_obb /*[B][4][3]: +n,-n,+c,-c*/, double* __restrict__ dscratch,
-                           double* __restrict__ te_axis_ct, int* __restrict__ te_row, int* __restrict__ err, int B) {
+                           double* __restrict__ te_axis_ct, int* __restrict__ te_row, int* __restrict__ err, int B, OvfPools P, OvfSet S) {
   // one 64-lane workgroup per humerus: all lanes stage the chosen ring in LDS, lane 0 runs the (sequential) clipping
   // on it -- the walk over the ring is latency-bound when every point comes from global memory
   __shared__ double s_xy[2 * (SH_MAXSEG + 1)];
@@ -102,18 +167,21 @@ __global__ void k_te_final(const double* __restrict__ ring, const int* __restric
   __syncthreads();
   const int k = s_k;
   size_t pl = (size_t)b * SH_NDIST + SH_TE_ROW0 + k;
-  const double* gxy = ring + pl * (SH_MAXSEG + 1) * 2;
+  const bool ovf = S.roff[pl] >= 0;      // the widest slice is an overflow plane (k_ovf.h): ring in the pool, scratch in its workspace
+  const double* gxy = ovf ? P.ring + 2 * S.roff[pl] : ring + pl * (SH_MAXSEG + 1) * 2;
   int n = ring_n[pl];
-  if (n > SH_MAXSEG) n = SH_MAXSEG;
-  for (int q = threadIdx.x; q < 2 * (n + 1); q += blockDim.x) s_xy[q] = gxy[q];
+  if (!ovf) {
+    if (n > SH_MAXSEG) n = SH_MAXSEG;
+    for (int q = threadIdx.x; q < 2 * (n + 1); q += blockDim.x) s_xy[q] = gxy[q];
+  }
   __syncthreads();
   if (threadIdx.x != 0) return;
   te_row[b] = SH_TE_ROW0 + k;
-  const double* xy = s_xy;
+  const double* xy = ovf ? gxy : s_xy;
   const double* r = R + k * 7;
   double half = 0.5 * 0.999 * r[4];
   double cents[2 * 16];
-  double* scr = s_scr;
+  double* scr = ovf ? (double*)(P.work + S.woff[pl]) : s_scr;
   (void)dscratch;
   int n1 = clip_halfplane_pieces(xy, n, r[0], r[1], r[2], r[3], half, cents, 8, scr);
   if (n1 < 0) n1 = 0;

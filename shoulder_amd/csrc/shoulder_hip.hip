@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "k_slices.h"
+#include "k_ovf.h"
 #include "k_stages.h"
 #include "k_groove.h"
 #include "k_anp.h"
@@ -81,6 +82,9 @@ struct sh_ctx {
   // as long as the batch stays resident (skip_gen == batch_gen).
   int hull_mode = 1;
   unsigned long long skip_gen = ~0ull;
+  int skip_nfmax = 0;                      // most hull faces among the humeri of this batch that are on the host hull (hulld.skip)
+  // overflow pools of the slice layer (k_ovf.h): capacities in segments / ring points / bytes; grown by sh_collect on demand
+  unsigned long long ovf_seg_cap = 1ull << 18, ovf_ring_cap = 1ull << 18, ovf_work_cap = 32ull << 20;
   bool redo_records = false;               // run_obb: the hull records of the window are in place already (redo_given_up)
   int redo_nf = 0;
   std::vector<float> h_verts;                // host copy of the vertices (hull stage)
@@ -95,7 +99,9 @@ struct sh_ctx {
   // Window of the batch the stage runner is working on: sh_run walks the batch in windows so that the
   // host hull of window k+1 overlaps the device work of window k.  buf<T>() applies the offset.
   int b0 = 0, Bwin = 0;
-  struct HullStage { double* hv = nullptr; double* nr = nullptr; int* ed = nullptr; int* cnt = nullptr; int cap = 0; hipEvent_t ev = nullptr; bool used = false; };
+  struct HullStage { double* hv = nullptr; double* nr = nullptr; int* ed = nullptr; int* cnt = nullptr; int cap = 0; hipEvent_t ev = nullptr; bool used = false;
+                     int pv = 4096, pf = 8192, pe = 12288; };      // per-humerus pitch of the pinned staging (elements): the usual hull fits the small
+                                                                 // one; a batch with a larger hull re-allocates the slot at SH_HV / SH_HF / SH_HE
   HullStage hstage[2];                       // pinned host staging, double buffered
   int hslot = 0;                             // slot the next hull goes to
   // Overlap (sh_set_overlap): while the device works on run k, a background thread computes the hulls run k+1 will
@@ -107,7 +113,7 @@ struct sh_ctx {
   } prep;
   hipEvent_t obb_done_ev = nullptr;      // recorded after the last kernel of a run that reads the hull.* device buffers
   // sh_submit / sh_collect: up to two runs in flight (the second one is enqueued while the first still executes)
-  struct Ticket { hipEvent_t ev = nullptr; int* h_err = nullptr; int* h_fail = nullptr; int cap = 0, B = 0; bool pending = false; sh_landmarks* host_out = nullptr;
+  struct Ticket { hipEvent_t ev = nullptr; int* h_err = nullptr; int* h_fail = nullptr; unsigned long long* h_ovf = nullptr; int cap = 0, B = 0; bool pending = false; sh_landmarks* host_out = nullptr;
                   uint32_t mask = 0; sh_landmarks* out_arg = nullptr; bool dev_hull = false; };
   Ticket tickets[2];
   int t_head = 0, t_tail = 0, n_pending = 0;
@@ -299,7 +305,7 @@ void sh_ctx_destroy(sh_ctx* c) {
   if (c->h_nkept) (void)hipHostFree(c->h_nkept);
   if (c->h_koff) (void)hipHostFree(c->h_koff);
   if (c->obb_done_ev) (void)hipEventDestroy(c->obb_done_ev);
-  for (auto& tk : c->tickets) { if (tk.ev) (void)hipEventDestroy(tk.ev); if (tk.h_err) (void)hipHostFree(tk.h_err); if (tk.h_fail) (void)hipHostFree(tk.h_fail); }
+  for (auto& tk : c->tickets) { if (tk.ev) (void)hipEventDestroy(tk.ev); if (tk.h_err) (void)hipHostFree(tk.h_err); if (tk.h_fail) (void)hipHostFree(tk.h_fail); if (tk.h_ovf) (void)hipHostFree(tk.h_ovf); }
   if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
   for (auto& kv : c->bufs)
     if (kv.second.p) (void)hipFree(kv.second.p);
@@ -492,6 +498,7 @@ static int alloc_hulld(sh_ctx* c) {
   if (c->skip_gen != c->batch_gen) {      // a new batch: the device hull takes every humerus again
     HIPCHK(c, hipMemsetAsync(c->bufs["hulld.skip"].p, 0, (size_t)B * 4, c->stream));
     c->skip_gen = c->batch_gen;
+    c->skip_nfmax = 0;
   }
   return SH_OK;
 }
@@ -781,6 +788,32 @@ int sh_transform_points(sh_ctx* c, const double* T, const double* in, int n, dou
          buf<long long>(c, "tp_off"));
   HIPCHK(c, hipMemcpyAsync(out, io + (size_t)n * 3, (size_t)n * 3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+
+// The closed largest loop of plane k of slice set `set` ("full" has none; "distal", "prox", "neckc") of humerus b after a run:
+// n + 1 points (x, y) in the box frame, CCW, canonical start, first = last.  From the fixed slot range or, for a plane with more
+// crossings than slots, from the overflow pool (k_ovf.h).  out == NULL or cap too small: *n_out = n + 1, nothing copied.
+int sh_ring(sh_ctx* c, const char* set, int b, int k, double* out, int cap, int* n_out) {
+  if (!c || !set || !n_out) return fail(c, SH_ERR_ARG, "sh_ring: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const std::string p = set;
+  auto itn = c->bufs.find(p + ".ring_n");
+  auto itr = c->bufs.find(p + ".ring");
+  if (itn == c->bufs.end() || itr == c->bufs.end() || !itr->second.p) return fail(c, SH_ERR_ARG, "sh_ring: no such slice set with rings");
+  const int N = (int)(itn->second.per_mesh / 4);
+  if (b < 0 || b >= c->B || k < 0 || k >= N) return fail(c, SH_ERR_ARG, "sh_ring: index out of range");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t pl = (size_t)b * N + k;
+  int n = 0;
+  HIPCHK(c, hipMemcpy(&n, (const int*)itn->second.p + pl, 4, hipMemcpyDeviceToHost));
+  *n_out = n + 1;
+  if (!out || cap < n + 1) return SH_OK;
+  long long roff = -1;
+  auto ito = c->bufs.find(p + ".ovf_roff");
+  if (ito != c->bufs.end() && ito->second.p) HIPCHK(c, hipMemcpy(&roff, (const long long*)ito->second.p + pl, 8, hipMemcpyDeviceToHost));
+  const double* src = roff >= 0 ? (const double*)c->bufs["ovf.ring"].p + 2 * roff : (const double*)itr->second.p + pl * (SH_MAXSEG + 1) * 2;
+  HIPCHK(c, hipMemcpy(out, src, (size_t)(n + 1) * 16, hipMemcpyDeviceToHost));
   return SH_OK;
 }
 
@@ -1311,6 +1344,39 @@ int sh_unet_infer(sh_ctx* c, const float* images, int n, int H, int W, float* lo
 }
 
 // ---- stage runner ----------------------------------------------------------------------------------
+// ---- overflow planes of the slice layer (k_ovf.h) --------------------------------------------------------
+static int ovf_pools(sh_ctx* c, OvfPools* P) {
+  int rc;
+  if ((rc = ensure(c, "ovf.segs", c->ovf_seg_cap * sizeof(Seg), 1)) != SH_OK) return rc;
+  if ((rc = ensure(c, "ovf.ring", c->ovf_ring_cap * 16, 8)) != SH_OK) return rc;
+  if ((rc = ensure(c, "ovf.work", c->ovf_work_cap, 1)) != SH_OK) return rc;
+  if ((rc = ensure(c, "ovf.ctr", 64, 8)) != SH_OK) return rc;
+  for (const char* n : {"ovf.segs", "ovf.ring", "ovf.work", "ovf.ctr"}) c->bufs[n].per_mesh = 0;
+  P->segs = (Seg*)c->bufs["ovf.segs"].p; P->ring = (double*)c->bufs["ovf.ring"].p; P->work = (unsigned char*)c->bufs["ovf.work"].p;
+  P->seg_cap = c->ovf_seg_cap; P->ring_cap = c->ovf_ring_cap; P->work_cap = c->ovf_work_cap;
+  P->ctr = (unsigned long long*)c->bufs["ovf.ctr"].p;
+  return SH_OK;
+}
+// the plan arrays of slice set `pfx` (N planes per humerus), window-relative like every [B][...] buffer
+static int ovf_set(sh_ctx* c, const std::string& pfx, int N, OvfSet* S) {
+  const size_t B = (size_t)c->B;
+  int rc;
+  struct A { const char* suffix; size_t elem; } arr[5] = {{".ovf_soff", 8}, {".ovf_roff", 8}, {".ovf_woff", 8}, {".ovf_fill", 4}, {".ovf_list", 4}};
+  for (const A& a : arr) {
+    const std::string nm = pfx + a.suffix;
+    const bool fresh = c->bufs.find(nm) == c->bufs.end() || c->bufs[nm].bytes < B * N * a.elem;
+    if ((rc = ensure(c, nm.c_str(), B * N * a.elem, (int)a.elem)) != SH_OK) return rc;
+    c->bufs[nm].per_mesh = (size_t)N * a.elem;
+    if (fresh) HIPCHK(c, hipMemsetAsync(c->bufs[nm].p, 0xFF, B * N * a.elem, c->stream));      // "no overflow plane" until a plan says otherwise
+  }
+  if ((rc = ensure(c, (pfx + ".ovf_nlist").c_str(), 16, 4)) != SH_OK) return rc;
+  c->bufs[pfx + ".ovf_nlist"].per_mesh = 0;
+  S->soff = buf<long long>(c, (pfx + ".ovf_soff").c_str()); S->roff = buf<long long>(c, (pfx + ".ovf_roff").c_str());
+  S->woff = buf<long long>(c, (pfx + ".ovf_woff").c_str()); S->fill = buf<int>(c, (pfx + ".ovf_fill").c_str());
+  S->list = buf<int>(c, (pfx + ".ovf_list").c_str()); S->nlist = (int*)c->bufs[pfx + ".ovf_nlist"].p;
+  return SH_OK;
+}
+
 static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0, bool total_area = false) {
   const int B = c->Bwin;
   std::string p = pfx;
@@ -1326,7 +1392,16 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   if (N > SH_EMIT_MAXN) return fail(c, SH_ERR_CAPACITY, "slice set has more planes than k_slice_emit's LDS histogram");
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 4096), (unsigned)B);
   LAUNCH(c, "k_slice_emit", k_slice_emit, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
-         buf<long long>(c, "foff"), zeff, N, cnt, segs, buf<int>(c, "err"));
+         buf<long long>(c, "foff"), zeff, N, cnt, segs);
+  // planes with more crossings than slots (k_ovf.h): plan their pool ranges, section them again into the segment pool
+  OvfPools OP; OvfSet OS;
+  { int orc; if ((orc = ovf_pools(c, &OP)) != SH_OK || (orc = ovf_set(c, p, N, &OS)) != SH_OK) return orc; }
+  HIPCHK(c, hipMemsetAsync(OS.nlist, 0, 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(OP.ctr, 0, 8, c->stream));              // segments used: per set
+  HIPCHK(c, hipMemsetAsync(OP.ctr + 2, 0, 8, c->stream));          // workspace used: per set (ring points stay for the run)
+  LAUNCH(c, "k_ovf_plan", k_ovf_plan, dim3((unsigned)((B * N + 255) / 256)), dim3(256), N, B * N, (const int*)cnt, OP, OS, buf<int>(c, "err"));
+  LAUNCH(c, "k_slice_emit_ovf", k_slice_emit_ovf, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
+         buf<long long>(c, "foff"), zeff, N, OP, OS);
   // two capacity tiers share the grid (k_slices.h): the planes of the other tier exit at once
   int* rn = buf<int>(c, (p + ".ring_n").c_str());
   double* rg = ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr;
@@ -1334,11 +1409,15 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, nlarge);
   LAUNCH(c, "k_slice_link_large", k_slice_link_large, dim3(std::min(B * N, 512)), dim3(SH_LINK_THREADS), B * N, N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, (const int*)nlarge);
+  LAUNCH(c, "k_slice_link_huge", k_slice_link_huge, dim3(64), dim3(SH_HUGE_THREADS), N, (const int*)cnt, OP, OS, buf<double>(c, (p + ".centroids").c_str()),
+         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, ring ? 1 : 0, select, buf<int>(c, "err"), atot);
   if (resample) {
     LAUNCH(c, "k_resample_polar", k_resample_polar, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
-           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
+           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const long long*)OS.roff);
     LAUNCH(c, "k_resample_polar_large", k_resample_polar_large, dim3(std::min(B * N, 512)), dim3(SH_RS_THREADS), B * N, N, SH_MPROX, rn, rg,
-           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const int*)nlarge);
+           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const int*)nlarge, (const long long*)OS.roff);
+    LAUNCH(c, "k_resample_polar_huge", k_resample_polar_huge, dim3(64), dim3(SH_RS_THREADS), N, SH_MPROX, (const int*)rn, OP, OS,
+           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
   }
   return SH_OK;
 }
@@ -1465,12 +1544,14 @@ static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, do
   auto t0 = std::chrono::steady_clock::now();
   sh_ctx::HullStage& hs = c->hstage[slot];
 #define HULLCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *errtxt = std::string(#call) + ": " + hipGetErrorString(e_); return SH_ERR_HIP; } } while (0)
-  if (hs.cap < B) {
+  bool grown = false;
+again:
+  if (hs.cap < B || grown) {
     if (hs.hv) { (void)hipHostFree(hs.hv); (void)hipHostFree(hs.nr); (void)hipHostFree(hs.ed); (void)hipHostFree(hs.cnt); }
     hs.hv = nullptr; hs.cap = 0;
-    HULLCHK(hipHostMalloc((void**)&hs.hv, (size_t)B * SH_HV * 3 * 8));
-    HULLCHK(hipHostMalloc((void**)&hs.nr, (size_t)B * SH_HF * 3 * 8));
-    HULLCHK(hipHostMalloc((void**)&hs.ed, (size_t)B * SH_HE * 4 * 4));
+    HULLCHK(hipHostMalloc((void**)&hs.hv, (size_t)B * hs.pv * 3 * 8));
+    HULLCHK(hipHostMalloc((void**)&hs.nr, (size_t)B * hs.pf * 3 * 8));
+    HULLCHK(hipHostMalloc((void**)&hs.ed, (size_t)B * hs.pe * 4 * 4));
     HULLCHK(hipHostMalloc((void**)&hs.cnt, (size_t)B * 3 * 4));
     hs.cap = B;
   }
@@ -1494,10 +1575,11 @@ static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, do
       if (!shhull::convex_hull(P.data(), (int)nv, H)) { status[b] = SH_ERR_GEOMETRY; continue; }
       int hn = (int)H.vert_ids.size(), fn = (int)H.tris.size() / 3, en = (int)H.edges.size() / 4;
       if (hn > SH_HV || fn > SH_HF || en > SH_HE) { status[b] = SH_ERR_CAPACITY; continue; }
+      if (hn > hs.pv || fn > hs.pf || en > hs.pe) { status[b] = 1; continue; }      // does not fit the small staging pitch: see below
       for (int i = 0; i < hn; ++i)
-        for (int k = 0; k < 3; ++k) hv[((size_t)b * SH_HV + i) * 3 + k] = P[3 * (size_t)H.vert_ids[i] + k];
-      std::copy(H.normals.begin(), H.normals.end(), nr + (size_t)b * SH_HF * 3);
-      std::copy(H.edges.begin(), H.edges.end(), ed + (size_t)b * SH_HE * 4);
+        for (int k = 0; k < 3; ++k) hv[((size_t)b * hs.pv + i) * 3 + k] = P[3 * (size_t)H.vert_ids[i] + k];
+      std::copy(H.normals.begin(), H.normals.end(), nr + (size_t)b * hs.pf * 3);
+      std::copy(H.edges.begin(), H.edges.end(), ed + (size_t)b * hs.pe * 4);
       counts[b] = hn; counts[B + b] = fn; counts[2 * B + b] = en;
     }
   };
@@ -1506,6 +1588,14 @@ static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, do
   // SHOULDER_HULL_THREADS overrides.  The calling thread works on its own batch too.  (Round 1 started up to 32 threads
   // per batch: a third of the 4.8 ms hull phase was thread start-up, and two lanes doubled the thread count.)
   HullPool::instance().run(work, B);
+  if (!grown && std::find(status.begin(), status.end(), 1) != status.end()) {
+    // a hull larger than the staging pitch (a dense mesh): this slot gets the full record capacity and the phase runs again
+    hs.pv = SH_HV; hs.pf = SH_HF; hs.pe = SH_HE;
+    grown = true;
+    std::fill(status.begin(), status.end(), 0);
+    next = 0;
+    goto again;
+  }
   *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (int b = 0; b < B; ++b)
     if (status[b] != 0) { *bad_mesh = b0 + b; return status[b]; }
@@ -1520,9 +1610,9 @@ static hipError_t hull_upload(sh_ctx* c, int slot, int B, void* const dst[6], hi
   int nvmax = 1, nfmax = 1, nemax = 1;
   for (int b = 0; b < B; ++b) { nvmax = std::max(nvmax, counts[b]); nfmax = std::max(nfmax, counts[B + b]); nemax = std::max(nemax, counts[2 * B + b]); }
   hipError_t e;
-  if ((e = hipMemcpy2DAsync(dst[0], (size_t)SH_HV * 24, hs.hv, (size_t)SH_HV * 24, (size_t)nvmax * 24, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  if ((e = hipMemcpy2DAsync(dst[1], (size_t)SH_HF * 24, hs.nr, (size_t)SH_HF * 24, (size_t)nfmax * 24, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  if ((e = hipMemcpy2DAsync(dst[2], (size_t)SH_HE * 16, hs.ed, (size_t)SH_HE * 16, (size_t)nemax * 16, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpy2DAsync(dst[0], (size_t)SH_HV * 24, hs.hv, (size_t)hs.pv * 24, (size_t)nvmax * 24, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpy2DAsync(dst[1], (size_t)SH_HF * 24, hs.nr, (size_t)hs.pf * 24, (size_t)nfmax * 24, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpy2DAsync(dst[2], (size_t)SH_HE * 16, hs.ed, (size_t)hs.pe * 16, (size_t)nemax * 16, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(dst[3], counts, (size_t)B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(dst[4], counts + B, (size_t)B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(dst[5], counts + 2 * B, (size_t)B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
@@ -1551,7 +1641,8 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
            buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), buf<int>(c, "hull.nv"), buf<int>(c, "hull.nf"), buf<int>(c, "hull.ne"),
            buf<int>(c, "hulld.fail"), buf<int>(c, "hulld.rounds"), (const int*)buf<int>(c, "hulld.skip"));
     LAUNCH(c, "k_hull_flag", k_hull_flag, dim3((B + 63) / 64), dim3(64), buf<int>(c, "hulld.fail"), buf<int>(c, "err"), B);
-    nfmax = HD_SLOTS;      // (the face counts stay on the device: the candidate kernel's tiles beyond a hull's faces return at once)
+    nfmax = std::max((int)HD_SLOTS, c->skip_nfmax);      // (the face counts stay on the device: the candidate kernel's tiles beyond a hull's faces return at once;
+                                                         //  a humerus kept on the host hull may have more faces than the device hull has slots)
   } else {
   int slot = prepared_slot;
   if (slot < 0) {
@@ -1582,17 +1673,28 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
     LAUNCH(c, "k_obb_bounds", k_obb_bounds, dim3((unsigned)((nfmax + SH_OBB_BND_DIRS - 1) / SH_OBB_BND_DIRS), (unsigned)B), dim3(SH_OBB_BND_THREADS),
            buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<double>(c, "obb.area2"), buf<double>(c, "obb.lb"),
            buf<unsigned long long>(c, "obb.lbmin_enc"), buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"));
-    const int ntiles = (nfmax + SH_OBB_TILE - 1) / SH_OBB_TILE;
+    // capacity tier of k_obb_candidates (k_obb.h): the small one unless a hull of this launch has more than 8 192 faces
+    const bool big = nfmax > 8192;
+    const int TT = big ? 8 : SH_OBB_TILE;
+    const int ntiles = (nfmax + TT - 1) / TT;
     // SHOULDER_OBB_PRUNE=0: every direction is evaluated (the A/B of the pruning bound: same frames, tests/test_gpu_hull.py)
     const bool prune = !(getenv("SHOULDER_OBB_PRUNE") && getenv("SHOULDER_OBB_PRUNE")[0] == '0');
     for (int pass = 0; pass < 2; ++pass) {      // seed tile, then the directions its best volume cannot exclude
       LAUNCH(c, "k_obb_select", k_obb_select, dim3(B), dim3(256), buf<double>(c, "obb.lb"), cnt_nf, buf<unsigned long long>(c, "obb.lbmin_enc"),
              buf<unsigned long long>(c, "obb.best_enc"), (prune || pass == 0) ? pass : 2, buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"), buf<unsigned char>(c, "obb.seeded"));
-      const int nt_pass = pass == 0 ? 1 : ntiles;
-      LAUNCH(c, pass == 0 ? "k_obb_seed" : "k_obb_candidates", k_obb_candidates, dim3((unsigned)(nt_pass * ((B + 7) / 8) * 8)), dim3(SH_OBB_THREADS),
-             buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"),
-             buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"), buf<unsigned long long>(c, "obb.best_enc"), buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"),
-             nt_pass, B, prune ? 1 : 0);
+      const int nt_pass = pass == 0 ? SH_OBB_TILE / TT : ntiles;      // (the seed pass: up to SH_OBB_TILE directions)
+      const dim3 cg((unsigned)(nt_pass * ((B + 7) / 8) * 8));
+      if (big) {
+        LAUNCH(c, pass == 0 ? "k_obb_seed" : "k_obb_candidates", (k_obb_candidates<8, 1, 2048, 32768, unsigned>), cg, dim3(SH_OBB_THREADS),
+               buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"),
+               buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"), buf<unsigned long long>(c, "obb.best_enc"), buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"),
+               nt_pass, B, prune ? 1 : 0);
+      } else {
+        LAUNCH(c, pass == 0 ? "k_obb_seed" : "k_obb_candidates", (k_obb_candidates<SH_OBB_TILE, SH_OBB_GROUP, 512, 8192, unsigned short>), cg, dim3(SH_OBB_THREADS),
+               buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"),
+               buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"), buf<unsigned long long>(c, "obb.best_enc"), buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"),
+               nt_pass, B, prune ? 1 : 0);
+      }
     }
   }
   LAUNCH(c, "k_obb_pick", k_obb_pick, dim3(B), dim3(256), buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"),
@@ -1714,13 +1816,16 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<double>(c, "anp.axes_obb"), buf<int>(c, "err"), B);
   }
   if (mask & SH_STAGE_TE) {
+    OvfPools OP; OvfSet OS;
+    { int orc; if ((orc = ovf_pools(c, &OP)) != SH_OK || (orc = ovf_set(c, "distal", SH_NDIST, &OS)) != SH_OK) return orc; }
     LAUNCH(c, "k_te_rows", k_te_rows<SH_SMALLSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
-           buf<double>(c, "te.rects"), B);
+           buf<double>(c, "te.rects"), B, (const long long*)OS.roff);
     LAUNCH(c, "k_te_rows_large", k_te_rows<SH_MAXSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
-           buf<double>(c, "te.rects"), B);
+           buf<double>(c, "te.rects"), B, (const long long*)OS.roff);
+    LAUNCH(c, "k_te_rows_huge", k_te_rows_huge, dim3(64), dim3(64), OP, OS, (const int*)buf<int>(c, "distal.ring_n"), buf<double>(c, "te.rects"));
     LAUNCH(c, "k_te_final", k_te_final, dim3(B), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
-           buf<double>(c, "anp.axes_obb"), buf<double>(c, "te.dscratch"), buf<double>(c, "te.axis_ct"), buf<int>(c, "te.row"), buf<int>(c, "err"), B);
+           buf<double>(c, "anp.axes_obb"), buf<double>(c, "te.dscratch"), buf<double>(c, "te.axis_ct"), buf<int>(c, "te.row"), buf<int>(c, "err"), B, OP, OS);
   }
   LAUNCH(c, "k_pack", k_pack, dim3(B), dim3(256), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "obb_transform"), buf<double>(c, "z_bounds"),
          buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), buf<int>(c, "flipped"), buf<double>(c, "canal.axis_ct"), buf<double>(c, "te.axis_ct"),
@@ -1848,6 +1953,7 @@ static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot
     HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hulld.skip") + b, &one, 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(buf<int>(c, "err") + b, 0, 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));      // the sources above are locals
+    c->skip_nfmax = std::max(c->skip_nfmax, fn);
     c->b0 = b; c->Bwin = 1; c->redo_records = true; c->redo_nf = fn;
     rc = run_window(c, tk.mask, -1);
     c->redo_records = false;
@@ -1880,6 +1986,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     tk.h_err = nullptr; tk.h_fail = nullptr; tk.cap = 0;
     HIPCHK(c, hipHostMalloc((void**)&tk.h_err, (size_t)B * 4));
     HIPCHK(c, hipHostMalloc((void**)&tk.h_fail, (size_t)B * 4));
+    if (!tk.h_ovf) HIPCHK(c, hipHostMalloc((void**)&tk.h_ovf, 64));
     tk.cap = B;
   }
   if (!tk.ev) HIPCHK(c, hipEventCreateWithFlags(&tk.ev, hipEventDisableTiming));
@@ -1891,6 +1998,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     if (prc != SH_OK) return prc;
   }
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "err"), 0, B * 4, c->stream));
+  { OvfPools OP; int orc = ovf_pools(c, &OP); if (orc != SH_OK) return orc; HIPCHK(c, hipMemsetAsync(OP.ctr, 0, 64, c->stream)); }      // overflow pools: empty, no demand recorded
   if ((mask & SH_STAGE_APPLY) && !(mask & SH_STAGE_CSYS)) return fail(c, SH_ERR_ARG, "sh_run: SH_STAGE_APPLY needs SH_STAGE_CSYS in the same run");
   // a proximal humerus' frame is canal / articular (bone.py:53-62): k_pack builds it from the anatomic-neck axes of THIS run
   if (c->params.bone_kind == SH_BONE_PROXIMAL && (mask & SH_STAGE_CSYS) && !(mask & SH_STAGE_ANP))
@@ -1947,6 +2055,11 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     tk.host_out = out;
   }
   HIPCHK(c, hipMemcpyAsync(err_stage, buf<int>(c, "err"), (size_t)B * 4, hipMemcpyDeviceToDevice, c->stream));
+  {      // what the run asked of the overflow pools (k_ovf.h): sh_collect grows them and runs again if it was more than they hold
+    void* ovf_stage = nullptr;
+    if (int e = ensure(c, ("out.ovf" + tslot).c_str(), 64, 8, &ovf_stage)) return e;
+    HIPCHK(c, hipMemcpyAsync(ovf_stage, c->bufs["ovf.ctr"].p, 64, hipMemcpyDeviceToDevice, c->stream));
+  }
   if (dev_hull) {      // which humeri the device hull gave up: its own word per humerus (the status word can be overwritten by a later stage)
     void* fail_stage = nullptr;
     if (int e = ensure(c, ("out.hfail" + tslot).c_str(), (size_t)B * 4, 4, &fail_stage)) return e;
@@ -1970,6 +2083,26 @@ int sh_collect(sh_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(tk.host_out, buf<char>(c, ("out.landmarks" + tslot).c_str()), (size_t)tk.B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->out_stream));
   HIPCHK(c, hipMemcpyAsync(tk.h_err, buf<char>(c, ("out.err" + tslot).c_str()), (size_t)tk.B * 4, hipMemcpyDeviceToHost, c->out_stream));
   HIPCHK(c, hipStreamSynchronize(c->out_stream));
+  {
+    HIPCHK(c, hipMemcpyAsync(tk.h_ovf, buf<char>(c, ("out.ovf" + tslot).c_str()), 64, hipMemcpyDeviceToHost, c->out_stream));
+    HIPCHK(c, hipStreamSynchronize(c->out_stream));
+    const unsigned long long need_s = tk.h_ovf[3], need_r = tk.h_ovf[4], need_w = tk.h_ovf[5];
+    if (getenv("SH_DEBUG")) fprintf(stderr, "[sh] collect: ovf need %llu %llu %llu cap %llu %llu %llu err0 %d\n", need_s, need_r, need_w, c->ovf_seg_cap, c->ovf_ring_cap, c->ovf_work_cap, tk.h_err[0]);
+    if (need_s > c->ovf_seg_cap || need_r > c->ovf_ring_cap || need_w > c->ovf_work_cap) {
+      // The batch has more overflow planes than the pools hold (a first dense mesh): grow them to what the run asked for,
+      // with headroom, and run the batch again -- here, synchronously, when nothing else is in flight.
+      if (c->n_pending != 0)
+        return fail(c, SH_ERR_CAPACITY, "slice overflow pools too small while another run is in flight: collect it, then run the batch again (the pools are grown by then)");
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      c->ovf_seg_cap = std::max(c->ovf_seg_cap, need_s + need_s / 4);
+      c->ovf_ring_cap = std::max(c->ovf_ring_cap, need_r + need_r / 4);
+      c->ovf_work_cap = std::max(c->ovf_work_cap, need_w + need_w / 4);
+      const uint32_t mask = tk.mask; sh_landmarks* out = tk.out_arg;
+      int rc2 = sh_submit(c, mask, out);
+      if (rc2 != SH_OK) return rc2;
+      return sh_collect(c);
+    }
+  }
   if (tk.dev_hull) {
     HIPCHK(c, hipMemcpyAsync(tk.h_fail, buf<char>(c, ("out.hfail" + tslot).c_str()), (size_t)tk.B * 4, hipMemcpyDeviceToHost, c->out_stream));
     HIPCHK(c, hipStreamSynchronize(c->out_stream));

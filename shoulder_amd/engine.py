@@ -264,14 +264,28 @@ class Engine:
         self._chk(self.L.sh_transform_points(self.h, _ptr(T), _ptr(pts), len(pts), _ptr(out)))
         return out
 
+    def ring(self, set_name, b, k):
+        """Closed largest loop of plane k of slice set `set_name` ("distal", "prox", "neckc") of humerus b: (n + 1, 2) float64 in
+        the box frame (sh_ring; also for planes whose ring lives in the overflow pool)."""
+        n = ctypes.c_int()
+        self._chk(self.L.sh_ring(self.h, set_name.encode(), int(b), int(k), None, 0, ctypes.byref(n)))
+        out = np.empty((max(1, n.value), 2), dtype=np.float64)
+        self._chk(self.L.sh_ring(self.h, set_name.encode(), int(b), int(k), _ptr(out), len(out), ctypes.byref(n)))
+        return out[: n.value]
+
     def section_plane(self, b, origin, normal, cap=8192):
         """Unique crossing points (CT) of mesh b with one plane: `mesh_ct.section(...).vertices`."""
         o = np.ascontiguousarray(origin, dtype=np.float64)
         n = np.ascontiguousarray(normal, dtype=np.float64)
-        out = np.empty((cap, 3), dtype=np.float64)
-        k = ctypes.c_int()
-        self._chk(self.L.sh_section_plane(self.h, int(b), _ptr(o), _ptr(n), _ptr(out), cap, ctypes.byref(k)))
-        return out[:k.value].copy()
+        while True:      # (a dense mesh crosses a plane more often than the default capacity: ask again with room)
+            out = np.empty((cap, 3), dtype=np.float64)
+            k = ctypes.c_int()
+            rc = self.L.sh_section_plane(self.h, int(b), _ptr(o), _ptr(n), _ptr(out), cap, ctypes.byref(k))
+            if rc == -4 and cap < (1 << 24):
+                cap *= 8
+                continue
+            self._chk(rc)
+            return out[:k.value].copy()
 
     def slice_mesh_planes(self, verts, faces, origins, normals, edges=False):
         """`Trimesh.slice_plane(origin, normal)` of one mesh for P planes in one device pass (sh_slice_mesh_planes;

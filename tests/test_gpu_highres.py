@@ -1,7 +1,7 @@
 """Meshes denser than the fixtures: one midpoint subdivision of humerus_left.stl (4x the triangles) doubles the crossing
 segments per plane (~300-650), which takes the sections through the large-capacity instantiations (k_slice_link_large,
-k_resample_polar_large, k_te_rows<1024>) that the fixture meshes never reach; two subdivisions exceed the 1024-segment
-capacity and must end in SH_ERR_CAPACITY for that humerus, not in a wrong answer."""
+k_resample_polar_large, k_te_rows<1024>) that the fixture meshes never reach; two subdivisions (519 k triangles) exceed the
+1024 segment slots of the fast path and go through the overflow tier (k_ovf.h) -- with the same results as the oracle."""
 import os
 
 import numpy as np
@@ -47,27 +47,74 @@ def test_large_capacity_tier_matches_oracle(engine, rfc_tables, unet_weights):
     np.testing.assert_allclose(r["anp_points"].reshape(-1, 3)[: int(r["n_anp"])], L["anp_points"], rtol=0, atol=1e-6)
 
 
-def test_over_capacity_is_an_error(engine):
+@pytest.fixture(scope="module")
+def dense16(oracle_bones, rfc_tables, unet_weights):
+    """humerus_left subdivided twice: 259 522 vertices, 519 040 triangles (an ordinary size for a CT-segmented STL) -- ~1 300 crossing
+    segments per plane, past the 1 024 slots of the fast path -- and its oracle."""
     v, f = load_stl(os.path.join(BONES, "humerus_left.stl"))
     v3, f3 = subdivide(*subdivide(v, f))
-    engine.upload([(v3, f3)])
-    with pytest.raises(ShoulderHipError) as err:
-        engine.run(_lib.STAGE_ALL)
-    assert err.value.code == -4 and "mesh 0" in str(err.value)
+    assert len(f3) == 16 * len(f)
+    return v3, f3, OracleHumerus(v3, f3, rfc_tables, unet_weights, unet_eval="chain")
 
 
-def test_slice_capacity_overflow_is_an_error(engine, oracle_bones):
-    """The 16x mesh past the hull stage (box frame injected): ~1 300 crossing segments per plane exceed SH_MAXSEG = 1024; the slice
-    stage must flag the humerus (SH_ERR_CAPACITY), and the engine must still work afterwards."""
-    h = oracle_bones("humerus_left")
-    v3, f3 = subdivide(*subdivide(h.verts, h.faces))
+def test_519k_triangle_humerus_matches_oracle_beside_a_fixture(engine, dense16, oracle_bones):
+    """VERDICT r2 missing 1: a valid reference input must give a result (`section_multiplane`, slice.py:26-28, and `apply_obb`,
+    mesh.py:82, have no size limit).  The 16x mesh and a fixture in ONE ragged batch through SH_STAGE_ALL: the dense humerus'
+    planes go through the overflow tier (k_ovf.h: count -> allocate -> emit, joins in global memory; the first run grows the
+    pools and repeats itself), the fixture through the fast path of the same launches.  Integer decisions equal, every landmark
+    within 1e-6 mm of the oracle."""
+    v3, f3, h = dense16
+    small = oracle_bones("humerus_right")
+    engine.reset_params()
+    engine.set_params(unet_dtype=_lib.UNET_F32)
+    engine.upload([(v3, f3), (small.verts, small.faces)])
+    lm = engine.run(_lib.STAGE_ALL)
+    assert (lm["status"] == 0).all()
+    cnt = engine.fetch("prox.seg_count", np.int32, (2, 600))
+    assert cnt[0].max() > 1024 and cnt[1].max() <= 384                      # the dense mesh really overflows the slots
+    for r, o in ((lm[0], h), (lm[1], small)):
+        L = o.landmarks()
+        assert bool(r["flipped"]) == o.obb["flipped"] and float(r["bg_theta"]) == L["bg_theta"] and int(r["n_anp"]) == len(L["anp_points"])
+        assert int(r["neck_index"]) == o.neck["bkp"]
+        for k in ("canal_axis", "te_axis", "groove_axis", "anp_plane_point", "anp_axis_normal", "anp_axis_central", "csys"):
+            np.testing.assert_allclose(np.asarray(r[k]).reshape(np.shape(L[k])), L[k], rtol=0, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(r["anp_points"].reshape(-1, 3)[: int(r["n_anp"])], L["anp_points"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(r["groove_points"], L["groove_points"], rtol=0, atol=1e-6)
+    # a second run needs no growing any more and gives the same bits
+    assert engine.run(_lib.STAGE_ALL).tobytes() == lm.tobytes()
+
+
+def test_overflow_planes_slice_layer_matches_oracle(engine, dense16):
+    """The slice layer of the dense mesh on its own (box frame injected), plane by plane against the oracle: crossing counts, loop
+    counts and ring lengths exact, AABB centres / areas / rings (through sh_ring: overflow planes live in the pool) / resampled
+    contours and polar images to 1e-9 mm -- for planes above AND below the 1 024-slot boundary in the same set."""
+    v3, f3, h = dense16
+    engine.reset_params()
     engine.upload([(v3, f3)])
     engine.store("obb_transform", h.T_obb[None])
-    with pytest.raises(ShoulderHipError) as err:
-        engine.run(_lib.STAGE_FULL | _lib.STAGE_PROXIMAL | _lib.STAGE_NECK)
-    assert err.value.code == -4
-    engine.upload([(h.verts, h.faces)])
-    assert engine.run(_lib.STAGE_ALL)["status"][0] == 0
+    engine.run(_lib.STAGE_FULL | _lib.STAGE_DISTAL | _lib.STAGE_NECK | _lib.STAGE_CANAL | _lib.STAGE_PROXIMAL, fetch=False)
+    for pfx, attr, N in (("full", "full", 200), ("distal", "distal", 200), ("prox", "proximal", 600)):
+        s = getattr(h, attr)
+        cnt = engine.fetch(pfx + ".seg_count", np.int32, (1, N))[0]
+        np.testing.assert_array_equal(cnt, [sum(len(r) - 1 for r in rings) for rings in s.loops])
+        np.testing.assert_array_equal(engine.fetch(pfx + ".nloops", np.int32, (1, N))[0], s.n_loops)
+        np.testing.assert_array_equal(engine.fetch(pfx + ".ring_n", np.int32, (1, N))[0], [len(r) - 1 for r in s.largest])
+        np.testing.assert_allclose(engine.fetch(pfx + ".centroids", np.float64, (1, N, 2))[0], s.centroids_all, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(engine.fetch(pfx + ".areas", np.float64, (1, N))[0], s.areas1_all, rtol=1e-12, atol=1e-9)
+        over = np.flatnonzero(cnt > 1024)
+        print(pfx, "planes over the slot range:", len(over), "of", N, " max crossings", int(cnt.max()))
+        if pfx != "full":
+            assert len(over) > 0
+            for k in list(over[:: max(1, len(over) // 6)]) + list(np.flatnonzero(cnt <= 1024)[::97]):
+                np.testing.assert_allclose(engine.ring(pfx, 0, int(k)), s.largest[k], rtol=0, atol=1e-9)      # same start, same direction
+    p = h.proximal
+    np.testing.assert_allclose(engine.fetch("prox.ixy", np.float64, (1, 600, 2, 512))[0], p.ixy_all, rtol=0, atol=1e-9)
+    for name, exp in (("prox.itr_start", p.itr_start_all), ("prox.itr_centered_start", p.itr_centered_start_all)):
+        got = engine.fetch(name, np.float64, (1, 600, 2, 512))[0]
+        np.testing.assert_array_equal(np.argmin(np.abs(got[:, 0, :] - exp[:, 0, :1]), axis=1), 0)      # roll index: exact
+        np.testing.assert_allclose(got, exp, rtol=0, atol=1e-9)
+    # the neck contour of the facade's SurgicalNeck.points (surgical_neck.py:37-54) is a ring too
+    np.testing.assert_allclose(engine.ring("neckc", 0, 0), h.neck["points_obb"][:, :2], rtol=0, atol=1e-9)
 
 
 def test_plane_cuts_of_the_dense_mesh(engine):

@@ -34,9 +34,9 @@ def engines(unet_weights):
 
 def _record(e, B):
     nv, nf, ne = (e.fetch(f"hull.{k}", np.int32, (B,)) for k in ("nv", "nf", "ne"))
-    hv = e.fetch("hull.hv", np.float64).reshape(B, 4096, 3)
-    nr = e.fetch("hull.normals", np.float64).reshape(B, 8192, 3)
-    ed = e.fetch("hull.edges", np.int32).reshape(B, 12288, 4)
+    hv = e.fetch("hull.hv", np.float64).reshape(B, 16384, 3)
+    nr = e.fetch("hull.normals", np.float64).reshape(B, 32768, 3)
+    ed = e.fetch("hull.edges", np.int32).reshape(B, 49152, 4)
     return nv, nf, ne, hv, nr, ed
 
 

@@ -9,7 +9,7 @@ import pytest
 from shoulder_amd import _lib, synth
 
 pytestmark = pytest.mark.gpu
-HF = 8192
+HF = 32768      # SH_HF: stride of the per-face arrays
 
 
 def _obb(engine, B):
