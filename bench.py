@@ -298,7 +298,7 @@ def main():
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     ap.add_argument("--from-stl", action="store_true", help="every step starts from the bytes of B binary STL files (device-side parse + vertex merge, sh_upload_stl)")
     ap.add_argument("--hull", choices=["auto", "host", "device"], default="auto", help="where the convex hull of the OBB stage runs (sh_set_hull_mode); "
-                    "auto = host quickhull on hosts with >= 48 hardware threads per rank, else the device hull")
+                    "auto = host quickhull where the rank has enough usable hardware threads (16 alone on its host, 48 per rank otherwise), else the device hull")
     ap.add_argument("--check-gather", action="store_true", help="after the timed region rank 0 compares the records the last gather delivered for its own shard with a run of its own engine")
     args = ap.parse_args()
 
@@ -566,8 +566,8 @@ def main():
             for e in dev_engs:
                 e.close()
         elif eng.hull_mode == "device" and pipelined:
-            # the headline ran with the hull on the device (what `auto` picks when this rank has fewer than 48 usable hardware
-            # threads, e.g. under a CPU quota): the same step with the host quickhull (two lanes, hulls of step k+1 computed by the
+            # the headline ran with the hull on the device (what `auto` picks when this rank has too few usable hardware
+            # threads, e.g. eight ranks on one host or a small CPU quota): the same step with the host quickhull (two lanes, hulls of step k+1 computed by the
             # host's worker threads behind the device work of step k), and whether both modes give the same records
             host_engs = [Engine(local) for _ in range(2)]
             for e in host_engs:

@@ -234,8 +234,8 @@ int  sh_enable_timing(sh_ctx*, int level);
  * sh_set_overlap), "device" (round-based quickhull, k_hull.h: nothing leaves the GPU; a humerus it gives up -- more than 8 192
  * prefilter survivors, a horizon pinched by nearly coplanar points -- is re-done ALONE from inside sh_run / sh_collect: host
  * quickhull for that humerus, its stages re-run as a window of one behind whatever else is in flight; it stays on the host
- * hull while the batch is resident) or "auto" (default, also SHOULDER_HULL: host while the rank has >= 48 usable hardware
- * threads -- affinity mask and cgroup CPU quota counted, divided by LOCAL_WORLD_SIZE).  Both give the
+ * hull while the batch is resident) or "auto" (default, also SHOULDER_HULL: host while the rank has enough usable hardware
+ * threads -- 16 for a single rank, 48 per rank with LOCAL_WORLD_SIZE > 1; affinity mask and cgroup CPU quota counted).  Both give the
  * same triangles and the same record bits, hence bit-identical frames.  sh_get_hull_mode: 0 host, 1 device. */
 int  sh_set_hull_mode(sh_ctx*, const char* mode);
 int  sh_get_hull_mode(const sh_ctx*);

@@ -85,6 +85,9 @@ struct sh_ctx {
   int skip_nfmax = 0;                      // most hull faces among the humeri of this batch that are on the host hull (hulld.skip)
   // overflow pools of the slice layer (k_ovf.h): capacities in segments / ring points / bytes; grown by sh_collect on demand
   unsigned long long ovf_seg_cap = 1ull << 18, ovf_ring_cap = 1ull << 18, ovf_work_cap = 32ull << 20;
+  // a run of the resident batch that planned no overflow plane in any set (ctr[4] == 0 at collect) lets later runs of the SAME batch
+  // and parameters skip the overflow tier's launches (they would all return at once: ~17 launches, ~60 us per step)
+  unsigned long long ovf_none_gen = ~0ull;
   bool redo_records = false;               // run_obb: the hull records of the window are in place already (redo_given_up)
   int redo_nf = 0;
   std::vector<float> h_verts;                // host copy of the vertices (hull stage)
@@ -114,7 +117,7 @@ struct sh_ctx {
   hipEvent_t obb_done_ev = nullptr;      // recorded after the last kernel of a run that reads the hull.* device buffers
   // sh_submit / sh_collect: up to two runs in flight (the second one is enqueued while the first still executes)
   struct Ticket { hipEvent_t ev = nullptr; int* h_err = nullptr; int* h_fail = nullptr; unsigned long long* h_ovf = nullptr; int cap = 0, B = 0; bool pending = false; sh_landmarks* host_out = nullptr;
-                  uint32_t mask = 0; sh_landmarks* out_arg = nullptr; bool dev_hull = false; };
+                  uint32_t mask = 0; sh_landmarks* out_arg = nullptr; bool dev_hull = false; unsigned long long gen = 0; };
   Ticket tickets[2];
   int t_head = 0, t_tail = 0, n_pending = 0;
   hipStream_t out_stream = nullptr;      // sh_collect copies the records / status words of a finished run to the host on this stream
@@ -227,7 +230,8 @@ int sh_default_params(sh_params* p) {
   return SH_OK;
 }
 
-// "host" | "device" | "auto" (default).  auto: the host quickhull while this rank has at least 48 hardware threads to itself (it
+// "host" | "device" | "auto" (default).  auto: the host quickhull while this rank has enough usable hardware threads to itself -- 16 when it is
+// the only rank of its host, 48 per rank otherwise -- (it
 // is free for the GPU and hidden behind the previous step: at ~7 000 humeri/s a rank keeps ~14 cores busy with hulls), the device
 // hull otherwise -- 8 ranks on a 256-thread host, a thin host, a rank pinned to a few cores (affinity mask), a cgroup CPU quota.
 // Hardware threads this process may actually use: its affinity mask (taskset, a pinned rank, a container's cpuset) capped by a
@@ -256,7 +260,12 @@ static unsigned threads_per_local_rank() {
 static int hull_mode_from(const char* e) {
   if (e && (e[0] == 'h' || e[0] == '0')) return 0;
   if (e && (e[0] == 'd' || e[0] == '1')) return 1;
-  return threads_per_local_rank() >= 48 ? 0 : 1;
+  // A rank keeps ~14 cores busy with hulls at ~7 000 humeri/s.  Several ranks on one host: host hull only with >= 48 threads per rank
+  // (the ranks' pools and submitting threads must not fight for the cores).  A single rank: >= 16 usable threads are enough --
+  // measured under a 16-CPU cgroup quota, B = 64, 20 steps: host hull 7 060 humeri/s (16 workers), device hull 6 720.
+  const char* w = getenv("LOCAL_WORLD_SIZE");
+  const bool alone = !(w && atoi(w) > 1);
+  return threads_per_local_rank() >= (alone ? 16u : 48u) ? 0 : 1;
 }
 
 int sh_set_hull_mode(sh_ctx* c, const char* mode) {
@@ -337,6 +346,7 @@ int sh_set_params(sh_ctx* c, const sh_params* p) {
   if (p->bone_kind != SH_BONE_HUMERUS && p->bone_kind != SH_BONE_PROXIMAL) return fail(c, SH_ERR_ARG, "bone_kind must be SH_BONE_HUMERUS or SH_BONE_PROXIMAL");
   if (c->prep.active && p->bone_kind != c->params.bone_kind) (void)join_prepared(c);
   c->params = *p;
+  c->ovf_none_gen = ~0ull;      // (the plane sets depend on the parameters)
   return SH_OK;
 }
 
@@ -725,6 +735,7 @@ int sh_store(sh_ctx* c, const char* name, const void* host, size_t nbytes) {
   if (nbytes > it->second.bytes) return fail(c, SH_ERR_ARG, std::string("sh_store: size exceeds buffer ") + name);
   HIPCHK(c, hipSetDevice(c->device));
   if (std::string(name) == "verts") { (void)join_prepared(c); ++c->batch_gen; c->h_verts_valid = false; }
+  c->ovf_none_gen = ~0ull;      // (an injected frame or intermediate moves the planes: the overflow tier runs again)
   if (std::string(name) == "params") c->packed_kind = -1;
   HIPCHK(c, hipMemcpyAsync(it->second.p, host, nbytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1396,12 +1407,15 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   // planes with more crossings than slots (k_ovf.h): plan their pool ranges, section them again into the segment pool
   OvfPools OP; OvfSet OS;
   { int orc; if ((orc = ovf_pools(c, &OP)) != SH_OK || (orc = ovf_set(c, p, N, &OS)) != SH_OK) return orc; }
-  HIPCHK(c, hipMemsetAsync(OS.nlist, 0, 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(OP.ctr, 0, 8, c->stream));              // segments used: per set
-  HIPCHK(c, hipMemsetAsync(OP.ctr + 2, 0, 8, c->stream));          // workspace used: per set (ring points stay for the run)
-  LAUNCH(c, "k_ovf_plan", k_ovf_plan, dim3((unsigned)((B * N + 255) / 256)), dim3(256), N, B * N, (const int*)cnt, OP, OS, buf<int>(c, "err"));
-  LAUNCH(c, "k_slice_emit_ovf", k_slice_emit_ovf, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
-         buf<long long>(c, "foff"), zeff, N, OP, OS);
+  const bool ovf_on = c->ovf_none_gen != c->batch_gen;      // (known from an earlier run of this batch: no plane overflows)
+  if (ovf_on) {
+    HIPCHK(c, hipMemsetAsync(OS.nlist, 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(OP.ctr, 0, 8, c->stream));              // segments used: per set
+    HIPCHK(c, hipMemsetAsync(OP.ctr + 2, 0, 8, c->stream));          // workspace used: per set (ring points stay for the run)
+    LAUNCH(c, "k_ovf_plan", k_ovf_plan, dim3((unsigned)((B * N + 255) / 256)), dim3(256), N, B * N, (const int*)cnt, OP, OS, buf<int>(c, "err"));
+    LAUNCH(c, "k_slice_emit_ovf", k_slice_emit_ovf, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
+           buf<long long>(c, "foff"), zeff, N, OP, OS);
+  }
   // two capacity tiers share the grid (k_slices.h): the planes of the other tier exit at once
   int* rn = buf<int>(c, (p + ".ring_n").c_str());
   double* rg = ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr;
@@ -1409,15 +1423,19 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, nlarge);
   LAUNCH(c, "k_slice_link_large", k_slice_link_large, dim3(std::min(B * N, 512)), dim3(SH_LINK_THREADS), B * N, N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, (const int*)nlarge);
-  LAUNCH(c, "k_slice_link_huge", k_slice_link_huge, dim3(64), dim3(SH_HUGE_THREADS), N, (const int*)cnt, OP, OS, buf<double>(c, (p + ".centroids").c_str()),
-         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, ring ? 1 : 0, select, buf<int>(c, "err"), atot);
+  if (ovf_on) {
+    LAUNCH(c, "k_slice_link_huge", k_slice_link_huge, dim3(64), dim3(SH_HUGE_THREADS), N, (const int*)cnt, OP, OS, buf<double>(c, (p + ".centroids").c_str()),
+           buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, ring ? 1 : 0, select, buf<int>(c, "err"), atot);
+  }
   if (resample) {
     LAUNCH(c, "k_resample_polar", k_resample_polar, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
            buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const long long*)OS.roff);
     LAUNCH(c, "k_resample_polar_large", k_resample_polar_large, dim3(std::min(B * N, 512)), dim3(SH_RS_THREADS), B * N, N, SH_MPROX, rn, rg,
            buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const int*)nlarge, (const long long*)OS.roff);
-    LAUNCH(c, "k_resample_polar_huge", k_resample_polar_huge, dim3(64), dim3(SH_RS_THREADS), N, SH_MPROX, (const int*)rn, OP, OS,
-           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
+    if (ovf_on) {
+      LAUNCH(c, "k_resample_polar_huge", k_resample_polar_huge, dim3(64), dim3(SH_RS_THREADS), N, SH_MPROX, (const int*)rn, OP, OS,
+             buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
+    }
   }
   return SH_OK;
 }
@@ -1822,7 +1840,9 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<double>(c, "te.rects"), B, (const long long*)OS.roff);
     LAUNCH(c, "k_te_rows_large", k_te_rows<SH_MAXSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), B, (const long long*)OS.roff);
-    LAUNCH(c, "k_te_rows_huge", k_te_rows_huge, dim3(64), dim3(64), OP, OS, (const int*)buf<int>(c, "distal.ring_n"), buf<double>(c, "te.rects"));
+    if (c->ovf_none_gen != c->batch_gen) {
+      LAUNCH(c, "k_te_rows_huge", k_te_rows_huge, dim3(64), dim3(64), OP, OS, (const int*)buf<int>(c, "distal.ring_n"), buf<double>(c, "te.rects"));
+    }
     LAUNCH(c, "k_te_final", k_te_final, dim3(B), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
            buf<double>(c, "anp.axes_obb"), buf<double>(c, "te.dscratch"), buf<double>(c, "te.axis_ct"), buf<int>(c, "te.row"), buf<int>(c, "err"), B, OP, OS);
@@ -2066,7 +2086,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     HIPCHK(c, hipMemcpyAsync(fail_stage, buf<int>(c, "hulld.fail"), (size_t)B * 4, hipMemcpyDeviceToDevice, c->stream));
   }
   HIPCHK(c, hipEventRecord(tk.ev, c->stream));
-  tk.B = B; tk.pending = true; tk.mask = mask; tk.out_arg = out; tk.dev_hull = dev_hull;
+  tk.B = B; tk.pending = true; tk.mask = mask; tk.out_arg = out; tk.dev_hull = dev_hull; tk.gen = c->batch_gen;
   c->t_head ^= 1; ++c->n_pending;
   return SH_OK;
 }
@@ -2087,6 +2107,10 @@ int sh_collect(sh_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(tk.h_ovf, buf<char>(c, ("out.ovf" + tslot).c_str()), 64, hipMemcpyDeviceToHost, c->out_stream));
     HIPCHK(c, hipStreamSynchronize(c->out_stream));
     const unsigned long long need_s = tk.h_ovf[3], need_r = tk.h_ovf[4], need_w = tk.h_ovf[5];
+    const uint32_t slice_stages = SH_STAGE_FULL | SH_STAGE_DISTAL | SH_STAGE_NECK | SH_STAGE_PROXIMAL;
+    if (need_r == 0 && need_s == 0 && (tk.mask & slice_stages) == (c->params.bone_kind == SH_BONE_PROXIMAL ? (slice_stages & ~(uint32_t)SH_STAGE_DISTAL) : slice_stages) &&
+        tk.gen == c->batch_gen)
+      c->ovf_none_gen = c->batch_gen;
     if (getenv("SH_DEBUG")) fprintf(stderr, "[sh] collect: ovf need %llu %llu %llu cap %llu %llu %llu err0 %d\n", need_s, need_r, need_w, c->ovf_seg_cap, c->ovf_ring_cap, c->ovf_work_cap, tk.h_err[0]);
     if (need_s > c->ovf_seg_cap || need_r > c->ovf_ring_cap || need_w > c->ovf_work_cap) {
       // The batch has more overflow planes than the pools hold (a first dense mesh): grow them to what the run asked for,
