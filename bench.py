@@ -150,9 +150,11 @@ PARITY_NOTE = {
             "bound asserted on this batch: plane point 0.3 mm, axis ends 1.5 mm, edge-point count +-60 (1e-4 mm is met by the f32_unet leg)",
     "f16": "mask-independent landmarks within 1e-4 mm of the oracle; anatomic-neck landmarks within the f16 bound asserted on this batch: "
            "plane point 0.06 mm, axis ends 0.4 mm, edge-point count +-12",
+    "f32x": "f32 tensors, MFMA layers on split-f16 operands (3 MFMAs per product): logits within 3e-6 of the exact f32 path, mask and every landmark "
+            "IDENTICAL to the f32 path's on the four fixtures and the 64 humeri of this batch (tests/test_gpu_unet_x3.py), hence within 1e-4 mm of the oracle",
 }
 
-UNET_ENUM = {"f32": 0, "bf16": 1, "f16": 2}
+UNET_ENUM = {"f32": 0, "bf16": 1, "f16": 2, "f32x": 3}
 
 
 def sym_key(name, unet, cout, fused_net=True):
@@ -163,6 +165,9 @@ def sym_key(name, unet, cout, fused_net=True):
     up = name.startswith("unet.up")
     if unet == "f32":
         return "k_conv_mfma_f32<%d,%d>" % (1 if up else 9, nt)
+    if unet == "f32x":
+        fuse = 4 if name in ("unet.enc0b", "unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
+        return "k_conv_mfma_x3<%d,%d,%d>" % (1 if up else 9, nt, fuse)
     # third template argument = fused ends (k_unet_bf16.h): UF_FIRST 1, UF_HEAD 2, UF_POOL 4
     fuse = 5 if name == "unet.enc0b" else 2 if name == "unet.dec0b" else 4 if name in ("unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
     if not fused_net:
@@ -283,7 +288,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="humeri per GPU per step")
-    ap.add_argument("--unet", choices=["f32", "bf16", "f16"], default="bf16",
+    ap.add_argument("--unet", choices=["f32", "bf16", "f16", "f32x"], default="bf16",
                     help="UNet arithmetic of the headline leg: bf16 = BASELINE configs[2]/[3] (throughput), f16 = configs[4]'s element type, "
                          "f32 = configs[1] parity path (bit-exact vs the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -486,7 +491,7 @@ def main():
             tt = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
-        ul_ = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512, eb=4 if unet == "f32" else 2)
+        ul_ = unet_layers(unet_spec.BASE, unet_spec.DEPTH, 512, 512, eb=4 if unet in ("f32", "f32x") else 2)
 
         def merged(name):       # (average ms, launches) over all lanes
             parts = [e.kernel_time_ms(name) for e in leg_engs]
@@ -539,6 +544,29 @@ def main():
             ach = g[dom32][1] / (g[dom32][0] * 1e-3) / 1e12
             extra["f32_unet"]["roofline"] = {"bound": "mfma", "kernel": dom32, "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s",
                                              "frac": round(ach / PEAK_MFMA_F32_TF, 4), "avg_ms": round(g[dom32][0] / g[dom32][2], 4), "launches": g[dom32][2]}
+        # SH_UNET_F32X: the tolerance-conformant configuration on the 16-bit matrix pipe (split-f16 operands, k_unet_x3.h), same protocol;
+        # the records of its last step against the exact f32 path's, humerus by humerus (mask-derived counts and every coordinate)
+        kx = max(3, min(args.steps, 10))
+        elx, regx, ulx = run_leg(engs, "f32x", kx, 1, pipelined)
+        lmx = engs[0].run(_lib.STAGE_ALL).copy()
+        engs[0].set_params(unet_dtype=UNET_ENUM["f32"])
+        lm32 = engs[0].run(_lib.STAGE_ALL).copy()
+        gx = {}
+        for name, (ms, n) in regx.items():
+            if name in ulx and n and name not in ("unet.head", "unet.enc0a"):
+                a = gx.setdefault(sym_key(name, "f32x", c32[name]), [0.0, 0.0, 0])
+                a[0] += ms * n; a[1] += ulx[name][0] * B * n; a[2] += n
+        domx = max(gx, key=lambda k: gx[k][0]) if gx else None
+        dev = max(float(np.abs(lmx[k] - lm32[k]).max()) for k in ("anp_plane_point", "anp_axis_normal", "anp_axis_central", "te_axis", "csys", "canal_axis", "groove_axis"))
+        extra["f32x_unet"] = {"value": round(B * kx / elx, 3), "unit": "meshes/s", "steps": kx, "warmup": 1, "ms_per_step": round(1e3 * elx / kx, 3),
+                              "dtype": "f64 geometry + f32 tensors, split-f16 MFMA UNet", "lanes": lanes, "speedup_vs_f32_unet": round((B * kx / elx) / (B * k32 / el32), 3),
+                              "humeri_with_the_f32_paths_edge_point_count": int((lmx["n_anp"] == lm32["n_anp"]).sum()), "humeri": int(B),
+                              "max_landmark_deviation_from_f32_path_mm": dev, "parity": PARITY_NOTE["f32x"]}
+        if domx:
+            achx = gx[domx][1] / (gx[domx][0] * 1e-3) / 1e12      # algorithmic (f32-equivalent) flops: the kernel issues three 16-bit MFMAs per product
+            extra["f32x_unet"]["roofline"] = {"bound": "mfma", "kernel": domx, "achieved": round(achx, 2), "peak": round(PEAK_MFMA_BF16_TF / 3.0, 1), "unit": "TFLOP/s",
+                                              "frac": round(achx / (PEAK_MFMA_BF16_TF / 3.0), 4), "avg_ms": round(gx[domx][0] / gx[domx][2], 4), "launches": gx[domx][2],
+                                              "peak_note": "dense f16 MFMA peak / 3: every product costs three MFMAs"}
         if args.unet == "bf16":      # the other 16-bit element type: same kernels and rate, 11 significant bits instead of 8
             k16 = max(3, min(args.steps, 10))
             el16, _, _ = run_leg(engs, "f16", k16, 1, pipelined)

@@ -58,7 +58,8 @@ enum {
  * F32  one float32 fma chain per output on v_mfma_f32_16x16x4_f32 -- bit-exact against oracle/unet_chain.c;
  * BF16 / F16  16-bit activations and weights on v_mfma_f32_16x16x32_{bf16,f16}, float32 accumulate (throughput paths;
  *      F16 carries 11 significant bits instead of 8 and needs activations below 65504). */
-enum { SH_UNET_F32 = 0, SH_UNET_BF16 = 1, SH_UNET_F16 = 2 };
+enum { SH_UNET_F32 = 0, SH_UNET_BF16 = 1, SH_UNET_F16 = 2,
+       SH_UNET_F32X = 3 };      /* f32 tensors, MFMA layers on split f16 operands (3 MFMAs per product): f32-grade logits at ~5x the f32 rate */
 /* Which facade class of bone.py the meshes are: `Humerus` (bone.py:110-157) or `ProximalHumerus` (bone.py:24-64: a
  * humerus cut in the shaft -- ProxObb head-end rule and canal range mesh.py:128-192, neck cut-off (0.2, 0.99)
  * surgical_neck.py:25-26, canal cut-offs from the box canal.py:33-38, no distal / trans-epicondylar stage,
@@ -104,7 +105,7 @@ typedef struct sh_params {
   double canal_cutoff[2];     /* canal.py:19          default (0.35, 0.75) */
   double groove_cutoff[2];    /* bicipital_groove.py:26 default (0.2, 0.75); rows must stay 330 */
   double groove_deg_window;   /* bicipital_groove.py:26 default 7 */
-  int32_t unet_dtype;         /* SH_UNET_F32 (parity), SH_UNET_BF16 or SH_UNET_F16 (throughput) */
+  int32_t unet_dtype;         /* SH_UNET_F32 (parity), SH_UNET_F32X (f32-grade, fast), SH_UNET_BF16 or SH_UNET_F16 (throughput) */
   int32_t bone_kind;          /* SH_BONE_HUMERUS (default) or SH_BONE_PROXIMAL */
 } sh_params;
 

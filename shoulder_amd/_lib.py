@@ -14,7 +14,7 @@ STAGE_OBB, STAGE_FULL, STAGE_NECK, STAGE_CANAL, STAGE_PROXIMAL = 1, 2, 4, 8, 16
 STAGE_GROOVE, STAGE_ANP, STAGE_DISTAL, STAGE_TE, STAGE_CSYS = 32, 64, 128, 256, 512
 STAGE_APPLY = 1024
 STAGE_ALL = 0x7FF
-UNET_F32, UNET_BF16, UNET_F16 = 0, 1, 2
+UNET_F32, UNET_BF16, UNET_F16, UNET_F32X = 0, 1, 2, 3
 BONE_HUMERUS, BONE_PROXIMAL = 0, 1
 
 

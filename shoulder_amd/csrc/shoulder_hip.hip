@@ -22,6 +22,7 @@
 #include "k_unet_bf16.h"
 #include "k_unet_bf16_dma.h"
 #include "k_unet16_ldr.h"
+#include "k_unet_x3.h"
 #include "k_unet16_l0.h"
 #include "k_unet16_dec0.h"
 #include "k_stl.h"
@@ -132,6 +133,7 @@ struct sh_ctx {
   std::map<std::tuple<int, int, int>, std::pair<int, int>> tk_tabs;      // (items, workgroups, cout groups) -> (offset, tickets) in "unet16.tk_tab"
   int tk_tab_used = 0;
   bool packtab_ready = false;      // layer table of k_pack_w_bf16_all uploaded (reset by sh_load_unet)
+  bool packed_x3 = false;          // "params_x3h/l" hold the split weights of the CURRENT parameter block (reset with packed_kind)
   int packed_kind = -1;            // element kind (0 bf16, 1 f16) "params_bf16" was packed for from the CURRENT parameter block; -1: repack.
                                    // Reset wherever the block can change: sh_load_*, sh_param_block (the pointer goes to the caller), sh_param_block_commit
   int num_cus = 0;
@@ -342,7 +344,8 @@ int sh_set_params(sh_ctx* c, const sh_params* p) {
   // the search window of the groove's local minimum is +-round(deg_window / (360 / 512)) samples of a 512-sample row
   // (bicipital_groove.py:190-229); beyond half a turn the reference's negative indices run off the row (IndexError there)
   if (!(p->groove_deg_window >= 0.0 && p->groove_deg_window <= 180.0)) return fail(c, SH_ERR_ARG, "groove_deg_window must lie in [0, 180] degrees");
-  if (p->unet_dtype != SH_UNET_F32 && p->unet_dtype != SH_UNET_BF16 && p->unet_dtype != SH_UNET_F16) return fail(c, SH_ERR_ARG, "unet_dtype must be SH_UNET_F32, SH_UNET_BF16 or SH_UNET_F16");
+  if (p->unet_dtype != SH_UNET_F32 && p->unet_dtype != SH_UNET_BF16 && p->unet_dtype != SH_UNET_F16 && p->unet_dtype != SH_UNET_F32X)
+    return fail(c, SH_ERR_ARG, "unet_dtype must be SH_UNET_F32, SH_UNET_F32X, SH_UNET_BF16 or SH_UNET_F16");
   if (p->bone_kind != SH_BONE_HUMERUS && p->bone_kind != SH_BONE_PROXIMAL) return fail(c, SH_ERR_ARG, "bone_kind must be SH_BONE_HUMERUS or SH_BONE_PROXIMAL");
   if (c->prep.active && p->bone_kind != c->params.bone_kind) (void)join_prepared(c);
   c->params = *p;
@@ -713,7 +716,7 @@ int sh_buffer_device(sh_ctx* c, const char* name, void** dev_ptr, size_t* nbytes
   if (it == c->bufs.end() || !it->second.p) return fail(c, SH_ERR_ARG, std::string("no buffer named ") + name);
   *dev_ptr = it->second.p;
   if (nbytes) *nbytes = it->second.bytes;
-  if (std::string(name) == "params") c->packed_kind = -1;      // (the caller may write it)
+  if (std::string(name) == "params") c->packed_kind = -1; c->packed_x3 = false;      // (the caller may write it)
   return SH_OK;
 }
 
@@ -736,7 +739,7 @@ int sh_store(sh_ctx* c, const char* name, const void* host, size_t nbytes) {
   HIPCHK(c, hipSetDevice(c->device));
   if (std::string(name) == "verts") { (void)join_prepared(c); ++c->batch_gen; c->h_verts_valid = false; }
   c->ovf_none_gen = ~0ull;      // (an injected frame or intermediate moves the planes: the overflow tier runs again)
-  if (std::string(name) == "params") c->packed_kind = -1;
+  if (std::string(name) == "params") c->packed_kind = -1; c->packed_x3 = false;
   HIPCHK(c, hipMemcpyAsync(it->second.p, host, nbytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (std::string(name) == "obb_transform") c->obb_injected = true;
@@ -960,11 +963,27 @@ int sh_mesh_transformed(sh_ctx* c, int b, const double* T, double* out) {
 
 // ---- UNet forward (f32 MFMA path) ----------------------------------------------------------------------
 static int conv_layer(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const float* src0, const float* src1, int C0, int C1, float* dst,
-                      int H, int W, int nimg, int relu) {
+                      int H, int W, int nimg, int relu, int fuse = 0, float* pooled = nullptr, const float* head_w = nullptr, const float* head_b = nullptr,
+                      float* logits = nullptr) {
   if (H % UN_TH || W % UN_TW) return fail(c, SH_ERR_ARG, "unet: feature map is not a multiple of 16");
   const float* P = buf<float>(c, "params");
   const float* w = P + L.w_off; const float* b = P + L.b_off;
   const int tiles = (H / UN_TH) * (W / UN_TW);
+  if (c->params.unet_dtype == SH_UNET_F32X && C0 % 32 == 0 && C1 % 32 == 0 && L.cout % 32 == 0) {
+    // split-f16 operands on the 16-bit matrix pipe (k_unet_x3.h); weights split once per parameter block by unet_forward
+    const u16* wh = buf<u16>(c, "params_x3h") + L.w_off;
+    const u16* wl = buf<u16>(c, "params_x3l") + L.w_off;
+    float* np_ = nullptr; const float* nf_ = nullptr;
+    if (L.taps == 9 && fuse == UF_HEAD && L.cout == 32) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_HEAD>), dim3(tiles, 1, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, head_w, head_b, logits); }
+    else if (L.taps == 9 && fuse == UF_POOL && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4, UF_POOL>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_); }
+    else if (L.taps == 9 && fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_POOL>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_); }
+    else if (fuse != 0) return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
+    else if (L.taps == 9 && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_); }
+    else if (L.taps == 9) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_); }
+    else if (L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<1, 4>), dim3(tiles, L.cout / 64, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, 0, np_, nf_, nf_, np_); }
+    else { LAUNCH(c, lname, (k_conv_mfma_x3<1, 2>), dim3(tiles, L.cout / 32, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, 0, np_, nf_, nf_, np_); }
+    return SH_OK;
+  }
   if (L.taps == 9) {
     if (L.cout % 64 == 0) {
       LAUNCH(c, lname, (k_conv_mfma_f32<9, 4>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu);
@@ -1027,6 +1046,26 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
   float* A = buf<float>(c, "unet.a");
   float* Bq = buf<float>(c, "unet.b");
   const float* P = buf<float>(c, "params");
+  if (c->params.unet_dtype == SH_UNET_F32X) {      // split the MFMA layers' weights into f16 high / low parts: one launch, once per parameter block
+    if ((rc = ensure(c, "params_x3h", c->unet_floats * 2, 2)) != SH_OK) return rc;
+    if ((rc = ensure(c, "params_x3l", c->unet_floats * 2, 2)) != SH_OK) return rc;
+    if (!c->packed_x3) {
+      std::vector<PackEntry> tab;
+      long long total = 0;
+      for (auto& kv : c->ulayers) {
+        const sh_ctx::ULayer& l = kv.second;
+        if (l.cin < 32 || l.cout < 32) continue;
+        tab.push_back(PackEntry{total, (long long)l.w_off, l.taps, l.cin, l.cout, 0});
+        total += (long long)l.taps * l.cin * l.cout;
+      }
+      if ((rc = ensure(c, "unet16.packtab", tab.size() * sizeof(PackEntry), 8)) != SH_OK) return rc;
+      HIPCHK(c, hipMemcpyAsync(c->bufs["unet16.packtab"].p, tab.data(), tab.size() * sizeof(PackEntry), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));      // `tab` is a local
+      c->packtab_ready = true;
+      LAUNCH(c, "k_pack_w_x3", k_pack_w_x3, dim3(2048), dim3(256), P, buf<u16>(c, "params_x3h"), buf<u16>(c, "params_x3l"), (const PackEntry*)c->bufs["unet16.packtab"].p, (int)tab.size(), total);
+      c->packed_x3 = true;
+    }
+  }
   auto L = [&](const std::string& n) -> const sh_ctx::ULayer& { return c->ulayers[n]; };
   int h = H, w = W;
   {
@@ -1034,17 +1073,23 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
     size_t npx = (size_t)nimg * h * w;
     LAUNCH(c, "unet.enc0a", k_conv_first, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, A, h, w, l.cout, nimg);
   }
-  if ((rc = conv_layer(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1)) != SH_OK) return rc;
+  // SH_UNET_F32X: the 2x2 pools ride in the epilogue of the conv before them and the head in dec0b's (k_unet_x3.h)
+  const bool x3 = c->params.unet_dtype == SH_UNET_F32X && base % 32 == 0;
+  if ((rc = conv_layer(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1, x3 ? UF_POOL : 0, Bq)) != SH_OK) return rc;
+  if (x3) std::swap(A, Bq);      // (the pooled tensor is the next level's input, which the loop below reads from A)
   int ch = base;
   for (int i = 1; i <= D; ++i) {
-    size_t e = (size_t)nimg * (h / 2) * (w / 2) * (ch / 4);
-    LAUNCH(c, "unet.pool", k_maxpool2, dim3((unsigned)std::min<size_t>((e + 255) / 256, 8192)), dim3(256), skip[i - 1], A, h, w, ch, nimg);
+    if (!x3) {
+      size_t e = (size_t)nimg * (h / 2) * (w / 2) * (ch / 4);
+      LAUNCH(c, "unet.pool", k_maxpool2, dim3((unsigned)std::min<size_t>((e + 255) / 256, 8192)), dim3(256), skip[i - 1], A, h, w, ch, nimg);
+    }
     h /= 2; w /= 2;
     std::string na = i < D ? "enc" + std::to_string(i) + "a" : "bota", nb = i < D ? "enc" + std::to_string(i) + "b" : "botb";
     if ((rc = conv_layer(c, ("unet." + na).c_str(), L(na), A, nullptr, ch, 0, Bq, h, w, nimg, 1)) != SH_OK) return rc;
     ch *= 2;
     float* dst = i < D ? skip[i] : A;
-    if ((rc = conv_layer(c, ("unet." + nb).c_str(), L(nb), Bq, nullptr, ch, 0, dst, h, w, nimg, 1)) != SH_OK) return rc;
+    // (A was consumed by the conv above: with the fused pool it receives the next level's input)
+    if ((rc = conv_layer(c, ("unet." + nb).c_str(), L(nb), Bq, nullptr, ch, 0, dst, h, w, nimg, 1, (x3 && i < D) ? UF_POOL : 0, A)) != SH_OK) return rc;
   }
   // decoder: x lives in A
   float* x = A; float* y = Bq;
@@ -1053,6 +1098,12 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
     if ((rc = conv_layer(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
     h *= 2; w *= 2; ch /= 2;
     if ((rc = conv_layer(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;
+    // (the head stays on k_head: its sequential f32 chain over the channels is the exact path's; fused into dec0b's epilogue
+    //  -- SHOULDER_X3_HEAD=1 -- the logits move by another ~1e-6 and one mask pixel of the 64-humerus bench batch flips)
+    if (x3 && i == 0 && ch == 32 && getenv("SHOULDER_X3_HEAD") && getenv("SHOULDER_X3_HEAD")[0] == '1') {
+      const sh_ctx::ULayer& l = L("head");
+      return conv_layer(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1, UF_HEAD, nullptr, P + l.w_off, P + l.b_off, logits);
+    }
     if ((rc = conv_layer(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1)) != SH_OK) return rc;
     std::swap(x, y);
   }
@@ -2180,7 +2231,7 @@ int sh_landmarks_device(sh_ctx* c, void** p, size_t* n) {
 
 // ---- parameters ------------------------------------------------------------------------------------
 static int upload_params(sh_ctx* c) {
-  c->packed_kind = -1;
+  c->packed_kind = -1; c->packed_x3 = false;
   const size_t N = c->h_feat.size(), T = c->h_roots.size();
   const size_t bytes = c->unet_floats * 4 + N * 4 * 5 + T * 4;
   int rc = ensure(c, "params", bytes ? bytes : 16, 4);
@@ -2281,7 +2332,7 @@ int sh_load_unet(sh_ctx* c, int base, int depth, const float* packed, size_t n_f
 
 int sh_param_block_commit(sh_ctx* c) {
   if (!c) return SH_ERR_ARG;
-  c->packed_kind = -1;
+  c->packed_kind = -1; c->packed_x3 = false;
   auto it = c->bufs.find("params");
   if (it == c->bufs.end()) return fail(c, SH_ERR_STATE, "sh_param_block_commit: no parameters loaded");
   HIPCHK(c, hipSetDevice(c->device));
@@ -2328,7 +2379,7 @@ int sh_param_block_commit(sh_ctx* c) {
 
 int sh_param_block(sh_ctx* c, void** p, size_t* n) {
   if (!c || !p || !n) return SH_ERR_ARG;
-  c->packed_kind = -1;      // the caller may write the block from here on (and confirms with sh_param_block_commit)
+  c->packed_kind = -1; c->packed_x3 = false;      // the caller may write the block from here on (and confirms with sh_param_block_commit)
   auto it = c->bufs.find("params");
   if (it == c->bufs.end()) return fail(c, SH_ERR_STATE, "sh_param_block: no parameters loaded");
   *p = it->second.p;
