@@ -48,7 +48,7 @@ __global__ void k_pack_w_x3(const float* __restrict__ P, u16* __restrict__ PH_, 
 // FUSE: 0; UF_POOL -- the 2x2 max pool (input of the next encoder level) written beside the output; UF_HEAD (NT = 2, Cout = 32)
 // -- the 1x1 head applied to the accumulators, only the logits leave the kernel (same operation order per logit as the
 // UF_HEAD epilogues of the 16-bit kernels).
-template <int TAPS, int NT, int FUSE = 0>
+template <int TAPS, int NT, int FUSE = 0, int DB = 1>
 __global__ void __launch_bounds__(UN_THREADS)
 k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, int C0, int C1,
                const u16* __restrict__ wh_, const u16* __restrict__ wl_ /*packed [phase][tap][Cin/32][Cout][32] f16: high / low part of 64 w*/,
@@ -62,8 +62,12 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
   constexpr int NC = 16 * NT;
   constexpr int IN_PIECES = PH * PW * 4, WT_PIECES = TAPS * NC * 4;
   constexpr int NIN = (IN_PIECES + UN_THREADS - 1) / UN_THREADS, NWT = (WT_PIECES + UN_THREADS - 1) / UN_THREADS;
-  __shared__ __attribute__((aligned(16))) ET s_xh[PH * PW * UB_PSTR];
-  __shared__ __attribute__((aligned(16))) ET s_xl[PH * PW * UB_PSTR];
+  // the input images are double buffered (2 x 2 x 20.7 KB; with the 64-cout weight images 157 KB): chunk c + 1 is split and written
+  // into the other pair in the middle of chunk c's taps -- its loads have landed by then -- so only the weights are stored
+  // between the two barriers
+  constexpr int XI = PH * PW * UB_PSTR;
+  __shared__ __attribute__((aligned(16))) ET s_xh[(DB ? 2 : 1) * XI];      // DB = 0: one pair, the input stored between the barriers as well
+  __shared__ __attribute__((aligned(16))) ET s_xl[(DB ? 2 : 1) * XI];
   __shared__ __attribute__((aligned(16))) ET s_wh[TAPS * NC * UB_PSTR];
   __shared__ __attribute__((aligned(16))) ET s_wl[TAPS * NC * UB_PSTR];
   const ET* wh = (const ET*)wh_;
@@ -126,7 +130,7 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
         rwl[k] = *(const u32x4*)(wl + o);
       }
   };
-  auto store_chunk = [&]() {
+  auto store_input = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < NIN; ++k)
       if (in_lds[k] >= 0) {
@@ -138,9 +142,11 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
           hi[j] = h;
           lo[j] = (ET)(v - (float)h);
         }
-        *(v8*)(s_xh + in_lds[k]) = hi;
-        *(v8*)(s_xl + in_lds[k]) = lo;
+        *(v8*)(s_xh + buf * XI + in_lds[k]) = hi;
+        *(v8*)(s_xl + buf * XI + in_lds[k]) = lo;
       }
+  };
+  auto store_weights = [&]() {
 #pragma unroll
     for (int k = 0; k < NWT; ++k)
       if (wt_lds[k] >= 0) { *(u32x4*)(s_wh + wt_lds[k]) = rwh[k]; *(u32x4*)(s_wl + wt_lds[k]) = rwl[k]; }
@@ -156,10 +162,15 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
     for (int m = 0; m < 4; ++m) acc[m][n] = bv;
   }
 
+  // One prefetch per chunk (input + weights of chunk c + 1 into registers), issued once the weights of chunk c are in LDS; its input
+  // half is consumed at tap 4 of chunk c, its weight half between the barriers in front of chunk c + 1.
   load_chunk(0);
+  store_input(0);
   for (int cc = 0; cc < nchunk; ++cc) {
-    __syncthreads();                  // every wave is done reading the previous chunk
-    store_chunk();
+    const int buf = DB ? (cc & 1) : 0;
+    __syncthreads();                  // every wave is done reading the previous chunk's weights (and the input buffer `buf ^ 1`)
+    if (!DB && cc > 0) store_input(0);
+    store_weights();
     __syncthreads();
     if (cc + 1 < nchunk) load_chunk(cc + 1);      // in flight during the MFMAs below
 #pragma unroll
@@ -168,7 +179,7 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
       v8 xh[4], xl[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const int off = UB_OFF((wave * 4 + m + dy) * PW + li + dx, lk);
+        const int off = buf * XI + UB_OFF((wave * 4 + m + dy) * PW + li + dx, lk);
         xh[m] = *(const v8*)(s_xh + off); xl[m] = *(const v8*)(s_xl + off);
       }
 #pragma unroll
@@ -182,6 +193,7 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
           acc[m][n] = E16<ET>::mfma(fl, xh[m], acc[m][n]);
         }
       }
+      if (DB && tap == (TAPS == 9 ? 4 : 0) && cc + 1 < nchunk) store_input(buf ^ 1);      // (the other pair: last read in chunk c - 1, a barrier ago)
     }
   }
   if constexpr ((FUSE & UF_HEAD) != 0) {

@@ -974,12 +974,15 @@ static int conv_layer(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, con
     const u16* wh = buf<u16>(c, "params_x3h") + L.w_off;
     const u16* wl = buf<u16>(c, "params_x3l") + L.w_off;
     float* np_ = nullptr; const float* nf_ = nullptr;
+    const bool db2 = getenv("SHOULDER_X3_DB2") && getenv("SHOULDER_X3_DB2")[0] == '1';      // 32-cout 3x3 layers: double-buffered input too (one workgroup per CU then)
     if (L.taps == 9 && fuse == UF_HEAD && L.cout == 32) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_HEAD>), dim3(tiles, 1, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, head_w, head_b, logits); }
     else if (L.taps == 9 && fuse == UF_POOL && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4, UF_POOL>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_); }
-    else if (L.taps == 9 && fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_POOL>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_); }
+    else if (L.taps == 9 && fuse == UF_POOL && db2) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_POOL, 1>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_); }
+    else if (L.taps == 9 && fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_POOL, 0>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_); }
     else if (fuse != 0) return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
     else if (L.taps == 9 && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_); }
-    else if (L.taps == 9) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_); }
+    else if (L.taps == 9 && db2) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, 0, 1>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_); }
+    else if (L.taps == 9) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, 0, 0>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_); }
     else if (L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<1, 4>), dim3(tiles, L.cout / 64, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, 0, np_, nf_, nf_, np_); }
     else { LAUNCH(c, lname, (k_conv_mfma_x3<1, 2>), dim3(tiles, L.cout / 32, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, 0, np_, nf_, nf_, np_); }
     return SH_OK;
