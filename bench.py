@@ -227,7 +227,7 @@ def hull_threads(world_local):
     """The worker pool of the host hull phase (HullPool, shoulder_hip.hip), one per process shared by its lanes: hardware threads / LOCAL_WORLD_SIZE, at most 32."""
     if os.environ.get("SHOULDER_HULL_THREADS"):
         return int(os.environ["SHOULDER_HULL_THREADS"])
-    return max(1, min(32, usable_cores() // max(1, world_local)))
+    return max(1, min(32, len(os.sched_getaffinity(0)) // max(1, world_local)))      # (pool size: affinity mask; the hull-mode decision counts a CPU quota too)
 
 
 def launch_ranks(n, argv, worker=None, timeout=None):
@@ -672,7 +672,7 @@ def main():
         # HBM traffic and MFMA-busy fraction of the dominant kernel from the committed PMC profiles of this same command
         # (rocprofv3 cannot run inside the bench); null when no profile matches the configuration
         if roof:
-            for rnd in ("r02", "r01"):
+            for rnd in ("r03", "r02", "r01"):
                 pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b{B}_{args.unet}.json")
                 if os.path.exists(pmc_path):
                     pk = json.load(open(pmc_path))["kernels"]
