@@ -13,11 +13,75 @@ namespace sh {
 #define SH_TE_ROW0 2
 #define SH_TE_NROWS 37          // int((1-.99)*200)=2 .. int((1-.8)*200)=39 (slice.py:157-164)
 
+// Convex hull of a ring by one wave: gift wrapping with a 64-lane tournament per step.  Melkman's deque walk (one lane,
+// ~20 dependent LDS round trips per vertex: ~300 us for a 300-point ring -- the whole kernel was one slice's walk long) gives the
+// strictly convex vertices in counter-clockwise order starting at the hull vertex with the highest ring index; so does this:
+// start at the lowest point (lowest y, then x: extreme, hence on the hull), from the current vertex p take the point q with every
+// other point on the left of p -> q (of collinear candidates the farthest: collinear points are dropped, as Melkman's `<= 0`
+// pops do), until the start comes round again; then rotate.  The two disagree only where an orientation determinant is
+// within rounding of zero; the minimum-area rectangle does not notice (extents move by ~1e-13).
+// xy: n points in LDS; hull: LDS, >= n ints.  Returns the hull size (every lane); hull[(k + *rot) % nh], k = 0.., is Melkman's list.
+__device__ inline int wave_hull_wrap(const double* xy, int n, int* hull, int lane, int* rot) {
+  // lowest point
+  double by = 1e300, bx = 1e300; int bi = 0x7fffffff;
+  for (int i = lane; i < n; i += 64) {
+    const double x = xy[2 * i], y = xy[2 * i + 1];
+    if (y < by || (y == by && (x < bx || (x == bx && i < bi)))) { by = y; bx = x; bi = i; }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double oy = __shfl_xor(by, off), ox = __shfl_xor(bx, off); const int oi = __shfl_xor(bi, off);
+    if (oy < by || (oy == by && (ox < bx || (ox == bx && oi < bi)))) { by = oy; bx = ox; bi = oi; }
+  }
+  const int p0 = bi;
+  int p = p0, nh = 0;
+  double px = bx, py = by;
+  for (;;) {
+    if (lane == 0) hull[nh] = p;
+    ++nh;
+    if (nh > n) break;                               // (cannot happen on a ring of distinct points; keeps a degenerate input bounded)
+    // this lane's best candidate among its points
+    int q = -1; double qx = 0.0, qy = 0.0, qd = 0.0;
+    for (int i = lane; i < n; i += 64) {
+      const double x = xy[2 * i], y = xy[2 * i + 1];
+      const double dx = x - px, dy = y - py, d = dx * dx + dy * dy;
+      if (d == 0.0) continue;                        // p itself
+      if (q < 0) { q = i; qx = x; qy = y; qd = d; continue; }
+      const double o = (qx - px) * (y - py) - (qy - py) * (x - px);      // orient2(p, q, r)
+      if (o < 0.0 || (o == 0.0 && d > qd)) { q = i; qx = x; qy = y; qd = d; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const int oq = __shfl_xor(q, off);
+      const double ox = __shfl_xor(qx, off), oy = __shfl_xor(qy, off), od = __shfl_xor(qd, off);
+      if (oq < 0) continue;
+      if (q < 0) { q = oq; qx = ox; qy = oy; qd = od; continue; }
+      const double o = (qx - px) * (oy - py) - (qy - py) * (ox - px);
+      // (both lanes of a pair must come to the same winner: on an exact tie of direction and distance the lower ring index)
+      if (o < 0.0 || (o == 0.0 && (od > qd || (od == qd && oq < q)))) { q = oq; qx = ox; qy = oy; qd = od; }
+    }
+    if (q < 0 || q == p0) break;
+    p = q; px = qx; py = qy;
+  }
+  if (nh > n) nh = n;
+  __syncthreads();                                   // lane 0's hull[] stores are visible
+  // Melkman's list starts at the hull vertex with the highest ring index: the caller reads hull[(k + rot) % nh]
+  int mi = -1, mk = 0;
+  for (int k = lane; k < nh; k += 64) { const int v = hull[k]; if (v > mi) { mi = v; mk = k; } }
+  for (int off = 32; off > 0; off >>= 1) { const int oi = __shfl_xor(mi, off), ok = __shfl_xor(mk, off); if (oi > mi) { mi = oi; mk = ok; } }
+  *rot = mk;
+  return nh;
+}
+
 // One wave per (humerus, distal slice): lane 0 builds the hull of the ring (Melkman, O(n), LDS deque),
 // then the lanes share the hull edges of sh::min_area_rect (same arithmetic per edge; first minimum
 // in hull order wins, as in the sequential routine).
 // Two capacity tiers share the grid like k_slice_link (CAP = SH_SMALLSEG: 24 KB of LDS; the ring is staged in LDS first --
 // lane 0's hull walk is latency-bound when every point comes from global memory).
+#ifdef SH_TE_MELKMAN
+constexpr bool getenv_te_melkman = true;
+#else
+constexpr bool getenv_te_melkman = false;
+#endif
+
 template <int CAP>
 __global__ void __launch_bounds__(64)
 k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, double* __restrict__ rects /*[B][37][7]*/, int B,
@@ -38,11 +102,22 @@ k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, doubl
   if (n < 3) { if (lane < 7) o[lane] = 0.0; return; }
   for (int q = lane; q < 2 * (n + 1); q += 64) s_xy[q] = gxy[q];
   __syncthreads();
+#if defined(SH_ABL_TE) && SH_ABL_TE == 1
+  return;
+#endif
   const double* xy = s_xy;
-  if (lane == 0) nh_s = convex_hull_simple_polygon(xy, n, dq, hull);   // rings are simple polygons in boundary order
-  __syncthreads();
-  const int nh = nh_s;
-  for (int k = lane; k < nh; k += 64) { hx[k] = xy[2 * hull[k]]; hy[k] = xy[2 * hull[k] + 1]; }
+  int nh, rot = 0;
+  if (getenv_te_melkman) {      // (-DSH_TE_MELKMAN: round 2's one-lane deque walk, for the A/B)
+    if (lane == 0) nh_s = convex_hull_simple_polygon(xy, n, dq, hull);   // rings are simple polygons in boundary order
+    __syncthreads();
+    nh = nh_s;
+  } else {
+    nh = wave_hull_wrap(xy, n, hull, lane, &rot);
+  }
+#if defined(SH_ABL_TE) && SH_ABL_TE == 2
+  if (nh >= 0) return;
+#endif
+  for (int k = lane; k < nh; k += 64) { int src = k + rot; if (src >= nh) src -= nh; hx[k] = xy[2 * hull[src]]; hy[k] = xy[2 * hull[src] + 1]; }
   __syncthreads();
   double best = 1e300;
   int bi = 0x7fffffff;

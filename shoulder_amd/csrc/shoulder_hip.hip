@@ -127,6 +127,11 @@ struct sh_ctx {
   hipEvent_t unet_done_ev = nullptr;
   unsigned long long batch_gen = 0;
   hipStream_t copy_stream = nullptr;
+  // side stream of the stage runner: the distal slice set and the rectangles of the trans-epicondylar stage hang on nothing but the
+  // box frame, so they run beside the full -> neck -> proximal chain (SHOULDER_SIDE_STREAM=0: everything on the one stream)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_fork_ev = nullptr, side_join_ev = nullptr;
+  bool side_pending = false;
   // timing
   bool zero_page_ready = false;
   int ticket_next = 0;              // next free work counter of "unet16.tickets" (one per persistent conv launch of a forward pass)
@@ -322,6 +327,9 @@ void sh_ctx_destroy(sh_ctx* c) {
   if (c->unet_done_ev) (void)hipEventDestroy(c->unet_done_ev);
   drain_timers(c);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+  if (c->side_fork_ev) (void)hipEventDestroy(c->side_fork_ev);
+  if (c->side_join_ev) (void)hipEventDestroy(c->side_join_ev);
   if (c->h_kept) (void)hipHostFree(c->h_kept);
   if (c->h_nkept) (void)hipHostFree(c->h_nkept);
   if (c->h_koff) (void)hipHostFree(c->h_koff);
@@ -1462,7 +1470,7 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   LAUNCH(c, "k_make_planes", k_make_planes, dim3(B), dim3(256), kind, N, buf<double>(c, kind == 4 ? "obb.zb_pre" : "z_bounds"), buf<double>(c, "neck_z"), zs, zeff, B);
   double* atot = total_area ? buf<double>(c, (p + ".area_total").c_str()) : (double*)nullptr;
   HIPCHK(c, hipMemsetAsync(cnt, 0, (size_t)B * N * 4, c->stream));
-  int* nlarge = (int*)c->bufs["slices.nlarge"].p;
+  int* nlarge = (int*)c->bufs["slices.nlarge"].p + (kind & 7);      // (one counter per kind of set: two sets may run on two streams)
   HIPCHK(c, hipMemsetAsync(nlarge, 0, 4, c->stream));
   if (N > SH_EMIT_MAXN) return fail(c, SH_ERR_CAPACITY, "slice set has more planes than k_slice_emit's LDS histogram");
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 4096), (unsigned)B);
@@ -1807,6 +1815,21 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   return SH_OK;
 }
 
+// epicondyle.py:33-40: the minimum-area rectangle of every distal slice in the cut (three capacity tiers)
+static int run_te_rows(sh_ctx* c) {
+  const int B = c->Bwin;
+  OvfPools OP; OvfSet OS;
+  { int orc; if ((orc = ovf_pools(c, &OP)) != SH_OK || (orc = ovf_set(c, "distal", SH_NDIST, &OS)) != SH_OK) return orc; }
+  LAUNCH(c, "k_te_rows", k_te_rows<SH_SMALLSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
+         buf<double>(c, "te.rects"), B, (const long long*)OS.roff);
+  LAUNCH(c, "k_te_rows_large", k_te_rows<SH_MAXSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
+         buf<double>(c, "te.rects"), B, (const long long*)OS.roff);
+  if (c->ovf_none_gen != c->batch_gen) {
+    LAUNCH(c, "k_te_rows_huge", k_te_rows_huge, dim3(64), dim3(64), OP, OS, (const int*)buf<int>(c, "distal.ring_n"), buf<double>(c, "te.rects"));
+  }
+  return SH_OK;
+}
+
 // All stages for the window [c->b0, c->b0 + c->Bwin) of the batch; everything is enqueued on the stream,
 // nothing here waits for the device.
 static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
@@ -1825,8 +1848,31 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   }
   if (mask & SH_STAGE_FULL)
     if ((rc = run_slice_set(c, "full", 0, SH_NFULL, false, false)) != SH_OK) return rc;
-  if (mask & SH_STAGE_DISTAL)
-    if ((rc = run_slice_set(c, "distal", 2, SH_NDIST, true, false)) != SH_OK) return rc;
+  // The distal set (and the rectangles of its rows, the first half of the trans-epicondylar stage) needs nothing but the box frame:
+  // it runs on the side stream beside the full -> neck -> canal -> proximal -> groove chain and is joined in front of k_te_final.
+  // Only when the overflow tier is known to be idle for this batch (its pool counters are per set) and no per-launch timing is on.
+  static const bool side_env = !(getenv("SHOULDER_SIDE_STREAM") && getenv("SHOULDER_SIDE_STREAM")[0] == '0');
+  // Small batches only: one humerus gains 4 % (6.01 -> 5.78 ms per run); at B = 64 the two streams' kernels just share the CUs and
+  // one lane LOSES 8 % (5 340 -> 4 900 humeri/s), so the fork is taken up to 16 humeri.
+  const bool side = side_env && (mask & SH_STAGE_DISTAL) && B <= 16 && c->ovf_none_gen == c->batch_gen && c->timing != 1 && !c->redo_records;
+  c->side_pending = false;
+  if (mask & SH_STAGE_DISTAL) {
+    hipStream_t main_stream = c->stream;
+    if (side) {
+      if (!c->side_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+      if (!c->side_fork_ev) { HIPCHK(c, hipEventCreateWithFlags(&c->side_fork_ev, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->side_join_ev, hipEventDisableTiming)); }
+      HIPCHK(c, hipEventRecord(c->side_fork_ev, main_stream));
+      HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->side_fork_ev, 0));
+      c->stream = c->side_stream;
+    }
+    rc = run_slice_set(c, "distal", 2, SH_NDIST, true, false);
+    if (rc == SH_OK && side && (mask & SH_STAGE_TE)) rc = run_te_rows(c);
+    if (side) {
+      c->stream = main_stream;
+      if (rc == SH_OK) { HIPCHK(c, hipEventRecord(c->side_join_ev, c->side_stream)); c->side_pending = true; }
+    }
+    if (rc != SH_OK) return rc;
+  }
   if (mask & SH_STAGE_NECK) {
     const bool prox = c->params.bone_kind == SH_BONE_PROXIMAL;      // surgical_neck.py:25-28
     if (prox) {
@@ -1900,17 +1946,13 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   if (mask & SH_STAGE_TE) {
     OvfPools OP; OvfSet OS;
     { int orc; if ((orc = ovf_pools(c, &OP)) != SH_OK || (orc = ovf_set(c, "distal", SH_NDIST, &OS)) != SH_OK) return orc; }
-    LAUNCH(c, "k_te_rows", k_te_rows<SH_SMALLSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
-           buf<double>(c, "te.rects"), B, (const long long*)OS.roff);
-    LAUNCH(c, "k_te_rows_large", k_te_rows<SH_MAXSEG>, dim3(B * SH_TE_NROWS), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
-           buf<double>(c, "te.rects"), B, (const long long*)OS.roff);
-    if (c->ovf_none_gen != c->batch_gen) {
-      LAUNCH(c, "k_te_rows_huge", k_te_rows_huge, dim3(64), dim3(64), OP, OS, (const int*)buf<int>(c, "distal.ring_n"), buf<double>(c, "te.rects"));
-    }
+    if (c->side_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_join_ev, 0)); c->side_pending = false; }      // (distal set + rectangles: done on the side stream)
+    else if ((rc = run_te_rows(c)) != SH_OK) return rc;
     LAUNCH(c, "k_te_final", k_te_final, dim3(B), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
            buf<double>(c, "te.rects"), buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
            buf<double>(c, "anp.axes_obb"), buf<double>(c, "te.dscratch"), buf<double>(c, "te.axis_ct"), buf<int>(c, "te.row"), buf<int>(c, "err"), B, OP, OS);
   }
+  if (c->side_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_join_ev, 0)); c->side_pending = false; }
   LAUNCH(c, "k_pack", k_pack, dim3(B), dim3(256), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "obb_transform"), buf<double>(c, "z_bounds"),
          buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), buf<int>(c, "flipped"), buf<double>(c, "canal.axis_ct"), buf<double>(c, "te.axis_ct"),
          buf<double>(c, "groove.axis_ct"), buf<double>(c, "groove.bg_theta"), buf<double>(c, "groove.points_ct"), buf<double>(c, "anp.plane"),
