@@ -76,10 +76,12 @@ __device__ inline int wave_hull_wrap(const double* xy, int n, int* hull, int lan
 // in hull order wins, as in the sequential routine).
 // Two capacity tiers share the grid like k_slice_link (CAP = SH_SMALLSEG: 24 KB of LDS; the ring is staged in LDS first --
 // lane 0's hull walk is latency-bound when every point comes from global memory).
-#ifdef SH_TE_MELKMAN
-constexpr bool getenv_te_melkman = true;
-#else
+// -DSH_TE_WRAP selects wave_hull_wrap (measured round 3: 0.21 ms for the hull phase either way -- the 64-lane tournament pays ~40
+// ds_bpermute per step for its reduction -- so the established one-lane walk stays the default)
+#ifdef SH_TE_WRAP
 constexpr bool getenv_te_melkman = false;
+#else
+constexpr bool getenv_te_melkman = true;
 #endif
 
 template <int CAP>
@@ -107,7 +109,7 @@ k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, doubl
 #endif
   const double* xy = s_xy;
   int nh, rot = 0;
-  if (getenv_te_melkman) {      // (-DSH_TE_MELKMAN: round 2's one-lane deque walk, for the A/B)
+  if (getenv_te_melkman) {
     if (lane == 0) nh_s = convex_hull_simple_polygon(xy, n, dq, hull);   // rings are simple polygons in boundary order
     __syncthreads();
     nh = nh_s;
