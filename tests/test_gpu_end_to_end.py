@@ -110,7 +110,9 @@ ORACLE_PICKS = (5, 23, 41, 63)      # humeri of the 64-batch that also go throug
 # anatomic-neck bounds per UNet element type, asserted below on the bench's own batch (mm; f32 is the north-star 1e-4):
 # the mask boundary moves by single pixels of the 512 x 512 polar image (~0.3 mm) where a 16-bit logit rounds across zero,
 # and the reference's plane / ellipse fits and ray casts amplify that
-ANP_MM = {"f32": dict(plane=MM, axes=MM, edge_pts=0), "bf16": dict(plane=0.3, axes=1.5, edge_pts=60), "f16": dict(plane=0.06, axes=0.4, edge_pts=12)}
+# `deg`: the ANP-derived angles (neckshaft, retroversion), `radius`: radius_curvature in mm -- ADVICE r2: bounded for the 16-bit types too
+ANP_MM = {"f32": dict(plane=MM, axes=MM, edge_pts=0, deg=1e-6, radius=1e-6), "f32x": dict(plane=MM, axes=MM, edge_pts=0, deg=1e-6, radius=1e-6),
+          "bf16": dict(plane=0.3, axes=1.5, edge_pts=60, deg=2.5, radius=0.05), "f16": dict(plane=0.06, axes=0.4, edge_pts=12, deg=0.6, radius=0.02)}
 
 
 @pytest.fixture(scope="module")
@@ -124,11 +126,11 @@ def oracle_picks(oracle_bones, rfc_tables, unet_weights):
     out = {}
     for b in ORACLE_PICKS:
         o = OracleHumerus(synth.apply_similarity(T[b], h.verts), h.faces, rfc_tables, unet_weights, unet_eval="chain")
-        out[b] = (o, o.landmarks())
+        out[b] = (o, o.landmarks(), o.metrics())
     return out
 
 
-@pytest.mark.parametrize("unet", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("unet", ["f32", "f32x", "bf16", "f16"])
 def test_full_size_batch_equivariance(engine, oracle_bones, oracle_picks, unet):
     """BASELINE configs[2] at full size, in every UNet element type: 64 synthetic humeri (the bench's batch, same seed).
     (1) oracle parity on ORACLE_PICKS: everything that does not read the mask within 1e-4 mm and integer decisions exact in all
@@ -139,15 +141,18 @@ def test_full_size_batch_equivariance(engine, oracle_bones, oracle_picks, unet):
     T = synth.similarity_transforms(B, h.verts, seed=1234)
     engine.upload([(h.verts, h.faces)])
     engine.synth_batch(np.concatenate([np.identity(4)[None], T[1:]]))
-    engine.set_params(unet_dtype={"f32": _lib.UNET_F32, "bf16": _lib.UNET_BF16, "f16": _lib.UNET_F16}[unet])
+    engine.set_params(unet_dtype={"f32": _lib.UNET_F32, "f32x": _lib.UNET_F32X, "bf16": _lib.UNET_BF16, "f16": _lib.UNET_F16}[unet])
     try:
         lm = engine.run(_lib.STAGE_ALL)
     finally:
         engine.set_params(unet_dtype=_lib.UNET_F32)
     assert (lm["status"] == 0).all()
     bound = ANP_MM[unet]
-    seen = dict(plane=0.0, axes=0.0, edge_pts=0, geom=0.0)
-    for b, (o, L) in oracle_picks.items():
+    seen = dict(plane=0.0, axes=0.0, edge_pts=0, geom=0.0, deg=0.0, radius=0.0)
+    for b, (o, L, M) in oracle_picks.items():
+        assert ("left", "right")[int(lm["side"][b])] == M["side"]
+        seen["deg"] = max(seen["deg"], abs(float(lm["neckshaft"][b]) - M["neckshaft"]), abs(float(lm["retroversion"][b]) - M["retroversion"]))
+        seen["radius"] = max(seen["radius"], abs(float(lm["radius_curvature"][b]) - M["radius_curvature"]))
         assert lm["neck_index"][b] == o.neck["bkp"] and bool(lm["flipped"][b]) == o.obb["flipped"]
         assert lm["bg_theta"][b] == L["bg_theta"]
         for key in ("canal_axis", "groove_axis", "groove_points", "te_axis"):
@@ -159,12 +164,14 @@ def test_full_size_batch_equivariance(engine, oracle_bones, oracle_picks, unet):
         seen["axes"] = max(seen["axes"], float(np.abs(lm["anp_axis_normal"][b] - L["anp_axis_normal"]).max()),
                            float(np.abs(lm["anp_axis_central"][b] - L["anp_axis_central"]).max()))
         seen["edge_pts"] = max(seen["edge_pts"], abs(int(lm["n_anp"][b]) - len(L["anp_points"])))
-        if unet == "f32":
+        if unet in ("f32", "f32x"):
             K = min(len(L["anp_points"]), 4096)
             np.testing.assert_allclose(lm["anp_points"][b][:K], L["anp_points"][:K], rtol=0, atol=MM)
     print(f"{unet}: vs oracle on {ORACLE_PICKS}: geometry {seen['geom']:.2e} mm, neck plane point {seen['plane']:.2e} mm, "
-          f"neck axes {seen['axes']:.2e} mm, edge-point count differs by <= {seen['edge_pts']}")
+          f"neck axes {seen['axes']:.2e} mm, edge-point count differs by <= {seen['edge_pts']}, neck-shaft / retroversion angle {seen['deg']:.2e} deg, "
+          f"radius of curvature {seen['radius']:.2e} mm")
     assert seen["plane"] <= bound["plane"] and seen["axes"] <= bound["axes"] and seen["edge_pts"] <= bound["edge_pts"]
+    assert seen["deg"] <= bound["deg"] and seen["radius"] <= bound["radius"]
     base = lm[0]
     worst = {}
     for key in ("canal_axis", "te_axis", "groove_axis", "anp_plane_point"):
