@@ -47,14 +47,17 @@ __global__ void k_pack_w_x3(const float* __restrict__ P, u16* __restrict__ PH_, 
 // Input channel c < C0 comes from src0, else from src1 (the decoder's cat([skip, up])); C0, C1 multiples of 32.
 // FUSE: 0; UF_POOL -- the 2x2 max pool (input of the next encoder level) written beside the output; UF_HEAD (NT = 2, Cout = 32)
 // -- the 1x1 head applied to the accumulators, only the logits leave the kernel (same operation order per logit as the
-// UF_HEAD epilogues of the 16-bit kernels).
+// UF_HEAD epilogues of the 16-bit kernels); UF_FIRST (Cin = 32 = the first conv's output) -- the layer's input is computed from
+// the 1-channel image while the halo tile is staged: per halo pixel and channel the f32 fma chain of k_conv_first (bias, then taps
+// 0..8, ReLU), bit for bit, so enc0a's 2.1 GB tensor is neither written nor read.
 template <int TAPS, int NT, int FUSE = 0, int DB = 1>
 __global__ void __launch_bounds__(UN_THREADS)
 k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, int C0, int C1,
                const u16* __restrict__ wh_, const u16* __restrict__ wl_ /*packed [phase][tap][Cin/32][Cout][32] f16: high / low part of 64 w*/,
                const float* __restrict__ bias, float* __restrict__ dst, int H, int W, int Cout, int relu,
                float* __restrict__ pooled /*UF_POOL: [nimg][H/2][W/2][Cout]*/, const float* __restrict__ head_w, const float* __restrict__ head_b,
-               float* __restrict__ logits /*UF_HEAD: [nimg][H][W]*/) {
+               float* __restrict__ logits /*UF_HEAD: [nimg][H][W]*/,
+               const float* __restrict__ image /*UF_FIRST: [nimg][H][W]*/, const float* __restrict__ w0 /*[9][32]*/, const float* __restrict__ b0 /*[32]*/) {
   using ET = _Float16;
   using v8 = typename E16<ET>::v8;
   constexpr int HALO = TAPS == 9 ? 1 : 0;
@@ -70,6 +73,8 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
   __shared__ __attribute__((aligned(16))) ET s_xl[(DB ? 2 : 1) * XI];
   __shared__ __attribute__((aligned(16))) ET s_wh[TAPS * NC * UB_PSTR];
   __shared__ __attribute__((aligned(16))) ET s_wl[TAPS * NC * UB_PSTR];
+  __shared__ float s_img[(FUSE & UF_FIRST) ? (UN_TH + 4) * (UN_TW + 4) : 1];
+  __shared__ float s_w0[(FUSE & UF_FIRST) ? 10 * 32 : 1];      // [9][32] weights, then the bias
   const ET* wh = (const ET*)wh_;
   const ET* wl = (const ET*)wl_;
   const int Cin = C0 + C1;
@@ -116,7 +121,7 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
       f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, b = a;
-      if (in_pix[k] >= 0) {
+      if (!(FUSE & UF_FIRST) && in_pix[k] >= 0) {
         const float* s = src + (size_t)in_pix[k] * Cs + cb + ((tid + k * UN_THREADS) & 3) * 8;
         a = *(const f32x4*)s; b = *(const f32x4*)(s + 4);
       }
@@ -135,9 +140,23 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
     for (int k = 0; k < NIN; ++k)
       if (in_lds[k] >= 0) {
         v8 hi, lo;
+        float pv[9];
+        if constexpr ((FUSE & UF_FIRST) != 0) {      // the 3x3 image patch of this halo pixel (zero outside the image: enc0a's padding)
+          const int e = tid + k * UN_THREADS, p = e >> 2;
+          const int px = p % PW, py = p / PW;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) pv[t] = s_img[(py + t / 3) * (UN_TW + 4) + px + t % 3];
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float v = rin[k][j >> 2][j & 3];
+          float v = rin[k][j >> 2][j & 3];
+          if constexpr ((FUSE & UF_FIRST) != 0) {
+            const int c = ((tid + k * UN_THREADS) & 3) * 8 + j;
+            float a = s_w0[9 * 32 + c];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = __builtin_fmaf(pv[t], s_w0[t * 32 + c], a);
+            v = in_pix[k] >= 0 ? fmaxf(a, 0.0f) : 0.0f;      // outside the image: enc0b's zero padding
+          }
           const ET h = (ET)v;
           hi[j] = h;
           lo[j] = (ET)(v - (float)h);
@@ -164,6 +183,17 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
 
   // One prefetch per chunk (input + weights of chunk c + 1 into registers), issued once the weights of chunk c are in LDS; its input
   // half is consumed at tap 4 of chunk c, its weight half between the barriers in front of chunk c + 1.
+  if constexpr ((FUSE & UF_FIRST) != 0) {
+    constexpr int IW = UN_TW + 4;
+    const float* im = image + (size_t)img * H * W;
+    for (int e = tid; e < (UN_TH + 4) * IW; e += UN_THREADS) {
+      const int gy = y0 - 2 + e / IW, gx = x0 - 2 + e % IW;
+      s_img[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.0f;
+    }
+    for (int e = tid; e < 9 * 32; e += UN_THREADS) s_w0[e] = w0[e];
+    if (tid < 32) s_w0[9 * 32 + tid] = b0[tid];
+    __syncthreads();
+  }
   load_chunk(0);
   store_input(0);
   for (int cc = 0; cc < nchunk; ++cc) {

@@ -982,7 +982,7 @@ int sh_mesh_transformed(sh_ctx* c, int b, const double* T, double* out) {
 // ---- UNet forward (f32 MFMA path) ----------------------------------------------------------------------
 static int conv_layer(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const float* src0, const float* src1, int C0, int C1, float* dst,
                       int H, int W, int nimg, int relu, int fuse = 0, float* pooled = nullptr, const float* head_w = nullptr, const float* head_b = nullptr,
-                      float* logits = nullptr) {
+                      float* logits = nullptr, const float* image = nullptr, const float* w0 = nullptr, const float* b0 = nullptr) {
   if (H % UN_TH || W % UN_TW) return fail(c, SH_ERR_ARG, "unet: feature map is not a multiple of 16");
   const float* P = buf<float>(c, "params");
   const float* w = P + L.w_off; const float* b = P + L.b_off;
@@ -993,16 +993,19 @@ static int conv_layer(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, con
     const u16* wl = buf<u16>(c, "params_x3l") + L.w_off;
     float* np_ = nullptr; const float* nf_ = nullptr;
     const bool db2 = getenv("SHOULDER_X3_DB2") && getenv("SHOULDER_X3_DB2")[0] == '1';      // 32-cout 3x3 layers: double-buffered input too (one workgroup per CU then)
-    if (L.taps == 9 && fuse == UF_HEAD && L.cout == 32) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_HEAD>), dim3(tiles, 1, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, head_w, head_b, logits); }
-    else if (L.taps == 9 && fuse == UF_POOL && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4, UF_POOL>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_); }
-    else if (L.taps == 9 && fuse == UF_POOL && db2) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_POOL, 1>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_); }
-    else if (L.taps == 9 && fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_POOL, 0>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_); }
+    if (L.taps == 9 && fuse == (UF_FIRST | UF_POOL) && L.cout == 32 && C0 == 32 && C1 == 0) {      // enc0b with enc0a computed while its halo tile is staged
+      LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_FIRST | UF_POOL, 0>), dim3(tiles, 1, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_, image, w0, b0);
+    }
+    else if (L.taps == 9 && fuse == UF_HEAD && L.cout == 32) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_HEAD>), dim3(tiles, 1, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, head_w, head_b, logits, nf_, nf_, nf_); }
+    else if (L.taps == 9 && fuse == UF_POOL && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4, UF_POOL>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_, nf_, nf_, nf_); }
+    else if (L.taps == 9 && fuse == UF_POOL && db2) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_POOL, 1>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_, nf_, nf_, nf_); }
+    else if (L.taps == 9 && fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_POOL, 0>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_, nf_, nf_, nf_); }
     else if (fuse != 0) return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
-    else if (L.taps == 9 && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_); }
-    else if (L.taps == 9 && db2) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, 0, 1>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_); }
-    else if (L.taps == 9) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, 0, 0>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_); }
-    else if (L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<1, 4>), dim3(tiles, L.cout / 64, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, 0, np_, nf_, nf_, np_); }
-    else { LAUNCH(c, lname, (k_conv_mfma_x3<1, 2>), dim3(tiles, L.cout / 32, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, 0, np_, nf_, nf_, np_); }
+    else if (L.taps == 9 && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_, nf_, nf_, nf_); }
+    else if (L.taps == 9 && db2) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, 0, 1>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_, nf_, nf_, nf_); }
+    else if (L.taps == 9) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, 0, 0>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_, nf_, nf_, nf_); }
+    else if (L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<1, 4>), dim3(tiles, L.cout / 64, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, 0, np_, nf_, nf_, np_, nf_, nf_, nf_); }
+    else { LAUNCH(c, lname, (k_conv_mfma_x3<1, 2>), dim3(tiles, L.cout / 32, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, 0, np_, nf_, nf_, np_, nf_, nf_, nf_); }
     return SH_OK;
   }
   if (L.taps == 9) {
@@ -1089,14 +1092,19 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
   }
   auto L = [&](const std::string& n) -> const sh_ctx::ULayer& { return c->ulayers[n]; };
   int h = H, w = W;
-  {
+  // SH_UNET_F32X: the 2x2 pools ride in the epilogue of the conv before them (k_unet_x3.h), and with 32 base channels the first
+  // conv is computed inside enc0b's staging (SHOULDER_X3_FIRST=0: as its own launch)
+  const bool x3 = c->params.unet_dtype == SH_UNET_F32X && base % 32 == 0;
+  const bool x3_first = x3 && base == 32 && !(getenv("SHOULDER_X3_FIRST") && getenv("SHOULDER_X3_FIRST")[0] == '0');
+  if (!x3_first) {
     const sh_ctx::ULayer& l = L("enc0a");
     size_t npx = (size_t)nimg * h * w;
     LAUNCH(c, "unet.enc0a", k_conv_first, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, A, h, w, l.cout, nimg);
   }
-  // SH_UNET_F32X: the 2x2 pools ride in the epilogue of the conv before them and the head in dec0b's (k_unet_x3.h)
-  const bool x3 = c->params.unet_dtype == SH_UNET_F32X && base % 32 == 0;
-  if ((rc = conv_layer(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1, x3 ? UF_POOL : 0, Bq)) != SH_OK) return rc;
+  if (x3_first) {
+    const sh_ctx::ULayer& l = L("enc0a");
+    if ((rc = conv_layer(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_FIRST | UF_POOL, Bq, nullptr, nullptr, nullptr, image, P + l.w_off, P + l.b_off)) != SH_OK) return rc;
+  } else if ((rc = conv_layer(c, "unet.enc0b", L("enc0b"), A, nullptr, base, 0, skip[0], h, w, nimg, 1, x3 ? UF_POOL : 0, Bq)) != SH_OK) return rc;
   if (x3) std::swap(A, Bq);      // (the pooled tensor is the next level's input, which the loop below reads from A)
   int ch = base;
   for (int i = 1; i <= D; ++i) {
