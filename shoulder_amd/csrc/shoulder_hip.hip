@@ -1151,6 +1151,17 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
 #define SH_UNET_TKTAB (1 << 18)
 // work tickets of the persistent convs (k_unet_bf16_dma.h; SHOULDER_DMA_TICKETS=0: fixed equal shares): the next free counter
 // of this forward pass and the table of item bounds of decreasing runs for (items, workgroups, cout groups), built once per shape
+// Workgroups of a persistent UNet launch.  Each takes a whole CU (158 KB of LDS, all of its registers), so while one is resident no
+// other kernel can start there: beside the UNet pass of one lane, every launch of the other lane's geometry chain (~100 per step)
+// waited ~50 us for a workgroup to end, and the chain took 7-8 ms instead of 3.2.  Contexts that take turns on a device
+// (sh_set_unet_turns: there IS another lane) therefore leave SHOULDER_CU_RESERVE CUs (default 32 = 4 per XCD) out of the grid;
+// the work tickets spread the items over whatever grid there is.  Measured on the two-lane headline: 0 / 8 / 16 / 32 / 48 / 64 / 96
+// reserved -> 8.72 / 8.80 / 8.73 / 8.27 / 8.54 / 8.56 / 9.35 ms per step.
+static int persistent_grid(const sh_ctx* c) {
+  static const int reserve = getenv("SHOULDER_CU_RESERVE") ? std::max(0, atoi(getenv("SHOULDER_CU_RESERVE"))) : 32;
+  return c->unet_turn ? std::max(8, c->num_cus - reserve) : c->num_cus;
+}
+
 static int dma_tickets(sh_ctx* c, int total, int nwg, int ngrp, unsigned** tk, const int** tk_tab, int* ntk) {
   *tk = nullptr; *tk_tab = nullptr; *ntk = 0;
   const bool tickets_on = !(getenv("SHOULDER_DMA_TICKETS") && getenv("SHOULDER_DMA_TICKETS")[0] == '0');      // (read per launch: the tests switch it in-process)
@@ -1210,7 +1221,7 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     // SHOULDER_DMA_GRIDMUL workgroups per CU (default 1): with more, shorter work ranges the hardware dispatcher balances the
     // launch over the CUs another lane's kernels leave free (a workgroup takes a whole CU's LDS, so it waits for a free CU)
     static const int gridmul = getenv("SHOULDER_DMA_GRIDMUL") ? std::max(1, atoi(getenv("SHOULDER_DMA_GRIDMUL"))) : 1;
-    const dim3 g((unsigned)std::min(total, c->num_cus * gridmul));
+    const dim3 g((unsigned)std::min(total, persistent_grid(c) * gridmul));
     unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
     { int rct; if ((rct = dma_tickets(c, total, (int)g.x, L.cout / (dma64 ? 64 : 32), &tk, &tk_tab, &ntk)) != SH_OK) return rct; }
     const u16* zp = (const u16*)c->bufs["unet16.zero"].p;
@@ -1324,7 +1335,7 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
     const sh_ctx::ULayer& lb = L("enc0b");
     if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
     const int total = nimg * (w / 32) * (h / 16);
-    LAUNCH(c, "unet.enc0b", (k_enc0_fused16<EK>), dim3((unsigned)std::min(total, c->num_cus)), dim3(L0_THREADS), image, P + la.w_off, P + la.b_off,
+    LAUNCH(c, "unet.enc0b", (k_enc0_fused16<EK>), dim3((unsigned)std::min(total, persistent_grid(c))), dim3(L0_THREADS), image, P + la.w_off, P + la.b_off,
            PW + lb.w_off, P + lb.b_off, skip[0], A, h, w, nimg);
   } else if (fused && !(ff && ff[0] == '0')) {
     const sh_ctx::ULayer& l = L("enc0a");
@@ -1372,7 +1383,7 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
       if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
       if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
       const int total = nimg * (w / 32) * (h / 16);
-      const dim3 g((unsigned)std::min(total, c->num_cus));
+      const dim3 g((unsigned)std::min(total, persistent_grid(c)));
       unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
       if ((rc = dma_tickets(c, total, (int)g.x, 1, &tk, &tk_tab, &ntk)) != SH_OK) return rc;
       LAUNCH(c, "unet.dec0a", (k_dec0a_up16<EK>), g, dim3(UD_THREADS), skip[0], x, PW + la.w_off, P + la.b_off, PW + lu.w_off, P + lu.b_off, y, h, w, nimg,
