@@ -1267,8 +1267,11 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, UF_HEAD>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
     else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
   } else if (L.cout % 32 == 0 && C1 == 0 && C0 % 32 == 0 && !(getenv("SHOULDER_UNET_UPCONV") && getenv("SHOULDER_UNET_UPCONV")[0] == '0')) {
-    // 2x2 transposed conv, all four phases per workgroup (k_unet16_l0.h)
-    LAUNCH(c, lname, (k_upconv16<EK>), dim3(tiles, L.cout / 32, nimg * 2), dim3(UPC_THREADS), src0, C0, w, b, dst, H, W, L.cout);
+    // 2x2 transposed conv (k_unet16_l0.h): source pixels in registers for Cin = 128 / 256 (SHOULDER_UPCONV_REG=0: the staged form everywhere)
+    const bool upr = W % 32 == 0 && H % 16 == 0 && (C0 == 128 || C0 == 256) && L.cout <= 512 && !(getenv("SHOULDER_UPCONV_REG") && getenv("SHOULDER_UPCONV_REG")[0] == '0');
+    if (upr && C0 == 128) { LAUNCH(c, lname, (k_upconv16r<EK, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
+    else if (upr) { LAUNCH(c, lname, (k_upconv16r<EK, 8>), dim3((W / 32) * (H / 16), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
+    else { LAUNCH(c, lname, (k_upconv16<EK>), dim3(tiles, L.cout / 32, nimg * 2), dim3(UPC_THREADS), src0, C0, w, b, dst, H, W, L.cout); }
   } else if (L.cout % 64 == 0) {
     LAUNCH(c, lname, (k_conv_mfma16<EK, 1, 4, 0>), dim3(tiles, L.cout / 64, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
   } else {

@@ -275,6 +275,29 @@ def test_loader_wave_conv_bit_identical(engine, monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_register_resident_upconv_bit_identical(engine, monkeypatch, name):
+    """k_upconv16r (k_unet16_l0.h: a wave keeps its 64 source pixels x Cin in MFMA fragments, the weights stream through LDS one
+    (group, phase) slice at a time; up1 and up2) against k_upconv16 (tile staged per chunk): same accumulation order -> logits and
+    a decoder tensor bit-identical, at both image sizes and an odd batch."""
+    rng = np.random.default_rng(29)
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        for H, W, n in ((256, 512, 3), (512, 512, 5)):
+            img = rng.random((n, H, W), dtype=np.float32)
+            monkeypatch.setenv("SHOULDER_UPCONV_REG", "0")
+            a = engine.unet_infer(img)
+            ua = engine.fetch("unet16.b", np.uint16).copy()
+            monkeypatch.setenv("SHOULDER_UPCONV_REG", "1")
+            for _ in range(2):
+                b = engine.unet_infer(img)
+                ub = engine.fetch("unet16.b", np.uint16).copy()
+                assert np.array_equal(a, b) and np.array_equal(ua, ub)
+    finally:
+        monkeypatch.delenv("SHOULDER_UPCONV_REG", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
 def test_row_upconv_matches_per_phase_kernel(engine, monkeypatch, name):
     """k_upconv16 (16x16 source tile x 32 channels x both column phases of a row parity per workgroup: full output lines per
     wave) sums every output in the order of the per-phase two-barrier kernel: logits and a decoder tensor are bit-identical."""
