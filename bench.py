@@ -177,6 +177,10 @@ def sym_key(name, unet, cout, fused_net=True):
     if name == "unet.dec0a" and fused_net and os.environ.get("SHOULDER_UNET_DEC0") != "0":
         return "k_dec0a_up16<%s>" % unet      # dec0a with up0 computed inside (k_unet16_dec0.h); no unet.up0 launch then
     if up and os.environ.get("SHOULDER_UNET_UPCONV") != "0":
+        from shoulder_amd import unet_spec
+        cin = unet_cins(unet_spec.BASE, unet_spec.DEPTH)[name]
+        if cin in (128, 256, 512) and os.environ.get("SHOULDER_UPCONV_REG") != "0":
+            return "k_upconv16r<%s,%d,%d>" % (unet, cin // 32, 2 if cin == 512 else 4)      # source pixels resident in MFMA fragments (k_unet16_l0.h)
         return "k_upconv16<%s>" % unet                           # 2x2 transposed conv, both column phases per workgroup (k_unet16_l0.h)
     dma = (not up and not (fuse & 1) and os.environ.get("SHOULDER_UNET_DMA") != "0" and (cout % 64 == 0 or os.environ.get("SHOULDER_UNET_DMA32") != "0"))
     if dma:      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h); last arguments = tap order (SCHED), weights resident (WRES)

@@ -353,10 +353,10 @@ k_upconv16(const u16* __restrict__ src_, int Cin, const u16* __restrict__ wgt_ /
 // Input bytes come from HBM exactly once, the two 64-byte halves of an output line (dx = 0, 1) leave the same wave in
 // consecutive slices.  Same accumulation (bias in the accumulator, chunks in order) and the same channel dealing as
 // k_upconv16: bit-identical results (tests/test_gpu_unet_bf16.py::test_register_resident_upconv_bit_identical).
-// Cin = 512 (up3, 32 x 32 source maps: 0.2 GB) would need 256 fragment registers and stays on k_upconv16.
+// Cin = 512 (up3): 2 rows per wave (MT = 2, 128 fragment registers), a 32 x 8 source tile per workgroup.
 #define UPR_THREADS 512
 
-template <int EK, int NCH>
+template <int EK, int NCH, int MT = 4>      // MT: source rows (16-pixel MFMA tiles) per wave; a workgroup owns 4 MT rows x 32 pixels
 __global__ void __launch_bounds__(UPR_THREADS)
 k_upconv16r(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed [4][NCH][Cout][32]*/, const float* __restrict__ bias,
             u16* __restrict__ dst_, int H, int W, int Cout) {
@@ -374,7 +374,7 @@ k_upconv16r(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed 
   if (tid < Cout) s_b[tid] = bias[tid];
   const int li = lane & 15, lk = lane >> 4;
   const int xh = wave & 1, rg = wave >> 1;
-  const int x0 = tx * 32 + xh * 16 + li, y0 = ty * 16 + rg * 4;
+  const int x0 = tx * 32 + xh * 16 + li, y0 = (ty * 4 + rg) * MT;
   const ET* in = (const ET*)src_ + (size_t)img * H * W * (NCH * 32);
   const int groups = Cout >> 5, nslice = groups * 4;
 
@@ -399,9 +399,9 @@ k_upconv16r(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed 
   };
   load_slice(0);
   // the wave's pixels: fragment (m, cc) = 8 channels 32 cc + 8 lk .. of pixel (y0 + m, x0)
-  v8 xf[4][NCH];
+  v8 xf[MT][NCH];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) xf[m][cc] = *(const v8*)(in + ((size_t)cc * H * W + (size_t)(y0 + m) * W + x0) * 32 + 8 * lk);
   put_slice(0);
@@ -412,12 +412,12 @@ k_upconv16r(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed 
   for (int t = 0; t < nslice; ++t) {
     const int g = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
     if (t + 1 < nslice) load_slice(t + 1);      // in flight during the MFMAs below
-    f32x4 acc[4][2];
+    f32x4 acc[MT][2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const f32x4 bv = *(const f32x4*)(s_b + g * 32 + 8 * lk + 4 * n);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[m][n] = bv;
+      for (int m = 0; m < MT; ++m) acc[m][n] = bv;
     }
     const ET* sw = s_w[t & 1];
 #pragma unroll
@@ -426,13 +426,13 @@ k_upconv16r(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed 
 #pragma unroll
       for (int n = 0; n < 2; ++n) wf[n] = *(const v8*)(sw + UB_OFF(cc * 32 + n * 16 + li, lk));
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xf[m][cc], acc[m][n]);
     }
     ET* out = out0 + (size_t)g * OH * OW * 32;      // this group's 32-channel plane
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
       v8 o;
 #pragma unroll
       for (int r = 0; r < 8; ++r) o[r] = (ET)acc[m][r >> 2][r & 3];

@@ -209,6 +209,33 @@ static inline bool timed_launch(const sh_ctx* c, const char* name) {
     HIPCHK(ctx, hipGetLastError());                                                         \
   } while (0)
 
+// Buffer clears of a run as ONE kernel launch per group of adjacent clears.  hipMemsetAsync costs the enqueuing thread ~60 us per
+// call on this stack (rocprofv3 trace of bench.py: the five clears that open a step spread over 0.3 ms before its first kernel;
+// ~17 per step = 1 ms of host time) -- a kernel launch costs ~5 us.
+struct FillList { void* p[6]; unsigned long long n[6]; unsigned v[6]; };
+__global__ void k_fill_list(FillList L) {
+  unsigned* p = (unsigned*)L.p[blockIdx.y];
+  const unsigned long long nw = L.n[blockIdx.y] >> 2;
+  const unsigned v = L.v[blockIdx.y];
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < nw; i += (unsigned long long)gridDim.x * blockDim.x) p[i] = v;
+}
+struct FillEnt { void* p; size_t bytes; unsigned char byte; };      // bytes: a multiple of 4, p 4-byte aligned
+static int fill_list(sh_ctx* c, std::initializer_list<FillEnt> ents) {
+  FillList L{};
+  int k = 0; size_t nmax = 0;
+  for (const FillEnt& e : ents) {
+    if (!e.p || e.bytes == 0) continue;
+    if (k == 6 || (e.bytes & 3) || ((uintptr_t)e.p & 3)) return fail(c, SH_ERR_STATE, "fill_list: bad entry");
+    L.p[k] = e.p; L.n[k] = e.bytes; L.v[k] = 0x01010101u * e.byte; ++k;
+    nmax = std::max(nmax, e.bytes);
+  }
+  if (k == 0) return SH_OK;
+  const unsigned gx = (unsigned)std::min<size_t>(512, std::max<size_t>(1, (nmax / 4 + 256 * 16 - 1) / (256 * 16)));
+  LAUNCH(c, "fill", k_fill_list, dim3(gx, (unsigned)k), dim3(256), L);
+  return SH_OK;
+}
+#define FILL(ctx, ...) do { int frc_ = fill_list(ctx, {__VA_ARGS__}); if (frc_ != SH_OK) return frc_; } while (0)
+
 static void drain_timers(sh_ctx* c) {
   for (auto& t : c->pending) {
     float ms = 0;
@@ -1312,7 +1339,7 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
   }
   if ((rc = ensure(c, "unet16.tickets", SH_UNET_TICKETS * 4, 4)) != SH_OK) return rc;
   if ((rc = ensure(c, "unet16.tk_tab", SH_UNET_TKTAB * 4, 4)) != SH_OK) return rc;
-  HIPCHK(c, hipMemsetAsync(buf<unsigned>(c, "unet16.tickets"), 0, SH_UNET_TICKETS * 4, c->stream));
+  FILL(c, {buf<unsigned>(c, "unet16.tickets"), (size_t)SH_UNET_TICKETS * 4, 0});
   c->ticket_next = 0;
   const char* unf = getenv("SHOULDER_UNET_UNFUSED");
   const bool fused = base == 32 && !(unf && unf[0] == '1');
@@ -1491,9 +1518,8 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   Seg* segs = buf<Seg>(c, (p + ".segs").c_str());
   LAUNCH(c, "k_make_planes", k_make_planes, dim3(B), dim3(256), kind, N, buf<double>(c, kind == 4 ? "obb.zb_pre" : "z_bounds"), buf<double>(c, "neck_z"), zs, zeff, B);
   double* atot = total_area ? buf<double>(c, (p + ".area_total").c_str()) : (double*)nullptr;
-  HIPCHK(c, hipMemsetAsync(cnt, 0, (size_t)B * N * 4, c->stream));
   int* nlarge = (int*)c->bufs["slices.nlarge"].p + (kind & 7);      // (one counter per kind of set: two sets may run on two streams)
-  HIPCHK(c, hipMemsetAsync(nlarge, 0, 4, c->stream));
+  FILL(c, {cnt, (size_t)B * N * 4, 0}, {nlarge, 4, 0});
   if (N > SH_EMIT_MAXN) return fail(c, SH_ERR_CAPACITY, "slice set has more planes than k_slice_emit's LDS histogram");
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 4096), (unsigned)B);
   LAUNCH(c, "k_slice_emit", k_slice_emit, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
@@ -1503,9 +1529,7 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   { int orc; if ((orc = ovf_pools(c, &OP)) != SH_OK || (orc = ovf_set(c, p, N, &OS)) != SH_OK) return orc; }
   const bool ovf_on = c->ovf_none_gen != c->batch_gen;      // (known from an earlier run of this batch: no plane overflows)
   if (ovf_on) {
-    HIPCHK(c, hipMemsetAsync(OS.nlist, 0, 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(OP.ctr, 0, 8, c->stream));              // segments used: per set
-    HIPCHK(c, hipMemsetAsync(OP.ctr + 2, 0, 8, c->stream));          // workspace used: per set (ring points stay for the run)
+    FILL(c, {OS.nlist, 4, 0}, {OP.ctr, 8, 0} /*segments used: per set*/, {OP.ctr + 2, 8, 0} /*workspace used: per set (ring points stay for the run)*/);
     LAUNCH(c, "k_ovf_plan", k_ovf_plan, dim3((unsigned)((B * N + 255) / 256)), dim3(256), N, B * N, (const int*)cnt, OP, OS, buf<int>(c, "err"));
     LAUNCH(c, "k_slice_emit_ovf", k_slice_emit_ovf, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
            buf<long long>(c, "foff"), zeff, N, OP, OS);
@@ -1776,9 +1800,8 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   const int* cnt_nf = buf<int>(c, "hull.nf");
   const int* cnt_ne = buf<int>(c, "hull.ne");
   {
-    HIPCHK(c, hipMemsetAsync(buf<unsigned long long>(c, "obb.best_enc"), 0xFF, (size_t)B * 8, c->stream));      // "no candidate volume yet"
-    HIPCHK(c, hipMemsetAsync(buf<unsigned long long>(c, "obb.lbmin_enc"), 0xFF, (size_t)B * 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(buf<double>(c, "obb.area2"), 0, (size_t)B * SH_HF * 8, c->stream));
+    FILL(c, {buf<unsigned long long>(c, "obb.best_enc"), (size_t)B * 8, 0xFF} /*"no candidate volume yet"*/, {buf<unsigned long long>(c, "obb.lbmin_enc"), (size_t)B * 8, 0xFF},
+         {buf<double>(c, "obb.area2"), (size_t)B * SH_HF * 8, 0});
     const int nemax = 3 * nfmax / 2 + 3;      // (a closed triangulated surface: 2 E = 3 F)
     LAUNCH(c, "k_obb_face_area2", k_obb_face_area2, dim3((unsigned)((std::min(nemax, SH_HE) + 255) / 256), (unsigned)B), dim3(256), buf<double>(c, "hull.hv"),
            buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.area2"));
@@ -1827,7 +1850,7 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
     c->obb_injected = true;
     return SH_OK;
   }
-  HIPCHK(c, hipMemsetAsync(buf<int>(c, "obb.endcnt"), 0, (size_t)B * 2 * 4, c->stream));
+  FILL(c, {buf<int>(c, "obb.endcnt"), (size_t)B * 2 * 4, 0});
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 1024), (unsigned)B);
   LAUNCH(c, "k_obb_end_points", k_obb_end_points, g, dim3(256), buf<float>(c, "verts"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
          buf<long long>(c, "foff"), buf<double>(c, "obb.T_pre"), buf<double>(c, "obb.zb_pre"), buf<double>(c, "obb.endpts"), buf<int>(c, "obb.endcnt"));
@@ -1959,7 +1982,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<int>(c, "err"));
     LAUNCH(c, "k_anp_plane", k_anp_plane, dim3(B), dim3(256), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
            buf<double>(c, "anp.plane"), buf<int>(c, "err"));
-    HIPCHK(c, hipMemsetAsync(buf<unsigned long long>(c, "anp.ray_t"), 0xFF, (size_t)B * 4 * 8, c->stream));
+    FILL(c, {buf<unsigned long long>(c, "anp.ray_t"), (size_t)B * 4 * 8, 0xFF});
     LAUNCH(c, "k_rays_hit", k_rays_hit, dim3(SH_RAY_CHUNKS, B), dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
            buf<long long>(c, "foff"), buf<double>(c, "anp.plane"), buf<unsigned long long>(c, "anp.ray_t"));
     LAUNCH(c, "k_rays", k_rays, dim3((4 * B + 63) / 64), dim3(64), buf<double>(c, "anp.plane"), buf<unsigned long long>(c, "anp.ray_t"),
@@ -2145,8 +2168,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     int prc = alloc_prox(c);
     if (prc != SH_OK) return prc;
   }
-  HIPCHK(c, hipMemsetAsync(buf<int>(c, "err"), 0, B * 4, c->stream));
-  { OvfPools OP; int orc = ovf_pools(c, &OP); if (orc != SH_OK) return orc; HIPCHK(c, hipMemsetAsync(OP.ctr, 0, 64, c->stream)); }      // overflow pools: empty, no demand recorded
+  { OvfPools OP; int orc = ovf_pools(c, &OP); if (orc != SH_OK) return orc; FILL(c, {buf<int>(c, "err"), (size_t)B * 4, 0}, {OP.ctr, 64, 0}); }      // overflow pools: empty, no demand recorded
   if ((mask & SH_STAGE_APPLY) && !(mask & SH_STAGE_CSYS)) return fail(c, SH_ERR_ARG, "sh_run: SH_STAGE_APPLY needs SH_STAGE_CSYS in the same run");
   // a proximal humerus' frame is canal / articular (bone.py:53-62): k_pack builds it from the anatomic-neck axes of THIS run
   if (c->params.bone_kind == SH_BONE_PROXIMAL && (mask & SH_STAGE_CSYS) && !(mask & SH_STAGE_ANP))
