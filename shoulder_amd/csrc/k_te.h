@@ -1,7 +1,8 @@
 // k_te.h -- trans-epicondylar axis, coordinate system and the landmark record
 // (reference src/shoulder/humerus/epicondyle.py:29-101, src/shoulder/bone.py:146-157).
 //   k_te_rows   :33-40  min-area rectangle of every distal slice in the cut (one lane per slice)
-//   k_te_final  :39-96  widest slice -> end slivers -> centroids -> farthest pair -> medial first
+//   k_te_ends   :39-89  widest slice -> end slivers -> centroids -> farthest pair (needs the distal set only: runs beside the UNet)
+//   k_te_orient :90-96  medial end first (needs the head's central axis, i.e. the anatomic neck)
 //   k_pack      bone.py:146-157 construct_csys(canal, TE) + fill sh_landmarks (CT coordinates)
 #pragma once
 #include "../../include/shoulder_hip.h"
@@ -71,6 +72,63 @@ __device__ inline int wave_hull_wrap(const double* xy, int n, int* hull, int lan
   return nh;
 }
 
+// sh::convex_hull_simple_polygon (sh_scalar.h) for one lane that has to wait for every LDS answer.  The plain form reads two deque
+// slots and then their points for every orientation test: ~20 dependent LDS round trips per vertex, 1 us per vertex, the whole
+// kernel one slice's walk long (0.35 ms).  Here the deque holds COORDINATES (dqx, dqy: slots 0 .. 2n + 1, the hull ends up in
+// dqx/dqy[*first .. *first + nh)), the three points at either end of it stay in registers (B0 B1 B2 from the bottom, T0 T1 T2 from
+// the top) and the next ring vertex is fetched while the current one is tested: a vertex that leaves the hull alone waits for
+// nothing, a push is two stores, a pop shifts the registers and refills the third one with a load nobody waits for unless a
+// second pop follows at once.  Same tests on the same values in the same order as the plain form: the same hull.
+//   invariants: Bk = slot bot + k for every k with bot + k <= top, Tk = slot top - k for top - k >= bot (a slot's content never
+//   changes while it is live; a push that makes a slot live which the other end's third register stands for refreshes it).
+// Returns -1 when the first three vertices are collinear (the caller takes the sort-based hull of the plain form).
+__device__ inline double orient2v(double ax, double ay, double bx, double by, double cx, double cy) {
+  return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
+}
+__device__ inline int hull_simple_polygon_cached(const double* xy, int n, double* dqx, double* dqy, int* first) {
+  const double o = orient2(xy, xy + 2, xy + 4);
+  if (o == 0.0) return -1;
+  int bot = n - 2, top = bot + 3;
+  const double v0x = xy[0], v0y = xy[1], v1x = xy[2], v1y = xy[3], v2x = xy[4], v2y = xy[5];
+  // slots bot .. top = 2, (0, 1 | 1, 0), 2
+  double b0x = v2x, b0y = v2y, t0x = v2x, t0y = v2y;
+  double b1x = o > 0 ? v0x : v1x, b1y = o > 0 ? v0y : v1y;
+  double t1x = o > 0 ? v1x : v0x, t1y = o > 0 ? v1y : v0y;
+  double b2x = t1x, b2y = t1y, t2x = b1x, t2y = b1y;
+  dqx[bot] = v2x; dqy[bot] = v2y; dqx[bot + 1] = b1x; dqy[bot + 1] = b1y; dqx[bot + 2] = t1x; dqy[bot + 2] = t1y; dqx[top] = v2x; dqy[top] = v2y;
+  double nx = n > 3 ? xy[6] : 0.0, ny = n > 3 ? xy[7] : 0.0;
+  for (int i = 3; i < n; ++i) {
+    const double vx = nx, vy = ny;
+    if (i + 1 < n) { nx = xy[2 * i + 2]; ny = xy[2 * i + 3]; }      // (in flight during the tests below)
+    double ob = orient2v(b0x, b0y, b1x, b1y, vx, vy);
+    double ot = orient2v(t1x, t1y, t0x, t0y, vx, vy);
+    if (ob > 0 && ot > 0) continue;
+    while (top - bot >= 2 && ob <= 0) {
+      ++bot;
+      b0x = b1x; b0y = b1y; b1x = b2x; b1y = b2y;
+      b2x = dqx[bot + 2]; b2y = dqy[bot + 2];      // (slot bot + 2 <= 2n + 1; not live when bot + 2 > top: never used then, see the pushes)
+      ob = orient2v(b0x, b0y, b1x, b1y, vx, vy);
+    }
+    --bot;
+    dqx[bot] = vx; dqy[bot] = vy;
+    b2x = b1x; b2y = b1y; b1x = b0x; b1y = b0y; b0x = vx; b0y = vy;
+    if (top - bot == 2) { t2x = vx; t2y = vy; }      // the new bottom slot is the top's third
+    // (the bottom of the deque never reaches its top two slots: `ot` still is the test of slots top - 1, top)
+    while (top - bot >= 2 && ot <= 0) {
+      --top;
+      t0x = t1x; t0y = t1y; t1x = t2x; t1y = t2y;
+      t2x = dqx[top >= 2 ? top - 2 : 0]; t2y = dqy[top >= 2 ? top - 2 : 0];
+      ot = orient2v(t1x, t1y, t0x, t0y, vx, vy);
+    }
+    ++top;
+    dqx[top] = vx; dqy[top] = vy;
+    t2x = t1x; t2y = t1y; t1x = t0x; t1y = t0y; t0x = vx; t0y = vy;
+    if (top - bot == 2) { b2x = vx; b2y = vy; }      // the new top slot is the bottom's third
+  }
+  *first = bot;
+  return top - bot;
+}
+
 // One wave per (humerus, distal slice): lane 0 builds the hull of the ring (Melkman, O(n), LDS deque),
 // then the lanes share the hull edges of sh::min_area_rect (same arithmetic per edge; first minimum
 // in hull order wins, as in the sequential routine).
@@ -88,11 +146,9 @@ template <int CAP>
 __global__ void __launch_bounds__(64)
 k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, double* __restrict__ rects /*[B][37][7]*/, int B,
           const long long* __restrict__ ovf_roff /*distal set: >= 0 = the slice's ring is in the overflow pool (k_te_rows_huge takes it)*/) {
-  __shared__ int dq[2 * CAP + 8];
-  __shared__ int hull[2 * CAP + 8];
-  __shared__ double hx[CAP], hy[CAP];
+  __shared__ double dqx[2 * CAP + 8], dqy[2 * CAP + 8];      // coordinate deque of the walk; the hull's points afterwards
   __shared__ double s_xy[2 * (CAP + 1)];
-  __shared__ int nh_s;
+  __shared__ int nh_s, first_s;
   const int gid = blockIdx.x, lane = threadIdx.x;
   const int b = gid / SH_TE_NROWS, j = gid % SH_TE_NROWS;
   const size_t pl = (size_t)b * SH_NDIST + SH_TE_ROW0 + j;
@@ -108,19 +164,45 @@ k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, doubl
   return;
 #endif
   const double* xy = s_xy;
-  int nh, rot = 0;
+  const double *hx = dqx, *hy = dqy;
+  int nh;
   if (getenv_te_melkman) {
-    if (lane == 0) nh_s = convex_hull_simple_polygon(xy, n, dq, hull);   // rings are simple polygons in boundary order
+    if (lane == 0) {
+      int first = 0;
+#ifdef SH_TE_CLOCK
+      const long long c0_ = clock64();
+#endif
+      int h = hull_simple_polygon_cached(xy, n, dqx, dqy, &first);   // rings are simple polygons in boundary order
+#ifdef SH_TE_CLOCK
+      dqx[2 * CAP + 7] = (double)(clock64() - c0_); dqy[2 * CAP + 7] = (double)n + 1e-3 * h;
+#endif
+      if (h < 0) {      // first three vertices collinear: the sort-based hull, its index arrays in the (idle) upper half of the deque
+        int* idx = (int*)(dqx + CAP + 4);
+        int* hl = (int*)(dqy + CAP + 4);
+        h = convex_hull_simple_polygon(xy, n, idx, hl);
+        for (int k = 0; k < h; ++k) { dqx[k] = xy[2 * hl[k]]; dqy[k] = xy[2 * hl[k] + 1]; }
+      }
+      nh_s = h; first_s = first;
+    }
     __syncthreads();
     nh = nh_s;
+    hx = dqx + first_s; hy = dqy + first_s;
   } else {
+    int rot = 0;
+    int* hull = (int*)(dqx + CAP + 4);
     nh = wave_hull_wrap(xy, n, hull, lane, &rot);
+    __syncthreads();
+    double px[(CAP + 63) / 64], py[(CAP + 63) / 64];      // (gather through registers: hull[] lives in the arrays being written)
+#pragma unroll
+    for (int t = 0; t < (CAP + 63) / 64; ++t) { const int k = lane + 64 * t; if (k < nh) { int src = k + rot; if (src >= nh) src -= nh; px[t] = xy[2 * hull[src]]; py[t] = xy[2 * hull[src] + 1]; } }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < (CAP + 63) / 64; ++t) { const int k = lane + 64 * t; if (k < nh) { dqx[k] = px[t]; dqy[k] = py[t]; } }
+    __syncthreads();
   }
 #if defined(SH_ABL_TE) && SH_ABL_TE == 2
   if (nh >= 0) return;
 #endif
-  for (int k = lane; k < nh; k += 64) { int src = k + rot; if (src >= nh) src -= nh; hx[k] = xy[2 * hull[src]]; hy[k] = xy[2 * hull[src] + 1]; }
-  __syncthreads();
   double best = 1e300;
   int bi = 0x7fffffff;
   Rect2 r;
@@ -158,6 +240,10 @@ k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, doubl
   wi = __shfl(wi, 0);
   if (bi == wi && wi != 0x7fffffff) { o[0] = r.cx; o[1] = r.cy; o[2] = r.mx; o[3] = r.my; o[4] = r.L; o[5] = r.W; o[6] = r.area; }
   else if (wi == 0x7fffffff && lane < 7) o[lane] = 0.0;
+#ifdef SH_TE_CLOCK
+  __syncthreads();
+  if (lane == 0) { o[5] = dqx[2 * CAP + 7]; o[6] = dqy[2 * CAP + 7]; }      // debug build: cycles of the walk, n + h / 1000
+#endif
   (void)B;
 }
 
@@ -224,10 +310,9 @@ k_te_rows_huge(OvfPools P, OvfSet S, const int* __restrict__ ring_n, double* __r
 }
 
 #define SH_TE_DSCR (6 * SH_MAXSEG + 64 * SH_TE_MAXCH)
-__global__ void k_te_final(const double* __restrict__ ring, const int* __restrict__ ring_n, const double* __restrict__ rects,
-                           const double* __restrict__ distal_zs, const double* __restrict__ T_obb, const double* __restrict__ canal_axis_ct,
-                           const double* __restrict__ axes_obb /*[B][4][3]: +n,-n,+c,-c*/, double* __restrict__ dscratch,
-                           double* __restrict__ te_axis_ct, int* __restrict__ te_row, int* __restrict__ err, int B, OvfPools P, OvfSet S) {
+__global__ void k_te_ends(const double* __restrict__ ring, const int* __restrict__ ring_n, const double* __restrict__ rects,
+                          const double* __restrict__ distal_zs, const double* __restrict__ T_obb, double* __restrict__ ends_ct /*[B][6]: the two ends, in piece order*/,
+                          int* __restrict__ te_row, int* __restrict__ err, int B, OvfPools P, OvfSet S) {
   // one 64-lane workgroup per humerus: all lanes stage the chosen ring in LDS, lane 0 runs the (sequential) clipping
   // on it -- the walk over the ring is latency-bound when every point comes from global memory
   __shared__ double s_xy[2 * (SH_MAXSEG + 1)];
@@ -259,7 +344,6 @@ __global__ void k_te_final(const double* __restrict__ ring, const int* __restric
   double half = 0.5 * 0.999 * r[4];
   double cents[2 * 16];
   double* scr = ovf ? (double*)(P.work + S.woff[pl]) : s_scr;
-  (void)dscratch;
   int n1 = clip_halfplane_pieces(xy, n, r[0], r[1], r[2], r[3], half, cents, 8, scr);
   if (n1 < 0) n1 = 0;
   if (n1 > 8) n1 = 8;
@@ -267,7 +351,7 @@ __global__ void k_te_final(const double* __restrict__ ring, const int* __restric
   if (n2 < 0) n2 = 0;
   if (n2 > 8) n2 = 8;
   int np_ = n1 + n2;
-  double* out = te_axis_ct + 6 * b;
+  double* out = ends_ct + 6 * b;
   if (np_ < 2) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); for (int q = 0; q < 6; ++q) out[q] = 0.0; return; }
   int bi = 0, bj = 1;
   double bd = -1.0;
@@ -281,10 +365,21 @@ __global__ void k_te_final(const double* __restrict__ ring, const int* __restric
   double z = distal_zs[pl];
   double Ti[16];
   inv_transform(T_obb + 16 * b, Ti);
-  double e0[3], e1[3];
-  xform_pt(Ti, cents[2 * i0], cents[2 * i0 + 1], z, e0);
-  xform_pt(Ti, cents[2 * i1], cents[2 * i1 + 1], z, e1);
-  // epicondyle.py:90-96: medial end = smaller x in construct_csys(canal axis, head central axis)
+  xform_pt(Ti, cents[2 * i0], cents[2 * i0 + 1], z, out);
+  xform_pt(Ti, cents[2 * i1], cents[2 * i1 + 1], z, out + 3);
+}
+
+// epicondyle.py:90-96: medial end = smaller x in construct_csys(canal axis, head central axis); one lane per humerus
+__global__ void k_te_orient(const double* __restrict__ ends_ct, const double* __restrict__ T_obb, const double* __restrict__ canal_axis_ct,
+                            const double* __restrict__ axes_obb /*[B][4][3]: +n,-n,+c,-c*/, double* __restrict__ te_axis_ct, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* e0 = ends_ct + 6 * b;
+  const double* e1 = e0 + 3;
+  double* out = te_axis_ct + 6 * b;
+  if (e0[0] == 0.0 && e0[1] == 0.0 && e0[2] == 0.0 && e1[0] == 0.0 && e1[1] == 0.0 && e1[2] == 0.0) { for (int q = 0; q < 6; ++q) out[q] = 0.0; return; }      // (no axis: k_te_ends flagged it)
+  double Ti[16];
+  inv_transform(T_obb + 16 * b, Ti);
   double central_ct[6], cs[16];
   xform_pt(Ti, axes_obb[((size_t)b * 4 + 2) * 3], axes_obb[((size_t)b * 4 + 2) * 3 + 1], axes_obb[((size_t)b * 4 + 2) * 3 + 2], central_ct);
   xform_pt(Ti, axes_obb[((size_t)b * 4 + 3) * 3], axes_obb[((size_t)b * 4 + 3) * 3 + 1], axes_obb[((size_t)b * 4 + 3) * 3 + 2], central_ct + 3);
@@ -295,6 +390,7 @@ __global__ void k_te_final(const double* __restrict__ ring, const int* __restric
   bool swap = q1[0] < q0[0];       // np.argmin: first minimum
   for (int q = 0; q < 3; ++q) { out[q] = swap ? e1[q] : e0[q]; out[3 + q] = swap ? e0[q] : e1[q]; }
 }
+
 
 __global__ void k_pack(sh_landmarks* __restrict__ lm, const double* __restrict__ T_obb, const double* __restrict__ zb,
                        const double* __restrict__ neck_z, const int* __restrict__ neck_index, const int* __restrict__ flipped,

@@ -483,6 +483,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("te.dscratch", (size_t)B * SH_TE_DSCR * 8, 8);
   ENS("te.rects", (size_t)B * SH_TE_NROWS * 7 * 8, 8);
   ENS("te.axis_ct", (size_t)B * 6 * 8, 8);
+  ENS("te.ends_ct", (size_t)B * 6 * 8, 8);
   ENS("te.row", (size_t)B * 4, 4);
   ENS("flipped", (size_t)B * 4, 4);
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "flipped"), 0, (size_t)B * 4, c->stream));
@@ -1860,7 +1861,8 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   return SH_OK;
 }
 
-// epicondyle.py:33-40: the minimum-area rectangle of every distal slice in the cut (three capacity tiers)
+// epicondyle.py:33-89, everything that needs the distal set only: the minimum-area rectangle of every distal slice in the cut (three
+// capacity tiers) and the two ends of the widest one
 static int run_te_rows(sh_ctx* c) {
   const int B = c->Bwin;
   OvfPools OP; OvfSet OS;
@@ -1872,6 +1874,9 @@ static int run_te_rows(sh_ctx* c) {
   if (c->ovf_none_gen != c->batch_gen) {
     LAUNCH(c, "k_te_rows_huge", k_te_rows_huge, dim3(64), dim3(64), OP, OS, (const int*)buf<int>(c, "distal.ring_n"), buf<double>(c, "te.rects"));
   }
+  // epicondyle.py:39-89: the widest slice's end slivers, their centroids, the farthest pair (CT coordinates, piece order)
+  LAUNCH(c, "k_te_ends", k_te_ends, dim3(B), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"), buf<double>(c, "te.rects"),
+         buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "te.ends_ct"), buf<int>(c, "te.row"), buf<int>(c, "err"), B, OP, OS);
   return SH_OK;
 }
 
@@ -1893,28 +1898,41 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   }
   if (mask & SH_STAGE_FULL)
     if ((rc = run_slice_set(c, "full", 0, SH_NFULL, false, false)) != SH_OK) return rc;
-  // The distal set (and the rectangles of its rows, the first half of the trans-epicondylar stage) needs nothing but the box frame:
-  // it runs on the side stream beside the full -> neck -> canal -> proximal -> groove chain and is joined in front of k_te_final.
-  // Only when the overflow tier is known to be idle for this batch (its pool counters are per set) and no per-launch timing is on.
+  // The distal set and the first part of the trans-epicondylar stage (the rectangles of its rows, the ends of the widest one) need
+  // nothing but the box frame.  Small batches (up to 16 humeri: one humerus gains 4 %, 6.01 -> 5.78 ms per run; at B = 64 two streams'
+  // kernels just share the CUs and one lane LOSES 8 %): the whole branch runs on the side stream beside the full -> neck -> canal ->
+  // proximal -> groove chain.  Larger batches: the distal set stays in the chain; SHOULDER_TE_EARLY=1 forks only the
+  // trans-epicondylar part (one lane's walk per slice: 0.24 + 0.32 ms of latency) so that it runs beside the lane's own UNet pass
+  // instead of behind it and only k_te_orient (medial end first: needs the head's central axis) stays on the critical path.
+  // Measured on the two-lane headline: 8.58 against 8.35 ms per step -- the 2 368 one-wave workgroups hold the 32 CUs the UNet
+  // leaves free while the lane's own chain wants them -- so it is off by default (same records bit for bit either way).
+  // Either fork only when the overflow tier is known to be idle for this batch (its pool counters are per set) and no per-launch
+  // timing is on.
   static const bool side_env = !(getenv("SHOULDER_SIDE_STREAM") && getenv("SHOULDER_SIDE_STREAM")[0] == '0');
-  // Small batches only: one humerus gains 4 % (6.01 -> 5.78 ms per run); at B = 64 the two streams' kernels just share the CUs and
-  // one lane LOSES 8 % (5 340 -> 4 900 humeri/s), so the fork is taken up to 16 humeri.
-  const bool side = side_env && (mask & SH_STAGE_DISTAL) && B <= 16 && c->ovf_none_gen == c->batch_gen && c->timing != 1 && !c->redo_records;
+  const bool te_early_env = getenv("SHOULDER_TE_EARLY") && getenv("SHOULDER_TE_EARLY")[0] == '1';      // (read per run: the tests switch it in-process)
+  const bool can_fork = side_env && (mask & SH_STAGE_DISTAL) && c->ovf_none_gen == c->batch_gen && c->timing != 1 && !c->redo_records;
+  const bool side = can_fork && B <= 16;
+  const bool te_early = can_fork && !side && te_early_env && (mask & SH_STAGE_TE) && (mask & SH_STAGE_ANP);
+  bool te_rows_done = false;
   c->side_pending = false;
   if (mask & SH_STAGE_DISTAL) {
     hipStream_t main_stream = c->stream;
-    if (side) {
+    auto fork = [&]() -> int {
       if (!c->side_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
       if (!c->side_fork_ev) { HIPCHK(c, hipEventCreateWithFlags(&c->side_fork_ev, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->side_join_ev, hipEventDisableTiming)); }
       HIPCHK(c, hipEventRecord(c->side_fork_ev, main_stream));
       HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->side_fork_ev, 0));
       c->stream = c->side_stream;
-    }
+      return SH_OK;
+    };
+    if (side && (rc = fork()) != SH_OK) return rc;
     rc = run_slice_set(c, "distal", 2, SH_NDIST, true, false);
-    if (rc == SH_OK && side && (mask & SH_STAGE_TE)) rc = run_te_rows(c);
-    if (side) {
+    if (rc == SH_OK && te_early) rc = fork();
+    if (rc == SH_OK && (side || te_early) && (mask & SH_STAGE_TE)) { rc = run_te_rows(c); te_rows_done = rc == SH_OK; }
+    if (side || te_early) {
+      const bool forked = c->stream == c->side_stream;
       c->stream = main_stream;
-      if (rc == SH_OK) { HIPCHK(c, hipEventRecord(c->side_join_ev, c->side_stream)); c->side_pending = true; }
+      if (rc == SH_OK && forked) { HIPCHK(c, hipEventRecord(c->side_join_ev, c->side_stream)); c->side_pending = true; }
     }
     if (rc != SH_OK) return rc;
   }
@@ -1989,13 +2007,10 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<double>(c, "anp.axes_obb"), buf<int>(c, "err"), B);
   }
   if (mask & SH_STAGE_TE) {
-    OvfPools OP; OvfSet OS;
-    { int orc; if ((orc = ovf_pools(c, &OP)) != SH_OK || (orc = ovf_set(c, "distal", SH_NDIST, &OS)) != SH_OK) return orc; }
-    if (c->side_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_join_ev, 0)); c->side_pending = false; }      // (distal set + rectangles: done on the side stream)
-    else if ((rc = run_te_rows(c)) != SH_OK) return rc;
-    LAUNCH(c, "k_te_final", k_te_final, dim3(B), dim3(64), buf<double>(c, "distal.ring"), buf<int>(c, "distal.ring_n"),
-           buf<double>(c, "te.rects"), buf<double>(c, "distal.zs"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
-           buf<double>(c, "anp.axes_obb"), buf<double>(c, "te.dscratch"), buf<double>(c, "te.axis_ct"), buf<int>(c, "te.row"), buf<int>(c, "err"), B, OP, OS);
+    if (c->side_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_join_ev, 0)); c->side_pending = false; }      // (rectangles and ends: done on the side stream)
+    if (!te_rows_done && (rc = run_te_rows(c)) != SH_OK) return rc;
+    LAUNCH(c, "k_te_orient", k_te_orient, dim3((B + 63) / 64), dim3(64), buf<double>(c, "te.ends_ct"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
+           buf<double>(c, "anp.axes_obb"), buf<double>(c, "te.axis_ct"), B);
   }
   if (c->side_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_join_ev, 0)); c->side_pending = false; }
   LAUNCH(c, "k_pack", k_pack, dim3(B), dim3(256), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "obb_transform"), buf<double>(c, "z_bounds"),

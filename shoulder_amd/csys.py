@@ -1,6 +1,6 @@
 """Host-side 4x4 frame construction for the facade (reference src/shoulder/utils.py:289-318
 `construct_csys`, :227-256 `inv_transform`).  One 4x4 at a time -- glue, not a hot path; the
-batched version runs on the device inside k_pack / k_te_final."""
+batched version runs on the device inside k_pack / k_te_orient."""
 import numpy as np
 
 

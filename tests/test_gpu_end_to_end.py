@@ -212,6 +212,28 @@ def test_synthetic_batch_equivariance(engine, oracle_bones):
         np.testing.assert_array_equal(v[b], synth.apply_similarity(T[b], h.verts))
 
 
+def test_forked_trans_epicondylar_part_gives_the_same_records(engine, oracle_bones, monkeypatch):
+    """SHOULDER_TE_EARLY=1: the rectangles of the distal rows and the ends of the widest one (k_te_rows, k_te_ends: they need the distal
+    set only) run on the side stream beside the proximal set, the groove and the UNet pass; k_te_orient (medial end first: needs the head's
+    central axis) joins them in front of the record.  Same kernels on the same inputs: the records are the sequential run's bit for bit,
+    run after run (the second run of a batch is the first that forks: the overflow tier is known to be idle by then)."""
+    h = oracle_bones("humerus_left")
+    B = 24
+    engine.reset_params()
+    engine.upload([(h.verts, h.faces)])
+    engine.synth_batch(synth.similarity_transforms(B, h.verts, seed=5))
+    try:
+        monkeypatch.delenv("SHOULDER_TE_EARLY", raising=False)
+        engine.run(_lib.STAGE_ALL)
+        a = engine.run(_lib.STAGE_ALL).copy()
+        monkeypatch.setenv("SHOULDER_TE_EARLY", "1")
+        for _ in range(3):
+            b = engine.run(_lib.STAGE_ALL)
+            assert (b["status"] == 0).all() and b.tobytes() == a.tobytes()
+    finally:
+        monkeypatch.delenv("SHOULDER_TE_EARLY", raising=False)
+
+
 def test_overlapped_hulls_identical_and_invalidated(engine, oracle_bones):
     """sh_set_overlap: hulls prepared in the background during run k give run k+1 bit-identical records, and a new
     batch (other transforms) voids them."""

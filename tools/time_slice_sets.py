@@ -20,7 +20,7 @@ for mask in (0x2, 0x10, 0x80, 0x20, 0x100):
     r(); eng.enable_timing(True); eng.reset_timers()
     for _ in range(5): r()
     print("mask", hex(mask))
-    for k in ("k_make_planes", "k_slice_emit", "k_slice_link", "k_resample_polar", "k_groove_rows", "k_te_rows", "k_te_final", "k_groove_kde", "k_groove_rfc", "k_groove_scale"):
+    for k in ("k_make_planes", "k_slice_emit", "k_slice_link", "k_resample_polar", "k_groove_rows", "k_te_rows", "k_te_ends", "k_te_orient", "k_groove_kde", "k_groove_rfc", "k_groove_scale"):
         ms, n = eng.kernel_time_ms(k)
         if n: print("  %-20s %7.3f ms x %.1f" % (k, ms, n / 5))
     eng.enable_timing(False)
