@@ -361,7 +361,7 @@ void sh_ctx_destroy(sh_ctx* c) {
   if (c->h_nkept) (void)hipHostFree(c->h_nkept);
   if (c->h_koff) (void)hipHostFree(c->h_koff);
   if (c->obb_done_ev) (void)hipEventDestroy(c->obb_done_ev);
-  for (auto& tk : c->tickets) { if (tk.ev) (void)hipEventDestroy(tk.ev); if (tk.h_err) (void)hipHostFree(tk.h_err); if (tk.h_fail) (void)hipHostFree(tk.h_fail); if (tk.h_ovf) (void)hipHostFree(tk.h_ovf); }
+  for (auto& tk : c->tickets) { if (tk.ev) (void)hipEventDestroy(tk.ev); if (tk.h_err) (void)hipHostFree(tk.h_err); }      // (one pinned block: h_ovf and h_fail point into it)
   if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
   for (auto& kv : c->bufs)
     if (kv.second.p) (void)hipFree(kv.second.p);
@@ -2159,6 +2159,16 @@ static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot
   return SH_OK;
 }
 
+static inline size_t status_ovf_off(int B) { return ((size_t)B * 4 + 7) & ~(size_t)7; }
+static inline size_t status_bytes(int B) { return status_ovf_off(B) + 64 + (size_t)B * 4; }
+// the status block of a run (layout: sh_submit) from the live words, one launch
+__global__ void k_stage_status(const int* __restrict__ err, const unsigned long long* __restrict__ ovf_ctr, const int* __restrict__ hull_fail /*or null*/,
+                               char* __restrict__ dst, int B, size_t ovf_off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) { ((int*)dst)[i] = err[i]; ((int*)(dst + ovf_off + 64))[i] = hull_fail ? hull_fail[i] : 0; }
+  if (i < 8) ((unsigned long long*)(dst + ovf_off))[i] = ovf_ctr[i];
+}
+
 int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   if (!c) return SH_ERR_ARG;
   if (c->B < 1) return fail(c, SH_ERR_STATE, "sh_run: no meshes uploaded");
@@ -2167,14 +2177,16 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   const int B = c->B;
   sh_ctx::Ticket& tk = c->tickets[c->t_head];
   if (tk.cap < B) {
+    // the status words of a run as ONE pinned block = one device-to-host copy and one wait in sh_collect (they were three copies and
+    // three waits: each a blit kernel that queues for a CU beside the other lane's UNet): [err: B ints | pad to 8 | overflow pool
+    // counters: 8 x u64 | device hull's give-up words: B ints]
     if (tk.h_err) (void)hipHostFree(tk.h_err);
-    if (tk.h_fail) (void)hipHostFree(tk.h_fail);
-    tk.h_err = nullptr; tk.h_fail = nullptr; tk.cap = 0;
-    HIPCHK(c, hipHostMalloc((void**)&tk.h_err, (size_t)B * 4));
-    HIPCHK(c, hipHostMalloc((void**)&tk.h_fail, (size_t)B * 4));
-    if (!tk.h_ovf) HIPCHK(c, hipHostMalloc((void**)&tk.h_ovf, 64));
+    tk.h_err = nullptr; tk.h_fail = nullptr; tk.h_ovf = nullptr; tk.cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&tk.h_err, status_bytes(B)));
     tk.cap = B;
   }
+  tk.h_ovf = (unsigned long long*)((char*)tk.h_err + status_ovf_off(B));      // (the layout follows THIS run's batch size)
+  tk.h_fail = (int*)((char*)tk.h_err + status_ovf_off(B) + 64);
   if (!tk.ev) HIPCHK(c, hipEventCreateWithFlags(&tk.ev, hipEventDisableTiming));
   if (!c->out_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
   c->b0 = 0; c->Bwin = B;
@@ -2230,7 +2242,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   (void)hipGetLastError();
   const std::string tslot = std::to_string(c->t_head);
   void *lm_stage = nullptr, *err_stage = nullptr;
-  if (int e = ensure(c, ("out.err" + tslot).c_str(), (size_t)B * 4, 4, &err_stage)) return e;
+  if (int e = ensure(c, ("out.err" + tslot).c_str(), status_bytes(B), 4, &err_stage)) return e;      // (the whole status block: the status words lead it)
   tk.host_out = nullptr;
   if (out_on_device) {
     HIPCHK(c, hipMemcpyAsync(out, buf<sh_landmarks>(c, "landmarks"), (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToDevice, c->stream));
@@ -2239,17 +2251,10 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     HIPCHK(c, hipMemcpyAsync(lm_stage, buf<sh_landmarks>(c, "landmarks"), (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToDevice, c->stream));
     tk.host_out = out;
   }
-  HIPCHK(c, hipMemcpyAsync(err_stage, buf<int>(c, "err"), (size_t)B * 4, hipMemcpyDeviceToDevice, c->stream));
-  {      // what the run asked of the overflow pools (k_ovf.h): sh_collect grows them and runs again if it was more than they hold
-    void* ovf_stage = nullptr;
-    if (int e = ensure(c, ("out.ovf" + tslot).c_str(), 64, 8, &ovf_stage)) return e;
-    HIPCHK(c, hipMemcpyAsync(ovf_stage, c->bufs["ovf.ctr"].p, 64, hipMemcpyDeviceToDevice, c->stream));
-  }
-  if (dev_hull) {      // which humeri the device hull gave up: its own word per humerus (the status word can be overwritten by a later stage)
-    void* fail_stage = nullptr;
-    if (int e = ensure(c, ("out.hfail" + tslot).c_str(), (size_t)B * 4, 4, &fail_stage)) return e;
-    HIPCHK(c, hipMemcpyAsync(fail_stage, buf<int>(c, "hulld.fail"), (size_t)B * 4, hipMemcpyDeviceToDevice, c->stream));
-  }
+  // status words, what the run asked of the overflow pools (k_ovf.h: sh_collect grows them and runs again if it was more than they
+  // hold) and which humeri the device hull gave up (its own word per humerus: the status word can be overwritten by a later stage)
+  LAUNCH(c, "k_stage_status", k_stage_status, dim3((unsigned)((std::max(B, 8) + 255) / 256)), dim3(256), (const int*)buf<int>(c, "err"), (const unsigned long long*)c->bufs["ovf.ctr"].p,
+         dev_hull ? (const int*)buf<int>(c, "hulld.fail") : (const int*)nullptr, (char*)err_stage, B, status_ovf_off(B));
   HIPCHK(c, hipEventRecord(tk.ev, c->stream));
   tk.B = B; tk.pending = true; tk.mask = mask; tk.out_arg = out; tk.dev_hull = dev_hull; tk.gen = c->batch_gen;
   c->t_head ^= 1; ++c->n_pending;
@@ -2266,11 +2271,9 @@ int sh_collect(sh_ctx* c) {
   HIPCHK(c, hipEventSynchronize(tk.ev));
   if (tk.host_out)
     HIPCHK(c, hipMemcpyAsync(tk.host_out, buf<char>(c, ("out.landmarks" + tslot).c_str()), (size_t)tk.B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->out_stream));
-  HIPCHK(c, hipMemcpyAsync(tk.h_err, buf<char>(c, ("out.err" + tslot).c_str()), (size_t)tk.B * 4, hipMemcpyDeviceToHost, c->out_stream));
+  HIPCHK(c, hipMemcpyAsync(tk.h_err, buf<char>(c, ("out.err" + tslot).c_str()), status_bytes(tk.B), hipMemcpyDeviceToHost, c->out_stream));      // status, pool counters, give-up words
   HIPCHK(c, hipStreamSynchronize(c->out_stream));
   {
-    HIPCHK(c, hipMemcpyAsync(tk.h_ovf, buf<char>(c, ("out.ovf" + tslot).c_str()), 64, hipMemcpyDeviceToHost, c->out_stream));
-    HIPCHK(c, hipStreamSynchronize(c->out_stream));
     const unsigned long long need_s = tk.h_ovf[3], need_r = tk.h_ovf[4], need_w = tk.h_ovf[5];
     const uint32_t slice_stages = SH_STAGE_FULL | SH_STAGE_DISTAL | SH_STAGE_NECK | SH_STAGE_PROXIMAL;
     if (need_r == 0 && need_s == 0 && (tk.mask & slice_stages) == (c->params.bone_kind == SH_BONE_PROXIMAL ? (slice_stages & ~(uint32_t)SH_STAGE_DISTAL) : slice_stages) &&
@@ -2293,8 +2296,6 @@ int sh_collect(sh_ctx* c) {
     }
   }
   if (tk.dev_hull) {
-    HIPCHK(c, hipMemcpyAsync(tk.h_fail, buf<char>(c, ("out.hfail" + tslot).c_str()), (size_t)tk.B * 4, hipMemcpyDeviceToHost, c->out_stream));
-    HIPCHK(c, hipStreamSynchronize(c->out_stream));
     std::vector<int> gave_up;
     for (int b = 0; b < tk.B; ++b) if (tk.h_fail[b] != 0) gave_up.push_back(b);
     if (!gave_up.empty()) {
