@@ -30,19 +30,29 @@ __device__ inline void hp_dir(int k, int* d) {      // k in [0, 26): the 27 sign
   d[0] = t % 3 - 1; d[1] = (t / 3) % 3 - 1; d[2] = t / 9 - 1;
 }
 
+// SH_HP_PARTS workgroups per humerus (a contiguous range of its vertices each) in the passes over the vertices: with one workgroup
+// per humerus a batch of 64 used 64 of the 256 CUs and the three passes took 0.29 + 0.28 + 0.19 ms (round 3: 0.83 ms of the CUs
+// the UNet leaves free, per step).  Partial extremes are merged by k_hullpre_polytope (ranges ascend, `>` keeps the first maximum:
+// the same vertex as one pass in index order); survivors are counted and written per range, every range at its own offset of the
+// batch's array (k_hullpre_offsets), in file order inside it -- the same array as before, byte for byte.
+#define SH_HP_PARTS 8
+
 __global__ void __launch_bounds__(256)
-k_hullpre_extremes(const float* __restrict__ verts, const long long* __restrict__ voff, int* __restrict__ ext /* B x 26 */) {
+k_hullpre_extremes(const float* __restrict__ verts, const long long* __restrict__ voff, double* __restrict__ pval /* B x PARTS x 26 */,
+                   int* __restrict__ pidx /* B x PARTS x 26; 0x7fffffff = empty range */) {
   __shared__ double s_v[4][SH_HP_NDIR];
   __shared__ int s_i[4][SH_HP_NDIR];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long v0 = voff[b];
   const int nv = (int)(voff[b + 1] - v0);
+  const int per = (nv + SH_HP_PARTS - 1) / SH_HP_PARTS;
+  const int a = min(nv, part * per), e = min(nv, a + per);
   const float* P = verts + 3 * v0;
   double best[SH_HP_NDIR];
   int bi[SH_HP_NDIR];
 #pragma unroll
   for (int k = 0; k < SH_HP_NDIR; ++k) { best[k] = -1e300; bi[k] = 0x7fffffff; }
-  for (int i = tid; i < nv; i += 256) {
+  for (int i = a + tid; i < e; i += 256) {
     const double x = P[3 * i], y = P[3 * i + 1], z = P[3 * i + 2];
 #pragma unroll
     for (int k = 0; k < SH_HP_NDIR; ++k) {
@@ -67,19 +77,28 @@ k_hullpre_extremes(const float* __restrict__ verts, const long long* __restrict_
     int i = s_i[0][tid];
     for (int w = 1; w < 4; ++w)
       if (s_v[w][tid] > v || (s_v[w][tid] == v && s_i[w][tid] < i)) { v = s_v[w][tid]; i = s_i[w][tid]; }
-    ext[b * SH_HP_NDIR + tid] = nv > 0 ? i : -1;
+    pval[((size_t)b * SH_HP_PARTS + part) * SH_HP_NDIR + tid] = v;
+    pidx[((size_t)b * SH_HP_PARTS + part) * SH_HP_NDIR + tid] = i;
   }
 }
 
 __global__ void __launch_bounds__(256)
-k_hullpre_polytope(const float* __restrict__ verts, const long long* __restrict__ voff, const int* __restrict__ ext,
-                   double* __restrict__ planes /* B x MAXPL x 4 */, int* __restrict__ nplanes /* B; -1 = no filter */) {
+k_hullpre_polytope(const float* __restrict__ verts, const long long* __restrict__ voff, const double* __restrict__ pval, const int* __restrict__ pidx,
+                   int* __restrict__ ext /* B x 26: the extreme vertices (out) */, double* __restrict__ planes /* B x MAXPL x 4 */, int* __restrict__ nplanes /* B; -1 = no filter */) {
   __shared__ double E[SH_HP_NDIR][3];
   __shared__ int id[SH_HP_NDIR];
   __shared__ int cnt;
   const int b = blockIdx.x, tid = threadIdx.x;
   if (tid < SH_HP_NDIR) {
-    const int i = ext[b * SH_HP_NDIR + tid];
+    double v = -1e300;
+    int i = 0x7fffffff;
+    for (int part = 0; part < SH_HP_PARTS; ++part) {      // ranges in ascending vertex order
+      const double pv = pval[((size_t)b * SH_HP_PARTS + part) * SH_HP_NDIR + tid];
+      const int pi = pidx[((size_t)b * SH_HP_PARTS + part) * SH_HP_NDIR + tid];
+      if (pi != 0x7fffffff && (pv > v || (pv == v && pi < i))) { v = pv; i = pi; }
+    }
+    if (i == 0x7fffffff) i = -1;
+    ext[b * SH_HP_NDIR + tid] = i;
     id[tid] = i;
     const float* p = verts + 3 * (voff[b] + (i < 0 ? 0 : i));
     E[tid][0] = p[0]; E[tid][1] = p[1]; E[tid][2] = p[2];
@@ -130,40 +149,67 @@ __device__ inline bool hp_keep(const float* P, int i, const double* PL, int np) 
   return false;
 }
 
-// WRITE = false: count the survivors of humerus b -> nkept[b].  WRITE = true: write them, in file order, at koff[b] of one
-// array shared by the batch (k_hullpre_offsets in between), so that ONE copy brings every humerus's points to the host.
+// WRITE = false: count the survivors of range `part` of humerus b -> pcnt[b][part].  WRITE = true: write them, in file order, at
+// poff[b][part] of one array shared by the batch (k_hullpre_offsets in between), so that ONE copy brings every humerus's points
+// to the host.  A wave takes 64 consecutive vertices at a time (coalesced reads; ballot + popcount give the positions).
 template <bool WRITE>
-__global__ void __launch_bounds__(SH_STL_SCAN_THREADS)
+__global__ void __launch_bounds__(256)
 k_hullpre_filter(const float* __restrict__ verts, const long long* __restrict__ voff, const double* __restrict__ planes,
-                 const int* __restrict__ nplanes, const long long* __restrict__ koff, float* __restrict__ kept, int* __restrict__ nkept) {
+                 const int* __restrict__ nplanes, const long long* __restrict__ poff, float* __restrict__ kept, int* __restrict__ pcnt) {
   __shared__ double PL[SH_HP_MAXPL * 4];
-  __shared__ int s_wave[SH_STL_SCAN_THREADS / 64];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_wave[2][4];
+  const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long v0 = voff[b];
   const int nv = (int)(voff[b + 1] - v0);
   const int np = nplanes[b];
-  for (int i = tid; i < 4 * max(np, 0); i += SH_STL_SCAN_THREADS) PL[i] = planes[(size_t)b * SH_HP_MAXPL * 4 + i];
+  for (int i = tid; i < 4 * max(np, 0); i += 256) PL[i] = planes[(size_t)b * SH_HP_MAXPL * 4 + i];
   __syncthreads();
   const float* P = verts + 3 * v0;
-  const int per = (nv + SH_STL_SCAN_THREADS - 1) / SH_STL_SCAN_THREADS;
-  const int a = min(nv, tid * per), e = min(nv, a + per);
-  int c = 0;
-  for (int i = a; i < e; ++i) c += hp_keep(P, i, PL, np) ? 1 : 0;
-  int total;
-  int pos = stl_block_scan(c, s_wave, &total);
-  if (!WRITE) { if (tid == 0) nkept[b] = total; return; }
-  float* K = kept + 3 * koff[b];
-  for (int i = a; i < e; ++i)
-    if (hp_keep(P, i, PL, np)) { K[3 * pos] = P[3 * i]; K[3 * pos + 1] = P[3 * i + 1]; K[3 * pos + 2] = P[3 * i + 2]; ++pos; }
+  const int per = (nv + SH_HP_PARTS - 1) / SH_HP_PARTS;
+  const int a = min(nv, part * per), e = min(nv, a + per);
+  float* K = WRITE ? kept + 3 * poff[(size_t)b * SH_HP_PARTS + part] : (float*)nullptr;
+  int run = 0, it = 0;
+  for (int base = a; base < e; base += 256, it ^= 1) {
+    const int i = base + tid;
+    const bool keep = i < e && hp_keep(P, i, PL, np);
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_wave[it][wave] = __popcll(bal);
+    __syncthreads();      // (s_wave alternates between two slots: one barrier per round is enough)
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int cw = s_wave[it][w]; if (w < wave) woff += cw; total += cw; }
+    if (WRITE && keep) {
+      const int pos = run + woff + __popcll(bal & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+      K[3 * pos] = P[3 * i]; K[3 * pos + 1] = P[3 * i + 1]; K[3 * pos + 2] = P[3 * i + 2];
+    }
+    run += total;
+  }
+  if (!WRITE && tid == 0) pcnt[(size_t)b * SH_HP_PARTS + part] = run;
 }
 
-// koff[b] = survivors of the humeri before b; koff[B] = all of them (one workgroup; B is a batch size, not a mesh size)
-__global__ void k_hullpre_offsets(const int* __restrict__ nkept, long long* __restrict__ koff, int B) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    long long acc = 0;
-    for (int b = 0; b < B; ++b) { koff[b] = acc; acc += nkept[b]; }
-    koff[B] = acc;
+// koff[b] = survivors of the humeri before b (koff[B] = all of them), poff[b][part] = those before range `part` of humerus b,
+// nkept[b] = survivors of humerus b.  One wave: a lane per humerus, 64 humeri per round, a wave prefix sum between them.
+__global__ void __launch_bounds__(64)
+k_hullpre_offsets(const int* __restrict__ pcnt, long long* __restrict__ koff, long long* __restrict__ poff, int* __restrict__ nkept, int B) {
+  const int lane = threadIdx.x;
+  long long carry = 0;
+  for (int base = 0; base < B; base += 64) {
+    const int b = base + lane;
+    int c[SH_HP_PARTS];
+    long long mine = 0;
+#pragma unroll
+    for (int p = 0; p < SH_HP_PARTS; ++p) { c[p] = b < B ? pcnt[(size_t)b * SH_HP_PARTS + p] : 0; mine += c[p]; }
+    long long incl = mine;
+    for (int off = 1; off < 64; off <<= 1) { const long long t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    long long acc = carry + incl - mine;
+    if (b < B) {
+      koff[b] = acc; nkept[b] = (int)mine;
+#pragma unroll
+      for (int p = 0; p < SH_HP_PARTS; ++p) { poff[(size_t)b * SH_HP_PARTS + p] = acc; acc += c[p]; }
+    }
+    carry += __shfl(incl, 63);
   }
+  if (lane == 0) koff[B] = carry;
 }
 
 }  // namespace sh

@@ -498,6 +498,10 @@ static int alloc_batch(sh_ctx* c) {
   ENS("hullpre.planes", (size_t)B * SH_HP_MAXPL * 4 * 8, 8);
   ENS("hullpre.npl", (size_t)B * 4, 4);
   ENS("hullpre.nkept", (size_t)B * 4, 4);
+  ENS("hullpre.pval", (size_t)B * SH_HP_PARTS * SH_HP_NDIR * 8, 8);
+  ENS("hullpre.pidx", (size_t)B * SH_HP_PARTS * SH_HP_NDIR * 4, 4);
+  ENS("hullpre.pcnt", (size_t)B * SH_HP_PARTS * 4, 4);
+  ENS("hullpre.poff", (size_t)B * SH_HP_PARTS * 8, 8);
   ENS("hullpre.koff", (size_t)(B + 1) * 8, 8);
   ENS("hullpre.kept", (size_t)c->sumV * 12, 4);
   if (c->h_kept_cap < c->sumV) {
@@ -1562,20 +1566,21 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
 // The hull's input points.  Host-provided batch: the caller's vertices.  Device-generated batch: the prefilter
 // (k_hullpre.h) drops the vertices strictly inside a 26-direction polytope on the device and only the rest comes back
 // (39 % of a humerus, into pinned memory).  Callable from the background thread: no buffer-map access, no timers.
-struct HullPre { const float* verts; const long long* voff; int* ext; double* planes; int* npl; float* kept; int* nkept; long long* koff; };
+struct HullPre { const float* verts; const long long* voff; int* ext; double* planes; int* npl; float* kept; int* nkept; long long* koff; double* pval; int* pidx; int* pcnt; long long* poff; };
 static HullPre hullpre_ptrs(sh_ctx* c) {      // calling thread only (buffer map)
   return HullPre{(const float*)c->bufs["verts"].p, (const long long*)c->bufs["voff"].p, (int*)c->bufs["hullpre.ext"].p, (double*)c->bufs["hullpre.planes"].p,
-                 (int*)c->bufs["hullpre.npl"].p, (float*)c->bufs["hullpre.kept"].p, (int*)c->bufs["hullpre.nkept"].p, (long long*)c->bufs["hullpre.koff"].p};
+                 (int*)c->bufs["hullpre.npl"].p, (float*)c->bufs["hullpre.kept"].p, (int*)c->bufs["hullpre.nkept"].p, (long long*)c->bufs["hullpre.koff"].p,
+                 (double*)c->bufs["hullpre.pval"].p, (int*)c->bufs["hullpre.pidx"].p, (int*)c->bufs["hullpre.pcnt"].p, (long long*)c->bufs["hullpre.poff"].p};
 }
 // the five launches of the device prefilter (k_hullpre.h): survivors of all B humeri compacted into hp.kept at hp.koff
 static void launch_prefilter(const HullPre& hp, int B, hipStream_t st) {
-  hipLaunchKernelGGL(k_hullpre_extremes, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, hp.ext);
-  hipLaunchKernelGGL(k_hullpre_polytope, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, (const int*)hp.ext, hp.planes, hp.npl);
-  hipLaunchKernelGGL(k_hullpre_filter<false>, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl,
-                     (const long long*)hp.koff, hp.kept, hp.nkept);
-  hipLaunchKernelGGL(k_hullpre_offsets, dim3(1), dim3(64), 0, st, (const int*)hp.nkept, hp.koff, B);
-  hipLaunchKernelGGL(k_hullpre_filter<true>, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl,
-                     (const long long*)hp.koff, hp.kept, hp.nkept);
+  hipLaunchKernelGGL(k_hullpre_extremes, dim3(SH_HP_PARTS, B), dim3(256), 0, st, hp.verts, hp.voff, hp.pval, hp.pidx);
+  hipLaunchKernelGGL(k_hullpre_polytope, dim3(B), dim3(256), 0, st, hp.verts, hp.voff, (const double*)hp.pval, (const int*)hp.pidx, hp.ext, hp.planes, hp.npl);
+  hipLaunchKernelGGL(k_hullpre_filter<false>, dim3(SH_HP_PARTS, B), dim3(256), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl,
+                     (const long long*)hp.poff, hp.kept, hp.pcnt);
+  hipLaunchKernelGGL(k_hullpre_offsets, dim3(1), dim3(64), 0, st, (const int*)hp.pcnt, hp.koff, hp.poff, hp.nkept, B);
+  hipLaunchKernelGGL(k_hullpre_filter<true>, dim3(SH_HP_PARTS, B), dim3(256), 0, st, hp.verts, hp.voff, (const double*)hp.planes, (const int*)hp.npl,
+                     (const long long*)hp.poff, hp.kept, hp.pcnt);
 }
 
 static hipError_t fetch_hull_points(sh_ctx* c, const HullPre& hp, hipStream_t st) {
