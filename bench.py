@@ -37,7 +37,7 @@ PEAK_MFMA_BF16_TF = 2500.0
 
 GEOM_KERNELS = ["k_hull_rounds", "k_hull_flag", "k_apply_csys", "k_obb_face_area2", "k_obb_bounds", "k_obb_select", "k_obb_seed", "k_obb_candidates", "k_obb_pick", "k_obb_end_points", "k_obb_ends", "k_transform_verts", "k_make_planes",
                 "k_slice_emit", "k_slice_link", "k_slice_link_large", "k_resample_polar", "k_resample_polar_large", "k_te_rows_large", "k_rfc_pack", "k_obb_seed", "k_neck", "k_canal", "k_groove_rows", "k_groove_scale",
-                "k_groove_rfc", "k_groove_kde", "k_groove_localmin", "k_groove_axis", "k_anp_rows", "k_anp_minmax", "k_anp_edge_count", "k_anp_edges",
+                "k_groove_rfc", "k_groove_kde", "k_groove_localmin", "k_groove_axis", "k_anp_rows", "k_anp_edge_count", "k_anp_edges",
                 "k_anp_plane", "k_rays_hit", "k_rays", "k_te_rows", "k_te_ends", "k_te_orient", "k_pack", "k_metrics", "k_sphere_partial", "k_anp_scale", "k_init_bounds",
                 "k_decode_bounds", "k_section_points"]
 
@@ -112,7 +112,6 @@ def geom_bytes(B, V, F):
         "k_resample_polar_large": (0, None),
         "k_groove_rows": (B * 330 * (2 * 512 * 8 + 512 * 8), B * 330 * 2 * 512 * 4),
         "k_anp_rows": (B * 512 * (2 * 512 * 8 + 2 * 512 * 8), B * 512 * 2 * 512 * 4 * 2),
-        "k_anp_minmax": (B * 512 * 512 * 8, None),
         "k_anp_scale": (B * 512 * 512 * (8 + 4), B * 512 * 512 * 4),
         "k_anp_edge_count": (B * 512 * 512 * 4, None),
         "k_anp_edges": (B * 512 * 512 * 4, B * 512 * 512 * 4),

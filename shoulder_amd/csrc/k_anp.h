@@ -16,7 +16,8 @@ namespace sh {
 #define SH_IMG (SH_ANP_ROWS * SH_MPROX)
 
 __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][512]*/, const double* __restrict__ bg_theta,
-                           double* __restrict__ raw, double* __restrict__ shft_theta, int* __restrict__ roll, int B) {
+                           double* __restrict__ raw, double* __restrict__ shft_theta, int* __restrict__ roll, int B,
+                           unsigned long long* __restrict__ mm_enc /*[B][2]: minimum / maximum of the humerus' image, order-preserving encoding (k_init_bounds before this launch)*/) {
   // One wave per image row, the (theta, r) row in LDS.  np.interp's search carries the previous index as a
   // guess; on a sorted xp the answer does not depend on the guess, so when theta[:-1] is non-decreasing every
   // lane interpolates its own samples; otherwise lane 0 replays NumPy's sequential loop exactly.
@@ -49,6 +50,7 @@ __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][51
   __syncthreads();
   double* o_r = raw + (size_t)gid * M;
   double* o_t = shft_theta + (size_t)gid * M;
+  double lo = 1e300, hi = -1e300;      // the row's share of the image's minimum / maximum (MinMaxScaler, :56-58): a separate pass read the image again
   if (!s_unsorted) {
     for (int j = lane; j < M; j += 64) {
       double t = linspace_at(t0, t1, M, j);
@@ -57,6 +59,7 @@ __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][51
       int dst = j - kbest; if (dst < 0) dst += M;
       o_r[dst] = v;
       o_t[dst] = t;
+      lo = fmin(lo, v); hi = fmax(hi, v);
     }
   } else if (lane == 0) {
     int jg = 0;
@@ -66,13 +69,16 @@ __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][51
       int dst = j - kbest; if (dst < 0) dst += M;
       o_r[dst] = v;
       o_t[dst] = t;
+      lo = fmin(lo, v); hi = fmax(hi, v);
     }
   }
+  for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_down(lo, off)); hi = fmax(hi, __shfl_down(hi, off)); }
+  if (lane == 0) { atomicMin(&mm_enc[2 * b], enc_f64(lo)); atomicMax(&mm_enc[2 * b + 1], enc_f64(hi)); }
   (void)B;
 }
 
-// Global min / max of one image with 16 workgroups per humerus (order-preserving encoded atomics), then
-// the sklearn MinMaxScaler arithmetic X * scale_ + min_ in a second pass; keeps small batches busy.
+// Global min / max of one image with 16 workgroups per humerus (order-preserving encoded atomics; k_anp_rows does this itself now,
+// the kernel stays for images that come from elsewhere), then the sklearn MinMaxScaler arithmetic X * scale_ + min_ in a second pass.
 __global__ void __launch_bounds__(256)
 k_anp_minmax_reduce(const double* __restrict__ raw, unsigned long long* __restrict__ mm_enc /*[B][2]*/) {
   const int b = blockIdx.y, tid = threadIdx.x;

@@ -1990,10 +1990,10 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   }
   if (mask & SH_STAGE_ANP) {
     if (!c->have_unet) return fail(c, SH_ERR_STATE, "sh_run: anatomic-neck stage needs sh_load_unet first");
-    LAUNCH(c, "k_anp_rows", k_anp_rows, dim3(B * SH_ANP_ROWS), dim3(64), buf<double>(c, "prox.itr_start"),
-           buf<double>(c, "groove.bg_theta"), buf<double>(c, "anp.raw"), buf<double>(c, "anp.shft_theta"), buf<int>(c, "anp.roll"), B);
     LAUNCH(c, "k_init_bounds", k_init_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "anp.mm_enc"), B);
-    LAUNCH(c, "k_anp_minmax", k_anp_minmax_reduce, dim3(16, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"));
+    LAUNCH(c, "k_anp_rows", k_anp_rows, dim3(B * SH_ANP_ROWS), dim3(64), buf<double>(c, "prox.itr_start"),
+           buf<double>(c, "groove.bg_theta"), buf<double>(c, "anp.raw"), buf<double>(c, "anp.shft_theta"), buf<int>(c, "anp.roll"), B,
+           buf<unsigned long long>(c, "anp.mm_enc"));      // (+ the image's minimum / maximum: no second pass over it)
     LAUNCH(c, "k_anp_scale", k_anp_scale, dim3(64, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"), buf<float>(c, "anp.image"));
     if ((rc = unet_turn_enter(c)) != SH_OK) return rc;
     rc = unet_dispatch(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
