@@ -25,6 +25,7 @@
 #include "k_unet_x3.h"
 #include "k_unet16_l0.h"
 #include "k_unet16_dec0.h"
+#include "k_unet16_occ.h"
 #include "k_stl.h"
 #include "k_clip.h"
 #include "k_hullpre.h"
@@ -1283,7 +1284,17 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
       if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
       else DMA_LAUNCH(0, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
     } else if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
-    else if (fuse == UF_HEAD) DMA_LAUNCH(UF_HEAD, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits, tk, tk_tab, ntk);
+    else if (fuse == UF_HEAD) {
+      // SHOULDER_DEC0B_OCC=1: dec0b + head as small workgroups that share a CU (k_unet16_occ.h; bit-identical, measured 4 % slower)
+      const bool occ = C0 == 32 && C1 == 0 && L.cout == 32 && relu && H % SH_OCC_TR == 0 && getenv("SHOULDER_DEC0B_OCC") && getenv("SHOULDER_DEC0B_OCC")[0] == '1';
+      if (occ) {
+        if (c->ticket_next >= SH_UNET_TICKETS) return fail(c, SH_ERR_CAPACITY, "unet: out of work counters");
+        unsigned* tko = buf<unsigned>(c, "unet16.tickets") + c->ticket_next++;
+        const int ntiles = nimg * (W / 32) * (H / SH_OCC_TR), ntko = (ntiles + SH_OCC_TK - 1) / SH_OCC_TK;
+        static const int occ_mul = getenv("SHOULDER_OCC_MUL") ? std::max(1, atoi(getenv("SHOULDER_OCC_MUL"))) : 2;      // workgroups per CU
+        LAUNCH(c, lname, (k_dec0b_head_occ<EK>), dim3((unsigned)std::min(ntko, persistent_grid(c) * occ_mul)), dim3(SH_OCC_THREADS), src0, w, b, fz.head_w, fz.head_b, fz.logits, H, W, nimg, zp, tko);
+      } else DMA_LAUNCH(UF_HEAD, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits, tk, tk_tab, ntk);
+    }
     else DMA_LAUNCH(0, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
 #undef DMA_LAUNCH
   } else if (L.taps == 9 && L.cout % 64 == 0) {

@@ -275,6 +275,27 @@ def test_loader_wave_conv_bit_identical(engine, monkeypatch, name):
 
 
 @pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_small_workgroup_dec0b_bit_identical(engine, monkeypatch, name):
+    """k_dec0b_head_occ (k_unet16_occ.h: 4-wave workgroups on 32 x 8 tiles, two per CU, weight fragments in registers, tickets of four
+    tiles) against k_conv3_dma16<.., UF_HEAD, 2, 1, 2> (one 8-wave workgroup per CU on 32 x 16 tiles): the same operations in the same
+    order per output -> the same logits bit for bit, at both image sizes, an odd batch, run after run (a race between the LDS-DMA of
+    the next tile and the reads of the current one would show as a changing result)."""
+    rng = np.random.default_rng(31)
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        for H, W, n in ((256, 512, 3), (512, 512, 5)):
+            img = rng.random((n, H, W), dtype=np.float32)
+            monkeypatch.setenv("SHOULDER_DEC0B_OCC", "0")
+            a = engine.unet_infer(img)
+            monkeypatch.setenv("SHOULDER_DEC0B_OCC", "1")
+            for _ in range(3):
+                assert np.array_equal(a, engine.unet_infer(img))
+    finally:
+        monkeypatch.delenv("SHOULDER_DEC0B_OCC", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
 def test_register_resident_upconv_bit_identical(engine, monkeypatch, name):
     """k_upconv16r (k_unet16_l0.h: a wave keeps its 64 source pixels x Cin in MFMA fragments, the weights stream through LDS one
     (group, phase) slice at a time; up1 and up2) against k_upconv16 (tile staged per chunk): same accumulation order -> logits and
