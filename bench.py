@@ -165,6 +165,11 @@ def sym_key(name, unet, cout, fused_net=True):
     if unet == "f32":
         return "k_conv_mfma_f32<%d,%d>" % (1 if up else 9, nt)
     if unet == "f32x":
+        if up and os.environ.get("SHOULDER_X3_UPREG") != "0":
+            from shoulder_amd import unet_spec
+            cin = unet_cins(unet_spec.BASE, unet_spec.DEPTH)[name]
+            if cin in (64, 128, 256, 512):      # source pixels resident in registers (k_unet_x3.h)
+                return "k_upconv_x3r<%d,%d>" % (cin // 32, {64: 4, 128: 4, 256: 2, 512: 1}[cin])
         fuse = 4 if name in ("unet.enc0b", "unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
         return "k_conv_mfma_x3<%d,%d,%d>" % (1 if up else 9, nt, fuse)
     # third template argument = fused ends (k_unet_bf16.h): UF_FIRST 1, UF_HEAD 2, UF_POOL 4

@@ -177,9 +177,12 @@ __global__ void k_maxpool2(const float* __restrict__ src, float* __restrict__ ds
 // 1x1 head: logit = fma chain over channels from the bias (anatomic_neck.py:76 output)
 // 256 pixels per workgroup pass: coalesced 16-byte loads into LDS (row stride C+1 floats, so the
 // per-pixel channel walk below is bank-conflict free), then one sequential chain per lane.
+// MAXC: 32 (the network's base width: a 33.8 KB tile, four workgroups per CU; with the 66.5 KB tile of the general form two fit and the
+// layer -- 2.1 GB in at B = 64 -- ran at 0.36 of the HBM roof) or 64.
+template <int MAXC>
 __global__ void __launch_bounds__(256)
 k_head(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bp, float* __restrict__ logits, int C, size_t npix) {
-  constexpr int TILE = 256 * 65;               // floats: 256 pixels per pass up to 64 channels, fewer pixels per pass above
+  constexpr int TILE = 256 * (MAXC + 1);       // floats: 256 pixels per pass up to MAXC channels, fewer pixels per pass above
   __shared__ float tile[TILE];
   __shared__ float sw[SH_UNET_MAXBASE];
   const int tid = threadIdx.x;

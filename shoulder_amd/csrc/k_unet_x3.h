@@ -289,4 +289,121 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
   }
 }
 
+
+// ---- 2x2 stride-2 transposed convolution of the F32X path with the source pixels held in registers ------------------------------
+// k_conv_mfma_x3<1, NT> runs one (16x16 source tile, 16 NT couts, phase) per workgroup: the f32 tile is read 4 Cout / (16 NT) times
+// and split again every time, a chunk is 12 NT MFMAs per wave between two barriers (up0..up3: 0.74 + 0.46 + 0.37 + 0.29 ms at
+// B = 64 for 1.9 + 1.0 + 0.5 + 0.3 GB of tensors).  As in k_upconv16r (k_unet16_l0.h) a workgroup of 8 waves owns a 32 x (4 MT)
+// source tile for all 4 Cout outputs: a wave loads its MT rows x 16 pixels x Cin once, splits them into the high / low f16
+// fragments (x_hi = f16(x), x_lo = f16(x - x_hi): the arithmetic of the staged form) and keeps both for the whole launch
+// (2 x 4 MT NCH registers); the split weights stream through LDS, one (32-cout group, phase) slice at a time, fetched into registers
+// while the previous slice is multiplied.  Per accumulator the same MFMAs in the same order (bias 2^6 in the accumulator, chunks
+// ascending, w_hi x_hi, w_hi x_lo, w_lo x_hi): bit-identical outputs (tests/test_gpu_unet_x3.py).
+#define UXR_THREADS 512
+
+template <int NCH, int MT>
+__global__ void __launch_bounds__(UXR_THREADS)
+k_upconv_x3r(const float* __restrict__ src /*[img][H W][32 NCH]*/, const u16* __restrict__ wh_, const u16* __restrict__ wl_ /*packed [4][1][NCH][Cout][32]*/,
+             const float* __restrict__ bias, float* __restrict__ dst /*[img][2H 2W][Cout]*/, int H, int W, int Cout) {
+  using ET = _Float16;
+  using v8 = typename E16<ET>::v8;
+  const ET* wh = (const ET*)wh_;
+  const ET* wl = (const ET*)wl_;
+  constexpr int Cin = 32 * NCH;
+  constexpr int WROWS = NCH * 32;                                         // LDS rows of a weight slice: [chunk][16 n + i]
+  constexpr int WPASS = (WROWS * 4 + UXR_THREADS - 1) / UXR_THREADS;      // 16-byte pieces per thread, slice and half
+  __shared__ __attribute__((aligned(16))) ET s_wh[2][WROWS * UB_PSTR];
+  __shared__ __attribute__((aligned(16))) ET s_wl[2][WROWS * UB_PSTR];
+  const int tiles_x = W / 32;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, img = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int xh_ = wave & 1, rg = wave >> 1;
+  const int x0 = tx * 32 + xh_ * 16 + li, y0 = (ty * 4 + rg) * MT;
+  const float* in = src + (size_t)img * H * W * Cin;
+  const int groups = Cout >> 5, nslice = groups * 4;
+
+  int wt_src[WPASS], wt_lds[WPASS];
+#pragma unroll
+  for (int k = 0; k < WPASS; ++k) {
+    const int e = tid + k * UXR_THREADS, q = e & 3, r = e >> 2, cc = r >> 5, j = r & 31;
+    wt_src[k] = e < WROWS * 4 ? (cc * Cout + j) * 32 + q * 8 : -1;
+    wt_lds[k] = UB_OFF(r, q);
+  }
+  u32x4 rwh[WPASS], rwl[WPASS];
+  auto load_slice = [&](int t) {      // slice t = (group t >> 2, phase t & 3)
+    const size_t o = ((size_t)(t & 3) * NCH * Cout + (size_t)(t >> 2) * 32) * 32;
+#pragma unroll
+    for (int k = 0; k < WPASS; ++k)
+      if (wt_src[k] >= 0) { rwh[k] = *(const u32x4*)(wh + o + wt_src[k]); rwl[k] = *(const u32x4*)(wl + o + wt_src[k]); }
+  };
+  auto put_slice = [&](int b) {
+#pragma unroll
+    for (int k = 0; k < WPASS; ++k)
+      if (wt_src[k] >= 0) { *(u32x4*)(s_wh[b] + wt_lds[k]) = rwh[k]; *(u32x4*)(s_wl[b] + wt_lds[k]) = rwl[k]; }
+  };
+  load_slice(0);
+  v8 xh[MT][NCH], xl[MT][NCH];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) {
+      const float* s = in + ((size_t)(y0 + m) * W + x0) * Cin + cc * 32 + lk * 8;
+      const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = j < 4 ? a[j & 3] : b[j & 3];
+        const ET h = (ET)v;
+        xh[m][cc][j] = h;
+        xl[m][cc][j] = (ET)(v - (float)h);
+      }
+    }
+  put_slice(0);
+  __syncthreads();
+
+  const int OW = 2 * W, OH = 2 * H;
+  float* out = dst + (size_t)img * OH * OW * Cout;
+  for (int t = 0; t < nslice; ++t) {
+    const int g = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
+    if (t + 1 < nslice) load_slice(t + 1);      // in flight during the MFMAs below
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      f32x4 bv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = bias[g * 32 + n * 16 + lk * 4 + r] * X3_WSCALE;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][n] = bv;
+    }
+    const ET* swh = s_wh[t & 1];
+    const ET* swl = s_wl[t & 1];
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int off = UB_OFF(cc * 32 + n * 16 + li, lk);
+        const v8 fh = *(const v8*)(swh + off), fl = *(const v8*)(swl + off);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          acc[m][n] = E16<ET>::mfma(fh, xh[m][cc], acc[m][n]);
+          acc[m][n] = E16<ET>::mfma(fh, xl[m][cc], acc[m][n]);
+          acc[m][n] = E16<ET>::mfma(fl, xh[m][cc], acc[m][n]);
+        }
+      }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const size_t opix = (size_t)(2 * (y0 + m) + dy) * OW + 2 * x0 + dx;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = acc[m][n][r] * (1.0f / X3_WSCALE);
+        *(f32x4*)(out + opix * Cout + g * 32 + n * 16 + lk * 4) = o;
+      }
+    }
+    if (t + 1 < nslice) put_slice((t + 1) & 1);      // its last readers passed the barrier that ended slice t - 1
+    __syncthreads();
+  }
+}
+
 }  // namespace sh

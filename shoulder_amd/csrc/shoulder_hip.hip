@@ -1037,6 +1037,13 @@ static int conv_layer(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, con
     else if (L.taps == 9 && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_, nf_, nf_, nf_); }
     else if (L.taps == 9 && db2) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, 0, 1>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_, nf_, nf_, nf_); }
     else if (L.taps == 9) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, 0, 0>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_, nf_, nf_, nf_); }
+    else if (C1 == 0 && W % 32 == 0 && H % 16 == 0 && (C0 == 64 || C0 == 128 || C0 == 256 || C0 == 512) && !(getenv("SHOULDER_X3_UPREG") && getenv("SHOULDER_X3_UPREG")[0] == '0')) {
+      // up-convolutions with the source pixels resident in registers (k_upconv_x3r; SHOULDER_X3_UPREG=0: the staged form, bit-identical)
+      if (C0 == 64) { LAUNCH(c, lname, (k_upconv_x3r<2, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UXR_THREADS), src0, wh, wl, b, dst, H, W, L.cout); }
+      else if (C0 == 128) { LAUNCH(c, lname, (k_upconv_x3r<4, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UXR_THREADS), src0, wh, wl, b, dst, H, W, L.cout); }
+      else if (C0 == 256) { LAUNCH(c, lname, (k_upconv_x3r<8, 2>), dim3((W / 32) * (H / 8), nimg), dim3(UXR_THREADS), src0, wh, wl, b, dst, H, W, L.cout); }
+      else { LAUNCH(c, lname, (k_upconv_x3r<16, 1>), dim3((W / 32) * (H / 4), nimg), dim3(UXR_THREADS), src0, wh, wl, b, dst, H, W, L.cout); }
+    }
     else if (L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<1, 4>), dim3(tiles, L.cout / 64, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, 0, np_, nf_, nf_, np_, nf_, nf_, nf_); }
     else { LAUNCH(c, lname, (k_conv_mfma_x3<1, 2>), dim3(tiles, L.cout / 32, nimg * 4), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, 0, np_, nf_, nf_, np_, nf_, nf_, nf_); }
     return SH_OK;
@@ -1172,7 +1179,8 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
   {
     const sh_ctx::ULayer& l = L("head");
     size_t npx = (size_t)nimg * H * W;
-    LAUNCH(c, "unet.head", k_head, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx);
+    if (l.cin <= 32) { LAUNCH(c, "unet.head", k_head<32>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 16384)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx); }
+    else { LAUNCH(c, "unet.head", k_head<64>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), x, P + l.w_off, P + l.b_off, logits, l.cin, npx); }
   }
   return SH_OK;
 }

@@ -68,3 +68,22 @@ def test_bench_batch_same_edge_pixels_as_f32(engine):
         assert np.array_equal(px[b, :n], p32[b, :n]), b                 # the edge points themselves, in order
     assert int(flips.sum()) == 0
     assert lmx.tobytes() == lm32.tobytes()
+
+
+def test_register_resident_upconv_bit_identical_f32x(engine, monkeypatch):
+    """k_upconv_x3r (k_unet_x3.h: a wave keeps the high / low f16 fragments of its source pixels, the split weights stream through LDS
+    one (group, phase) slice at a time; up0..up3) against k_conv_mfma_x3<1, NT> (tile staged and split per chunk and workgroup): per
+    accumulator the same MFMAs in the same order -> the logits are bit-identical, at both image sizes and an odd batch."""
+    rng = np.random.default_rng(37)
+    engine.set_params(unet_dtype=_lib.UNET_F32X)
+    try:
+        for H, W, n in ((256, 512, 3), (512, 512, 2)):
+            img = rng.random((n, H, W), dtype=np.float32)
+            monkeypatch.setenv("SHOULDER_X3_UPREG", "0")
+            a = engine.unet_infer(img)
+            monkeypatch.setenv("SHOULDER_X3_UPREG", "1")
+            for _ in range(2):
+                assert np.array_equal(a, engine.unet_infer(img))
+    finally:
+        monkeypatch.delenv("SHOULDER_X3_UPREG", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
