@@ -96,13 +96,23 @@ __device__ inline int hull_simple_polygon_cached(const double* xy, int n, double
   double t1x = o > 0 ? v1x : v0x, t1y = o > 0 ? v1y : v0y;
   double b2x = t1x, b2y = t1y, t2x = b1x, t2y = b1y;
   dqx[bot] = v2x; dqy[bot] = v2y; dqx[bot + 1] = b1x; dqy[bot + 1] = b1y; dqx[bot + 2] = t1x; dqy[bot + 2] = t1y; dqx[top] = v2x; dqy[top] = v2y;
+#ifdef SH_TE_CLOCK
+  long long c_int = 0, c_hull = 0; int n_int = 0, n_hull = 0;
+#endif
   double nx = n > 3 ? xy[6] : 0.0, ny = n > 3 ? xy[7] : 0.0;
   for (int i = 3; i < n; ++i) {
+#ifdef SH_TE_CLOCK
+    const long long cs_ = clock64();
+#endif
     const double vx = nx, vy = ny;
     if (i + 1 < n) { nx = xy[2 * i + 2]; ny = xy[2 * i + 3]; }      // (in flight during the tests below)
     double ob = orient2v(b0x, b0y, b1x, b1y, vx, vy);
     double ot = orient2v(t1x, t1y, t0x, t0y, vx, vy);
+#ifdef SH_TE_CLOCK
+    if (ob > 0 && ot > 0) { c_int += clock64() - cs_; ++n_int; continue; }
+#else
     if (ob > 0 && ot > 0) continue;
+#endif
     while (top - bot >= 2 && ob <= 0) {
       ++bot;
       b0x = b1x; b0y = b1y; b1x = b2x; b1y = b2y;
@@ -124,7 +134,13 @@ __device__ inline int hull_simple_polygon_cached(const double* xy, int n, double
     dqx[top] = vx; dqy[top] = vy;
     t2x = t1x; t2y = t1y; t1x = t0x; t1y = t0y; t0x = vx; t0y = vy;
     if (top - bot == 2) { b2x = vx; b2y = vy; }      // the new top slot is the bottom's third
+#ifdef SH_TE_CLOCK
+    c_hull += clock64() - cs_; ++n_hull;
+#endif
   }
+#ifdef SH_TE_CLOCK
+  dqx[2 * n + 4] = (double)c_int; dqx[2 * n + 5] = (double)n_int; dqx[2 * n + 6] = (double)c_hull; dqx[2 * n + 7] = (double)n_hull;
+#endif
   *first = bot;
   return top - bot;
 }
@@ -175,6 +191,7 @@ k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, doubl
       int h = hull_simple_polygon_cached(xy, n, dqx, dqy, &first);   // rings are simple polygons in boundary order
 #ifdef SH_TE_CLOCK
       dqx[2 * CAP + 7] = (double)(clock64() - c0_); dqy[2 * CAP + 7] = (double)n + 1e-3 * h;
+      dqy[2 * CAP + 3] = dqx[2 * n + 4]; dqy[2 * CAP + 4] = dqx[2 * n + 5]; dqy[2 * CAP + 5] = dqx[2 * n + 6]; dqy[2 * CAP + 6] = dqx[2 * n + 7];
 #endif
       if (h < 0) {      // first three vertices collinear: the sort-based hull, its index arrays in the (idle) upper half of the deque
         int* idx = (int*)(dqx + CAP + 4);
@@ -242,7 +259,7 @@ k_te_rows(const double* __restrict__ ring, const int* __restrict__ ring_n, doubl
   else if (wi == 0x7fffffff && lane < 7) o[lane] = 0.0;
 #ifdef SH_TE_CLOCK
   __syncthreads();
-  if (lane == 0) { o[5] = dqx[2 * CAP + 7]; o[6] = dqy[2 * CAP + 7]; }      // debug build: cycles of the walk, n + h / 1000
+  if (lane == 0) { o[5] = dqx[2 * CAP + 7]; o[6] = dqy[2 * CAP + 7]; o[0] = dqy[2 * CAP + 3]; o[1] = dqy[2 * CAP + 4]; o[2] = dqy[2 * CAP + 5]; o[3] = dqy[2 * CAP + 6]; }      // debug build: cycles of the walk, n + h / 1000, cycles / count of untouched and of hull-changing vertices
 #endif
   (void)B;
 }
