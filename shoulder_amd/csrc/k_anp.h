@@ -1,6 +1,6 @@
 // k_anp.h -- anatomic neck around the UNet (reference src/shoulder/humerus/anatomic_neck.py).
 //   k_anp_rows    :40-54   even-theta re-interpolation + roll to the groove angle (one lane per row)
-//   k_anp_minmax_reduce / k_anp_scale  :56-58  global min-max (sklearn MinMaxScaler arithmetic) -> float32 image (:73-75)
+//   k_anp_scale   :56-58   global min-max (taken by k_anp_rows; sklearn MinMaxScaler arithmetic) -> float32 image (:73-75)
 //   k_anp_edges   :79-118  mask = logit > 0, |diff(mask, prepend=0)| along theta, compaction -> points
 //   k_anp_plane   :123-153 plane fit (covariance, smallest eigenvector) + LSQ-ellipse centre
 //   k_rays        :174-236 4 rays (+-normal, +-central) vs all triangles, nearest hit (B-6)
@@ -77,18 +77,8 @@ __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][51
   (void)B;
 }
 
-// Global min / max of one image with 16 workgroups per humerus (order-preserving encoded atomics; k_anp_rows does this itself now,
-// the kernel stays for images that come from elsewhere), then the sklearn MinMaxScaler arithmetic X * scale_ + min_ in a second pass.
-__global__ void __launch_bounds__(256)
-k_anp_minmax_reduce(const double* __restrict__ raw, unsigned long long* __restrict__ mm_enc /*[B][2]*/) {
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const double* x = raw + (size_t)b * SH_IMG;
-  double lo = 1e300, hi = -1e300;
-  for (int i = blockIdx.x * 256 + tid; i < SH_IMG; i += gridDim.x * 256) { lo = fmin(lo, x[i]); hi = fmax(hi, x[i]); }
-  for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_down(lo, off)); hi = fmax(hi, __shfl_down(hi, off)); }
-  if ((tid & 63) == 0) { atomicMin(&mm_enc[2 * b], enc_f64(lo)); atomicMax(&mm_enc[2 * b + 1], enc_f64(hi)); }
-}
-
+// The sklearn MinMaxScaler arithmetic X * scale_ + min_ over the image (its minimum / maximum: k_anp_rows, order-preserving encoded
+// atomics); 64 workgroups per humerus keep small batches busy.
 __global__ void __launch_bounds__(256)
 k_anp_scale(const double* __restrict__ raw, const unsigned long long* __restrict__ mm_enc, float* __restrict__ image) {
   const int b = blockIdx.y, tid = threadIdx.x;

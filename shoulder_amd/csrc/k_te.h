@@ -441,7 +441,6 @@ __device__ inline int clip_halfplane_pieces_wave(const double* pts, int n, doubl
   return __shfl(npieces, 0);
 }
 
-#define SH_TE_DSCR (6 * SH_MAXSEG + 64 * SH_TE_MAXCH)
 __global__ void k_te_ends(const double* __restrict__ ring, const int* __restrict__ ring_n, const double* __restrict__ rects,
                           const double* __restrict__ distal_zs, const double* __restrict__ T_obb, double* __restrict__ ends_ct /*[B][6]: the two ends, in piece order*/,
                           int* __restrict__ te_row, int* __restrict__ err, int B, OvfPools P, OvfSet S) {

@@ -481,7 +481,6 @@ static int alloc_batch(sh_ctx* c) {
   ENS("anp.plane", (size_t)B * 6 * 8, 8);
   ENS("anp.axes_obb", (size_t)B * 12 * 8, 8);
   // trans-epicondylar
-  ENS("te.dscratch", (size_t)B * SH_TE_DSCR * 8, 8);
   ENS("te.rects", (size_t)B * SH_TE_NROWS * 7 * 8, 8);
   ENS("te.axis_ct", (size_t)B * 6 * 8, 8);
   ENS("te.ends_ct", (size_t)B * 6 * 8, 8);
