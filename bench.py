@@ -454,6 +454,7 @@ def main():
             # step are collected (and gathered) once `depth` later steps are enqueued.  All K submits and all K collects lie
             # inside the timed region.
             depth = int(os.environ.get("SH_BENCH_DEPTH", "0")) or (nl if nl > 1 else 2)      # steps in flight (an engine takes two)
+            trace_host = os.environ.get("SH_BENCH_TRACE") == "1" and rank == 0
             pend = []
 
             def finish(k, e):
@@ -473,12 +474,15 @@ def main():
                 if len(pend) >= depth:
                     finish(*pend.pop(0))
                 hand_over(e)       # (the lane is idle here: its previous step was collected above)
+                ts_ = time.perf_counter()
                 if use_dist:
                     if send_free[s_ % nsend] is not None:
                         send_free[s_ % nsend].synchronize()       # (2 * lanes steps old: long done)
                     e.submit(_lib.STAGE_ALL, fetch=False, out_ptr=send[s_ % nsend].data_ptr())
                 else:
                     e.submit(_lib.STAGE_ALL, fetch="view")
+                if trace_host:
+                    print("[bench] step %d lane %d: submit returned after %.2f ms (at %.2f ms of the region)" % (s_, s_ % nl, 1e3 * (time.perf_counter() - ts_), 1e3 * (time.perf_counter() - t0)), file=sys.stderr)
                 pend.append((s_, e))
             for k_e in pend:
                 finish(*k_e)
@@ -624,6 +628,14 @@ def main():
             for e in host_engs:
                 e.close()
         extra["single_humerus_f32"] = single_humerus_leg(local, weights, verts, faces)
+        if lanes > 1 and pipelined:
+            # the headline configuration over a timed region ten times as long: what the lanes sustain once they are full.  `value`
+            # above times exactly --steps steps from idle lanes -- the first hull phase (no device work to hide behind) and the
+            # first geometry chain are inside it, ~7 ms that 20 steps carry as 0.35 ms each
+            ks = 10 * args.steps
+            els, _, _ = run_leg(engs, args.unet, ks, 2, pipelined)
+            extra["steady_state"] = {"value": round(B * ks / els, 3), "unit": "meshes/s", "steps": ks, "warmup": 2, "ms_per_step": round(1e3 * els / ks, 3),
+                                     "lanes": lanes, "note": "same configuration as the headline; 10 x its steps in one timed region"}
         if lanes > 1:
             el1, _, _ = run_leg(engs[:1], args.unet, args.steps, 1, pipelined)
             extra["one_lane"] = {"value": round(B * args.steps / el1, 3), "unit": "meshes/s", "steps": args.steps, "warmup": 1,

@@ -1700,7 +1700,27 @@ class HullPool {
 // boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
 // Host phase of the OBB stage for meshes [b0, b0 + B): one quickhull per humerus on worker threads into pinned slot
 // `slot`.  Callable from the background thread: touches no error string, no timers; HIP errors come back as text.
-static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, double* ms, std::string* errtxt) {
+// One hull phase at a time per process, the one a run is WAITING for first.  The pool is shared by the lanes of a process; two
+// phases at once (a run's own and another lane's background preparation) interleaved on the same workers and both came late:
+// measured at the start of a timed region, lanes idle -- the second lane's first hull phase took 12.8 ms instead of 5.1 beside
+// the first lane's preparation of its NEXT step, the first UNet passes were 10-17 ms apart and 20 steps carried 0.5-0.8 ms each
+// of it.  A background preparation now waits while a foreground phase is running or waiting, and one that is under way hands the
+// pool over at the next hull boundary (its workers take no further humerus; it finishes the rest after the foreground phase).
+struct HullPhaseGate {
+  std::mutex m; std::condition_variable cv; bool busy = false; std::atomic<int> fg_waiting{0};
+  void enter(bool background) {
+    std::unique_lock<std::mutex> l(m);
+    if (!background) ++fg_waiting;
+    cv.wait(l, [&] { return !busy && (!background || fg_waiting.load() == 0); });
+    if (!background) --fg_waiting;
+    busy = true;
+  }
+  bool foreground_waits() const { return fg_waiting.load(std::memory_order_relaxed) > 0; }
+  void leave() { { std::lock_guard<std::mutex> l(m); busy = false; } cv.notify_all(); }
+  static HullPhaseGate& instance() { static HullPhaseGate g; return g; }
+};
+
+static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, double* ms, std::string* errtxt, bool background = false) {
   auto t0 = std::chrono::steady_clock::now();
   sh_ctx::HullStage& hs = c->hstage[slot];
 #define HULLCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *errtxt = std::string(#call) + ": " + hipGetErrorString(e_); return SH_ERR_HIP; } } while (0)
@@ -1717,14 +1737,30 @@ again:
   }
   if (!hs.ev) HULLCHK(hipEventCreateWithFlags(&hs.ev, hipEventDisableTiming));
   if (hs.used) HULLCHK(hipEventSynchronize(hs.ev));     // the previous copies out of this slot are done
+  {
+    // the other slot of the double buffer is allocated with the first one: pinning its 31 MB costs ~7 ms, and a context that had run
+    // once (a warm-up step) paid that in its SECOND run -- the first timed step of a lane (round 3: 12 ms instead of 5 for that hull
+    // phase, the first UNet passes of a 20-step region 14 ms apart)
+    sh_ctx::HullStage& ho = c->hstage[slot ^ 1];
+    if (!ho.hv && !grown) {
+      ho.pv = hs.pv; ho.pf = hs.pf; ho.pe = hs.pe;
+      HULLCHK(hipHostMalloc((void**)&ho.hv, (size_t)B * ho.pv * 3 * 8));
+      HULLCHK(hipHostMalloc((void**)&ho.nr, (size_t)B * ho.pf * 3 * 8));
+      HULLCHK(hipHostMalloc((void**)&ho.ed, (size_t)B * ho.pe * 4 * 4));
+      HULLCHK(hipHostMalloc((void**)&ho.cnt, (size_t)B * 3 * 4));
+      ho.cap = B;
+    }
+  }
 #undef HULLCHK
   double* hv = hs.hv; double* nr = hs.nr; int* ed = hs.ed; int* counts = hs.cnt;
   std::vector<int> status(B, 0);
+  static const bool gate_on = !(getenv("SHOULDER_HULL_GATE") && getenv("SHOULDER_HULL_GATE")[0] == '0');
   std::atomic<int> next(0);
   auto work = [&]() {
     std::vector<double> P;
     shhull::Hull H;
     for (;;) {
+      if (background && gate_on && HullPhaseGate::instance().foreground_waits()) break;      // a run is waiting for ITS hulls: hand the pool over
       int b = next.fetch_add(1);
       if (b >= B) break;
       counts[b] = counts[B + b] = counts[2 * B + b] = 0;
@@ -1747,7 +1783,11 @@ again:
   // hardware threads divided between the ranks of this node (torchrun exports LOCAL_WORLD_SIZE), at most 32 per process;
   // SHOULDER_HULL_THREADS overrides.  The calling thread works on its own batch too.  (Round 1 started up to 32 threads
   // per batch: a third of the 4.8 ms hull phase was thread start-up, and two lanes doubled the thread count.)
-  HullPool::instance().run(work, B);
+  do {
+    if (gate_on) HullPhaseGate::instance().enter(background);
+    HullPool::instance().run(work, B);
+    if (gate_on) HullPhaseGate::instance().leave();
+  } while (next.load() < B);      // (a background phase that handed the pool over: the remaining humeri)
   if (!grown && std::find(status.begin(), status.end(), 1) != status.end()) {
     // a hull larger than the staging pitch (a dense mesh): this slot gets the full record capacity and the phase runs again
     hs.pv = SH_HV; hs.pf = SH_HF; hs.pe = SH_HE;
@@ -1809,6 +1849,7 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
     slot = c->hslot; c->hslot ^= 1;
     int bad = -1; double ms = 0; std::string et;
     int hrc = hull_host_phase(c, slot, b0, B, &bad, &ms, &et);
+    if (getenv("SH_DEBUG")) fprintf(stderr, "[sh] run_obb: foreground hull phase %.2f ms\n", ms);
     if (c->timing) { KTimer& h = c->timers["host.hull"]; h.ms += ms; h.n += 1; }
     if (hrc == SH_ERR_HIP) { c->err = et; return hrc; }
     if (hrc != SH_OK) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", bad, hrc); return fail(c, hrc, m); }
@@ -2092,7 +2133,7 @@ static void start_prepare(sh_ctx* c) {
       if (fetch_hull_points(c, hp, c->copy_stream) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
       q.d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    q.rc = hull_host_phase(c, q.slot, 0, q.B, &q.bad_mesh, &q.hull_ms, &q.err);
+    q.rc = hull_host_phase(c, q.slot, 0, q.B, &q.bad_mesh, &q.hull_ms, &q.err, true);
     if (q.rc == SH_OK && can_upload) {
       // the records go to the device as soon as the running step no longer reads the hull.* buffers (after its k_obb_pick)
       if (hipStreamWaitEvent(c->copy_stream, c->obb_done_ev, 0) == hipSuccess && hull_upload(c, q.slot, q.B, dst.p, c->copy_stream) == hipSuccess &&
@@ -2211,6 +2252,22 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   tk.h_ovf = (unsigned long long*)((char*)tk.h_err + status_ovf_off(B));      // (the layout follows THIS run's batch size)
   tk.h_fail = (int*)((char*)tk.h_err + status_ovf_off(B) + 64);
   if (!tk.ev) HIPCHK(c, hipEventCreateWithFlags(&tk.ev, hipEventDisableTiming));
+  {      // the other ticket's pinned block, event and device staging with the first one (else the context's SECOND run pays for them)
+    sh_ctx::Ticket& to = c->tickets[c->t_head ^ 1];
+    if (!to.pending && to.cap < B) {
+      if (to.h_err) (void)hipHostFree(to.h_err);
+      to.h_err = nullptr; to.h_fail = nullptr; to.h_ovf = nullptr; to.cap = 0;
+      HIPCHK(c, hipHostMalloc((void**)&to.h_err, status_bytes(B)));
+      to.cap = B;
+    }
+    if (!to.ev) HIPCHK(c, hipEventCreateWithFlags(&to.ev, hipEventDisableTiming));
+    const std::string oslot = std::to_string(c->t_head ^ 1);
+    if (!to.pending) {
+      if (int e = ensure(c, ("out.err" + oslot).c_str(), status_bytes(B), 4)) return e;
+      if (out) { hipPointerAttribute_t at{}; const bool dev = hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeDevice; (void)hipGetLastError();
+                 if (!dev) { if (int e = ensure(c, ("out.landmarks" + oslot).c_str(), (size_t)B * sizeof(sh_landmarks), 1)) return e; } }
+    }
+  }
   if (!c->out_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
   c->b0 = 0; c->Bwin = B;
   if (c->params.bone_kind == SH_BONE_PROXIMAL) {
@@ -2242,6 +2299,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     // the host hull needs its points (a device-generated batch: every run, a new batch is new data)
     auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, fetch_hull_points(c, hullpre_ptrs(c), c->stream));
+    if (getenv("SH_DEBUG")) fprintf(stderr, "[sh] submit: hull points fetched after %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (c->timing && !c->h_verts_valid) { KTimer& a = c->timers["host.verts_d2h"]; a.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); a.n += 1; }
   }
   int rc = SH_OK, widx = 0;

@@ -59,6 +59,9 @@ def test_bench_line():
     assert sh["status_ok"] is True and 0 < sh["engine_run_ms_min"] <= sh["engine_run_ms"] and sh["facade_readme_flow_ms"] > 0
     assert {"obb", "slices", "bicipital_groove", "anatomic_neck.unet", "trans_epicondylar", "csys"} <= set(sh["device_ms_by_stage"])
     assert sh["device_ms_total"] <= sh["engine_run_ms"] * 1.05
+    # the headline configuration over a timed region ten times as long (full lanes: fill and drain weigh a tenth)
+    ss = d["steady_state"]
+    assert ss["steps"] == 10 * d["steps"] and ss["lanes"] == d["config"]["lanes"] and ss["value"] > 0.9 * d["value"]
 
 
 def test_rccl_leg_single_rank():
