@@ -637,7 +637,15 @@ def main():
             extra["steady_state"] = {"value": round(B * ks / els, 3), "unit": "meshes/s", "steps": ks, "warmup": 2, "ms_per_step": round(1e3 * els / ks, 3),
                                      "lanes": lanes, "note": "same configuration as the headline; 10 x its steps in one timed region"}
         if lanes > 1:
-            el1, _, _ = run_leg(engs[:1], args.unet, args.steps, 1, pipelined)
+            # a context of its own, alone on the device: no turns to take, no CUs to leave to another lane (what `--lanes 1` runs)
+            e1 = Engine(local)
+            e1.load_rfc()
+            e1.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
+            e1.set_hull_mode(eng.hull_mode)
+            e1.upload([(verts, faces)])
+            e1.synth_batch(T)
+            el1, _, _ = run_leg([e1], args.unet, args.steps, 1, pipelined)
+            e1.close()
             extra["one_lane"] = {"value": round(B * args.steps / el1, 3), "unit": "meshes/s", "steps": args.steps, "warmup": 1,
                                  "ms_per_step": round(1e3 * el1 / args.steps, 3), "lanes": 1}
 
