@@ -213,9 +213,9 @@ def test_synthetic_batch_equivariance(engine, oracle_bones):
 
 
 def test_forked_trans_epicondylar_part_gives_the_same_records(engine, oracle_bones, monkeypatch):
-    """SHOULDER_TE_EARLY=1: the rectangles of the distal rows and the ends of the widest one (k_te_rows, k_te_ends: they need the distal
-    set only) run on the side stream beside the proximal set, the groove and the UNet pass; k_te_orient (medial end first: needs the head's
-    central axis) joins them in front of the record.  Same kernels on the same inputs: the records are the sequential run's bit for bit,
+    """The rectangles of the distal rows and the ends of the widest one (k_te_rows, k_te_ends: they need the distal set only) run in
+    front of the UNet pass by default, on the side stream beside the proximal set, the groove and the UNet pass with SHOULDER_TE_EARLY=1,
+    behind the UNet with =0; k_te_orient (medial end first: needs the head's central axis) follows in front of the record.  Same kernels on the same inputs: the records are the sequential run's bit for bit,
     run after run (the second run of a batch is the first that forks: the overflow tier is known to be idle by then)."""
     h = oracle_bones("humerus_left")
     B = 24
@@ -223,13 +223,17 @@ def test_forked_trans_epicondylar_part_gives_the_same_records(engine, oracle_bon
     engine.upload([(h.verts, h.faces)])
     engine.synth_batch(synth.similarity_transforms(B, h.verts, seed=5))
     try:
-        monkeypatch.delenv("SHOULDER_TE_EARLY", raising=False)
+        monkeypatch.setenv("SHOULDER_TE_EARLY", "0")      # behind the UNet (the order of the reference's accessors)
         engine.run(_lib.STAGE_ALL)
         a = engine.run(_lib.STAGE_ALL).copy()
-        monkeypatch.setenv("SHOULDER_TE_EARLY", "1")
-        for _ in range(3):
-            b = engine.run(_lib.STAGE_ALL)
-            assert (b["status"] == 0).all() and b.tobytes() == a.tobytes()
+        for mode in ("1", None):      # forked beside the UNet; in the chain in front of it (the default)
+            if mode is None:
+                monkeypatch.delenv("SHOULDER_TE_EARLY", raising=False)
+            else:
+                monkeypatch.setenv("SHOULDER_TE_EARLY", mode)
+            for _ in range(3):
+                b = engine.run(_lib.STAGE_ALL)
+                assert (b["status"] == 0).all() and b.tobytes() == a.tobytes()
     finally:
         monkeypatch.delenv("SHOULDER_TE_EARLY", raising=False)
 
