@@ -139,6 +139,7 @@ struct sh_ctx {
   std::map<std::tuple<int, int, int>, std::pair<int, int>> tk_tabs;      // (items, workgroups, cout groups) -> (offset, tickets) in "unet16.tk_tab"
   int tk_tab_used = 0;
   bool packtab_ready = false;      // layer table of k_pack_w_bf16_all uploaded (reset by sh_load_unet)
+  bool packed_rfc = false;         // "rfc.nodes" holds the packed forest of the CURRENT parameter block
   bool packed_x3 = false;          // "params_x3h/l" hold the split weights of the CURRENT parameter block (reset with packed_kind)
   int packed_kind = -1;            // element kind (0 bf16, 1 f16) "params_bf16" was packed for from the CURRENT parameter block; -1: repack.
                                    // Reset wherever the block can change: sh_load_*, sh_param_block (the pointer goes to the caller), sh_param_block_commit
@@ -766,7 +767,7 @@ int sh_buffer_device(sh_ctx* c, const char* name, void** dev_ptr, size_t* nbytes
   if (it == c->bufs.end() || !it->second.p) return fail(c, SH_ERR_ARG, std::string("no buffer named ") + name);
   *dev_ptr = it->second.p;
   if (nbytes) *nbytes = it->second.bytes;
-  if (std::string(name) == "params") c->packed_kind = -1; c->packed_x3 = false;      // (the caller may write it)
+  if (std::string(name) == "params") c->packed_kind = -1; c->packed_x3 = false; c->packed_rfc = false;      // (the caller may write it)
   return SH_OK;
 }
 
@@ -789,7 +790,7 @@ int sh_store(sh_ctx* c, const char* name, const void* host, size_t nbytes) {
   HIPCHK(c, hipSetDevice(c->device));
   if (std::string(name) == "verts") { (void)join_prepared(c); ++c->batch_gen; c->h_verts_valid = false; }
   c->ovf_none_gen = ~0ull;      // (an injected frame or intermediate moves the planes: the overflow tier runs again)
-  if (std::string(name) == "params") c->packed_kind = -1; c->packed_x3 = false;
+  if (std::string(name) == "params") c->packed_kind = -1; c->packed_x3 = false; c->packed_rfc = false;
   HIPCHK(c, hipMemcpyAsync(it->second.p, host, nbytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (std::string(name) == "obb_transform") c->obb_injected = true;
@@ -2040,7 +2041,10 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<double>(c, "groove.stats"), B);
     if ((rc = ensure(c, "rfc.nodes", N * 16, 4)) != SH_OK) return rc;
     int4* nodes = (int4*)c->bufs["rfc.nodes"].p;
-    LAUNCH(c, "k_rfc_pack", k_rfc_pack, dim3((unsigned)((N + 255) / 256)), dim3(256), feat, thr, ti, fi, lw, nodes, (int)N);
+    if (!c->packed_rfc) {      // once per parameter block (it was a launch of every step's chain: 5 us alone, ~50 us beside a UNet pass)
+      LAUNCH(c, "k_rfc_pack", k_rfc_pack, dim3((unsigned)((N + 255) / 256)), dim3(256), feat, thr, ti, fi, lw, nodes, (int)N);
+      c->packed_rfc = true;
+    }
     LAUNCH(c, "k_groove_rfc", k_groove_rfc, dim3((B * SH_GSLOTS + 63) / 64), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
            buf<double>(c, "groove.stats"), nodes, roots, c->rfc_trees, buf<double>(c, "groove.xs"), buf<float>(c, "groove.proba"), B);
     LAUNCH(c, "k_groove_kde", k_groove_kde, dim3(B), dim3(256), buf<double>(c, "groove.ptheta"), buf<float>(c, "groove.proba"),
@@ -2431,7 +2435,7 @@ int sh_landmarks_device(sh_ctx* c, void** p, size_t* n) {
 
 // ---- parameters ------------------------------------------------------------------------------------
 static int upload_params(sh_ctx* c) {
-  c->packed_kind = -1; c->packed_x3 = false;
+  c->packed_kind = -1; c->packed_x3 = false; c->packed_rfc = false;
   const size_t N = c->h_feat.size(), T = c->h_roots.size();
   const size_t bytes = c->unet_floats * 4 + N * 4 * 5 + T * 4;
   int rc = ensure(c, "params", bytes ? bytes : 16, 4);
@@ -2478,7 +2482,7 @@ int sh_load_rfc(sh_ctx* c, const int32_t* feat, const float* thr, const int32_t*
   HIPCHK(c, hipSetDevice(c->device));
   c->h_feat.assign(feat, feat + n_nodes); c->h_thr.assign(thr, thr + n_nodes); c->h_ti.assign(ti, ti + n_nodes);
   c->h_fi.assign(fi, fi + n_nodes); c->h_lw.assign(lw, lw + n_nodes); c->h_roots.assign(roots, roots + n_trees);
-  c->rfc_nodes = n_nodes; c->rfc_trees = n_trees; c->have_rfc = true;
+  c->rfc_nodes = n_nodes; c->rfc_trees = n_trees; c->have_rfc = true; c->packed_rfc = false;
   return upload_params(c);
 }
 
@@ -2532,7 +2536,7 @@ int sh_load_unet(sh_ctx* c, int base, int depth, const float* packed, size_t n_f
 
 int sh_param_block_commit(sh_ctx* c) {
   if (!c) return SH_ERR_ARG;
-  c->packed_kind = -1; c->packed_x3 = false;
+  c->packed_kind = -1; c->packed_x3 = false; c->packed_rfc = false;
   auto it = c->bufs.find("params");
   if (it == c->bufs.end()) return fail(c, SH_ERR_STATE, "sh_param_block_commit: no parameters loaded");
   HIPCHK(c, hipSetDevice(c->device));
@@ -2579,7 +2583,7 @@ int sh_param_block_commit(sh_ctx* c) {
 
 int sh_param_block(sh_ctx* c, void** p, size_t* n) {
   if (!c || !p || !n) return SH_ERR_ARG;
-  c->packed_kind = -1; c->packed_x3 = false;      // the caller may write the block from here on (and confirms with sh_param_block_commit)
+  c->packed_kind = -1; c->packed_x3 = false; c->packed_rfc = false;      // the caller may write the block from here on (and confirms with sh_param_block_commit)
   auto it = c->bufs.find("params");
   if (it == c->bufs.end()) return fail(c, SH_ERR_STATE, "sh_param_block: no parameters loaded");
   *p = it->second.p;
