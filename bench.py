@@ -34,6 +34,13 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 PEAK_MFMA_F32_TF = 157.3       # dense f32 MFMA (= vector rate)
 PEAK_MFMA_BF16_TF = 2500.0
+ROUNDS = ("r04", "r03", "r02", "r01")      # committed profile sets, newest first
+
+
+def mfma_peak_tf(unet):
+    """Peak of USEFUL flops per UNet arithmetic: f32 MFMA = the vector rate; f32x issues three 16-bit MFMAs per product (k_unet_x3.h),
+    so its algorithmic flops are priced against a third of the dense 16-bit peak (shared with tools/bench_unet.py)."""
+    return {"f32": PEAK_MFMA_F32_TF, "f32x": PEAK_MFMA_BF16_TF / 3.0}.get(unet, PEAK_MFMA_BF16_TF)
 
 GEOM_KERNELS = ["k_hull_rounds", "k_hull_flag", "k_apply_csys", "k_obb_face_area2", "k_obb_bounds", "k_obb_select", "k_obb_seed", "k_obb_candidates", "k_obb_pick", "k_obb_end_points", "k_obb_ends", "k_transform_verts", "k_make_planes",
                 "k_slice_emit", "k_slice_link", "k_slice_link_large", "k_resample_polar", "k_resample_polar_large", "k_te_rows_large", "k_rfc_pack", "k_obb_seed", "k_neck", "k_canal", "k_groove_rows", "k_groove_scale",
@@ -681,7 +688,7 @@ def main():
             g = sym[dom]
             common = dict(kernel=dom, avg_ms=round(g["ms"] / g["n"], 4), launches=g["n"], share_of_device_time=round(g["ms"] / total_dev, 3), traffic=None)
             if g["flops"] > 0:
-                peak = PEAK_MFMA_F32_TF if args.unet == "f32" else PEAK_MFMA_BF16_TF
+                peak = mfma_peak_tf(args.unet)
                 ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
                 roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                             algorithmic_gbytes_per_launch=round(g["bytes"] / g["n"] / 1e9, 4), **common)
@@ -700,7 +707,7 @@ def main():
         # HBM traffic and MFMA-busy fraction of the dominant kernel from the committed PMC profiles of this same command
         # (rocprofv3 cannot run inside the bench); null when no profile matches the configuration
         if roof:
-            for rnd in ("r03", "r02", "r01"):
+            for rnd in ROUNDS:
                 pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b{B}_{args.unet}.json")
                 if os.path.exists(pmc_path):
                     pk = json.load(open(pmc_path))["kernels"]
@@ -709,13 +716,15 @@ def main():
                         roof["traffic"] = pk[key]["hbm_bytes_per_launch"]
                         roof["traffic_source"] = os.path.relpath(pmc_path, ROOT)
                         break
-            sq_path = os.path.join(ROOT, "profiles", f"r02_pmc_sq_b{B}_{args.unet}.json")
-            if os.path.exists(sq_path):
-                pk = json.load(open(sq_path))["kernels"]
-                key = rocprof_name(dom)
-                if key in pk and "mfma_busy_frac" in pk[key]:
-                    roof["mfma_busy_frac"] = pk[key]["mfma_busy_frac"]
-                    roof["mfma_busy_source"] = os.path.relpath(sq_path, ROOT)
+            for rnd in ROUNDS:
+                sq_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_sq_b{B}_{args.unet}.json")
+                if os.path.exists(sq_path):
+                    pk = json.load(open(sq_path))["kernels"]
+                    key = rocprof_name(dom)
+                    if key in pk and "mfma_busy_frac" in pk[key]:
+                        roof["mfma_busy_frac"] = pk[key]["mfma_busy_frac"]
+                        roof["mfma_busy_source"] = os.path.relpath(sq_path, ROOT)
+                        break
         unet_ms = sum(times[k][0] for k in times if k.startswith("unet."))
         unet_tf = sum(v[0] for v in ul.values()) * B / (unet_ms * 1e-3) / 1e12 if unet_ms else None
         top = sorted(((k, round(v["ms"] / args.steps, 3)) for k, v in sym.items()), key=lambda kv: -kv[1])[:10]
@@ -724,7 +733,7 @@ def main():
         # this implementation's algorithmic bytes for exactly those launches, SURVEY 8(d)'s bytes where it names them, and the
         # memory-side bytes rocprofv3 counted for the same kernel (profiles/, null without a matching profile).
         pmc_geom = {}
-        for rnd in ("r03", "r02"):
+        for rnd in ROUNDS:
             pth = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b{B}_{args.unet}.json")
             if os.path.exists(pth):
                 pmc_geom = json.load(open(pth))["kernels"]

@@ -59,7 +59,12 @@ enum {
  * BF16 / F16  16-bit activations and weights on v_mfma_f32_16x16x32_{bf16,f16}, float32 accumulate (throughput paths;
  *      F16 carries 11 significant bits instead of 8 and needs activations below 65504). */
 enum { SH_UNET_F32 = 0, SH_UNET_BF16 = 1, SH_UNET_F16 = 2,
-       SH_UNET_F32X = 3 };      /* f32 tensors, MFMA layers on split f16 operands (3 MFMAs per product): f32-grade logits at ~5x the f32 rate */
+       SH_UNET_F32X = 3 };      /* f32 tensors, MFMA layers on split f16 operands (3 MFMAs per product): f32-grade logits at ~5x the f32 rate.
+                                 * Range (the operands are pairs of f16 values): weights of the >= 32-channel layers need |w| < 1023.5
+                                 * (= 65504 / 64; a run with a larger weight returns SH_ERR_ARG and names the layer), activations need
+                                 * |x| < 65504 (beyond it an operand's high part is an infinity and the logits NaN, as in F16), and the
+                                 * low part of an activation below 2^-14 falls into f16's subnormals (absolute error <= 2^-25).  The
+                                 * reference's input is an image in [0, 1] (anatomic_neck.py:57); SH_UNET_F32 has none of these limits. */
 /* Which facade class of bone.py the meshes are: `Humerus` (bone.py:110-157) or `ProximalHumerus` (bone.py:24-64: a
  * humerus cut in the shaft -- ProxObb head-end rule and canal range mesh.py:128-192, neck cut-off (0.2, 0.99)
  * surgical_neck.py:25-26, canal cut-offs from the box canal.py:33-38, no distal / trans-epicondylar stage,

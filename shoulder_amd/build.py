@@ -43,7 +43,7 @@ def build_lib(force=False, verbose=True):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-o", LIB] + sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+           "-fno-gpu-rdc", "-Wall", "-Wmisleading-indentation", "-Wno-unused-function", "-o", LIB] + sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     cmd += os.environ.get("SHOULDER_HIPCC_FLAGS", "").split()      # experiments only (e.g. -DSH_... ablation switches)
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -460,9 +460,13 @@ k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ s
 __global__ void __launch_bounds__(SH_LINK_THREADS)
 k_slice_link_large(int nplanes, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs, double* __restrict__ centroids, double* __restrict__ areas,
                    int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total,
-                   const int* __restrict__ nlarge) {
+                   const int* __restrict__ nlarge, unsigned long long* __restrict__ ovf_missed /*null while the overflow tier runs*/) {
   if (*nlarge == 0) return;      // (the usual case: the sweep below is ~75 dependent loads per workgroup for nothing)
   for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
+    // An overflow plane belongs to k_slice_link_huge (k_ovf.h).  When the host skipped that tier for a resident batch "known" to need
+    // none and the planes have moved since (another frame, other parameters), nobody joins this plane: say so, sh_collect runs the
+    // batch again with the tier on instead of handing out the previous run's section.
+    if (seg_count[pl] > SH_MAXSEG && ovf_missed && threadIdx.x == 0) atomicExch(ovf_missed, 1ull);
     if (seg_count[pl] <= SH_SMALLSEG || seg_count[pl] > SH_MAXSEG) continue;
     slice_link_plane<SH_MAXSEG>(pl, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total);
     __syncthreads();

@@ -767,7 +767,8 @@ int sh_buffer_device(sh_ctx* c, const char* name, void** dev_ptr, size_t* nbytes
   if (it == c->bufs.end() || !it->second.p) return fail(c, SH_ERR_ARG, std::string("no buffer named ") + name);
   *dev_ptr = it->second.p;
   if (nbytes) *nbytes = it->second.bytes;
-  if (std::string(name) == "params") c->packed_kind = -1; c->packed_x3 = false; c->packed_rfc = false;      // (the caller may write it)
+  if (std::string(name) == "params") { c->packed_kind = -1; c->packed_x3 = false; c->packed_rfc = false; }      // (the caller may write it)
+  c->ovf_none_gen = ~0ull;      // (... or a frame / an intermediate that moves the planes: the overflow tier runs again)
   return SH_OK;
 }
 
@@ -790,7 +791,7 @@ int sh_store(sh_ctx* c, const char* name, const void* host, size_t nbytes) {
   HIPCHK(c, hipSetDevice(c->device));
   if (std::string(name) == "verts") { (void)join_prepared(c); ++c->batch_gen; c->h_verts_valid = false; }
   c->ovf_none_gen = ~0ull;      // (an injected frame or intermediate moves the planes: the overflow tier runs again)
-  if (std::string(name) == "params") c->packed_kind = -1; c->packed_x3 = false; c->packed_rfc = false;
+  if (std::string(name) == "params") { c->packed_kind = -1; c->packed_x3 = false; c->packed_rfc = false; }
   HIPCHK(c, hipMemcpyAsync(it->second.p, host, nbytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (std::string(name) == "obb_transform") c->obb_injected = true;
@@ -1121,6 +1122,18 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
         if (l.cin < 32 || l.cout < 32) continue;
         tab.push_back(PackEntry{total, (long long)l.w_off, l.taps, l.cin, l.cout, 0});
         total += (long long)l.taps * l.cin * l.cout;
+        // range of the split: 64 w must be a finite f16 (|w| < 65504 / 64); beyond it the high part is an infinity and the layer's
+        // outputs NaN, silently (include/shoulder_hip.h, SH_UNET_F32X)
+        if (c->h_unet.size() >= l.w_off + (size_t)l.taps * l.cin * l.cout) {
+          const float* wl = c->h_unet.data() + l.w_off;
+          for (size_t i = 0, n = (size_t)l.taps * l.cin * l.cout; i < n; ++i)
+            if (!(fabsf(wl[i]) < 65504.0f / X3_WSCALE)) {
+              char m[200];
+              snprintf(m, sizeof m, "SH_UNET_F32X: layer %s has a weight of magnitude %g; the split-f16 operands hold |w| < %g (use SH_UNET_F32 for this network)",
+                       kv.first.c_str(), (double)fabsf(wl[i]), (double)(65504.0f / X3_WSCALE));
+              return fail(c, SH_ERR_ARG, m);
+            }
+        }
       }
       if ((rc = ensure(c, "unet16.packtab", tab.size() * sizeof(PackEntry), 8)) != SH_OK) return rc;
       HIPCHK(c, hipMemcpyAsync(c->bufs["unet16.packtab"].p, tab.data(), tab.size() * sizeof(PackEntry), hipMemcpyHostToDevice, c->stream));
@@ -1564,7 +1577,8 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   LAUNCH(c, "k_slice_link", k_slice_link, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, nlarge);
   LAUNCH(c, "k_slice_link_large", k_slice_link_large, dim3(std::min(B * N, 512)), dim3(SH_LINK_THREADS), B * N, N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
-         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, (const int*)nlarge);
+         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, (const int*)nlarge,
+         ovf_on ? (unsigned long long*)nullptr : OP.ctr + 6);
   if (ovf_on) {
     LAUNCH(c, "k_slice_link_huge", k_slice_link_huge, dim3(64), dim3(SH_HUGE_THREADS), N, (const int*)cnt, OP, OS, buf<double>(c, (p + ".centroids").c_str()),
            buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, ring ? 1 : 0, select, buf<int>(c, "err"), atot);
@@ -2177,7 +2191,7 @@ int sh_discard_prepared(sh_ctx* c) {
 // stages run again as a window of one humerus.  All of it is enqueued on the context's stream: behind a second run that may
 // be in flight (which finished with this batch's scratch buffers by then, and has parked its own results per ticket).
 // hulld.skip[b] is set, so later runs of the resident batch get these humeri right the first time.
-static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot, const std::vector<int>& list) {
+static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot, const std::vector<int>& list, unsigned long long* need /*[4]: pool demand, [3] = rerun*/) {
   const int B = tk.B;
   std::vector<float> hv32;
   std::vector<double> P;
@@ -2224,6 +2238,19 @@ static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot
     HIPCHK(c, hipMemcpyAsync((int*)c->bufs["out.err" + tslot].p + b, buf<int>(c, "err") + b, 4, hipMemcpyDeviceToDevice, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  {
+    // The one-humerus windows above took their overflow ranges from the pools the void first pass had already drawn on, past
+    // sh_collect's grow-and-rerun check.  A dense humerus (the kind the device hull gives up) may have asked for more than the
+    // pools hold: k_ovf_plan flagged it SH_ERR_CAPACITY_DEV.  Report the demand; sh_collect grows the pools and runs the whole
+    // batch again (hulld.skip keeps the device hull off these humeri by then).
+    unsigned long long ctr[8];
+    HIPCHK(c, hipMemcpyAsync(ctr, c->bufs["ovf.ctr"].p, 64, hipMemcpyDeviceToHost, c->out_stream));
+    HIPCHK(c, hipStreamSynchronize(c->out_stream));
+    if (ctr[3] > c->ovf_seg_cap || ctr[4] > c->ovf_ring_cap || ctr[5] > c->ovf_work_cap || ctr[6] != 0) {
+      if (need) { need[0] = ctr[3]; need[1] = ctr[4]; need[2] = ctr[5]; need[3] = 1; }
+      return SH_OK;
+    }
+  }
   if (tk.host_out)
     HIPCHK(c, hipMemcpyAsync(tk.host_out, c->bufs["out.landmarks" + tslot].p, (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->out_stream));
   HIPCHK(c, hipMemcpyAsync(tk.h_err, c->bufs["out.err" + tslot].p, (size_t)B * 4, hipMemcpyDeviceToHost, c->out_stream));
@@ -2365,9 +2392,24 @@ int sh_collect(sh_ctx* c) {
   {
     const unsigned long long need_s = tk.h_ovf[3], need_r = tk.h_ovf[4], need_w = tk.h_ovf[5];
     const uint32_t slice_stages = SH_STAGE_FULL | SH_STAGE_DISTAL | SH_STAGE_NECK | SH_STAGE_PROXIMAL;
-    if (need_r == 0 && need_s == 0 && (tk.mask & slice_stages) == (c->params.bone_kind == SH_BONE_PROXIMAL ? (slice_stages & ~(uint32_t)SH_STAGE_DISTAL) : slice_stages) &&
+    // (only a run that computed its own frame may vouch for the batch: a run on an injected frame says nothing about the planes of
+    // the next SH_STAGE_OBB, and the `pobb` set of a proximal humerus runs inside that stage)
+    if (need_r == 0 && need_s == 0 && (tk.mask & SH_STAGE_OBB) &&
+        (tk.mask & slice_stages) == (c->params.bone_kind == SH_BONE_PROXIMAL ? (slice_stages & ~(uint32_t)SH_STAGE_DISTAL) : slice_stages) &&
         tk.gen == c->batch_gen)
       c->ovf_none_gen = c->batch_gen;
+    if (tk.h_ovf[6] != 0) {
+      // the overflow tier was skipped and a plane needed it (k_slice_link_large): the planes moved after the run that vouched for the
+      // batch.  The records of this run are void -- run it again with the tier on.
+      c->ovf_none_gen = ~0ull;
+      if (c->n_pending != 0)
+        return fail(c, SH_ERR_CAPACITY, "a section needs the overflow tier while another run is in flight: collect it, then run the batch again (the tier is on by then)");
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      const uint32_t mask = tk.mask; sh_landmarks* out = tk.out_arg;
+      int rc2 = sh_submit(c, mask, out);
+      if (rc2 != SH_OK) return rc2;
+      return sh_collect(c);
+    }
     if (getenv("SH_DEBUG")) fprintf(stderr, "[sh] collect: ovf need %llu %llu %llu cap %llu %llu %llu err0 %d\n", need_s, need_r, need_w, c->ovf_seg_cap, c->ovf_ring_cap, c->ovf_work_cap, tk.h_err[0]);
     if (need_s > c->ovf_seg_cap || need_r > c->ovf_ring_cap || need_w > c->ovf_work_cap) {
       // The batch has more overflow planes than the pools hold (a first dense mesh): grow them to what the run asked for,
@@ -2388,8 +2430,22 @@ int sh_collect(sh_ctx* c) {
     std::vector<int> gave_up;
     for (int b = 0; b < tk.B; ++b) if (tk.h_fail[b] != 0) gave_up.push_back(b);
     if (!gave_up.empty()) {
-      int rc2 = redo_given_up(c, tk, tslot, gave_up);
+      unsigned long long need[4] = {0, 0, 0, 0};
+      int rc2 = redo_given_up(c, tk, tslot, gave_up, need);
       if (rc2 != SH_OK) return rc2;
+      if (need[3]) {
+        if (c->n_pending != 0)
+          return fail(c, SH_ERR_CAPACITY, "slice overflow pools too small while another run is in flight: collect it, then run the batch again (the pools are grown by then)");
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->ovf_none_gen = ~0ull;
+        c->ovf_seg_cap = std::max(c->ovf_seg_cap, need[0] + need[0] / 4);
+        c->ovf_ring_cap = std::max(c->ovf_ring_cap, need[1] + need[1] / 4);
+        c->ovf_work_cap = std::max(c->ovf_work_cap, need[2] + need[2] / 4);
+        const uint32_t mask = tk.mask; sh_landmarks* out = tk.out_arg;
+        int rc3 = sh_submit(c, mask, out);
+        if (rc3 != SH_OK) return rc3;
+        return sh_collect(c);
+      }
     }
   }
   for (int b = 0; b < tk.B; ++b)

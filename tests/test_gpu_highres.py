@@ -154,3 +154,88 @@ def test_stl_ingest_of_the_dense_mesh(engine, tmp_path):
     rv, rf = load_stl(os.path.join(BONES, "humerus_right.stl"))
     assert np.array_equal(gv[engine.voff[1]:].view(np.uint32), rv.view(np.uint32)) and np.array_equal(gf[engine.foff[1]:], rf)
     assert (engine.run(_lib.STAGE_ALL)["status"] == 0).all()
+
+
+def test_skipped_overflow_tier_is_caught_when_the_planes_move(unet_weights):
+    """ADVICE r3 (k_slices.h:250): a resident batch whose run planned no overflow plane skips the overflow tier afterwards.  If the
+    planes then move behind the library's back -- here through a device pointer the caller kept (sh_buffer_device) -- a plane
+    can need the tier after all; it used to keep the PREVIOUS run's section without a word.  Now k_slice_link_large reports the
+    missed plane and sh_collect repeats the run with the tier on: same buffers as a context that never skipped anything."""
+    import torch
+    from shoulder_amd import dist as shd, unet_spec
+    from shoulder_amd.engine import Engine
+    v, f = load_stl(os.path.join(BONES, "humerus_left.stl"))
+    v2, f2 = subdivide(v, f)
+    slices = _lib.STAGE_FULL | _lib.STAGE_DISTAL | _lib.STAGE_NECK | _lib.STAGE_PROXIMAL | _lib.STAGE_CANAL
+
+    def fetch_sets(e):
+        out = {}
+        for s, n in (("full", 200), ("distal", 200), ("prox", 600)):
+            out[s + ".seg_count"] = e.fetch(s + ".seg_count", np.int32, (1, n)).copy()
+            out[s + ".areas"] = e.fetch(s + ".areas", np.float64, (1, n)).copy()
+            out[s + ".centroids"] = e.fetch(s + ".centroids", np.float64, (1, n, 2)).copy()
+        return out
+
+    def run_quiet(e, mask):
+        try:
+            e.run(mask, fetch=False)
+            return 0
+        except ShoulderHipError as ex:      # (a humerus cut lengthwise may well fail a later stage: the slice layer is what is compared)
+            return ex.code
+
+    a, b = Engine(0), Engine(0)
+    try:
+        for e in (a, b):
+            e.load_rfc()
+            e.load_unet(unet_weights, unet_spec.BASE, unet_spec.DEPTH)
+            e.upload([(v2, f2)])
+        ptr, nbytes = a.buffer_device("obb_transform")
+        assert run_quiet(a, _lib.STAGE_OBB | slices) == 0               # own frame: no plane beyond the slots -> vouches for the batch
+        assert a.fetch("prox.seg_count", np.int32, (1, 600)).max() <= 1024
+        T = a.fetch("obb_transform", np.float64, (1, 4, 4))[0]
+        P = np.array([[0, 0, 1, 0], [0, 1, 0, 0], [-1, 0, 0, 0], [0, 0, 0, 1.0]])      # z := the box's x axis: sections along the shaft
+        Trot = np.ascontiguousarray(P @ T)
+        shd.as_byte_tensor((ptr, 128), device="cuda:0").copy_(torch.from_numpy(Trot.view(np.uint8).reshape(-1)))      # behind the library's back
+        torch.cuda.synchronize()
+        rc_a = run_quiet(a, slices)
+        got = fetch_sets(a)
+        b.store("obb_transform", Trot.reshape(1, 4, 4))
+        rc_b = run_quiet(b, slices)
+        want = fetch_sets(b)
+        assert max(int(want[s + ".seg_count"].max()) for s in ("full", "distal", "prox")) > 1024      # the moved planes do need the tier
+        assert rc_a == rc_b
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_device_hull_gives_up_a_dense_humerus_and_the_redo_grows_the_pools(dense16, oracle_bones, unet_weights):
+    """ADVICE r3 (redo_given_up): the 519 k-triangle humerus has more prefilter survivors than the device hull takes, so
+    k_hull_rounds gives it up, and it has > 1 024 crossings per plane, so its one-humerus redo asks more of the overflow pools
+    than a fresh context holds.  The redo reports the demand, sh_collect grows the pools and runs the batch again: same records
+    as the host-hull run of the same batch (which test_519k_... holds against the oracle)."""
+    from shoulder_amd import unet_spec
+    from shoulder_amd.engine import Engine
+    v3, f3, _ = dense16
+    small = oracle_bones("humerus_right")
+    recs = {}
+    for mode in ("host", "device"):
+        e = Engine(0)
+        try:
+            e.load_rfc()
+            e.load_unet(unet_weights, unet_spec.BASE, unet_spec.DEPTH)
+            e.set_params(unet_dtype=_lib.UNET_F32)
+            e.set_hull_mode(mode)
+            e.upload([(v3, f3), (small.verts, small.faces)])
+            recs[mode] = e.run(_lib.STAGE_ALL).copy()
+            if mode == "device":
+                assert e.fetch("hulld.fail", np.int32, (2,))[0] != 0 or e.fetch("hulld.skip", np.int32, (2,))[0] == 1      # it really was given up
+                again = e.run(_lib.STAGE_ALL).copy()                     # the resident batch: right the first time now
+                assert again.tobytes() == recs[mode].tobytes()
+        finally:
+            e.close()
+    assert (recs["device"]["status"] == 0).all()
+    for k in ("obb_transform", "canal_axis", "te_axis", "groove_axis", "anp_plane_point", "anp_axis_normal", "anp_axis_central", "csys", "n_anp", "neck_index", "bg_theta"):
+        np.testing.assert_array_equal(recs["device"][k], recs["host"][k], err_msg=k)

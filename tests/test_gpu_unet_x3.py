@@ -87,3 +87,30 @@ def test_register_resident_upconv_bit_identical_f32x(engine, monkeypatch):
     finally:
         monkeypatch.delenv("SHOULDER_X3_UPREG", raising=False)
         engine.set_params(unet_dtype=_lib.UNET_F32)
+
+
+def test_f32x_rejects_weights_beyond_the_split_range(unet_weights):
+    """the split operands are f16 pairs of 64 w, so |w| >= 65504 / 64 would turn into an infinity and the logits
+    into NaN without a word.  Such a network is refused by name (SH_ERR_ARG) on SH_UNET_F32X; the exact f32 path takes it."""
+    from shoulder_amd import unet_spec
+    from shoulder_amd.engine import Engine, ShoulderHipError
+    w = {k: np.array(v, copy=True) for k, v in unet_weights.items()}
+    w["dec2a_w"][1, 1, 5, 7] = 2000.0
+    e = Engine(0)
+    try:
+        e.load_unet(w, unet_spec.BASE, unet_spec.DEPTH)
+        img = np.random.default_rng(3).random((1, 256, 512), dtype=np.float32)
+        e.set_params(unet_dtype=_lib.UNET_F32X)
+        with pytest.raises(ShoulderHipError) as ei:
+            e.unet_infer(img)
+        assert ei.value.code == -1 and "dec2a" in str(ei.value)
+        e.set_params(unet_dtype=_lib.UNET_F32)
+        assert np.isfinite(e.unet_infer(img)).all()
+        w["dec2a_w"][1, 1, 5, 7] = 1000.0                               # inside the range: accepted, finite, close to the f32 path
+        e.load_unet(w, unet_spec.BASE, unet_spec.DEPTH)
+        a = e.unet_infer(img)
+        e.set_params(unet_dtype=_lib.UNET_F32X)
+        b = e.unet_infer(img)
+        assert np.isfinite(b).all() and np.abs(a - b).max() <= 1e-4 * max(1.0, float(np.abs(a).max()))
+    finally:
+        e.close()

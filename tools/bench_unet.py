@@ -40,4 +40,4 @@ for H, W in ((256, 512), (512, 512)):
     eng.enable_timing(False)
     print(json.dumps({"workload": f"UNet alone f32[{args.batch},1,{H},{W}] U(0,1) seed 1234", "dtype": args.unet,
                       "device_ms_per_forward": round(tot_ms, 3), "images_per_s": round(args.batch / tot_ms * 1e3, 1),
-                      "conv_TFLOP_per_s": round(conv_fl / conv_ms * 1e-9, 1), "conv_frac_of_peak": round(conv_fl / conv_ms * 1e-9 / (157.3 if args.unet == "f32" else 2500.0 / 3 if args.unet == "f32x" else 2500.0), 3)}))
+                      "conv_TFLOP_per_s": round(conv_fl / conv_ms * 1e-9, 1), "conv_frac_of_peak": round(conv_fl / conv_ms * 1e-9 / bench.mfma_peak_tf(args.unet), 3)}))
