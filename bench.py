@@ -317,6 +317,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not compute the host hulls of step k+1 during the device work of step k")
     ap.add_argument("--from-host", action="store_true", help="re-upload the batch from host memory every step (PCIe-inclusive rate)")
     ap.add_argument("--from-stl", action="store_true", help="every step starts from the bytes of B binary STL files (device-side parse + vertex merge, sh_upload_stl)")
+    ap.add_argument("--sync-upload", action="store_true", help="with --from-host / --from-stl: hand every batch over with the synchronous sh_upload_* (round 2's schedule) instead of the staging side (sh_stage_* / sh_commit_staged)")
+    ap.add_argument("--stream-batches", type=int, default=4, help="distinct batches the streaming legs cycle through (every step gets a batch different from the one its lane holds)")
     ap.add_argument("--hull", choices=["auto", "host", "device"], default="auto", help="where the convex hull of the OBB stage runs (sh_set_hull_mode); "
                     "auto = host quickhull where the rank has enough usable hardware threads (16 alone on its host, 48 per rank otherwise), else the device hull")
     ap.add_argument("--check-gather", action="store_true", help="after the timed region rank 0 compares the records the last gather delivered for its own shard with a run of its own engine")
@@ -398,15 +400,19 @@ def main():
     T = synth.similarity_transforms(B, verts, seed=1234, start=rank * B)
     host_batch = None
     stl_blobs = None
-    if args.from_stl:       # STL bytes -> landmarks: the files of the synthetic batch are serialised here, outside the timed region
-        stl_blobs = [stl_bytes(synth.apply_similarity(T[i], verts), faces) for i in range(B)]
-        for e in engs:
-            e.upload_stl(stl_blobs)
-        host_batch = stl_blobs
-    elif args.from_host:      # PCIe-inclusive variant (never the headline `value`): the meshes are handed over as host buffers every step
-        host_batch = [(synth.apply_similarity(T[i], verts), faces) for i in range(B)]
-        for e in engs:
-            e.upload(host_batch)
+    stream = None      # the PCIe-inclusive variants (never the headline `value`): a NEW batch is handed over for every step
+    if args.from_stl or args.from_host:
+        stream = make_stream("stl" if args.from_stl else "host", verts, faces, B, args.stream_batches, start=rank * B)
+        if args.from_stl:
+            stl_blobs = host_batch = stream["batches"][0]
+            for e in engs:
+                e.upload_stl(stl_blobs)
+        else:
+            host_batch = stream["batches"][0]
+            for e in engs:
+                e.upload_packed(host_batch)
+        if args.sync_upload or args.no_pipeline:
+            stream = None
     else:
         for e in engs:
             e.upload([(verts, faces)])
@@ -424,12 +430,21 @@ def main():
         if stl_blobs is not None:
             e.upload_stl(stl_blobs)
         elif host_batch is not None:
-            e.upload(host_batch)
+            e.upload_packed(host_batch)
 
-    def run_leg(leg_engs, unet, steps, warmup, pipelined):
+    leg_info = {"error_status": 0, "records": 0}
+
+    def run_leg(leg_engs, unet, steps, warmup, pipelined, stream=None):
         """`warmup` untimed steps, then exactly `steps` timed steps of SH_STAGE_ALL on `leg_engs` (step s on lane s % len),
-        bracketed by barrier + synchronize on both sides.  -> (seconds: max over ranks, per-layer HIP-event times of the region)."""
+        bracketed by barrier + synchronize on both sides.  -> (seconds: max over ranks, per-layer HIP-event times of the region).
+        `stream` (make_stream): step s works on batch s % n of the stream, handed over through the lane's staging side -- staged
+        right behind the lane's previous submit (copies, device-side checks / STL merge and hulls run beside that step), committed
+        when that step has been collected; every stage, commit, submit and collect of the K steps lies inside the timed region."""
         nl = len(leg_engs)
+        nb_ = len(stream["batches"]) if stream else 0
+
+        def stage_for(e, k):
+            (e.stage_stl if stream["kind"] == "stl" else e.stage)(stream["batches"][k % nb_])
         for e in leg_engs:
             e.set_params(unet_dtype=UNET_ENUM[unet])
             e.set_overlap(False)
@@ -450,7 +465,8 @@ def main():
         # off before the last step): K hull passes and K device passes lie between t0 and t1.
         for e in leg_engs:
             e.discard_prepared()
-            e.set_overlap(overlap)
+            e.set_overlap(overlap and not stream)      # (a streamed batch runs once: its hulls are prepared by the staging side)
+        leg_info.update(error_status=0, records=0)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -460,12 +476,15 @@ def main():
             # device goes from one step to the next without waiting for the host and the lanes' streams overlap; the records of a
             # step are collected (and gathered) once `depth` later steps are enqueued.  All K submits and all K collects lie
             # inside the timed region.
-            depth = int(os.environ.get("SH_BENCH_DEPTH", "0")) or (nl if nl > 1 else 2)      # steps in flight (an engine takes two)
+            depth = int(os.environ.get("SH_BENCH_DEPTH", "0")) or (nl if (nl > 1 or stream) else 2)      # steps in flight (an engine takes two; a lane that streams, one)
             trace_host = os.environ.get("SH_BENCH_TRACE") == "1" and rank == 0
             pend = []
 
             def finish(k, e):
-                e.collect()
+                rec = e.collect()
+                if rec is not None:
+                    leg_info["error_status"] += int((rec["status"] != 0).sum())
+                    leg_info["records"] += len(rec)
                 if use_dist:
                     # asynchronous on the host: the gather is enqueued on torch's stream behind the finished run (collect waited
                     # for its event) and an event behind it says when send[k] may be overwritten -- the host goes straight on
@@ -480,7 +499,12 @@ def main():
                     e.set_overlap(False)                           # the last step of a lane prepares nothing
                 if len(pend) >= depth:
                     finish(*pend.pop(0))
-                hand_over(e)       # (the lane is idle here: its previous step was collected above)
+                if stream:         # (the lane is idle here: its previous step was collected above)
+                    if not e.staged:
+                        stage_for(e, s_)      # the lane's first step of the region: nothing was staged ahead
+                    e.commit_staged()
+                else:
+                    hand_over(e)
                 ts_ = time.perf_counter()
                 if use_dist:
                     if send_free[s_ % nsend] is not None:
@@ -491,6 +515,8 @@ def main():
                 if trace_host:
                     print("[bench] step %d lane %d: submit returned after %.2f ms (at %.2f ms of the region)" % (s_, s_ % nl, 1e3 * (time.perf_counter() - ts_), 1e3 * (time.perf_counter() - t0)), file=sys.stderr)
                 pend.append((s_, e))
+                if stream and s_ + nl < steps:
+                    stage_for(e, s_ + nl)      # the batch of this lane's NEXT step: copied, checked, merged and hulled beside this one
             for k_e in pend:
                 finish(*k_e)
         else:
@@ -523,7 +549,7 @@ def main():
         return el, region, ul_
 
     pipelined = not args.no_pipeline
-    el, region_times, ul = run_leg(engs, args.unet, args.steps, args.warmup, pipelined)
+    el, region_times, ul = run_leg(engs, args.unet, args.steps, args.warmup, pipelined, stream)
 
     eng.enable_timing(1)
     eng.run(_lib.STAGE_ALL, fetch=False)      # profiling pass outside the timed region, one lane alone: every kernel between events
@@ -655,6 +681,30 @@ def main():
             e1.close()
             extra["one_lane"] = {"value": round(B * args.steps / el1, 3), "unit": "meshes/s", "steps": args.steps, "warmup": 1,
                                  "ms_per_step": round(1e3 * el1 / args.steps, 3), "lanes": 1}
+
+        if pipelined:
+            # A stream of NEW batches (the reference's unit of work is a new STL): every step gets a batch its lane does not hold --
+            # page-locked staging, H2D, device-side checks (from_host) or parse + vertex merge (from_stl), hull prefilter and host
+            # hulls of step k + 2 all run beside step k of the same lane (sh_stage_* / sh_commit_staged); PCIe inclusive, never `value`.
+            for kind in ("host", "stl"):
+                st_engs = [Engine(local) for _ in range(2)]
+                strm = make_stream(kind, verts, faces, B, args.stream_batches)
+                for e in st_engs:
+                    e.load_rfc()
+                    e.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
+                    e.set_hull_mode(eng.hull_mode)
+                    e.set_unet_turns(True)
+                    (e.upload_stl if kind == "stl" else lambda b: e.upload_packed(b))(strm["batches"][-1])
+                el_s, _, _ = run_leg(st_engs, args.unet, args.steps, 1, True, strm)
+                extra["from_" + kind] = {"value": round(B * args.steps / el_s, 3), "unit": "meshes/s", "steps": args.steps, "warmup": 1,
+                                         "ms_per_step": round(1e3 * el_s / args.steps, 3), "lanes": 2, "distinct_batches": len(strm["batches"]),
+                                         "records": leg_info["records"], "meshes_with_error_status": leg_info["error_status"],
+                                         "input": ("B binary STL images per step (104 MB): page-locked staging, H2D, parse + vertex merge on the device" if kind == "stl" else
+                                                   "packed float32 vertices + int32 faces per step (37 MB, pageable caller memory): page-locked staging, H2D, checks on the device")
+                                                  + "; staged beside the lane's previous step, all inside the timed region"}
+                for e in st_engs:
+                    e.close()
+                del strm
 
     if rank == 0:
         ul_cout = unet_couts(unet_spec.BASE, unet_spec.DEPTH)
@@ -832,6 +882,20 @@ def single_humerus_leg(device, weights, verts, faces, reps=10):
             "facade_readme_flow_ms": round(med(fw), 3), "facade_readme_flow_ms_min": round(min(fw), 3),
             "facade_flow": "Humerus(stl) -> apply_csys_canal_transepiconylar() -> canal.axis(), trans_epiconylar.axis(), anatomic_neck.points(), bicipital_groove.axis(); file read + parse included",
             "landmarks_checked": int(len(got)), "parity": PARITY_NOTE["f32"]}
+
+
+def make_stream(kind, verts, faces, B, nbatches, start=0):
+    """`nbatches` DISTINCT batches of B humeri (similarity copies of the template, seed 1234, transforms start + k B ...), as the
+    caller of a streaming pipeline would hold them in host memory: kind "host" -> the four packed arrays of sh_stage_meshes
+    (pageable NumPy memory), kind "stl" -> B binary STL images per batch.  Built outside every timed region."""
+    from shoulder_amd import synth
+    from shoulder_amd.engine import Engine
+    out = []
+    for k in range(nbatches):
+        T = synth.similarity_transforms(B, verts, seed=1234, start=start + k * B)
+        meshes = [(synth.apply_similarity(T[i], verts), faces) for i in range(B)]
+        out.append([stl_bytes(v, f) for v, f in meshes] if kind == "stl" else Engine.pack_meshes(meshes))
+    return {"kind": kind, "batches": out}
 
 
 def stl_bytes(verts, faces):

@@ -151,6 +151,23 @@ int  sh_upload_meshes(sh_ctx*, const float* verts /* sumV x 3 */, const int32_t*
  * one, numbered by first appearance in the file; triangles that use a vertex twice are dropped.  v_off_out / f_off_out
  * (B+1 each, nullable) receive the resulting offsets. */
 int  sh_upload_stl(sh_ctx*, const void* const* files, const size_t* nbytes, int B, int64_t* v_off_out, int64_t* f_off_out);
+/* A stream of NEW batches (the reference's unit of work is a new STL: mesh.py:22-27, bone.py:110-131).  sh_upload_* hands a
+ * batch over synchronously; the staging calls hand the NEXT batch over while a run of the resident one executes:
+ *   sh_stage_meshes / sh_stage_stl  same arguments and checks as sh_upload_meshes / sh_upload_stl.  The arrays / files go
+ *     through page-locked staging (copied by worker threads before the call returns; page-locked caller memory -- sh_host_alloc --
+ *     is read in place and must stay unchanged until sh_commit_staged has returned) into buffers of their own on a copy stream,
+ *     element checks and the STL parse / vertex merge run on the device, and the convex hulls of the staged batch (host hull
+ *     mode) are computed by a background thread.  Returns at once.  One batch can be staged at a time; staging again, or any
+ *     sh_upload_* / sh_synth_batch, replaces it.
+ *   sh_commit_staged  makes the staged batch the resident one (buffer entries are swapped, nothing is copied).  Needs the context
+ *     idle (sh_collect every run first).  Reports what sh_upload_* would have reported for a bad batch (SH_ERR_ARG; the resident
+ *     batch stays).  The next sh_submit / sh_run finds the hulls prepared.  v_off_out / f_off_out (B+1 each, nullable): offsets.
+ * A run submitted between stage and commit belongs to the resident batch and voids the staged batch's prepared hulls (they are
+ * computed again by its first run).  Records are identical to sh_upload_* followed by the same runs. */
+int  sh_stage_meshes(sh_ctx*, const float* verts, const int32_t* faces, const int64_t* v_off, const int64_t* f_off, int B);
+int  sh_stage_stl(sh_ctx*, const void* const* files, const size_t* nbytes, int B);
+int  sh_commit_staged(sh_ctx*, int64_t* v_off_out, int64_t* f_off_out);
+int  sh_staged(const sh_ctx*);      /* 1 while a staged batch waits for its commit */
 /* Synthetic batch (BASELINE config 3/4): mesh i = similarity transform T[i] (4x4, float64)
  * of uploaded mesh 0, evaluated on the device in float64 and stored as float32. */
 int  sh_synth_batch(sh_ctx*, const double* T /* B x 16 */, int B);

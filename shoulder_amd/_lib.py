@@ -66,6 +66,7 @@ EXPORTS = ["sh_ctx_create", "sh_ctx_destroy", "sh_last_error", "sh_default_param
            "sh_load_unet", "sh_param_block", "sh_upload_meshes", "sh_synth_batch", "sh_batch_size", "sh_run",
            "sh_landmarks_device", "sh_affine_apply", "sh_mesh_transformed", "sh_transform_points", "sh_section_plane", "sh_buffer_info", "sh_fetch", "sh_store",
            "sh_kernel_time_ms", "sh_enable_timing", "sh_set_overlap", "sh_discard_prepared", "sh_unet_infer", "sh_host_alloc", "sh_host_free", "sh_upload_stl", "sh_submit", "sh_collect",
+           "sh_stage_meshes", "sh_stage_stl", "sh_commit_staged", "sh_staged",
            "sh_slice_mesh_planes", "sh_set_unet_turns", "sh_get_params", "sh_buffer_device", "sh_param_block_commit", "sh_set_hull_mode", "sh_get_hull_mode", "sh_ring"]
 
 _lib = None
@@ -135,6 +136,10 @@ def load(build_if_missing=True):
     L.sh_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.sh_host_free.argtypes = [vp, vp]
     L.sh_upload_stl.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, vp, vp]
+    L.sh_stage_meshes.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int]
+    L.sh_stage_stl.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int]
+    L.sh_commit_staged.argtypes = [vp, vp, vp]
+    L.sh_staged.argtypes = [vp]
     L.sh_unet_infer.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     _lib = L
     return L

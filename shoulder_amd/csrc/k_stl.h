@@ -138,4 +138,22 @@ __global__ void k_stl_emit(const float* __restrict__ corners, const long long* _
   }
 }
 
+// What sh_upload_meshes checks on the host, for a batch that is staged asynchronously (sh_stage_meshes): every face index inside
+// its mesh, every coordinate finite.  flag |= 1 / 2.
+__global__ void k_validate_meshes(const float* __restrict__ verts, const int* __restrict__ faces, const long long* __restrict__ voff,
+                                  const long long* __restrict__ foff, int* __restrict__ flag) {
+  const int b = blockIdx.y;
+  const long long v0 = voff[b], nv = voff[b + 1] - v0, f0 = foff[b], nf = foff[b + 1] - f0;
+  int bad = 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < 3 * nf; i += (long long)gridDim.x * blockDim.x) {
+    const int id = faces[3 * f0 + i];
+    if (id < 0 || id >= nv) bad |= 1;
+  }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < 3 * nv; i += (long long)gridDim.x * blockDim.x) {
+    const float x = verts[3 * v0 + i];
+    if (!(fabsf(x) <= 3.402823466e+38f)) bad |= 2;
+  }
+  if (bad) atomicOr(flag, bad);
+}
+
 }  // namespace sh

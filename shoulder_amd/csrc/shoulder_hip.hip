@@ -97,10 +97,28 @@ struct sh_ctx {
   // device-generated batches: the hull's points come back through the prefilter (k_hullpre.h) into pinned memory
   float* h_kept = nullptr; long long h_kept_cap = 0;
   int* h_nkept = nullptr; int h_nkept_cap = 0;
-  const float* hull_src = nullptr;           // what hull_host_phase reads: h_verts.data() or h_kept
-  std::vector<long long> hull_off;           // first point of humerus b in hull_src
-  std::vector<int> hull_cnt;                 // points of humerus b in hull_src
+  struct HullPts { const float* src = nullptr;            // what hull_host_phase reads: h_verts.data() or the pinned survivors
+                   std::vector<long long> off;            // first point of humerus b in src
+                   std::vector<int> cnt; };               // points of humerus b in src
+  HullPts hull_in;                           // ... of the resident batch
   long long* h_koff = nullptr;               // pinned: offsets of the survivors (B + 1)
+  // The STAGING SIDE of the mesh slot (sh_stage_meshes / sh_stage_stl / sh_commit_staged): the next batch is copied into buffers of
+  // its own ("verts.s", "faces.s", "voff.s", "foff.s") on the copy stream while a run of the resident batch executes, its hull
+  // points come back through a prefilter scratch of its own ("hullpre.*.s") and its hulls are computed by the background thread
+  // (`prep`, gen = batch_gen + 1) -- sh_commit_staged then only swaps the buffer entries and the next sh_submit finds its hulls.
+  struct StageSide {
+    bool active = false, from_stl = false;
+    int B = 0; long long sumV = 0, sumF = 0, maxV = 0, maxF = 0;
+    std::vector<long long> voff, foff;
+    void* h_src = nullptr; size_t h_src_cap = 0;            // pinned staging of the caller's arrays / files
+    int* h_flag = nullptr;                                  // pinned: validation word (+ STL: counts and non-finite words behind it)
+    size_t h_flag_cap = 0;
+    float* h_kept = nullptr; long long h_kept_cap = 0;      // pinned: prefilter survivors of the staged batch
+    long long* h_koff = nullptr; int h_koff_cap = 0;
+    HullPts pts;
+    hipEvent_t ready_ev = nullptr;                          // everything the commit needs is on the device
+    std::mutex m; std::condition_variable cv; bool meta_ready = true; int meta_rc = 0; std::string meta_err;      // STL: sizes known
+  } stg;
   // Window of the batch the stage runner is working on: sh_run walks the batch in windows so that the
   // host hull of window k+1 overlaps the device work of window k.  buf<T>() applies the offset.
   int b0 = 0, Bwin = 0;
@@ -115,6 +133,7 @@ struct sh_ctx {
     std::thread th; bool active = false; int slot = 0, B = 0, rc = SH_OK, bad_mesh = -1; unsigned long long gen = 0;
     double d2h_ms = 0, hull_ms = 0; std::string err;
     bool uploaded = false;      // the hull records are already in the device buffers (copied by the background thread)
+    bool staged = false;        // the thread works for the STAGED batch (gen = the generation the batch gets at sh_commit_staged)
   } prep;
   hipEvent_t obb_done_ev = nullptr;      // recorded after the last kernel of a run that reads the hull.* device buffers
   // sh_submit / sh_collect: up to two runs in flight (the second one is enqueued while the first still executes)
@@ -128,6 +147,7 @@ struct sh_ctx {
   hipEvent_t unet_done_ev = nullptr;
   unsigned long long batch_gen = 0;
   hipStream_t copy_stream = nullptr;
+  hipEvent_t stl_counted_ev = nullptr;      // sh_stage_stl: the device has counted the merged vertices / faces
   // side stream of the stage runner: the distal slice set and the rectangles of the trans-epicondylar stage hang on nothing but the
   // box frame, so they run beside the full -> neck -> proximal chain (SHOULDER_SIDE_STREAM=0: everything on the one stream)
   hipStream_t side_stream = nullptr;
@@ -355,10 +375,17 @@ void sh_ctx_destroy(sh_ctx* c) {
   unet_turn_forget(c);
   if (c->unet_done_ev) (void)hipEventDestroy(c->unet_done_ev);
   drain_timers(c);
+  if (c->stl_counted_ev) (void)hipEventDestroy(c->stl_counted_ev);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
   if (c->side_fork_ev) (void)hipEventDestroy(c->side_fork_ev);
   if (c->side_join_ev) (void)hipEventDestroy(c->side_join_ev);
+  if (c->stg.active) (void)hipEventSynchronize(c->stg.ready_ev);
+  if (c->stg.h_src) (void)hipHostFree(c->stg.h_src);
+  if (c->stg.h_flag) (void)hipHostFree(c->stg.h_flag);
+  if (c->stg.h_kept) (void)hipHostFree(c->stg.h_kept);
+  if (c->stg.h_koff) (void)hipHostFree(c->stg.h_koff);
+  if (c->stg.ready_ev) (void)hipEventDestroy(c->stg.ready_ev);
   if (c->h_kept) (void)hipHostFree(c->h_kept);
   if (c->h_nkept) (void)hipHostFree(c->h_nkept);
   if (c->h_koff) (void)hipHostFree(c->h_koff);
@@ -376,6 +403,7 @@ void sh_ctx_destroy(sh_ctx* c) {
 }
 
 static int join_prepared(sh_ctx* c);
+static void discard_staged(sh_ctx* c);
 
 const char* sh_last_error(const sh_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
@@ -611,7 +639,7 @@ int sh_upload_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const 
   const long long sumV = v_off[B], sumF = f_off[B];
   for (long long i = 0; i < 3 * sumV; ++i)
     if (!std::isfinite(verts[i])) return fail(c, SH_ERR_ARG, "sh_upload_meshes: NaN / infinite vertex coordinate");
-  (void)join_prepared(c); ++c->batch_gen;      // hulls prepared for the previous batch are void
+  discard_staged(c); (void)join_prepared(c); ++c->batch_gen;      // hulls prepared for the previous batch are void
   c->B = 0;                                     // (a HIP / allocation failure below leaves "no meshes uploaded", never a half-committed batch)
   c->h_voff.assign(v_off, v_off + B + 1);
   c->h_foff.assign(f_off, f_off + B + 1);
@@ -638,6 +666,7 @@ int sh_upload_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const 
 int sh_upload_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int B, int64_t* v_off_out, int64_t* f_off_out) {
   if (!c || !files || !nbytes || B <= 0) return fail(c, SH_ERR_ARG, "sh_upload_stl: bad argument");
   HIPCHK(c, hipSetDevice(c->device));
+  discard_staged(c);      // (a staged STL batch works in the same stl.* scratch)
   std::vector<long long> file_off(B + 1, 0), coff(B + 1, 0);
   long long maxc = 0;
   for (int b = 0; b < B; ++b) {
@@ -693,7 +722,7 @@ int sh_upload_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int
     n_foff[b + 1] = n_foff[b] + counts[2 * b + 1];
     maxV = std::max<long long>(maxV, counts[2 * b]); maxF = std::max<long long>(maxF, counts[2 * b + 1]);
   }
-  (void)join_prepared(c); ++c->batch_gen;
+  discard_staged(c); (void)join_prepared(c); ++c->batch_gen;
   c->B = 0;                        // (a HIP / allocation failure below leaves "no meshes uploaded")
   c->h_voff.swap(n_voff); c->h_foff.swap(n_foff);
   c->maxV = maxV; c->maxF = maxF;
@@ -720,7 +749,7 @@ int sh_synth_batch(sh_ctx* c, const double* T, int B) {
   if (!c || !T || B <= 0) return fail(c, SH_ERR_ARG, "sh_synth_batch: bad argument");
   if (c->B < 1) return fail(c, SH_ERR_STATE, "sh_synth_batch: upload a template mesh first");
   HIPCHK(c, hipSetDevice(c->device));
-  (void)join_prepared(c); ++c->batch_gen;
+  discard_staged(c); (void)join_prepared(c); ++c->batch_gen;
   const long long V = c->h_voff[1] - c->h_voff[0], F = c->h_foff[1] - c->h_foff[0];
   // keep the template aside
   int rc;
@@ -789,7 +818,7 @@ int sh_store(sh_ctx* c, const char* name, const void* host, size_t nbytes) {
   if (it == c->bufs.end()) return fail(c, SH_ERR_ARG, std::string("no buffer named ") + name);
   if (nbytes > it->second.bytes) return fail(c, SH_ERR_ARG, std::string("sh_store: size exceeds buffer ") + name);
   HIPCHK(c, hipSetDevice(c->device));
-  if (std::string(name) == "verts") { (void)join_prepared(c); ++c->batch_gen; c->h_verts_valid = false; }
+  if (std::string(name) == "verts") { discard_staged(c); (void)join_prepared(c); ++c->batch_gen; c->h_verts_valid = false; }
   c->ovf_none_gen = ~0ull;      // (an injected frame or intermediate moves the planes: the overflow tier runs again)
   if (std::string(name) == "params") { c->packed_kind = -1; c->packed_x3 = false; c->packed_rfc = false; }
   HIPCHK(c, hipMemcpyAsync(it->second.p, host, nbytes, hipMemcpyHostToDevice, c->stream));
@@ -1616,13 +1645,31 @@ static void launch_prefilter(const HullPre& hp, int B, hipStream_t st) {
                      (const long long*)hp.poff, hp.kept, hp.pcnt);
 }
 
+// survivors of the device prefilter of a batch of B humeri (sumV vertices in all) -> pinned h_kept / h_koff, described by *out
+static hipError_t fetch_prefiltered(const HullPre& hp, int B, long long sumV, long long* h_koff, float* h_kept, sh_ctx::HullPts* out, hipStream_t st) {
+  hipError_t e;
+  launch_prefilter(hp, B, st);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync(h_koff, hp.koff, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  const long long total = h_koff[B];
+  if (total < 0 || total > sumV) return hipErrorUnknown;
+  if (total > 0 && (e = hipMemcpyAsync(h_kept, hp.kept, (size_t)total * 12, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;      // one copy for the batch
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+  out->off.resize(B); out->cnt.resize(B);
+  for (int b = 0; b < B; ++b) { out->off[b] = h_koff[b]; out->cnt[b] = (int)(h_koff[b + 1] - h_koff[b]); }
+  out->src = h_kept;
+  return hipSuccess;
+}
+
 static hipError_t fetch_hull_points(sh_ctx* c, const HullPre& hp, hipStream_t st) {
   const int B = c->B;
-  c->hull_cnt.resize(B);
+  sh_ctx::HullPts& in = c->hull_in;
+  in.cnt.resize(B);
   if (c->h_verts_valid) {
-    c->hull_off.assign(c->h_voff.begin(), c->h_voff.begin() + B);
-    for (int b = 0; b < B; ++b) c->hull_cnt[b] = (int)(c->h_voff[b + 1] - c->h_voff[b]);
-    c->hull_src = c->h_verts.data();
+    in.off.assign(c->h_voff.begin(), c->h_voff.begin() + B);
+    for (int b = 0; b < B; ++b) in.cnt[b] = (int)(c->h_voff[b + 1] - c->h_voff[b]);
+    in.src = c->h_verts.data();
     return hipSuccess;
   }
   static const bool prefilter = !(getenv("SHOULDER_HULL_PREFILTER") && getenv("SHOULDER_HULL_PREFILTER")[0] == '0');
@@ -1631,23 +1678,12 @@ static hipError_t fetch_hull_points(sh_ctx* c, const HullPre& hp, hipStream_t st
     c->h_verts.resize(3 * (size_t)c->sumV);
     if ((e = hipMemcpyAsync(c->h_verts.data(), hp.verts, c->sumV * 3 * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    c->hull_off.assign(c->h_voff.begin(), c->h_voff.begin() + B);
-    for (int b = 0; b < B; ++b) c->hull_cnt[b] = (int)(c->h_voff[b + 1] - c->h_voff[b]);
-    c->hull_src = c->h_verts.data();
+    in.off.assign(c->h_voff.begin(), c->h_voff.begin() + B);
+    for (int b = 0; b < B; ++b) in.cnt[b] = (int)(c->h_voff[b + 1] - c->h_voff[b]);
+    in.src = c->h_verts.data();
     return hipSuccess;
   }
-  launch_prefilter(hp, B, st);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(c->h_koff, hp.koff, (size_t)(B + 1) * 8, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-  const long long total = c->h_koff[B];
-  if (total < 0 || total > c->sumV) return hipErrorUnknown;
-  if (total > 0 && (e = hipMemcpyAsync(c->h_kept, hp.kept, (size_t)total * 12, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;      // one copy for the batch
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-  c->hull_off.resize(B);
-  for (int b = 0; b < B; ++b) { c->hull_off[b] = c->h_koff[b]; c->hull_cnt[b] = (int)(c->h_koff[b + 1] - c->h_koff[b]); }
-  c->hull_src = c->h_kept;
-  return hipSuccess;
+  return fetch_prefiltered(hp, B, c->sumV, c->h_koff, c->h_kept, &in, st);
 }
 
 // Process-wide worker pool of the host hull phase.  A job is a callable every participating thread runs to completion
@@ -1735,7 +1771,7 @@ struct HullPhaseGate {
   static HullPhaseGate& instance() { static HullPhaseGate g; return g; }
 };
 
-static int hull_host_phase(sh_ctx* c, int slot, int b0, int B, int* bad_mesh, double* ms, std::string* errtxt, bool background = false) {
+static int hull_host_phase(sh_ctx* c, const sh_ctx::HullPts& in, int slot, int b0, int B, int* bad_mesh, double* ms, std::string* errtxt, bool background = false) {
   auto t0 = std::chrono::steady_clock::now();
   sh_ctx::HullStage& hs = c->hstage[slot];
 #define HULLCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *errtxt = std::string(#call) + ": " + hipGetErrorString(e_); return SH_ERR_HIP; } } while (0)
@@ -1779,9 +1815,9 @@ again:
       int b = next.fetch_add(1);
       if (b >= B) break;
       counts[b] = counts[B + b] = counts[2 * B + b] = 0;
-      long long v0 = c->hull_off[b0 + b], nv = c->hull_cnt[b0 + b];
+      long long v0 = in.off[b0 + b], nv = in.cnt[b0 + b];
       P.resize(3 * (size_t)nv);
-      const float* src = c->hull_src + 3 * v0;
+      const float* src = in.src + 3 * v0;
       for (long long i = 0; i < 3 * nv; ++i) P[i] = (double)src[i];
       if (!shhull::convex_hull(P.data(), (int)nv, H)) { status[b] = SH_ERR_GEOMETRY; continue; }
       int hn = (int)H.vert_ids.size(), fn = (int)H.tris.size() / 3, en = (int)H.edges.size() / 4;
@@ -1863,7 +1899,7 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   if (slot < 0) {
     slot = c->hslot; c->hslot ^= 1;
     int bad = -1; double ms = 0; std::string et;
-    int hrc = hull_host_phase(c, slot, b0, B, &bad, &ms, &et);
+    int hrc = hull_host_phase(c, c->hull_in, slot, b0, B, &bad, &ms, &et);
     if (getenv("SH_DEBUG")) fprintf(stderr, "[sh] run_obb: foreground hull phase %.2f ms\n", ms);
     if (c->timing) { KTimer& h = c->timers["host.hull"]; h.ms += ms; h.n += 1; }
     if (hrc == SH_ERR_HIP) { c->err = et; return hrc; }
@@ -2141,7 +2177,7 @@ static int join_prepared(sh_ctx* c) {
 static void start_prepare(sh_ctx* c) {
   sh_ctx::Prepared& p = c->prep;
   p.active = true; p.slot = c->hslot; p.B = c->B; p.gen = c->batch_gen; p.rc = SH_OK; p.bad_mesh = -1; p.d2h_ms = p.hull_ms = 0; p.err.clear();
-  p.uploaded = false;
+  p.uploaded = false; p.staged = false;
   // device pointers are looked up here: the buffer map belongs to the calling thread
   const HullPre hp = hullpre_ptrs(c);
   struct Dst { void* p[6]; } dst = {{buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), buf<int>(c, "hull.nv"), buf<int>(c, "hull.nf"), buf<int>(c, "hull.ne")}};
@@ -2155,7 +2191,7 @@ static void start_prepare(sh_ctx* c) {
       if (fetch_hull_points(c, hp, c->copy_stream) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
       q.d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    q.rc = hull_host_phase(c, q.slot, 0, q.B, &q.bad_mesh, &q.hull_ms, &q.err, true);
+    q.rc = hull_host_phase(c, c->hull_in, q.slot, 0, q.B, &q.bad_mesh, &q.hull_ms, &q.err, true);
     if (q.rc == SH_OK && can_upload) {
       // the records go to the device as soon as the running step no longer reads the hull.* buffers (after its k_obb_pick)
       if (hipStreamWaitEvent(c->copy_stream, c->obb_done_ev, 0) == hipSuccess && hull_upload(c, q.slot, q.B, dst.p, c->copy_stream) == hipSuccess &&
@@ -2184,6 +2220,343 @@ int sh_discard_prepared(sh_ctx* c) {
   c->prep.gen = ~0ull;
   return SH_OK;
 }
+
+// ---- the staging side of the mesh slot: a stream of NEW batches at the resident rate -------------------------------------------
+// The reference's unit of work is a new STL (mesh.py:22-27, bone.py:110-131).  sh_upload_* hands a batch over synchronously:
+// host-side validation, pageable copies, a stream synchronize, and hulls that can only start once the run is submitted.  The
+// staging calls below do the same hand-over beside a run of the resident batch:
+//   sh_stage_meshes / sh_stage_stl   copy the caller's arrays / files through page-locked staging (worker threads) or straight
+//                    from page-locked caller memory, enqueue the H2D copies, the validation (on the device) -- for STL files
+//                    the parse / vertex-merge kernels of k_stl.h -- and the hull prefilter on the COPY stream, start the
+//                    background hull thread, and return;
+//   sh_commit_staged waits for the copies (long done when a run was in flight meanwhile), swaps the buffer entries of the two
+//                    sides and makes the staged batch the resident one; the next sh_submit finds its hulls prepared.
+// One batch can be staged at a time; commit needs the context idle (sh_collect first): the buffers that become the staging side
+// are the ones the collected run read.  A rejected batch (bad index, NaN, not an STL) is reported by sh_commit_staged and leaves
+// the resident batch untouched.  Records are identical to sh_upload_* + sh_run: same device buffers, same kernels.
+static void discard_staged(sh_ctx* c) {
+  sh_ctx::StageSide& S = c->stg;
+  if (!S.active) return;
+  if (c->prep.staged) { (void)join_prepared(c); c->prep.gen = ~0ull; c->prep.staged = false; }
+  (void)hipEventSynchronize(S.ready_ev);      // nothing reads the pinned staging or writes the staging side any more
+  S.active = false;
+}
+
+// memcpy by the hull pool's workers (the caller takes part): page-locked staging of 37 MB of arrays / 104 MB of files per batch
+static void parallel_copy(void* dst, const void* src, size_t n) {
+  const size_t chunk = (size_t)2 << 20;
+  if (n <= 2 * chunk) { memcpy(dst, src, n); return; }
+  const size_t nch = (n + chunk - 1) / chunk;
+  std::atomic<size_t> next(0);
+  auto work = [&]() {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= nch) break;
+      const size_t o = k * chunk;
+      memcpy((char*)dst + o, (const char*)src + o, std::min(chunk, n - o));
+    }
+  };
+  HullPool::instance().run(work, (int)std::min<size_t>(nch, 8));
+}
+
+static bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t at{};
+  const bool pinned = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost;
+  (void)hipGetLastError();
+  return pinned;
+}
+
+static int stage_common_alloc(sh_ctx* c, int B, long long sumV_cap, long long sumF_cap, size_t flag_ints) {
+  sh_ctx::StageSide& S = c->stg;
+  int rc;
+  if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!S.ready_ev) HIPCHK(c, hipEventCreateWithFlags(&S.ready_ev, hipEventDisableTiming));
+  if (S.h_flag_cap < flag_ints) {
+    if (S.h_flag) (void)hipHostFree(S.h_flag);
+    S.h_flag = nullptr; S.h_flag_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&S.h_flag, flag_ints * 4));
+    S.h_flag_cap = flag_ints;
+  }
+  if (S.h_kept_cap < sumV_cap) {
+    if (S.h_kept) (void)hipHostFree(S.h_kept);
+    S.h_kept = nullptr; S.h_kept_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&S.h_kept, (size_t)sumV_cap * 12));
+    S.h_kept_cap = sumV_cap;
+  }
+  if (S.h_koff_cap < B + 1) {
+    if (S.h_koff) (void)hipHostFree(S.h_koff);
+    S.h_koff = nullptr; S.h_koff_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&S.h_koff, (size_t)(B + 1) * 8));
+    S.h_koff_cap = B + 1;
+  }
+#define ENSS(name, bytes, elem) do { if ((rc = ensure(c, name, (size_t)(bytes), elem)) != SH_OK) return rc; c->bufs[name].per_mesh = 0; } while (0)
+  ENSS("verts.s", sumV_cap * 12, 4);
+  ENSS("faces.s", sumF_cap * 12, 4);
+  ENSS("voff.s", (size_t)(B + 1) * 8, 8);
+  ENSS("foff.s", (size_t)(B + 1) * 8, 8);
+  ENSS("stage.flag", 64, 4);
+  ENSS("hullpre.ext.s", (size_t)B * SH_HP_NDIR * 4, 4);
+  ENSS("hullpre.planes.s", (size_t)B * SH_HP_MAXPL * 4 * 8, 8);
+  ENSS("hullpre.npl.s", (size_t)B * 4, 4);
+  ENSS("hullpre.nkept.s", (size_t)B * 4, 4);
+  ENSS("hullpre.pval.s", (size_t)B * SH_HP_PARTS * SH_HP_NDIR * 8, 8);
+  ENSS("hullpre.pidx.s", (size_t)B * SH_HP_PARTS * SH_HP_NDIR * 4, 4);
+  ENSS("hullpre.pcnt.s", (size_t)B * SH_HP_PARTS * 4, 4);
+  ENSS("hullpre.poff.s", (size_t)B * SH_HP_PARTS * 8, 8);
+  ENSS("hullpre.koff.s", (size_t)(B + 1) * 8, 8);
+  ENSS("hullpre.kept.s", (size_t)sumV_cap * 12, 4);
+#undef ENSS
+  return SH_OK;
+}
+
+static HullPre hullpre_ptrs_staged(sh_ctx* c) {      // calling thread only (buffer map)
+  return HullPre{(const float*)c->bufs["verts.s"].p, (const long long*)c->bufs["voff.s"].p, (int*)c->bufs["hullpre.ext.s"].p, (double*)c->bufs["hullpre.planes.s"].p,
+                 (int*)c->bufs["hullpre.npl.s"].p, (float*)c->bufs["hullpre.kept.s"].p, (int*)c->bufs["hullpre.nkept.s"].p, (long long*)c->bufs["hullpre.koff.s"].p,
+                 (double*)c->bufs["hullpre.pval.s"].p, (int*)c->bufs["hullpre.pidx.s"].p, (int*)c->bufs["hullpre.pcnt.s"].p, (long long*)c->bufs["hullpre.poff.s"].p};
+}
+
+// what the STL variant's thread does first (phase 1): sizes of the merged meshes -> offsets -> k_stl_emit
+struct StlPhase { bool on = false; int tsize = 0; long long maxc = 0; void *corners, *coff, *table, *slot, *vid, *fpos, *voff_d, *foff_d, *verts_d, *faces_d; hipEvent_t counted = nullptr; };
+
+// The background thread of a staged batch: (STL: phase 1,) hull points through the prefilter, host hulls into pinned slot
+// `prep.slot`, records to the device as soon as the run in flight no longer reads hull.*.  `hulls` false (device hull): phase 1 only.
+static void start_prepare_staged(sh_ctx* c, bool hulls, const StlPhase stl) {
+  sh_ctx::Prepared& p = c->prep;
+  sh_ctx::StageSide& S = c->stg;
+  p.active = true; p.staged = true; p.slot = c->hslot; p.B = S.B; p.gen = hulls ? c->batch_gen + 1 : ~0ull; p.rc = SH_OK; p.bad_mesh = -1; p.d2h_ms = p.hull_ms = 0; p.err.clear();
+  p.uploaded = false;
+  const HullPre hp = hullpre_ptrs_staged(c);
+  struct Dst { void* p[6]; } dst = {{c->bufs["hull.hv"].p, c->bufs["hull.normals"].p, c->bufs["hull.edges"].p, c->bufs["hull.nv"].p, c->bufs["hull.nf"].p, c->bufs["hull.ne"].p}};
+  // early upload only into buffers that will not be re-allocated by the commit (alloc_batch grows them for a larger batch)
+  const size_t nB = (size_t)S.B;
+  const bool can_upload = c->obb_done_ev != nullptr && dst.p[0] && c->bufs["hull.hv"].bytes >= nB * SH_HV * 24 && c->bufs["hull.normals"].bytes >= nB * SH_HF * 24 &&
+                          c->bufs["hull.edges"].bytes >= nB * SH_HE * 16 && c->bufs["hull.nv"].bytes >= nB * 4 && c->bufs["hull.nf"].bytes >= nB * 4 && c->bufs["hull.ne"].bytes >= nB * 4;
+  const int B = S.B;
+  p.th = std::thread([c, hp, dst, can_upload, hulls, stl, B]() {
+    sh_ctx::Prepared& q = c->prep;
+    sh_ctx::StageSide& S = c->stg;
+    auto meta = [&](int rc, const char* msg) {
+      { std::lock_guard<std::mutex> lk(S.m); S.meta_rc = rc; if (msg) S.meta_err = msg; S.meta_ready = true; }
+      S.cv.notify_all();
+    };
+    if (hipSetDevice(c->device) != hipSuccess) { q.rc = SH_ERR_HIP; if (stl.on) meta(SH_ERR_HIP, "hipSetDevice"); return; }
+    long long sumV = S.sumV;
+    if (stl.on) {
+      if (hipEventSynchronize(stl.counted) != hipSuccess) { q.rc = SH_ERR_HIP; meta(SH_ERR_HIP, "sh_stage_stl: the parse kernels failed"); return; }
+      const int* counts = S.h_flag + 16;            // [2 B] merged vertices, faces per file
+      const int* nonfin = S.h_flag + 16 + 2 * B;    // [B]
+      S.voff.assign(B + 1, 0); S.foff.assign(B + 1, 0);
+      long long maxV = 0, maxF = 0;
+      for (int b = 0; b < B; ++b) {
+        if (nonfin[b]) { q.rc = SH_ERR_ARG; meta(SH_ERR_ARG, "sh_stage_stl: a file holds NaN / infinite coordinates"); return; }
+        if (counts[2 * b] < 4 || counts[2 * b + 1] < 4) { q.rc = SH_ERR_ARG; meta(SH_ERR_ARG, "sh_stage_stl: a mesh has fewer than 4 vertices/faces after merging"); return; }
+        S.voff[b + 1] = S.voff[b] + counts[2 * b];
+        S.foff[b + 1] = S.foff[b] + counts[2 * b + 1];
+        maxV = std::max<long long>(maxV, counts[2 * b]); maxF = std::max<long long>(maxF, counts[2 * b + 1]);
+      }
+      S.maxV = maxV; S.maxF = maxF; S.sumV = S.voff[B]; S.sumF = S.foff[B];
+      sumV = S.sumV;
+      hipStream_t st = c->copy_stream;
+      bool ok = hipMemcpyAsync(stl.voff_d, S.voff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st) == hipSuccess &&
+                hipMemcpyAsync(stl.foff_d, S.foff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+      if (ok) {
+        const dim3 gc((unsigned)std::min<long long>((stl.maxc + 255) / 256, 1024), (unsigned)B);
+        hipLaunchKernelGGL(k_stl_emit, gc, dim3(256), 0, st, (const float*)stl.corners, (const long long*)stl.coff, (const int2*)stl.table, stl.tsize, (const int*)stl.slot,
+                           (const int*)stl.vid, (const int*)stl.fpos, (const long long*)stl.voff_d, (const long long*)stl.foff_d, (float*)stl.verts_d, (int*)stl.faces_d);
+        ok = hipGetLastError() == hipSuccess && hipEventRecord(S.ready_ev, st) == hipSuccess;
+      }
+      if (!ok) { q.rc = SH_ERR_HIP; meta(SH_ERR_HIP, "sh_stage_stl: enqueueing the merge failed"); return; }
+      meta(SH_OK, nullptr);
+    }
+    if (!hulls) return;
+    {
+      auto t0 = std::chrono::steady_clock::now();
+      if (fetch_prefiltered(hp, B, sumV, S.h_koff, S.h_kept, &S.pts, c->copy_stream) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
+      q.d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (!stl.on && S.h_flag[0] != 0) { q.rc = SH_ERR_ARG; return; }      // (the validation word came back in front of the survivors; the commit reports it)
+    q.rc = hull_host_phase(c, S.pts, q.slot, 0, B, &q.bad_mesh, &q.hull_ms, &q.err, true);
+    if (q.rc == SH_OK && can_upload) {
+      if (hipStreamWaitEvent(c->copy_stream, c->obb_done_ev, 0) == hipSuccess && hull_upload(c, q.slot, B, dst.p, c->copy_stream) == hipSuccess &&
+          hipStreamSynchronize(c->copy_stream) == hipSuccess)
+        q.uploaded = true;
+    }
+  });
+}
+
+int sh_stage_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const int64_t* v_off, const int64_t* f_off, int B) {
+  if (!c || !verts || !faces || !v_off || !f_off || B <= 0) return fail(c, SH_ERR_ARG, "sh_stage_meshes: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (v_off[0] != 0 || f_off[0] != 0) return fail(c, SH_ERR_ARG, "sh_stage_meshes: offsets must start at 0");
+  long long maxV = 0, maxF = 0;
+  for (int b = 0; b < B; ++b) {
+    const long long nv = v_off[b + 1] - v_off[b], nf = f_off[b + 1] - f_off[b];
+    if (nv < 4 || nf < 4) return fail(c, SH_ERR_ARG, "sh_stage_meshes: a mesh has fewer than 4 vertices/faces");
+    if (nv > 0x7fffffffLL / 3 || nf > 0x7fffffffLL / 3) return fail(c, SH_ERR_ARG, "sh_stage_meshes: a mesh is too large");
+    maxV = std::max(maxV, nv); maxF = std::max(maxF, nf);
+  }
+  discard_staged(c);
+  (void)join_prepared(c);      // one background job per context
+  sh_ctx::StageSide& S = c->stg;
+  const long long sumV = v_off[B], sumF = f_off[B];
+  int rc;
+  if ((rc = stage_common_alloc(c, B, sumV, sumF, 64)) != SH_OK) return rc;
+  // the caller's arrays -> page-locked memory (unless they are page-locked already: then the caller keeps them unchanged until
+  // sh_commit_staged has returned)
+  const size_t vb = (size_t)sumV * 12, fb = (size_t)sumF * 12, vpad = (vb + 255) & ~(size_t)255;
+  const bool vpin = is_pinned_host(verts), fpin = is_pinned_host(faces);
+  const size_t need = (vpin ? 0 : vpad) + (fpin ? 0 : fb);
+  if (S.h_src_cap < need) {
+    if (S.h_src) (void)hipHostFree(S.h_src);
+    S.h_src = nullptr; S.h_src_cap = 0;
+    HIPCHK(c, hipHostMalloc(&S.h_src, need + need / 8));
+    S.h_src_cap = need + need / 8;
+  }
+  const void* vsrc = verts; const void* fsrc = faces;
+  if (!vpin) { parallel_copy(S.h_src, verts, vb); vsrc = S.h_src; }
+  if (!fpin) { void* d = (char*)S.h_src + (vpin ? 0 : vpad); parallel_copy(d, faces, fb); fsrc = d; }
+  S.B = B; S.sumV = sumV; S.sumF = sumF; S.maxV = maxV; S.maxF = maxF; S.from_stl = false;
+  S.voff.assign(v_off, v_off + B + 1); S.foff.assign(f_off, f_off + B + 1);
+  S.meta_ready = true; S.meta_rc = SH_OK; S.meta_err.clear();
+  hipStream_t st = c->copy_stream;
+  int* flag = (int*)c->bufs["stage.flag"].p;
+  HIPCHK(c, hipMemcpyAsync(c->bufs["verts.s"].p, vsrc, vb, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->bufs["faces.s"].p, fsrc, fb, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->bufs["voff.s"].p, S.voff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->bufs["foff.s"].p, S.foff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(flag, 0, 4, st));
+  S.h_flag[0] = 0;
+  hipLaunchKernelGGL(k_validate_meshes, dim3((unsigned)std::min<long long>((3 * std::max(maxV, maxF) + 255) / 256, 256), (unsigned)B), dim3(256), 0, st,
+                     (const float*)c->bufs["verts.s"].p, (const int*)c->bufs["faces.s"].p, (const long long*)c->bufs["voff.s"].p, (const long long*)c->bufs["foff.s"].p, flag);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(S.h_flag, flag, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventRecord(S.ready_ev, st));
+  S.active = true;
+  if (!device_hull_now(c)) start_prepare_staged(c, true, StlPhase{});
+  return SH_OK;
+}
+
+int sh_stage_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int B) {
+  if (!c || !files || !nbytes || B <= 0) return fail(c, SH_ERR_ARG, "sh_stage_stl: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<long long> file_off(B + 1, 0), coff(B + 1, 0);
+  long long maxc = 0;
+  for (int b = 0; b < B; ++b) {
+    if (!files[b] || nbytes[b] < 84) return fail(c, SH_ERR_ARG, "sh_stage_stl: a file is too short for a binary STL");
+    uint32_t nt;
+    memcpy(&nt, (const char*)files[b] + 80, 4);
+    if (nbytes[b] != 84 + 50ull * nt) return fail(c, SH_ERR_ARG, "sh_stage_stl: not a binary STL (size does not match the triangle count)");
+    if (nt < 4 || nt > 0x7fffffffu / 3) return fail(c, SH_ERR_ARG, "sh_stage_stl: a mesh has fewer than 4 (or too many) triangles");
+    file_off[b + 1] = file_off[b] + (long long)((nbytes[b] + 3) & ~(size_t)3);
+    coff[b + 1] = coff[b] + 3ll * nt;
+    maxc = std::max(maxc, 3ll * nt);
+  }
+  discard_staged(c);
+  (void)join_prepared(c);
+  sh_ctx::StageSide& S = c->stg;
+  int tsize = 1024;
+  while (tsize < 2 * maxc) tsize <<= 1;
+  const long long sumC = coff[B];
+  int rc;
+  // the merged meshes are at most as large as the corner lists: the staging side is sized by that bound, the true offsets are
+  // made by the thread once the device has counted
+  if ((rc = stage_common_alloc(c, B, sumC, sumC / 3, 16 + 3 * (size_t)B)) != SH_OK) return rc;
+#define ENSS(name, bytes, elem) do { if ((rc = ensure(c, name, (size_t)(bytes), elem)) != SH_OK) return rc; c->bufs[name].per_mesh = 0; } while (0)
+  ENSS("stl.raw", (size_t)file_off[B], 1);
+  ENSS("stl.file_off", (B + 1) * 8, 8);
+  ENSS("stl.coff", (B + 1) * 8, 8);
+  ENSS("stl.corners", (size_t)sumC * 12, 4);
+  ENSS("stl.table", (size_t)B * tsize * 8, 4);
+  ENSS("stl.slot", (size_t)sumC * 4, 4);
+  ENSS("stl.vid", (size_t)sumC * 4, 4);
+  ENSS("stl.fpos", (size_t)(sumC / 3) * 4, 4);
+  ENSS("stl.counts", (size_t)B * 8, 4);
+  ENSS("stl.nonfinite", (size_t)B * 4, 4);
+#undef ENSS
+  // files -> one page-locked image (file starts 4-byte aligned) + the two offset tables behind it
+  const size_t raw_bytes = (size_t)file_off[B], tab_off = (raw_bytes + 255) & ~(size_t)255, need = tab_off + 2 * (size_t)(B + 1) * 8;
+  if (S.h_src_cap < need) {
+    if (S.h_src) (void)hipHostFree(S.h_src);
+    S.h_src = nullptr; S.h_src_cap = 0;
+    HIPCHK(c, hipHostMalloc(&S.h_src, need + need / 8));
+    S.h_src_cap = need + need / 8;
+  }
+  {
+    std::atomic<int> next(0);
+    auto work = [&]() { for (;;) { const int b = next.fetch_add(1); if (b >= B) break; memcpy((char*)S.h_src + file_off[b], files[b], nbytes[b]); } };
+    HullPool::instance().run(work, std::min(B, 8));
+  }
+  long long* h_tabs = (long long*)((char*)S.h_src + tab_off);
+  memcpy(h_tabs, file_off.data(), (size_t)(B + 1) * 8);
+  memcpy(h_tabs + B + 1, coff.data(), (size_t)(B + 1) * 8);
+  S.B = B; S.from_stl = true; S.sumV = S.sumF = S.maxV = S.maxF = 0;
+  S.meta_ready = false; S.meta_rc = SH_OK; S.meta_err.clear();
+  S.h_flag[0] = 0;
+  hipStream_t st = c->copy_stream;
+  unsigned char* raw = (unsigned char*)c->bufs["stl.raw"].p;
+  HIPCHK(c, hipMemcpyAsync(raw, S.h_src, raw_bytes, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->bufs["stl.file_off"].p, h_tabs, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->bufs["stl.coff"].p, h_tabs + B + 1, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(c->bufs["stl.nonfinite"].p, 0, (size_t)B * 4, st));
+  const dim3 gc((unsigned)std::min<long long>((maxc + 255) / 256, 1024), (unsigned)B);
+  hipLaunchKernelGGL(k_stl_corners, gc, dim3(256), 0, st, (const unsigned char*)raw, (const long long*)c->bufs["stl.file_off"].p, (const long long*)c->bufs["stl.coff"].p,
+                     (float*)c->bufs["stl.corners"].p, (int*)c->bufs["stl.nonfinite"].p);
+  hipLaunchKernelGGL(k_stl_table_init, dim3(1024), dim3(256), 0, st, (int2*)c->bufs["stl.table"].p, (size_t)B * tsize);
+  hipLaunchKernelGGL(k_stl_hash, gc, dim3(256), 0, st, (const float*)c->bufs["stl.corners"].p, (const long long*)c->bufs["stl.coff"].p, (int2*)c->bufs["stl.table"].p, tsize,
+                     (int*)c->bufs["stl.slot"].p);
+  hipLaunchKernelGGL(k_stl_rank, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, (const long long*)c->bufs["stl.coff"].p, (const int2*)c->bufs["stl.table"].p, tsize,
+                     (const int*)c->bufs["stl.slot"].p, (int*)c->bufs["stl.vid"].p, (int*)c->bufs["stl.fpos"].p, (int*)c->bufs["stl.counts"].p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(S.h_flag + 16, c->bufs["stl.counts"].p, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(S.h_flag + 16 + 2 * B, c->bufs["stl.nonfinite"].p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  StlPhase ph;
+  ph.on = true; ph.tsize = tsize; ph.maxc = maxc;
+  ph.corners = c->bufs["stl.corners"].p; ph.coff = c->bufs["stl.coff"].p; ph.table = c->bufs["stl.table"].p; ph.slot = c->bufs["stl.slot"].p;
+  ph.vid = c->bufs["stl.vid"].p; ph.fpos = c->bufs["stl.fpos"].p; ph.voff_d = c->bufs["voff.s"].p; ph.foff_d = c->bufs["foff.s"].p;
+  ph.verts_d = c->bufs["verts.s"].p; ph.faces_d = c->bufs["faces.s"].p;
+  if (!c->stl_counted_ev) HIPCHK(c, hipEventCreateWithFlags(&c->stl_counted_ev, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->stl_counted_ev, st));
+  HIPCHK(c, hipEventRecord(S.ready_ev, st));      // (recorded again behind k_stl_emit by the thread; this one covers an early discard)
+  ph.counted = c->stl_counted_ev;
+  S.active = true;
+  start_prepare_staged(c, !device_hull_now(c), ph);
+  return SH_OK;
+}
+
+int sh_commit_staged(sh_ctx* c, int64_t* v_off_out, int64_t* f_off_out) {
+  if (!c) return SH_ERR_ARG;
+  sh_ctx::StageSide& S = c->stg;
+  if (!S.active) return fail(c, SH_ERR_STATE, "sh_commit_staged: no batch is staged");
+  if (c->n_pending != 0) return fail(c, SH_ERR_STATE, "sh_commit_staged: runs are in flight (sh_collect them first: they read the buffers that become the staging side)");
+  HIPCHK(c, hipSetDevice(c->device));
+  { std::unique_lock<std::mutex> lk(S.m); S.cv.wait(lk, [&] { return S.meta_ready; }); }
+  if (S.meta_rc != SH_OK) { const int rc = S.meta_rc; const std::string msg = S.meta_err; discard_staged(c); return fail(c, rc, msg); }
+  HIPCHK(c, hipEventSynchronize(S.ready_ev));
+  if (!S.from_stl && S.h_flag[0] != 0) {
+    const int f = S.h_flag[0];
+    discard_staged(c);
+    return fail(c, SH_ERR_ARG, (f & 1) ? "sh_stage_meshes: face index out of range" : "sh_stage_meshes: NaN / infinite vertex coordinate");
+  }
+  // a resident-overlap preparation cannot be under way (staging joined it); the staged batch's own thread keeps running
+  for (const char* nm : {"verts", "faces", "voff", "foff"}) std::swap(c->bufs[nm], c->bufs[std::string(nm) + ".s"]);
+  c->B = 0;
+  c->h_voff.swap(S.voff); c->h_foff.swap(S.foff);
+  c->sumV = S.sumV; c->sumF = S.sumF; c->maxV = S.maxV; c->maxF = S.maxF;
+  c->h_verts_valid = false;
+  ++c->batch_gen;
+  c->bufs["verts"].per_mesh = 0; c->bufs["faces"].per_mesh = 0;
+  c->bufs["verts.s"].per_mesh = 0; c->bufs["faces.s"].per_mesh = 0; c->bufs["voff.s"].per_mesh = 0; c->bufs["foff.s"].per_mesh = 0;
+  const int B = S.B;
+  S.active = false;
+  if (v_off_out) for (int b = 0; b <= B; ++b) v_off_out[b] = c->h_voff[b];
+  if (f_off_out) for (int b = 0; b <= B; ++b) f_off_out[b] = c->h_foff[b];
+  c->B = B;
+  int rc = alloc_batch(c);
+  if (rc != SH_OK) c->B = 0;
+  return rc;
+}
+
+int sh_staged(const sh_ctx* c) { return c ? (c->stg.active ? 1 : 0) : SH_ERR_ARG; }
 
 // The device hull gave the humeri in `list` up during the run of ticket `tk` (k_hull.h writes a unit tetrahedron for them, so
 // everything queued behind ran on finite data and their records are void).  Each of them gets the host quickhull -- which
@@ -2329,6 +2702,9 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     int prc = join_prepared(c);
     if ((mask & SH_STAGE_OBB) && win == B && prc == SH_OK && c->prep.gen == c->batch_gen && c->prep.B == B) { prepared = c->prep.slot; c->hslot = prepared ^ 1; }
   }
+  // a run of the resident batch while hulls for the STAGED one are waiting: its own hull phase takes the same pinned slot and
+  // the same hull.* device buffers, so those hulls are void (the staged batch stays; its first run computes them again)
+  if ((mask & SH_STAGE_OBB) && c->prep.staged && c->prep.gen != c->batch_gen) c->prep.gen = ~0ull;
   if (dev_hull) prepared = -1;
   if ((mask & SH_STAGE_OBB) && prepared < 0 && !dev_hull) {
     // the host hull needs its points (a device-generated batch: every run, a new batch is new data)
@@ -2343,7 +2719,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     rc = run_window(c, mask, widx == 0 ? prepared : -1);
   }
   // everything of this run is enqueued: the host is free until the device is done -> hulls of the next run
-  if (rc == SH_OK && c->overlap && (mask & SH_STAGE_OBB) && win == B && !dev_hull) start_prepare(c);
+  if (rc == SH_OK && c->overlap && (mask & SH_STAGE_OBB) && win == B && !dev_hull && !c->stg.active) start_prepare(c);
   c->b0 = 0; c->Bwin = B;
   if (mask & SH_STAGE_OBB) c->obb_injected = true;
   if (rc != SH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }

@@ -137,13 +137,14 @@ class Engine:
         """meshes: list of (verts float32 (V,3), faces int32 (F,3))."""
         if len(meshes) == 0:
             raise ValueError("upload() needs at least one mesh")
-        verts = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float32).reshape(-1, 3) for v, _ in meshes]))
-        faces = np.ascontiguousarray(np.concatenate([np.asarray(f, dtype=np.int32).reshape(-1, 3) for _, f in meshes]))
-        voff = np.zeros(len(meshes) + 1, dtype=np.int64)
-        foff = np.zeros(len(meshes) + 1, dtype=np.int64)
-        voff[1:] = np.cumsum([len(v) for v, _ in meshes])
-        foff[1:] = np.cumsum([len(f) for _, f in meshes])
+        verts, faces, voff, foff = self.pack_meshes(meshes)
         self._chk(self.L.sh_upload_meshes(self.h, _ptr(verts), _ptr(faces), _ptr(voff), _ptr(foff), len(meshes)))
+        self.voff, self.foff = voff, foff
+
+    def upload_packed(self, packed):
+        """sh_upload_meshes from the 4-tuple of pack_meshes()."""
+        verts, faces, voff, foff = packed
+        self._chk(self.L.sh_upload_meshes(self.h, _ptr(verts), _ptr(faces), _ptr(voff), _ptr(foff), len(voff) - 1))
         self.voff, self.foff = voff, foff
 
     def upload_stl(self, files):
@@ -158,6 +159,54 @@ class Engine:
         foff = np.zeros(n + 1, dtype=np.int64)
         self._chk(self.L.sh_upload_stl(self.h, ptrs, sizes, n, _ptr(voff), _ptr(foff)))
         self.voff, self.foff = voff, foff
+
+    # ---- the staging side: the NEXT batch is handed over while a run of the resident one executes -----------------------------
+    @staticmethod
+    def pack_meshes(meshes):
+        """list of (verts, faces) -> (verts float32 (sumV,3), faces int32 (sumF,3), voff int64 (B+1), foff int64 (B+1)): the arrays
+        sh_upload_meshes / sh_stage_meshes take.  A caller that streams batches packs each one once, outside its hot loop."""
+        if len(meshes) == 0:
+            raise ValueError("at least one mesh")
+        verts = np.ascontiguousarray(np.concatenate([np.asarray(v, dtype=np.float32).reshape(-1, 3) for v, _ in meshes]))
+        faces = np.ascontiguousarray(np.concatenate([np.asarray(f, dtype=np.int32).reshape(-1, 3) for _, f in meshes]))
+        voff = np.zeros(len(meshes) + 1, dtype=np.int64)
+        foff = np.zeros(len(meshes) + 1, dtype=np.int64)
+        voff[1:] = np.cumsum([len(v) for v, _ in meshes])
+        foff[1:] = np.cumsum([len(f) for _, f in meshes])
+        return verts, faces, voff, foff
+
+    def stage(self, meshes):
+        """sh_stage_meshes: `meshes` = list of (verts, faces) or the 4-tuple of pack_meshes().  Returns at once; commit_staged()
+        makes the batch the resident one."""
+        packed = meshes if (isinstance(meshes, tuple) and len(meshes) == 4 and getattr(meshes[2], "dtype", None) == np.int64) else self.pack_meshes(meshes)
+        verts, faces, voff, foff = packed
+        self._chk(self.L.sh_stage_meshes(self.h, _ptr(verts), _ptr(faces), _ptr(voff), _ptr(foff), len(voff) - 1))
+        self._staged_off = (voff, foff)
+
+    def stage_stl(self, files):
+        """sh_stage_stl: list of paths or bytes objects (binary STL); parse + vertex merge on the device, beside the run in flight."""
+        import pathlib
+        keep = [bytes(f) if isinstance(f, (bytes, bytearray)) else pathlib.Path(f).read_bytes() for f in files]
+        n = len(keep)
+        ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(k), ctypes.c_void_p) for k in keep])
+        sizes = (ctypes.c_size_t * n)(*[len(k) for k in keep])
+        self._chk(self.L.sh_stage_stl(self.h, ptrs, sizes, n))      # (the bytes are in page-locked staging when the call returns)
+        self._staged_off = None
+
+    def commit_staged(self):
+        """sh_commit_staged: the staged batch becomes the resident one (needs every submitted run collected)."""
+        self._chk(self.L.sh_commit_staged(self.h, None, None))
+        B = self.L.sh_batch_size(self.h)
+        if getattr(self, "_staged_off", None) is not None:
+            self.voff, self.foff = self._staged_off
+        else:      # STL: the offsets were made on the device
+            self.voff = self.fetch("voff", np.int64, (B + 1,)).copy()
+            self.foff = self.fetch("foff", np.int64, (B + 1,)).copy()
+        self._staged_off = None
+
+    @property
+    def staged(self):
+        return self.L.sh_staged(self.h) == 1
 
     def synth_batch(self, T):
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(-1, 16)
