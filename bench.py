@@ -450,7 +450,11 @@ def main():
             e.set_overlap(False)
         for w_ in range(warmup):
             for e in (leg_engs if w_ == 0 else leg_engs[:1]):      # every lane's scratch is allocated before t0
-                hand_over(e)
+                if stream:      # (the staging side's page-locked memory and device buffers as well)
+                    stage_for(e, nb_ - 1 - w_)
+                    e.commit_staged()
+                else:
+                    hand_over(e)
                 e.run(_lib.STAGE_ALL, fetch=False)
             if use_dist:
                 dist.gather(lm_t, gather_list, dst=0)

@@ -153,12 +153,12 @@ int  sh_upload_meshes(sh_ctx*, const float* verts /* sumV x 3 */, const int32_t*
 int  sh_upload_stl(sh_ctx*, const void* const* files, const size_t* nbytes, int B, int64_t* v_off_out, int64_t* f_off_out);
 /* A stream of NEW batches (the reference's unit of work is a new STL: mesh.py:22-27, bone.py:110-131).  sh_upload_* hands a
  * batch over synchronously; the staging calls hand the NEXT batch over while a run of the resident one executes:
- *   sh_stage_meshes / sh_stage_stl  same arguments and checks as sh_upload_meshes / sh_upload_stl.  The arrays / files go
- *     through page-locked staging (copied by worker threads before the call returns; page-locked caller memory -- sh_host_alloc --
- *     is read in place and must stay unchanged until sh_commit_staged has returned) into buffers of their own on a copy stream,
- *     element checks and the STL parse / vertex merge run on the device, and the convex hulls of the staged batch (host hull
- *     mode) are computed by a background thread.  Returns at once.  One batch can be staged at a time; staging again, or any
- *     sh_upload_* / sh_synth_batch, replaces it.
+ *   sh_stage_meshes / sh_stage_stl  same arguments and checks as sh_upload_meshes / sh_upload_stl.  The call checks sizes and
+ *     headers and returns at once; a background thread copies the arrays / files through page-locked staging (page-locked
+ *     caller memory -- sh_host_alloc -- is read in place) into buffers of their own on a copy stream, element checks and the STL
+ *     parse / vertex merge run on the device, and the convex hulls of the staged batch (host hull mode) are computed by the same
+ *     thread.  THE CALLER KEEPS THE ARRAYS / FILES UNCHANGED UNTIL sh_commit_staged HAS RETURNED (or the batch is replaced: staging
+ *     again, any sh_upload_* / sh_synth_batch).  One batch can be staged at a time.
  *   sh_commit_staged  makes the staged batch the resident one (buffer entries are swapped, nothing is copied).  Needs the context
  *     idle (sh_collect every run first).  Reports what sh_upload_* would have reported for a bad batch (SH_ERR_ARG; the resident
  *     batch stays).  The next sh_submit / sh_run finds the hulls prepared.  v_off_out / f_off_out (B+1 each, nullable): offsets.

@@ -692,6 +692,8 @@ int sh_upload_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int
   if ((rc = ensure(c, "stl.vid", (size_t)sumC * 4, 4)) != SH_OK) return rc;
   if ((rc = ensure(c, "stl.fpos", (size_t)(sumC / 3) * 4, 4)) != SH_OK) return rc;
   if ((rc = ensure(c, "stl.counts", (size_t)B * 8, 4)) != SH_OK) return rc;
+  if ((rc = ensure(c, "stl.bsum", stl_rank_scratch_ints(B, maxc) * 4, 4)) != SH_OK) return rc;
+  c->bufs["stl.bsum"].per_mesh = 0;
   if ((rc = ensure(c, "stl.nonfinite", (size_t)B * 4, 4)) != SH_OK) return rc;
   c->bufs["stl.nonfinite"].per_mesh = 0;
   HIPCHK(c, hipMemsetAsync(c->bufs["stl.nonfinite"].p, 0, (size_t)B * 4, c->stream));
@@ -705,8 +707,9 @@ int sh_upload_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int
   LAUNCH(c, "k_stl_corners", k_stl_corners, gc, dim3(256), raw, buf<long long>(c, "stl.file_off"), buf<long long>(c, "stl.coff"), buf<float>(c, "stl.corners"), (int*)c->bufs["stl.nonfinite"].p);
   LAUNCH(c, "k_stl_table_init", k_stl_table_init, dim3(1024), dim3(256), buf<int2>(c, "stl.table"), (size_t)B * tsize);
   LAUNCH(c, "k_stl_hash", k_stl_hash, gc, dim3(256), buf<float>(c, "stl.corners"), buf<long long>(c, "stl.coff"), buf<int2>(c, "stl.table"), tsize, buf<int>(c, "stl.slot"));
-  LAUNCH(c, "k_stl_rank", k_stl_rank, dim3(B), dim3(SH_STL_SCAN_THREADS), buf<long long>(c, "stl.coff"), buf<int2>(c, "stl.table"), tsize, buf<int>(c, "stl.slot"),
-         buf<int>(c, "stl.vid"), buf<int>(c, "stl.fpos"), buf<int>(c, "stl.counts"));
+  stl_rank_launch(c->stream, B, maxc, buf<long long>(c, "stl.coff"), buf<int2>(c, "stl.table"), tsize, buf<int>(c, "stl.slot"), buf<int>(c, "stl.vid"), buf<int>(c, "stl.fpos"),
+                  buf<int>(c, "stl.counts"), buf<int>(c, "stl.bsum"));
+  HIPCHK(c, hipGetLastError());
   std::vector<int> counts(2 * B), nonfin(B);
   HIPCHK(c, hipMemcpyAsync(counts.data(), buf<int>(c, "stl.counts"), (size_t)B * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(nonfin.data(), c->bufs["stl.nonfinite"].p, (size_t)B * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2242,21 +2245,31 @@ static void discard_staged(sh_ctx* c) {
   S.active = false;
 }
 
-// memcpy by the hull pool's workers (the caller takes part): page-locked staging of 37 MB of arrays / 104 MB of files per batch
-static void parallel_copy(void* dst, const void* src, size_t n) {
-  const size_t chunk = (size_t)2 << 20;
-  if (n <= 2 * chunk) { memcpy(dst, src, n); return; }
+// The caller's (pageable) memory -> page-locked staging -> device, chunk by chunk on a few threads of their own (the hull pool's
+// workers may all be inside another lane's hull phase): a thread copies a chunk and enqueues its H2D copy at once, so the PCIe
+// transfer runs behind the memcpy instead of after it.  37 MB of arrays / 104 MB of files per batch.
+static hipError_t staged_h2d(void* dev, void* pinned, const void* src, size_t n, hipStream_t st) {
+  const size_t chunk = (size_t)4 << 20;
   const size_t nch = (n + chunk - 1) / chunk;
+  if (nch == 0) return hipSuccess;
   std::atomic<size_t> next(0);
+  std::atomic<int> err((int)hipSuccess);
   auto work = [&]() {
     for (;;) {
       const size_t k = next.fetch_add(1);
       if (k >= nch) break;
-      const size_t o = k * chunk;
-      memcpy((char*)dst + o, (const char*)src + o, std::min(chunk, n - o));
+      const size_t o = k * chunk, m = std::min(chunk, n - o);
+      memcpy((char*)pinned + o, (const char*)src + o, m);
+      const hipError_t e = hipMemcpyAsync((char*)dev + o, (char*)pinned + o, m, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) err.store((int)e);
     }
   };
-  HullPool::instance().run(work, (int)std::min<size_t>(nch, 8));
+  static const int nthreads = [] { const char* e = getenv("SHOULDER_COPY_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads && (size_t)t < nch; ++t) th.emplace_back(work);
+  work();
+  for (auto& t : th) t.join();
+  return (hipError_t)err.load();
 }
 
 static bool is_pinned_host(const void* p) {
@@ -2320,7 +2333,7 @@ struct StlPhase { bool on = false; int tsize = 0; long long maxc = 0; void *corn
 
 // The background thread of a staged batch: (STL: phase 1,) hull points through the prefilter, host hulls into pinned slot
 // `prep.slot`, records to the device as soon as the run in flight no longer reads hull.*.  `hulls` false (device hull): phase 1 only.
-static void start_prepare_staged(sh_ctx* c, bool hulls, const StlPhase stl) {
+static void start_prepare_staged(sh_ctx* c, bool hulls, const StlPhase stl, std::function<int(std::string*)> phase0) {
   sh_ctx::Prepared& p = c->prep;
   sh_ctx::StageSide& S = c->stg;
   p.active = true; p.staged = true; p.slot = c->hslot; p.B = S.B; p.gen = hulls ? c->batch_gen + 1 : ~0ull; p.rc = SH_OK; p.bad_mesh = -1; p.d2h_ms = p.hull_ms = 0; p.err.clear();
@@ -2332,14 +2345,25 @@ static void start_prepare_staged(sh_ctx* c, bool hulls, const StlPhase stl) {
   const bool can_upload = c->obb_done_ev != nullptr && dst.p[0] && c->bufs["hull.hv"].bytes >= nB * SH_HV * 24 && c->bufs["hull.normals"].bytes >= nB * SH_HF * 24 &&
                           c->bufs["hull.edges"].bytes >= nB * SH_HE * 16 && c->bufs["hull.nv"].bytes >= nB * 4 && c->bufs["hull.nf"].bytes >= nB * 4 && c->bufs["hull.ne"].bytes >= nB * 4;
   const int B = S.B;
-  p.th = std::thread([c, hp, dst, can_upload, hulls, stl, B]() {
+  p.th = std::thread([c, hp, dst, can_upload, hulls, stl, B, phase0]() {
     sh_ctx::Prepared& q = c->prep;
     sh_ctx::StageSide& S = c->stg;
     auto meta = [&](int rc, const char* msg) {
       { std::lock_guard<std::mutex> lk(S.m); S.meta_rc = rc; if (msg) S.meta_err = msg; S.meta_ready = true; }
       S.cv.notify_all();
     };
-    if (hipSetDevice(c->device) != hipSuccess) { q.rc = SH_ERR_HIP; if (stl.on) meta(SH_ERR_HIP, "hipSetDevice"); return; }
+    if (hipSetDevice(c->device) != hipSuccess) { q.rc = SH_ERR_HIP; meta(SH_ERR_HIP, "hipSetDevice"); return; }
+    const bool dbg = getenv("SH_DEBUG") != nullptr;
+    const auto tt0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count(); };
+    double t_p0 = 0, t_meta = 0, t_pts = 0;
+    {      // phase 0: the caller's memory -> page-locked staging, the copies and the first kernels enqueued (the staging call has returned)
+      std::string et;
+      const int rc0 = phase0(&et);
+      if (rc0 != SH_OK) { q.rc = rc0; meta(rc0, et.c_str()); return; }
+      if (!stl.on) meta(SH_OK, nullptr);
+      t_p0 = since();
+    }
     long long sumV = S.sumV;
     if (stl.on) {
       if (hipEventSynchronize(stl.counted) != hipSuccess) { q.rc = SH_ERR_HIP; meta(SH_ERR_HIP, "sh_stage_stl: the parse kernels failed"); return; }
@@ -2367,6 +2391,7 @@ static void start_prepare_staged(sh_ctx* c, bool hulls, const StlPhase stl) {
       }
       if (!ok) { q.rc = SH_ERR_HIP; meta(SH_ERR_HIP, "sh_stage_stl: enqueueing the merge failed"); return; }
       meta(SH_OK, nullptr);
+      t_meta = since();
     }
     if (!hulls) return;
     {
@@ -2374,8 +2399,10 @@ static void start_prepare_staged(sh_ctx* c, bool hulls, const StlPhase stl) {
       if (fetch_prefiltered(hp, B, sumV, S.h_koff, S.h_kept, &S.pts, c->copy_stream) != hipSuccess) { q.rc = SH_ERR_HIP; return; }
       q.d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    t_pts = since();
     if (!stl.on && S.h_flag[0] != 0) { q.rc = SH_ERR_ARG; return; }      // (the validation word came back in front of the survivors; the commit reports it)
     q.rc = hull_host_phase(c, S.pts, q.slot, 0, B, &q.bad_mesh, &q.hull_ms, &q.err, true);
+    if (dbg) fprintf(stderr, "[sh] staged batch: copies enqueued %.2f ms, sizes known %.2f, hull points back %.2f, hulls done %.2f (hull phase %.2f)\n", t_p0, t_meta, t_pts, since(), q.hull_ms);
     if (q.rc == SH_OK && can_upload) {
       if (hipStreamWaitEvent(c->copy_stream, c->obb_done_ev, 0) == hipSuccess && hull_upload(c, q.slot, B, dst.p, c->copy_stream) == hipSuccess &&
           hipStreamSynchronize(c->copy_stream) == hipSuccess)
@@ -2401,8 +2428,8 @@ int sh_stage_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const i
   const long long sumV = v_off[B], sumF = f_off[B];
   int rc;
   if ((rc = stage_common_alloc(c, B, sumV, sumF, 64)) != SH_OK) return rc;
-  // the caller's arrays -> page-locked memory (unless they are page-locked already: then the caller keeps them unchanged until
-  // sh_commit_staged has returned)
+  // the caller's arrays -> page-locked memory (unless they are page-locked already) -> device, all by the background thread: the
+  // caller keeps its arrays unchanged until sh_commit_staged has returned
   const size_t vb = (size_t)sumV * 12, fb = (size_t)sumF * 12, vpad = (vb + 255) & ~(size_t)255;
   const bool vpin = is_pinned_host(verts), fpin = is_pinned_host(faces);
   const size_t need = (vpin ? 0 : vpad) + (fpin ? 0 : fb);
@@ -2412,27 +2439,34 @@ int sh_stage_meshes(sh_ctx* c, const float* verts, const int32_t* faces, const i
     HIPCHK(c, hipHostMalloc(&S.h_src, need + need / 8));
     S.h_src_cap = need + need / 8;
   }
-  const void* vsrc = verts; const void* fsrc = faces;
-  if (!vpin) { parallel_copy(S.h_src, verts, vb); vsrc = S.h_src; }
-  if (!fpin) { void* d = (char*)S.h_src + (vpin ? 0 : vpad); parallel_copy(d, faces, fb); fsrc = d; }
   S.B = B; S.sumV = sumV; S.sumF = sumF; S.maxV = maxV; S.maxF = maxF; S.from_stl = false;
   S.voff.assign(v_off, v_off + B + 1); S.foff.assign(f_off, f_off + B + 1);
-  S.meta_ready = true; S.meta_rc = SH_OK; S.meta_err.clear();
-  hipStream_t st = c->copy_stream;
-  int* flag = (int*)c->bufs["stage.flag"].p;
-  HIPCHK(c, hipMemcpyAsync(c->bufs["verts.s"].p, vsrc, vb, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->bufs["faces.s"].p, fsrc, fb, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->bufs["voff.s"].p, S.voff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->bufs["foff.s"].p, S.foff.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemsetAsync(flag, 0, 4, st));
+  S.meta_ready = false; S.meta_rc = SH_OK; S.meta_err.clear();
   S.h_flag[0] = 0;
-  hipLaunchKernelGGL(k_validate_meshes, dim3((unsigned)std::min<long long>((3 * std::max(maxV, maxF) + 255) / 256, 256), (unsigned)B), dim3(256), 0, st,
-                     (const float*)c->bufs["verts.s"].p, (const int*)c->bufs["faces.s"].p, (const long long*)c->bufs["voff.s"].p, (const long long*)c->bufs["foff.s"].p, flag);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(S.h_flag, flag, 4, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipEventRecord(S.ready_ev, st));
+  struct P0 { sh_ctx* c; const float* verts; const int32_t* faces; size_t vb, fb, vpad; bool vpin, fpin; void *dv, *df, *dvo, *dfo; int* flag; int B; long long maxV, maxF; } a =
+      {c, verts, faces, vb, fb, vpad, vpin, fpin, c->bufs["verts.s"].p, c->bufs["faces.s"].p, c->bufs["voff.s"].p, c->bufs["foff.s"].p, (int*)c->bufs["stage.flag"].p, B, maxV, maxF};
+  auto phase0 = [a](std::string* et) -> int {
+    sh_ctx::StageSide& S = a.c->stg;
+    hipStream_t st = a.c->copy_stream;
+#define P0CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *et = std::string(#call) + ": " + hipGetErrorString(e_); return SH_ERR_HIP; } } while (0)
+    if (a.vpin) P0CHK(hipMemcpyAsync(a.dv, a.verts, a.vb, hipMemcpyHostToDevice, st));
+    else P0CHK(staged_h2d(a.dv, S.h_src, a.verts, a.vb, st));
+    if (a.fpin) P0CHK(hipMemcpyAsync(a.df, a.faces, a.fb, hipMemcpyHostToDevice, st));
+    else P0CHK(staged_h2d(a.df, (char*)S.h_src + (a.vpin ? 0 : a.vpad), a.faces, a.fb, st));
+    P0CHK(hipMemcpyAsync(a.dvo, S.voff.data(), (size_t)(a.B + 1) * 8, hipMemcpyHostToDevice, st));
+    P0CHK(hipMemcpyAsync(a.dfo, S.foff.data(), (size_t)(a.B + 1) * 8, hipMemcpyHostToDevice, st));
+    P0CHK(hipMemsetAsync(a.flag, 0, 4, st));
+    hipLaunchKernelGGL(k_validate_meshes, dim3((unsigned)std::min<long long>((3 * std::max(a.maxV, a.maxF) + 255) / 256, 256), (unsigned)a.B), dim3(256), 0, st,
+                       (const float*)a.dv, (const int*)a.df, (const long long*)a.dvo, (const long long*)a.dfo, a.flag);
+    P0CHK(hipGetLastError());
+    P0CHK(hipMemcpyAsync(S.h_flag, a.flag, 4, hipMemcpyDeviceToHost, st));
+    P0CHK(hipEventRecord(S.ready_ev, st));
+#undef P0CHK
+    return SH_OK;
+  };
+  HIPCHK(c, hipEventRecord(S.ready_ev, c->copy_stream));      // (a discard before the thread gets there waits for this one)
   S.active = true;
-  if (!device_hull_now(c)) start_prepare_staged(c, true, StlPhase{});
+  start_prepare_staged(c, !device_hull_now(c), StlPhase{}, phase0);
   return SH_OK;
 }
 
@@ -2471,6 +2505,7 @@ int sh_stage_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int 
   ENSS("stl.vid", (size_t)sumC * 4, 4);
   ENSS("stl.fpos", (size_t)(sumC / 3) * 4, 4);
   ENSS("stl.counts", (size_t)B * 8, 4);
+  ENSS("stl.bsum", stl_rank_scratch_ints(B, maxc) * 4, 4);
   ENSS("stl.nonfinite", (size_t)B * 4, 4);
 #undef ENSS
   // files -> one page-locked image (file starts 4-byte aligned) + the two offset tables behind it
@@ -2481,45 +2516,73 @@ int sh_stage_stl(sh_ctx* c, const void* const* files, const size_t* nbytes, int 
     HIPCHK(c, hipHostMalloc(&S.h_src, need + need / 8));
     S.h_src_cap = need + need / 8;
   }
-  {
-    std::atomic<int> next(0);
-    auto work = [&]() { for (;;) { const int b = next.fetch_add(1); if (b >= B) break; memcpy((char*)S.h_src + file_off[b], files[b], nbytes[b]); } };
-    HullPool::instance().run(work, std::min(B, 8));
-  }
   long long* h_tabs = (long long*)((char*)S.h_src + tab_off);
   memcpy(h_tabs, file_off.data(), (size_t)(B + 1) * 8);
   memcpy(h_tabs + B + 1, coff.data(), (size_t)(B + 1) * 8);
   S.B = B; S.from_stl = true; S.sumV = S.sumF = S.maxV = S.maxF = 0;
   S.meta_ready = false; S.meta_rc = SH_OK; S.meta_err.clear();
   S.h_flag[0] = 0;
-  hipStream_t st = c->copy_stream;
-  unsigned char* raw = (unsigned char*)c->bufs["stl.raw"].p;
-  HIPCHK(c, hipMemcpyAsync(raw, S.h_src, raw_bytes, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->bufs["stl.file_off"].p, h_tabs, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->bufs["stl.coff"].p, h_tabs + B + 1, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemsetAsync(c->bufs["stl.nonfinite"].p, 0, (size_t)B * 4, st));
-  const dim3 gc((unsigned)std::min<long long>((maxc + 255) / 256, 1024), (unsigned)B);
-  hipLaunchKernelGGL(k_stl_corners, gc, dim3(256), 0, st, (const unsigned char*)raw, (const long long*)c->bufs["stl.file_off"].p, (const long long*)c->bufs["stl.coff"].p,
-                     (float*)c->bufs["stl.corners"].p, (int*)c->bufs["stl.nonfinite"].p);
-  hipLaunchKernelGGL(k_stl_table_init, dim3(1024), dim3(256), 0, st, (int2*)c->bufs["stl.table"].p, (size_t)B * tsize);
-  hipLaunchKernelGGL(k_stl_hash, gc, dim3(256), 0, st, (const float*)c->bufs["stl.corners"].p, (const long long*)c->bufs["stl.coff"].p, (int2*)c->bufs["stl.table"].p, tsize,
-                     (int*)c->bufs["stl.slot"].p);
-  hipLaunchKernelGGL(k_stl_rank, dim3(B), dim3(SH_STL_SCAN_THREADS), 0, st, (const long long*)c->bufs["stl.coff"].p, (const int2*)c->bufs["stl.table"].p, tsize,
-                     (const int*)c->bufs["stl.slot"].p, (int*)c->bufs["stl.vid"].p, (int*)c->bufs["stl.fpos"].p, (int*)c->bufs["stl.counts"].p);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(S.h_flag + 16, c->bufs["stl.counts"].p, (size_t)B * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(S.h_flag + 16 + 2 * B, c->bufs["stl.nonfinite"].p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  if (!c->stl_counted_ev) HIPCHK(c, hipEventCreateWithFlags(&c->stl_counted_ev, hipEventDisableTiming));
+  // the files themselves are read by the background thread: the caller keeps them unchanged until sh_commit_staged has returned
+  struct P0 { sh_ctx* c; std::vector<const void*> files; std::vector<size_t> nbytes; std::vector<long long> file_off; std::vector<char> pinned; size_t raw_bytes; long long* h_tabs; int B, tsize; long long maxc;
+              unsigned char* raw; void *d_file_off, *d_coff, *corners, *table, *slot, *vid, *fpos, *counts, *nonfin, *bsum; };
+  auto a = std::make_shared<P0>();
+  a->pinned.resize(B);
+  for (int b = 0; b < B; ++b) a->pinned[b] = is_pinned_host(files[b]) ? 1 : 0;
+  a->c = c; a->files.assign(files, files + B); a->nbytes.assign(nbytes, nbytes + B); a->file_off = file_off; a->raw_bytes = raw_bytes; a->h_tabs = h_tabs; a->B = B; a->tsize = tsize; a->maxc = maxc;
+  a->raw = (unsigned char*)c->bufs["stl.raw"].p; a->d_file_off = c->bufs["stl.file_off"].p; a->d_coff = c->bufs["stl.coff"].p; a->corners = c->bufs["stl.corners"].p;
+  a->table = c->bufs["stl.table"].p; a->slot = c->bufs["stl.slot"].p; a->vid = c->bufs["stl.vid"].p; a->fpos = c->bufs["stl.fpos"].p; a->counts = c->bufs["stl.counts"].p;
+  a->nonfin = c->bufs["stl.nonfinite"].p; a->bsum = c->bufs["stl.bsum"].p;
+  auto phase0 = [a](std::string* et) -> int {
+    sh_ctx* c = a->c;
+    sh_ctx::StageSide& S = c->stg;
+    hipStream_t st = c->copy_stream;
+    const int B = a->B;
+#define P0CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { *et = std::string(#call) + ": " + hipGetErrorString(e_); return SH_ERR_HIP; } } while (0)
+    {      // file by file: page-locked files go as they are, the others through the staging image; each file's H2D follows its memcpy at once
+      std::atomic<int> next(0);
+      std::atomic<int> err((int)hipSuccess);
+      auto work = [&]() {
+        for (;;) {
+          const int b = next.fetch_add(1);
+          if (b >= B) break;
+          const void* src = a->files[b];
+          if (!a->pinned[b]) { memcpy((char*)S.h_src + a->file_off[b], a->files[b], a->nbytes[b]); src = (char*)S.h_src + a->file_off[b]; }
+          const hipError_t e = hipMemcpyAsync(a->raw + a->file_off[b], src, a->nbytes[b], hipMemcpyHostToDevice, st);
+          if (e != hipSuccess) err.store((int)e);
+        }
+      };
+      static const int nthreads = [] { const char* e = getenv("SHOULDER_COPY_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+      std::vector<std::thread> th;
+      for (int t = 1; t < nthreads && t < B; ++t) th.emplace_back(work);
+      work();
+      for (auto& t : th) t.join();
+      P0CHK((hipError_t)err.load());
+    }
+    P0CHK(hipMemcpyAsync(a->d_file_off, a->h_tabs, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
+    P0CHK(hipMemcpyAsync(a->d_coff, a->h_tabs + B + 1, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, st));
+    P0CHK(hipMemsetAsync(a->nonfin, 0, (size_t)B * 4, st));
+    const dim3 gc((unsigned)std::min<long long>((a->maxc + 255) / 256, 1024), (unsigned)B);
+    hipLaunchKernelGGL(k_stl_corners, gc, dim3(256), 0, st, (const unsigned char*)a->raw, (const long long*)a->d_file_off, (const long long*)a->d_coff, (float*)a->corners, (int*)a->nonfin);
+    hipLaunchKernelGGL(k_stl_table_init, dim3(1024), dim3(256), 0, st, (int2*)a->table, (size_t)B * a->tsize);
+    hipLaunchKernelGGL(k_stl_hash, gc, dim3(256), 0, st, (const float*)a->corners, (const long long*)a->d_coff, (int2*)a->table, a->tsize, (int*)a->slot);
+    stl_rank_launch(st, B, a->maxc, (const long long*)a->d_coff, (const int2*)a->table, a->tsize, (const int*)a->slot, (int*)a->vid, (int*)a->fpos, (int*)a->counts, (int*)a->bsum);
+    P0CHK(hipGetLastError());
+    P0CHK(hipMemcpyAsync(S.h_flag + 16, a->counts, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+    P0CHK(hipMemcpyAsync(S.h_flag + 16 + 2 * B, a->nonfin, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    P0CHK(hipEventRecord(c->stl_counted_ev, st));
+#undef P0CHK
+    return SH_OK;
+  };
   StlPhase ph;
   ph.on = true; ph.tsize = tsize; ph.maxc = maxc;
   ph.corners = c->bufs["stl.corners"].p; ph.coff = c->bufs["stl.coff"].p; ph.table = c->bufs["stl.table"].p; ph.slot = c->bufs["stl.slot"].p;
   ph.vid = c->bufs["stl.vid"].p; ph.fpos = c->bufs["stl.fpos"].p; ph.voff_d = c->bufs["voff.s"].p; ph.foff_d = c->bufs["foff.s"].p;
   ph.verts_d = c->bufs["verts.s"].p; ph.faces_d = c->bufs["faces.s"].p;
-  if (!c->stl_counted_ev) HIPCHK(c, hipEventCreateWithFlags(&c->stl_counted_ev, hipEventDisableTiming));
-  HIPCHK(c, hipEventRecord(c->stl_counted_ev, st));
-  HIPCHK(c, hipEventRecord(S.ready_ev, st));      // (recorded again behind k_stl_emit by the thread; this one covers an early discard)
+  HIPCHK(c, hipEventRecord(S.ready_ev, c->copy_stream));      // (recorded again behind k_stl_emit by the thread; this one covers an early discard)
   ph.counted = c->stl_counted_ev;
   S.active = true;
-  start_prepare_staged(c, !device_hull_now(c), ph);
+  start_prepare_staged(c, !device_hull_now(c), ph, phase0);
   return SH_OK;
 }
 

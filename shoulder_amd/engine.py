@@ -182,6 +182,7 @@ class Engine:
         verts, faces, voff, foff = packed
         self._chk(self.L.sh_stage_meshes(self.h, _ptr(verts), _ptr(faces), _ptr(voff), _ptr(foff), len(voff) - 1))
         self._staged_off = (voff, foff)
+        self._staged_keep = packed      # the library reads the arrays from a background thread until the commit
 
     def stage_stl(self, files):
         """sh_stage_stl: list of paths or bytes objects (binary STL); parse + vertex merge on the device, beside the run in flight."""
@@ -190,12 +191,16 @@ class Engine:
         n = len(keep)
         ptrs = (ctypes.c_void_p * n)(*[ctypes.cast(ctypes.c_char_p(k), ctypes.c_void_p) for k in keep])
         sizes = (ctypes.c_size_t * n)(*[len(k) for k in keep])
-        self._chk(self.L.sh_stage_stl(self.h, ptrs, sizes, n))      # (the bytes are in page-locked staging when the call returns)
+        self._chk(self.L.sh_stage_stl(self.h, ptrs, sizes, n))
         self._staged_off = None
+        self._staged_keep = keep        # the library reads the files from a background thread until the commit
 
     def commit_staged(self):
         """sh_commit_staged: the staged batch becomes the resident one (needs every submitted run collected)."""
-        self._chk(self.L.sh_commit_staged(self.h, None, None))
+        try:
+            self._chk(self.L.sh_commit_staged(self.h, None, None))
+        finally:
+            self._staged_keep = None
         B = self.L.sh_batch_size(self.h)
         if getattr(self, "_staged_off", None) is not None:
             self.voff, self.foff = self._staged_off
