@@ -44,8 +44,8 @@ def mfma_peak_tf(unet):
 
 GEOM_KERNELS = ["k_hull_rounds", "k_hull_flag", "k_apply_csys", "k_obb_face_area2", "k_obb_bounds", "k_obb_select", "k_obb_seed", "k_obb_candidates", "k_obb_pick", "k_obb_end_points", "k_obb_ends", "k_transform_verts", "k_make_planes",
                 "k_slice_emit", "k_slice_link", "k_slice_link_large", "k_resample_polar", "k_resample_polar_large", "k_te_rows_large", "k_rfc_pack", "k_obb_seed", "k_neck", "k_canal", "k_groove_rows", "k_groove_scale",
-                "k_groove_rfc", "k_groove_kde", "k_groove_localmin", "k_groove_axis", "k_anp_rows", "k_anp_edge_count", "k_anp_edges",
-                "k_anp_plane", "k_rays_hit", "k_rays", "k_te_rows", "k_te_ends", "k_te_orient", "k_pack", "k_metrics", "k_sphere_partial", "k_anp_scale", "k_init_bounds",
+                "k_groove_rfc", "k_groove_tail", "k_anp_rows", "k_anp_edge_count", "k_anp_edges",
+                "k_anp_plane", "k_rays_hit", "k_tail", "k_te_rows", "k_te_ends", "k_sphere_partial", "k_anp_scale", "fill", "k_stage_status", "k_te_rows_huge", "k_slice_link_huge", "k_resample_polar_huge", "k_ovf_plan", "k_slice_emit_ovf",
                 "k_decode_bounds", "k_section_points"]
 
 
@@ -141,7 +141,7 @@ def stage_of(name):
                     ("k_init_bounds", "slices"), ("k_decode_bounds", "slices"), ("k_slice", "slices"), ("k_resample", "slices"),
                     ("k_neck", "surgical_neck"), ("k_canal", "canal"), ("k_groove", "bicipital_groove"), ("k_rfc", "bicipital_groove"),
                     ("k_anp", "anatomic_neck.geometry"), ("k_rays", "anatomic_neck.geometry"), ("k_te", "trans_epicondylar"),
-                    ("k_pack", "csys"), ("k_metrics", "csys"), ("k_sphere", "csys"), ("k_apply", "csys"), ("k_section", "csys")):
+                    ("k_tail", "csys"), ("fill", "other"), ("k_stage", "csys"), ("k_ovf", "slices"), ("k_sphere", "csys"), ("k_apply", "csys"), ("k_section", "csys")):
         if name.startswith(pfx):
             return st
     return "other"
@@ -754,7 +754,22 @@ def main():
                     a_fl = sum(ul[nm][0] * B * alone_times[nm][1] for nm in members)
                     if a_ms > 0:
                         roof["one_lane_alone"] = dict(avg_ms=round(a_ms / sum(alone_times[nm][1] for nm in members), 4),
-                                                      achieved=round(a_fl / (a_ms * 1e-3) / 1e12, 2), frac=round(a_fl / (a_ms * 1e-3) / 1e12 / peak, 4))
+                                                      achieved=round(a_fl / (a_ms * 1e-3) / 1e12, 2), frac=round(a_fl / (a_ms * 1e-3) / 1e12 / peak, 4),
+                                                      note="HIP events around every launch of ONE profiling pass on a grid of all 256 CUs; an event pair spans the launch's "
+                                                           "dispatch as well (~10-20 us of a ~0.3 ms launch), so rocprofv3's kernel-trace duration of the same launches "
+                                                           "(profiles/*_kernel_stats_*_one_lane.csv) reads 5-8 % shorter")
+                        for rnd in ROUNDS:      # the same symbol in the committed one-lane kernel trace
+                            csvp = os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats_b{B}_{args.unet}_one_lane.csv")
+                            if os.path.exists(csvp):
+                                import csv
+                                want = rocprof_name(dom).replace("sh::", "")
+                                for row in csv.DictReader(open(csvp)):
+                                    if want in row["Name"]:
+                                        r_ms = float(row["AverageNs"]) * 1e-6
+                                        roof["one_lane_alone"].update(rocprof_avg_ms=round(r_ms, 4), rocprof_frac=round(a_fl / sum(alone_times[nm][1] for nm in members) / (r_ms * 1e-3) / 1e12 / peak, 4),
+                                                                      rocprof_source=os.path.relpath(csvp, ROOT))
+                                        break
+                                break
             else:
                 ach = g["bytes"] / (g["ms"] * 1e-3) / 1e9
                 roof = dict(bound="hbm", achieved=round(ach, 2), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), **common)
@@ -779,6 +794,27 @@ def main():
                         roof["mfma_busy_frac"] = pk[key]["mfma_busy_frac"]
                         roof["mfma_busy_source"] = os.path.relpath(sq_path, ROOT)
                         break
+        # Level 0 of the network (the three fused full-resolution kernels): algorithmic flops and bytes per launch, time inside the timed
+        # region, and the fraction of their COMBINED roofline -- the larger of flops / MFMA peak and bytes / HBM peak is the time the
+        # launch cannot beat (these kernels sit furthest below any roofline)
+        level0 = None
+        if args.unet in ("bf16", "f16") and all(k in times for k in ("unet.enc0b", "unet.dec0a", "unet.dec0b")) and "unet.up0" not in times and "unet.enc0a" not in times:
+            HW = 512 * 512
+            spec = {"unet.enc0b": ("enc0a + enc0b + 2x2 pool", ul["unet.enc0a"][0] + ul["unet.enc0b"][0], HW * (4 + 2 * 32 + 2 * 32 // 4)),
+                    "unet.dec0a": ("up0 + dec0a", ul["unet.up0"][0] + ul["unet.dec0a"][0], HW * (2 * 32 + 2 * 64 // 4 + 2 * 32)),
+                    "unet.dec0b": ("dec0b + head", ul["unet.dec0b"][0] + ul["unet.head"][0], HW * (2 * 32 + 4))}
+            level0 = {"kernels": {}}
+            l0_ms = l0_floor = 0.0
+            for nm, (what, fl, by) in spec.items():
+                ms = times[nm][0]
+                t_mfma, t_hbm = fl * B / (PEAK_MFMA_BF16_TF * 1e12) * 1e3, by * B / (PEAK_HBM_GBS * 1e9) * 1e3
+                level0["kernels"][sym_of.get(nm, nm)] = {"layers": what, "gflop_per_launch": round(fl * B / 1e9, 1), "gbytes_per_launch": round(by * B / 1e9, 3), "avg_ms": round(ms, 4),
+                                                         "frac_of_mfma_peak": round(t_mfma / ms, 3), "frac_of_hbm_peak": round(t_hbm / ms, 3),
+                                                         "frac_of_combined_roofline": round(max(t_mfma, t_hbm) / ms, 3)}
+                l0_ms += ms
+                l0_floor += max(t_mfma, t_hbm)
+            level0.update(ms_per_pass=round(l0_ms, 3), frac_of_combined_roofline=round(l0_floor / l0_ms, 3),
+                          share_of_unet_ms=round(l0_ms / sum(times[k][0] for k in times if k.startswith("unet.")), 3))
         unet_ms = sum(times[k][0] for k in times if k.startswith("unet."))
         unet_tf = sum(v[0] for v in ul.values()) * B / (unet_ms * 1e-3) / 1e12 if unet_ms else None
         top = sorted(((k, round(v["ms"] / args.steps, 3)) for k, v in sym.items()), key=lambda kv: -kv[1])[:10]
@@ -820,11 +856,15 @@ def main():
                "parity": PARITY_NOTE[args.unet],
                "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)
+        if level0 is not None:
+            out["level0"] = level0
         if gather_check is not None:
             out["gather_check"] = gather_check
         out.update({"unet_tflops": None if unet_tf is None else round(unet_tf, 2), "device_ms_per_step_top": top,
                     "device_ms_per_step_total": round(total_dev / args.steps, 3), "host_ms_per_step": {k: round(v, 3) for k, v in host_ms.items()},
-                    "geometry_ms_per_step_one_lane": round(geom_ms, 3), "geometry_kernels": geom_tab})
+                    "geometry_ms_per_step_one_lane": round(geom_ms, 3),
+                    "geometry_launches_per_step": int(sum(n for name, (ms, n) in extra_times.items() if n and not name.startswith("unet.") and name not in ("k_synth_batch", "k_pack_w_bf16"))),
+                    "geometry_kernels": geom_tab})
         print(json.dumps(out))
     for e in engs:
         e.close()

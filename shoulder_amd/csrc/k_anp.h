@@ -17,7 +17,7 @@ namespace sh {
 
 __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][512]*/, const double* __restrict__ bg_theta,
                            double* __restrict__ raw, double* __restrict__ shft_theta, int* __restrict__ roll, int B,
-                           unsigned long long* __restrict__ mm_enc /*[B][2]: minimum / maximum of the humerus' image, order-preserving encoding (k_init_bounds before this launch)*/) {
+                           unsigned long long* __restrict__ mm_enc /*[B][2]: minimum / maximum of the humerus' image, order-preserving encoding, the maximum complemented (both words all ones before this launch)*/) {
   // One wave per image row, the (theta, r) row in LDS.  np.interp's search carries the previous index as a
   // guess; on a sorted xp the answer does not depend on the guess, so when theta[:-1] is non-decreasing every
   // lane interpolates its own samples; otherwise lane 0 replays NumPy's sequential loop exactly.
@@ -73,7 +73,7 @@ __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][51
     }
   }
   for (int off = 32; off > 0; off >>= 1) { lo = fmin(lo, __shfl_down(lo, off)); hi = fmax(hi, __shfl_down(hi, off)); }
-  if (lane == 0) { atomicMin(&mm_enc[2 * b], enc_f64(lo)); atomicMax(&mm_enc[2 * b + 1], enc_f64(hi)); }
+  if (lane == 0) { atomicMin(&mm_enc[2 * b], enc_f64(lo)); atomicMin(&mm_enc[2 * b + 1], ~enc_f64(hi)); }
   (void)B;
 }
 
@@ -82,7 +82,7 @@ __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][51
 __global__ void __launch_bounds__(256)
 k_anp_scale(const double* __restrict__ raw, const unsigned long long* __restrict__ mm_enc, float* __restrict__ image) {
   const int b = blockIdx.y, tid = threadIdx.x;
-  const double lo = dec_f64(mm_enc[2 * b]), hi = dec_f64(mm_enc[2 * b + 1]);
+  const double lo = dec_f64(mm_enc[2 * b]), hi = dec_f64(~mm_enc[2 * b + 1]);
   double rng = hi - lo;
   if (rng == 0.0) rng = 1.0;
   const double sc = 1.0 / rng, mn = 0.0 - lo * sc;
@@ -187,9 +187,11 @@ __device__ inline void block_sum(double* v, double* sh /*[NV][blockDim/64]*/, in
 
 // Plane.best_fit + LsqEllipse centre (anatomic_neck.py:123-153); one block of 256 per humerus
 __global__ void __launch_bounds__(256)
-k_anp_plane(const double* __restrict__ pts_obb, const int* __restrict__ counts, double* __restrict__ plane /*[B][6]*/, int* __restrict__ err) {
+k_anp_plane(const double* __restrict__ pts_obb, const int* __restrict__ counts, double* __restrict__ plane /*[B][6]*/, int* __restrict__ err,
+            unsigned long long* __restrict__ ray_t /*[B][4]: "no hit yet" for k_rays_hit (was a fill launch)*/) {
   __shared__ double sh[21 * 4];
   int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 4) ray_t[4 * b + tid] = ~0ull;
   int K = counts[2 * b];
   if (K > SH_ANP_CAP) K = SH_ANP_CAP;
   const double* P = pts_obb + (size_t)b * SH_ANP_CAP * 3;
@@ -288,11 +290,9 @@ k_rays_hit(const double* __restrict__ vobb, const int* __restrict__ faces, const
     if ((tid & 63) == 0 && t < 1e299) atomicMin(&tmin[4 * b + ray], (unsigned long long)__double_as_longlong(t));
   }
 }
-__global__ void k_rays(const double* __restrict__ plane, const unsigned long long* __restrict__ tmin, double* __restrict__ axes_obb,
-                       int* __restrict__ err, int B) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= 4 * B) return;
-  const int b = g >> 2, ray = g & 3;
+// the point of ray `ray` (0..3: +-normal, +-central) of humerus b from its nearest hit parameter; one lane per ray (k_tail, k_te.h)
+__device__ inline void rays_point(const double* plane, const unsigned long long* tmin, double* axes_obb, int* err, int b, int ray) {
+  const int g = 4 * b + ray;
   const double* pl = plane + 6 * b;
   double d[3];
   ray_dir(pl, ray, d);

@@ -341,14 +341,16 @@ k_groove_rfc(const double* __restrict__ xraw, const int* __restrict__ npk, const
 // (found by a randomized sweep: one similarity copy in ~140 had a plateau 11 grid points wide).  Grid points within 1e-9
 // (relative) of the maximum count as tied and the LOWEST index wins; off a plateau neighbouring grid values differ by >= 2e-5.
 #define SH_KDE_TIE 1e-9
-__global__ void k_groove_kde(const double* __restrict__ ptheta, const float* __restrict__ proba, double* __restrict__ bg_theta,
-                             int* __restrict__ err) {
+// (a device function of k_groove_tail: 256 lanes of the humerus' workgroup; returns bg_theta to every lane)
+__device__ inline double groove_kde_wg(const double* __restrict__ ptheta, const float* __restrict__ proba, double* __restrict__ bg_theta,
+                                       int* __restrict__ err, int b) {
   __shared__ double sel[SH_GSLOTS];
   __shared__ double dens[1024];
   __shared__ int nsel;
   __shared__ double wv[4];
   __shared__ int wi[4];
-  int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ double s_bg;
+  int tid = threadIdx.x;
   // the selected peaks in slot order (ordered compaction by ballots; one lane walking 2 310 dependent global loads was most
   // of the kernel)
   __shared__ int s_wc[4];
@@ -369,7 +371,7 @@ __global__ void k_groove_kde(const double* __restrict__ ptheta, const float* __r
     __syncthreads();
   }
   const int n = nsel;
-  if (n == 0) { if (tid == 0) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); bg_theta[b] = 0.0; } return; }
+  if (n == 0) { if (tid == 0) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); bg_theta[b] = 0.0; } return 0.0; }      // (uniform: every lane leaves)
   double best = -1.0;
   for (int j = tid; j < 1024; j += blockDim.x) {
     double t = linspace_at(-1.0 * M_PI, M_PI, 1024, j);
@@ -395,20 +397,22 @@ __global__ void k_groove_kde(const double* __restrict__ ptheta, const float* __r
   __syncthreads();
   if (tid == 0) {
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) bi = min(bi, wi[w]);
-    bg_theta[b] = linspace_at(-1.0 * M_PI, M_PI, 1024, bi);
+    s_bg = linspace_at(-1.0 * M_PI, M_PI, 1024, bi);
+    bg_theta[b] = s_bg;
   }
+  __syncthreads();
+  return s_bg;
 }
 
-__global__ void k_groove_localmin(const double* __restrict__ itr_cs, const double* __restrict__ r0, const double* __restrict__ prox_zs,
-                                  const double* __restrict__ prox_centroids, const double* __restrict__ bg_theta, int row0, double deg_window,
-                                  int* __restrict__ local_idx, double* __restrict__ pts_obb, int B) {
-  int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= B * SH_GROOVE_NROWS) return;
-  int b = gid / SH_GROOVE_NROWS, i = gid % SH_GROOVE_NROWS;
+// row i of humerus b (one lane)
+__device__ inline void groove_localmin_row(const double* __restrict__ itr_cs, const double* __restrict__ r0, const double* __restrict__ prox_zs,
+                                           const double* __restrict__ prox_centroids, double bg, int row0, double deg_window,
+                                           int* __restrict__ local_idx, double* pts_obb, int b, int i) {
+  const int gid = b * SH_GROOVE_NROWS + i;
   const double* row = itr_cs + ((size_t)b * SH_NPROX + row0 + i) * 2 * SH_MPROX;
   int ivar = (int)rint(deg_window / (360.0 / (double)SH_MPROX));
   if (ivar < 1) ivar = 1;
-  int loc = groove_local_min(row, r0 + (size_t)gid * SH_MPROX, SH_MPROX, bg_theta[b], ivar);
+  int loc = groove_local_min(row, r0 + (size_t)gid * SH_MPROX, SH_MPROX, bg, ivar);
   local_idx[gid] = loc;
   int k = loc < 0 ? loc + SH_MPROX : loc;      // python negative index
   k = k < 0 ? 0 : (k >= SH_MPROX ? SH_MPROX - 1 : k);      // never off the row (sh_set_params keeps the window within half a turn; the reference raises IndexError beyond)
@@ -420,9 +424,10 @@ __global__ void k_groove_localmin(const double* __restrict__ itr_cs, const doubl
   p[2] = prox_zs[(size_t)b * SH_NPROX + row0 + i] + 0.0;
 }
 
-__global__ void k_groove_axis(const double* __restrict__ pts_obb, const double* __restrict__ T_obb, double* __restrict__ axis_ct,
-                              double* __restrict__ pts_ct) {
-  int b = blockIdx.x, lane = threadIdx.x;
+// (one wave)
+__device__ inline void groove_axis_wave(const double* pts_obb, const double* __restrict__ T_obb, double* __restrict__ axis_ct,
+                                        double* __restrict__ pts_ct, int b) {
+  int lane = threadIdx.x & 63;
   const double* P = pts_obb + (size_t)b * SH_GROOVE_NROWS * 3;
   double mean[3], d[3];
   wave_line_fit(P, SH_GROOVE_NROWS, 3, mean, d);
@@ -439,6 +444,20 @@ __global__ void k_groove_axis(const double* __restrict__ pts_obb, const double* 
     xform_pt(Ti, mean[0] + d[0] * h, mean[1] + d[1] * h, mean[2] + d[2] * h, axis_ct + 6 * b);
     xform_pt(Ti, mean[0] - d[0] * h, mean[1] - d[1] * h, mean[2] - d[2] * h, axis_ct + 6 * b + 3);
   }
+}
+
+// bicipital_groove.py:184-265 behind the forest, per humerus, as ONE launch (were three: k_groove_kde, k_groove_localmin,
+// k_groove_axis): KDE argmax -> bg_theta, the radius minimum of every row near it -> groove points, line fit -> axis.
+__global__ void __launch_bounds__(256)
+k_groove_tail(const double* __restrict__ ptheta, const float* __restrict__ proba, double* __restrict__ bg_theta, int* __restrict__ err,
+              const double* __restrict__ itr_cs, const double* __restrict__ r0, const double* __restrict__ prox_zs, const double* __restrict__ prox_centroids,
+              int row0, double deg_window, int* __restrict__ local_idx, double* pts_obb, const double* __restrict__ T_obb,
+              double* __restrict__ axis_ct, double* __restrict__ pts_ct) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const double bg = groove_kde_wg(ptheta, proba, bg_theta, err, b);
+  for (int i = tid; i < SH_GROOVE_NROWS; i += 256) groove_localmin_row(itr_cs, r0, prox_zs, prox_centroids, bg, row0, deg_window, local_idx, pts_obb, b, i);
+  __syncthreads();      // (the points of all rows, written by this workgroup, are read by its first wave)
+  if (tid < 64) groove_axis_wave(pts_obb, T_obb, axis_ct, pts_ct, b);
 }
 
 }  // namespace sh

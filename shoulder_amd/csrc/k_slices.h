@@ -54,13 +54,13 @@ __global__ void k_transform_verts(const float* __restrict__ verts, const long lo
   }
   if ((threadIdx.x & 63) == 0) {
     atomicMin(&zb_enc[2 * b], enc_f64(zmin));
-    atomicMax(&zb_enc[2 * b + 1], enc_f64(zmax));
+    atomicMin(&zb_enc[2 * b + 1], ~enc_f64(zmax));      // (the maximum as the minimum of the complement: both words start as all ones = one uniform fill)
   }
 }
 
 __global__ void k_decode_bounds(const unsigned long long* zb_enc, double* zb, int B) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2 * B) zb[i] = dec_f64(zb_enc[i]);
+  if (i < 2 * B) zb[i] = dec_f64((i & 1) ? ~zb_enc[i] : zb_enc[i]);
 }
 
 // NumPy pairwise summation (np.add.reduce on a contiguous float64 vector)
@@ -90,15 +90,32 @@ __device__ inline double np_pairwise_sum(const double* a, int n) {
 // kind 2: distal linspace(.99 zmin, 0, N)             kind 3: the one plane z = neck_z
 // kind 4: ProxObb area scan linspace(.99 zmin, .99 zmax, N) of the raw box bounds, every plane cut at its own z
 //         (`mesh.section(plane_origin=[0,0,z])` in a loop, mesh.py:157-160)
+// The launch also does the set's bookkeeping, which were launches of their own (round 4): the crossing counters of its planes and
+// the large-tier counter start at zero, the overflow tier's per-set words are reset (when that tier runs), and the first set behind
+// k_transform_verts decodes the box's z bounds (were k_decode_bounds) for everything after it.
+struct PlaneAux {
+  const unsigned long long* zb_enc; double* zb_out;      // nullable: z bounds from the encoded atomics of k_transform_verts, also written to zb_out
+  int* seg_count; int* nlarge;                           // [B][N] crossing counters of this set; its large-tier counter
+  int* ovf_nlist; unsigned long long* ovf_ctr;           // nullable: overflow tier (k_ovf.h): list length of the set, pool counters [0] and [2]
+};
 __global__ void k_make_planes(int kind, int N, const double* __restrict__ zb /*[B][2]*/, const double* __restrict__ neck_z,
-                              double* __restrict__ zs, double* __restrict__ zeff, int B) {
+                              double* __restrict__ zs, double* __restrict__ zeff, int B, PlaneAux A) {
   int b = blockIdx.x;
   if (b >= B) return;
+  for (int k = threadIdx.x; k < N; k += blockDim.x) A.seg_count[(size_t)b * N + k] = 0;
+  if (b == 0 && threadIdx.x == 0) {
+    *A.nlarge = 0;
+    if (A.ovf_nlist) { *A.ovf_nlist = 0; A.ovf_ctr[0] = 0ull; A.ovf_ctr[2] = 0ull; }
+  }
   if (kind == 3) {   // one plane at neck_z: `mesh.section(plane_origin=[0,0,neck_z])` (surgical_neck.py:37-39)
     if (threadIdx.x == 0) { zs[b] = neck_z[b]; zeff[b] = neck_z[b]; }
     return;
   }
-  double zmin = zb[2 * b], zmax = zb[2 * b + 1];
+  double zmin, zmax;
+  if (A.zb_enc) {
+    zmin = dec_f64(A.zb_enc[2 * b]); zmax = dec_f64(~A.zb_enc[2 * b + 1]);
+    if (threadIdx.x == 0) { A.zb_out[2 * b] = zmin; A.zb_out[2 * b + 1] = zmax; }
+  } else { zmin = zb[2 * b]; zmax = zb[2 * b + 1]; }
   double a, e;
   if (kind == 4) {
     for (int k = threadIdx.x; k < N; k += blockDim.x) { double z = linspace_at(zmin * 0.99, zmax * 0.99, N, k); zs[(size_t)b * N + k] = z; zeff[(size_t)b * N + k] = z; }

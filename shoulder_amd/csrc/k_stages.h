@@ -72,11 +72,6 @@ __global__ void k_section_points(const float* __restrict__ verts, const int* __r
   }
 }
 
-__global__ void k_init_bounds(unsigned long long* zb_enc, int B) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2 * B) zb_enc[i] = (i & 1) ? 0ull : ~0ull;
-}
-
 // k-th smallest (0-based) of n NON-NEGATIVE doubles by one 64-lane workgroup: radix select on the bit patterns (which order
 // like the values), one byte per pass -- the same value any selection algorithm returns (sh::kth_smallest on the host).
 // hist: 256 counters + 2 words in LDS.

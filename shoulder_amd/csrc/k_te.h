@@ -504,10 +504,8 @@ __global__ void k_te_ends(const double* __restrict__ ring, const int* __restrict
 }
 
 // epicondyle.py:90-96: medial end = smaller x in construct_csys(canal axis, head central axis); one lane per humerus
-__global__ void k_te_orient(const double* __restrict__ ends_ct, const double* __restrict__ T_obb, const double* __restrict__ canal_axis_ct,
-                            const double* __restrict__ axes_obb /*[B][4][3]: +n,-n,+c,-c*/, double* __restrict__ te_axis_ct, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+__device__ inline void te_orient_one(const double* ends_ct, const double* T_obb, const double* canal_axis_ct,
+                                     const double* axes_obb /*[B][4][3]: +n,-n,+c,-c*/, double* te_axis_ct, int b) {
   const double* e0 = ends_ct + 6 * b;
   const double* e1 = e0 + 3;
   double* out = te_axis_ct + 6 * b;
@@ -526,15 +524,20 @@ __global__ void k_te_orient(const double* __restrict__ ends_ct, const double* __
 }
 
 
-__global__ void k_pack(sh_landmarks* __restrict__ lm, const double* __restrict__ T_obb, const double* __restrict__ zb,
-                       const double* __restrict__ neck_z, const int* __restrict__ neck_index, const int* __restrict__ flipped,
-                       const double* __restrict__ canal_axis_ct, const double* __restrict__ te_axis_ct,
-                       const double* __restrict__ groove_axis_ct, const double* __restrict__ bg_theta,
-                       const double* __restrict__ groove_pts_ct, const double* __restrict__ plane, const double* __restrict__ axes_obb,
-                       const double* __restrict__ anp_pts_obb, const int* __restrict__ anp_counts, const int* __restrict__ err,
-                       uint32_t mask, int B, int bone_kind, const double* __restrict__ canal_cut /*[B][2] or null*/, double cc0, double cc1) {
-  int b = blockIdx.x;
-  if (b >= B) return;
+// the record of humerus b by its workgroup (every lane copies points, lane 0 writes the scalars)
+struct PackArgs {
+  sh_landmarks* lm; const double* T_obb; const double* zb; const double* neck_z; const int* neck_index; const int* flipped;
+  const double* canal_axis_ct; double* te_axis_ct; const double* groove_axis_ct; const double* bg_theta; const double* groove_pts_ct;
+  const double* plane; double* axes_obb; const double* anp_pts_obb; const int* anp_counts; int* err;
+  uint32_t mask; int B, bone_kind; const double* canal_cut /*[B][2] or null*/; double cc0, cc1;
+  const unsigned long long* ray_t; const double* te_ends_ct; const double* sphere_partial; int metrics;
+};
+__device__ inline void pack_one(const PackArgs& A, int b) {
+  sh_landmarks* lm = A.lm; const double* T_obb = A.T_obb; const double* zb = A.zb; const double* neck_z = A.neck_z; const int* neck_index = A.neck_index;
+  const int* flipped = A.flipped; const double* canal_axis_ct = A.canal_axis_ct; const double* te_axis_ct = A.te_axis_ct; const double* groove_axis_ct = A.groove_axis_ct;
+  const double* bg_theta = A.bg_theta; const double* groove_pts_ct = A.groove_pts_ct; const double* plane = A.plane; const double* axes_obb = A.axes_obb;
+  const double* anp_pts_obb = A.anp_pts_obb; const int* anp_counts = A.anp_counts; const int* err = A.err; const uint32_t mask = A.mask; const int bone_kind = A.bone_kind;
+  const double* canal_cut = A.canal_cut; const double cc0 = A.cc0, cc1 = A.cc1;
   sh_landmarks* L = lm + b;
   int tid = threadIdx.x;
   double Ti[16];
@@ -640,9 +643,8 @@ k_sphere_partial(const float* __restrict__ logits, const double* __restrict__ ra
   if (tid < 14) partial[((size_t)b * SH_SPH_PARTS + part) * 14 + tid] = a[tid];
 }
 
-__global__ void __launch_bounds__(64)
-k_metrics(sh_landmarks* __restrict__ lm, const double* __restrict__ partial, int* __restrict__ err, int bone_kind) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+__device__ inline void metrics_one(sh_landmarks* lm, const double* partial, int* err, int bone_kind, int b) {
+  const int tid = threadIdx.x;
   sh_landmarks* L = lm + b;
   double radius = 0.0;
   {
@@ -702,6 +704,25 @@ k_metrics(sh_landmarks* __restrict__ lm, const double* __restrict__ partial, int
     unitxyz_to_spherical_deg(v, &th, &ph);
     L->retroversion = L->side == 1 ? -th : th;
   }
+}
+
+// The end of a run as ONE launch (were four: k_rays, k_te_orient, k_pack, k_metrics -- each a handful of lanes per humerus in a
+// dependent chain behind the UNet pass): one workgroup per humerus, the steps separated by workgroup barriers.
+//   rays (anatomic_neck.py:174-236)  the four axis points from the nearest hit parameters of k_rays_hit
+//   trans-epicondylar order (epicondyle.py:90-96)  medial end first, needs the head's central axis
+//   record (bone.py:146-157, utils.py:289-318)  landmarks in CT, csys
+//   metrics (bone_props.py)  side, neck-shaft, retroversion, radius of curvature from k_sphere_partial's sums
+__global__ void __launch_bounds__(256)
+k_tail(PackArgs A) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= A.B) return;
+  if ((A.mask & SH_STAGE_ANP) && tid < 4) rays_point(A.plane, A.ray_t, A.axes_obb, A.err, b, tid);
+  __syncthreads();
+  if ((A.mask & SH_STAGE_TE) && tid == 0) te_orient_one(A.te_ends_ct, A.T_obb, A.canal_axis_ct, A.axes_obb, A.te_axis_ct, b);
+  __syncthreads();
+  pack_one(A, b);
+  __syncthreads();
+  if (A.metrics && tid < 64) metrics_one(A.lm, A.sphere_partial, A.err, A.bone_kind, b);
 }
 
 }  // namespace sh

@@ -77,6 +77,7 @@ struct sh_ctx {
   std::map<std::string, ULayer> ulayers;
   size_t unet_floats = 0;
   bool obb_injected = false;
+  bool bounds_cleared = false;               // run_obb's first fill of this window covered zb_enc / anp.mm_enc (run_window skips its own)
   // hull of SH_STAGE_OBB: 1 = on the device (k_hull.h), 0 = host quickhull (sh_hull.h).  sh_set_hull_mode / SHOULDER_HULL=host|device|auto.
   // A humerus the device hull gives up (pinched horizon on nearly coplanar clouds, capacities) is re-done ALONE by sh_collect:
   // host quickhull for that humerus, its record patched into the device buffers, its stages re-run as a window of one behind
@@ -1578,27 +1579,30 @@ static int ovf_set(sh_ctx* c, const std::string& pfx, int N, OvfSet* S) {
   return SH_OK;
 }
 
-static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0, bool total_area = false) {
+static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0, bool total_area = false, bool decode_bounds = false) {
   const int B = c->Bwin;
   std::string p = pfx;
   double* zs = buf<double>(c, (p + ".zs").c_str());
   double* zeff = buf<double>(c, (p + ".zeff").c_str());
   int* cnt = buf<int>(c, (p + ".seg_count").c_str());
   Seg* segs = buf<Seg>(c, (p + ".segs").c_str());
-  LAUNCH(c, "k_make_planes", k_make_planes, dim3(B), dim3(256), kind, N, buf<double>(c, kind == 4 ? "obb.zb_pre" : "z_bounds"), buf<double>(c, "neck_z"), zs, zeff, B);
+  if (N > SH_EMIT_MAXN) return fail(c, SH_ERR_CAPACITY, "slice set has more planes than k_slice_emit's LDS histogram");
   double* atot = total_area ? buf<double>(c, (p + ".area_total").c_str()) : (double*)nullptr;
   int* nlarge = (int*)c->bufs["slices.nlarge"].p + (kind & 7);      // (one counter per kind of set: two sets may run on two streams)
-  FILL(c, {cnt, (size_t)B * N * 4, 0}, {nlarge, 4, 0});
-  if (N > SH_EMIT_MAXN) return fail(c, SH_ERR_CAPACITY, "slice set has more planes than k_slice_emit's LDS histogram");
-  dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 4096), (unsigned)B);
-  LAUNCH(c, "k_slice_emit", k_slice_emit, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
-         buf<long long>(c, "foff"), zeff, N, cnt, segs);
   // planes with more crossings than slots (k_ovf.h): plan their pool ranges, section them again into the segment pool
   OvfPools OP; OvfSet OS;
   { int orc; if ((orc = ovf_pools(c, &OP)) != SH_OK || (orc = ovf_set(c, p, N, &OS)) != SH_OK) return orc; }
   const bool ovf_on = c->ovf_none_gen != c->batch_gen;      // (known from an earlier run of this batch: no plane overflows)
+  // the plane heights; the same launch zeroes the set's crossing counters and its large-tier counter, resets the overflow tier's
+  // per-set words (segments / workspace used: per set; ring points stay for the run) and, for the first set behind
+  // k_transform_verts, decodes the z bounds (run_window)
+  PlaneAux aux{decode_bounds ? (const unsigned long long*)buf<unsigned long long>(c, "zb_enc") : (const unsigned long long*)nullptr, buf<double>(c, "z_bounds"), cnt, nlarge,
+               ovf_on ? OS.nlist : (int*)nullptr, OP.ctr};
+  LAUNCH(c, "k_make_planes", k_make_planes, dim3(B), dim3(256), kind, N, buf<double>(c, kind == 4 ? "obb.zb_pre" : "z_bounds"), buf<double>(c, "neck_z"), zs, zeff, B, aux);
+  dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 4096), (unsigned)B);
+  LAUNCH(c, "k_slice_emit", k_slice_emit, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
+         buf<long long>(c, "foff"), zeff, N, cnt, segs);
   if (ovf_on) {
-    FILL(c, {OS.nlist, 4, 0}, {OP.ctr, 8, 0} /*segments used: per set*/, {OP.ctr + 2, 8, 0} /*workspace used: per set (ring points stay for the run)*/);
     LAUNCH(c, "k_ovf_plan", k_ovf_plan, dim3((unsigned)((B * N + 255) / 256)), dim3(256), N, B * N, (const int*)cnt, OP, OS, buf<int>(c, "err"));
     LAUNCH(c, "k_slice_emit_ovf", k_slice_emit_ovf, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
            buf<long long>(c, "foff"), zeff, N, OP, OS);
@@ -1920,7 +1924,9 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   const int* cnt_ne = buf<int>(c, "hull.ne");
   {
     FILL(c, {buf<unsigned long long>(c, "obb.best_enc"), (size_t)B * 8, 0xFF} /*"no candidate volume yet"*/, {buf<unsigned long long>(c, "obb.lbmin_enc"), (size_t)B * 8, 0xFF},
-         {buf<double>(c, "obb.area2"), (size_t)B * SH_HF * 8, 0});
+         {buf<double>(c, "obb.area2"), (size_t)B * SH_HF * 8, 0}, {buf<int>(c, "obb.endcnt"), (size_t)B * 2 * 4, 0},
+         {buf<unsigned long long>(c, "zb_enc"), (size_t)B * 16, 0xFF} /*z bounds: "nothing seen yet"*/, {buf<unsigned long long>(c, "anp.mm_enc"), (size_t)B * 16, 0xFF});
+    c->bounds_cleared = true;
     const int nemax = 3 * nfmax / 2 + 3;      // (a closed triangulated surface: 2 E = 3 F)
     LAUNCH(c, "k_obb_face_area2", k_obb_face_area2, dim3((unsigned)((std::min(nemax, SH_HE) + 255) / 256), (unsigned)B), dim3(256), buf<double>(c, "hull.hv"),
            buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.area2"));
@@ -1959,9 +1965,9 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   if (c->params.bone_kind == SH_BONE_PROXIMAL) {
     // mesh.py:134-192 ProxObb: 100 sections of the mesh in the raw box frame, head = largest area, canal range
     dim3 gv((unsigned)std::min<long long>((c->maxV + 255) / 256, 1024), (unsigned)B);
-    LAUNCH(c, "k_init_bounds", k_init_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "zb_enc"), B);
     LAUNCH(c, "k_transform_verts", k_transform_verts, gv, dim3(256), buf<float>(c, "verts"), buf<long long>(c, "voff"),
-           buf<double>(c, "obb.T_pre"), buf<double>(c, "verts_obb"), buf<unsigned long long>(c, "zb_enc"));
+           buf<double>(c, "obb.T_pre"), buf<double>(c, "verts_obb"), buf<unsigned long long>(c, "zb_enc"));      // (zb_enc: cleared by the fill above; its values are not used here)
+    c->bounds_cleared = false;      // ... and run_window clears it again for the box frame's pass
     int rc2;
     if ((rc2 = run_slice_set(c, "pobb", 4, SH_NPSCAN, false, false, 0, true)) != SH_OK) return rc2;
     LAUNCH(c, "k_prox_obb", k_prox_obb, dim3((B + 63) / 64), dim3(64), buf<double>(c, "pobb.area_total"), buf<double>(c, "pobb.zs"), buf<double>(c, "obb.T_pre"),
@@ -1969,7 +1975,6 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
     c->obb_injected = true;
     return SH_OK;
   }
-  FILL(c, {buf<int>(c, "obb.endcnt"), (size_t)B * 2 * 4, 0});
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 1024), (unsigned)B);
   LAUNCH(c, "k_obb_end_points", k_obb_end_points, g, dim3(256), buf<float>(c, "verts"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
          buf<long long>(c, "foff"), buf<double>(c, "obb.T_pre"), buf<double>(c, "obb.zb_pre"), buf<double>(c, "obb.endpts"), buf<int>(c, "obb.endcnt"));
@@ -2003,19 +2008,24 @@ static int run_te_rows(sh_ctx* c) {
 static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   const int B = c->Bwin;
   int rc;
+  c->bounds_cleared = false;
   if (mask & SH_STAGE_OBB)
     if ((rc = run_obb(c, prepared_slot)) != SH_OK) return rc;
-  if (mask & (SH_STAGE_OBB | SH_STAGE_FULL)) {
+  // the encoded minima / maxima (z bounds of the box frame, the anatomic-neck image's range) start as all ones: one fill for both,
+  // in run_obb's first fill when that stage runs (they were a launch each)
+  if (!c->bounds_cleared && (mask & (SH_STAGE_OBB | SH_STAGE_FULL | SH_STAGE_ANP)))
+    FILL(c, {buf<unsigned long long>(c, "zb_enc"), (size_t)B * 16, 0xFF}, {buf<unsigned long long>(c, "anp.mm_enc"), (size_t)B * 16, 0xFF});
+  const bool transformed = (mask & (SH_STAGE_OBB | SH_STAGE_FULL)) != 0;
+  if (transformed) {
     // verts_obb + z bounds (mesh.py:85-86)
-    LAUNCH(c, "k_init_bounds", k_init_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "zb_enc"), B);
     dim3 g((unsigned)std::min<long long>((c->maxV + 255) / 256, 1024), (unsigned)B);
     LAUNCH(c, "k_transform_verts", k_transform_verts, g, dim3(256), buf<float>(c, "verts"), buf<long long>(c, "voff"),
            buf<double>(c, "obb_transform"), buf<double>(c, "verts_obb"), buf<unsigned long long>(c, "zb_enc"));
-    LAUNCH(c, "k_decode_bounds", k_decode_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "zb_enc"),
-           buf<double>(c, "z_bounds"), B);
+    if (!(mask & SH_STAGE_FULL))      // (with the full set in the run its k_make_planes decodes them)
+      LAUNCH(c, "k_decode_bounds", k_decode_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "zb_enc"), buf<double>(c, "z_bounds"), B);
   }
   if (mask & SH_STAGE_FULL)
-    if ((rc = run_slice_set(c, "full", 0, SH_NFULL, false, false)) != SH_OK) return rc;
+    if ((rc = run_slice_set(c, "full", 0, SH_NFULL, false, false, 0, false, transformed)) != SH_OK) return rc;
   // The distal set and the first part of the trans-epicondylar stage (the rectangles of its rows, the ends of the widest one) need
   // nothing but the box frame.  Small batches (up to 16 humeri: one humerus gains 4 %, 6.01 -> 5.78 ms per run; at B = 64 two streams'
   // kernels just share the CUs and one lane LOSES 8 %): the whole branch runs on the side stream beside the full -> neck -> canal ->
@@ -2100,17 +2110,12 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     }
     LAUNCH(c, "k_groove_rfc", k_groove_rfc, dim3((B * SH_GSLOTS + 63) / 64), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
            buf<double>(c, "groove.stats"), nodes, roots, c->rfc_trees, buf<double>(c, "groove.xs"), buf<float>(c, "groove.proba"), B);
-    LAUNCH(c, "k_groove_kde", k_groove_kde, dim3(B), dim3(256), buf<double>(c, "groove.ptheta"), buf<float>(c, "groove.proba"),
-           buf<double>(c, "groove.bg_theta"), buf<int>(c, "err"));
-    LAUNCH(c, "k_groove_localmin", k_groove_localmin, dim3((rows + 63) / 64), dim3(64), buf<double>(c, "prox.itr_centered_start"),
-           buf<double>(c, "groove.r0"), buf<double>(c, "prox.zs"), buf<double>(c, "prox.centroids"), buf<double>(c, "groove.bg_theta"), ga,
-           c->params.groove_deg_window, buf<int>(c, "groove.local_idx"), buf<double>(c, "groove.points_obb"), B);
-    LAUNCH(c, "k_groove_axis", k_groove_axis, dim3(B), dim3(64), buf<double>(c, "groove.points_obb"), buf<double>(c, "obb_transform"),
-           buf<double>(c, "groove.axis_ct"), buf<double>(c, "groove.points_ct"));
+    LAUNCH(c, "k_groove_tail", k_groove_tail, dim3(B), dim3(256), buf<double>(c, "groove.ptheta"), buf<float>(c, "groove.proba"), buf<double>(c, "groove.bg_theta"), buf<int>(c, "err"),
+           buf<double>(c, "prox.itr_centered_start"), buf<double>(c, "groove.r0"), buf<double>(c, "prox.zs"), buf<double>(c, "prox.centroids"), ga, c->params.groove_deg_window,
+           buf<int>(c, "groove.local_idx"), buf<double>(c, "groove.points_obb"), buf<double>(c, "obb_transform"), buf<double>(c, "groove.axis_ct"), buf<double>(c, "groove.points_ct"));
   }
   if (mask & SH_STAGE_ANP) {
     if (!c->have_unet) return fail(c, SH_ERR_STATE, "sh_run: anatomic-neck stage needs sh_load_unet first");
-    LAUNCH(c, "k_init_bounds", k_init_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "anp.mm_enc"), B);
     LAUNCH(c, "k_anp_rows", k_anp_rows, dim3(B * SH_ANP_ROWS), dim3(64), buf<double>(c, "prox.itr_start"),
            buf<double>(c, "groove.bg_theta"), buf<double>(c, "anp.raw"), buf<double>(c, "anp.shft_theta"), buf<int>(c, "anp.roll"), B,
            buf<unsigned long long>(c, "anp.mm_enc"));      // (+ the image's minimum / maximum: no second pass over it)
@@ -2124,34 +2129,32 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<int>(c, "anp.rowcnt"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
            buf<int>(c, "err"));
     LAUNCH(c, "k_anp_plane", k_anp_plane, dim3(B), dim3(256), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
-           buf<double>(c, "anp.plane"), buf<int>(c, "err"));
-    FILL(c, {buf<unsigned long long>(c, "anp.ray_t"), (size_t)B * 4 * 8, 0xFF});
+           buf<double>(c, "anp.plane"), buf<int>(c, "err"), buf<unsigned long long>(c, "anp.ray_t"));      // (+ "no hit yet" for the rays)
     LAUNCH(c, "k_rays_hit", k_rays_hit, dim3(SH_RAY_CHUNKS, B), dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
            buf<long long>(c, "foff"), buf<double>(c, "anp.plane"), buf<unsigned long long>(c, "anp.ray_t"));
-    LAUNCH(c, "k_rays", k_rays, dim3((4 * B + 63) / 64), dim3(64), buf<double>(c, "anp.plane"), buf<unsigned long long>(c, "anp.ray_t"),
-           buf<double>(c, "anp.axes_obb"), buf<int>(c, "err"), B);
   }
   if (mask & SH_STAGE_TE) {
     if (c->side_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_join_ev, 0)); c->side_pending = false; }      // (rectangles and ends: done on the side stream)
     if (!te_rows_done && (rc = run_te_rows(c)) != SH_OK) return rc;
-    LAUNCH(c, "k_te_orient", k_te_orient, dim3((B + 63) / 64), dim3(64), buf<double>(c, "te.ends_ct"), buf<double>(c, "obb_transform"), buf<double>(c, "canal.axis_ct"),
-           buf<double>(c, "anp.axes_obb"), buf<double>(c, "te.axis_ct"), B);
   }
   if (c->side_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_join_ev, 0)); c->side_pending = false; }
-  LAUNCH(c, "k_pack", k_pack, dim3(B), dim3(256), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "obb_transform"), buf<double>(c, "z_bounds"),
-         buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), buf<int>(c, "flipped"), buf<double>(c, "canal.axis_ct"), buf<double>(c, "te.axis_ct"),
-         buf<double>(c, "groove.axis_ct"), buf<double>(c, "groove.bg_theta"), buf<double>(c, "groove.points_ct"), buf<double>(c, "anp.plane"),
-         buf<double>(c, "anp.axes_obb"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"), buf<int>(c, "err"), mask, B,
-         (int)c->params.bone_kind, c->params.bone_kind == SH_BONE_PROXIMAL ? buf<double>(c, "pobb.cutoff") : (const double*)nullptr,
-         c->params.canal_cutoff[0], c->params.canal_cutoff[1]);
-  {
-    const uint32_t need = SH_STAGE_GROOVE | SH_STAGE_ANP | SH_STAGE_CSYS | (c->params.bone_kind == SH_BONE_PROXIMAL ? 0u : (uint32_t)SH_STAGE_TE);
-    if ((mask & need) == need)      // metrics of bone_props.py (side, retroversion, neck-shaft angle, radius of curvature)
-    {
-      LAUNCH(c, "k_sphere_partial", k_sphere_partial, dim3(SH_SPH_PARTS, B), dim3(256), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
-             buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.plane"), buf<double>(c, "metrics.partial"));
-      LAUNCH(c, "k_metrics", k_metrics, dim3(B), dim3(64), buf<sh_landmarks>(c, "landmarks"), buf<double>(c, "metrics.partial"), buf<int>(c, "err"), (int)c->params.bone_kind);
-    }
+  // metrics of bone_props.py (side, retroversion, neck-shaft angle, radius of curvature): the sphere's sums need the mask and the neck plane only
+  const uint32_t need = SH_STAGE_GROOVE | SH_STAGE_ANP | SH_STAGE_CSYS | (c->params.bone_kind == SH_BONE_PROXIMAL ? 0u : (uint32_t)SH_STAGE_TE);
+  const bool metrics = (mask & need) == need;
+  if (metrics)
+    LAUNCH(c, "k_sphere_partial", k_sphere_partial, dim3(SH_SPH_PARTS, B), dim3(256), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
+           buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.plane"), buf<double>(c, "metrics.partial"));
+  {      // ray points -> trans-epicondylar order -> record -> metrics: one launch, one workgroup per humerus (k_tail, k_te.h)
+    PackArgs A{};
+    A.lm = buf<sh_landmarks>(c, "landmarks"); A.T_obb = buf<double>(c, "obb_transform"); A.zb = buf<double>(c, "z_bounds"); A.neck_z = buf<double>(c, "neck_z");
+    A.neck_index = buf<int>(c, "neck_index"); A.flipped = buf<int>(c, "flipped"); A.canal_axis_ct = buf<double>(c, "canal.axis_ct"); A.te_axis_ct = buf<double>(c, "te.axis_ct");
+    A.groove_axis_ct = buf<double>(c, "groove.axis_ct"); A.bg_theta = buf<double>(c, "groove.bg_theta"); A.groove_pts_ct = buf<double>(c, "groove.points_ct");
+    A.plane = buf<double>(c, "anp.plane"); A.axes_obb = buf<double>(c, "anp.axes_obb"); A.anp_pts_obb = buf<double>(c, "anp.points_obb"); A.anp_counts = buf<int>(c, "anp.counts");
+    A.err = buf<int>(c, "err"); A.mask = mask; A.B = B; A.bone_kind = (int)c->params.bone_kind;
+    A.canal_cut = c->params.bone_kind == SH_BONE_PROXIMAL ? buf<double>(c, "pobb.cutoff") : (const double*)nullptr;
+    A.cc0 = c->params.canal_cutoff[0]; A.cc1 = c->params.canal_cutoff[1];
+    A.ray_t = buf<unsigned long long>(c, "anp.ray_t"); A.te_ends_ct = buf<double>(c, "te.ends_ct"); A.sphere_partial = buf<double>(c, "metrics.partial"); A.metrics = metrics ? 1 : 0;
+    LAUNCH(c, "k_tail", k_tail, dim3(B), dim3(256), A);
   }
   if (mask & SH_STAGE_APPLY) {      // bone.py:155: the mesh of every humerus in its own canal / trans-epicondylar (or canal / articular) frame
     dim3 g((unsigned)std::min<long long>((c->maxV + 255) / 256, 1024), (unsigned)B);
