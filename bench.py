@@ -319,6 +319,8 @@ def main():
     ap.add_argument("--from-stl", action="store_true", help="every step starts from the bytes of B binary STL files (device-side parse + vertex merge, sh_upload_stl)")
     ap.add_argument("--sync-upload", action="store_true", help="with --from-host / --from-stl: hand every batch over with the synchronous sh_upload_* (round 2's schedule) instead of the staging side (sh_stage_* / sh_commit_staged)")
     ap.add_argument("--stream-batches", type=int, default=4, help="distinct batches the streaming legs cycle through (every step gets a batch different from the one its lane holds)")
+    ap.add_argument("--record-rows", type=int, default=2560, help="anatomic-neck rows per record on the wire (sh_set_record_rows): records of 8 680 + 24 R bytes instead of the full "
+                    "104 KB (4 096 padded rows; these humeri have ~2 300 edge points); 0 = full records.  Every other field is in both formats; n_anp keeps the true count")
     ap.add_argument("--hull", choices=["auto", "host", "device"], default="auto", help="where the convex hull of the OBB stage runs (sh_set_hull_mode); "
                     "auto = host quickhull where the rank has enough usable hardware threads (16 alone on its host, 48 per rank otherwise), else the device hull")
     ap.add_argument("--check-gather", action="store_true", help="after the timed region rank 0 compares the records the last gather delivered for its own shard with a run of its own engine")
@@ -361,6 +363,9 @@ def main():
         eng.set_hull_mode(args.hull)
     lanes = (args.lanes if args.lanes > 0 else (3 if eng.hull_mode == "device" else 2)) if not args.no_pipeline else 1
     engs = [eng] + [Engine(local) for _ in range(lanes - 1)]
+    REC = _lib.record_dtype(args.record_rows)
+    for e in engs:
+        e.set_record_rows(args.record_rows)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -418,9 +423,10 @@ def main():
             e.upload([(verts, faces)])
             e.synth_batch(T)                           # batch resident in HBM (of every lane) before the timed region
 
-    lm_t = shd.as_byte_tensor(eng.landmarks_device(), device=f"cuda:{local}") if use_dist else None
+    # the records of a step go to rank 0 in the wire format (packed unless --record-rows 0): B x REC.itemsize bytes per rank and step
+    lm_t = torch.zeros(B * REC.itemsize, dtype=torch.uint8, device=f"cuda:{local}") if use_dist else None
     gather_list = [torch.empty_like(lm_t) for _ in range(world)] if (use_dist and rank == 0) else None
-    # pipelined schedule: every run copies its records (device to device, on its engine's stream) into one of the send buffers
+    # pipelined schedule: every run writes its records (on its engine's stream) into one of the send buffers
     nsend = 2 * lanes
     send = [torch.empty_like(lm_t) for _ in range(nsend)] if use_dist else None
     send_free = [None] * nsend      # event recorded behind the gather that last read send[k]
@@ -529,9 +535,12 @@ def main():
                 if s_ == steps - 1:
                     e.set_overlap(False)
                 hand_over(e)
-                e.run(_lib.STAGE_ALL, fetch=False if use_dist else "view")      # records land in the engine's page-locked buffer (or are gathered device to device)
                 if use_dist:
+                    e.submit(_lib.STAGE_ALL, fetch=False, out_ptr=lm_t.data_ptr())
+                    e.collect()
                     dist.gather(lm_t, gather_list, dst=0)      # landmark records of every rank to rank 0 (device to device)
+                else:
+                    e.run(_lib.STAGE_ALL, fetch="view")        # records land in the engine's page-locked buffer
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -563,7 +572,7 @@ def main():
 
     gather_check = None
     if use_dist and rank == 0:      # what rank 0 holds after the last gather: every rank's records, in rank order
-        lm = torch.cat(gather_list).cpu().numpy().view(_lib.LANDMARKS_DTYPE)
+        lm = torch.cat(gather_list).cpu().numpy().view(REC)
         assert len(lm) == world * B
         if args.check_gather:
             own = eng.run(_lib.STAGE_ALL)
@@ -627,6 +636,7 @@ def main():
             # serial chains with a 6.5 ms hull kernel at the head, so three of them are needed to keep the chip busy.
             dev_engs = [Engine(local) for _ in range(3)]
             for e in dev_engs:
+                e.set_record_rows(args.record_rows)
                 e.load_rfc()
                 e.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
                 e.set_hull_mode("device")
@@ -648,6 +658,7 @@ def main():
             # host's worker threads behind the device work of step k), and whether both modes give the same records
             host_engs = [Engine(local) for _ in range(2)]
             for e in host_engs:
+                e.set_record_rows(args.record_rows)
                 e.load_rfc()
                 e.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
                 e.set_hull_mode("host")
@@ -676,6 +687,7 @@ def main():
         if lanes > 1:
             # a context of its own, alone on the device: no turns to take, no CUs to leave to another lane (what `--lanes 1` runs)
             e1 = Engine(local)
+            e1.set_record_rows(args.record_rows)
             e1.load_rfc()
             e1.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
             e1.set_hull_mode(eng.hull_mode)
@@ -694,6 +706,7 @@ def main():
                 st_engs = [Engine(local) for _ in range(2)]
                 strm = make_stream(kind, verts, faces, B, args.stream_batches)
                 for e in st_engs:
+                    e.set_record_rows(args.record_rows)
                     e.load_rfc()
                     e.load_unet(weights, unet_spec.BASE, unet_spec.DEPTH)
                     e.set_hull_mode(eng.hull_mode)
@@ -852,6 +865,8 @@ def main():
                           "parallelism": f"dp{world}", "input": "binary STL bytes every step (device parse + merge, PCIe inclusive)" if args.from_stl else "host buffers re-uploaded every step (PCIe inclusive)" if args.from_host else "resident in HBM",
                           "lanes": lanes, "hull": eng.hull_mode, "hull_threads_per_process": hull_threads(int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), "host": host_info(),
                           "schedule": ((f"{lanes} engine contexts per GPU, step s on lane s % {lanes}, their streams overlap on the device (sh_submit / sh_collect); " if lanes > 1 else "two steps in flight (sh_submit / sh_collect); ") if pipelined else "") + ("host hulls of step k+1 overlap the device work of step k; pipeline filled and drained inside the timed region" if overlap else "serial hulls"),
+                          "records": {"format": "packed (sh_set_record_rows)" if args.record_rows else "full sh_landmarks", "anp_rows": args.record_rows or 4096, "bytes_per_record": REC.itemsize,
+                                      "bytes_per_step_to_rank0": world * B * REC.itemsize, "humeri_with_more_points_than_rows": int((lm["n_anp"] > (args.record_rows or 4096)).sum())},
                           "meshes_with_error_status": n_bad},
                "parity": PARITY_NOTE[args.unet],
                "roofline": roof, "cpu_baseline": cpu}

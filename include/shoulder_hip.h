@@ -173,6 +173,17 @@ int  sh_staged(const sh_ctx*);      /* 1 while a staged batch waits for its comm
 int  sh_synth_batch(sh_ctx*, const double* T /* B x 16 */, int B);
 int  sh_batch_size(const sh_ctx*);
 
+/* Records on the wire.  A full sh_landmarks record is 104 KB, 96 KB of it the padded anatomic-neck point list (4 096 rows; a
+ * humerus has about a thousand).  sh_set_record_rows(R), R > 0: every record a run hands out through `out` of sh_run /
+ * sh_submit (host memory or a gather's device send buffer) is PACKED to sh_record_bytes(R) = 8 680 + 24 R bytes:
+ *   [the bytes of sh_landmarks in front of anp_points] [its six trailing int32 fields: n_anp, n_articular, neck_index,
+ *   flipped, status, side] [R rows of anp_points: the first min(n_anp, R), zeros behind them]
+ * n_anp keeps the true count; sh_anp_points returns every point of one humerus of the last run (CT, the record's own
+ * arithmetic) whatever the format.  R = 0 (default): full records.  The device records (sh_landmarks_device) are always full. */
+int  sh_set_record_rows(sh_ctx*, int anp_rows);
+size_t sh_record_bytes(int anp_rows);
+int  sh_anp_points(sh_ctx*, int b, double* out /* cap x 3 */, int cap, int* n_out);
+
 /* ---- the hot path -------------------------------------------------------------------- */
 int  sh_run(sh_ctx*, uint32_t stage_mask, sh_landmarks* out /* B, host, nullable */);
 /* The same in two halves, for callers that stream runs: sh_submit enqueues a run (all device work, the copy of the records to

@@ -57,6 +57,17 @@ LANDMARKS_DTYPE = np.dtype([
 assert LANDMARKS_DTYPE.itemsize == ctypes.sizeof(Landmarks)
 
 
+def record_dtype(anp_rows=0):
+    """NumPy dtype of the records a run hands out: the full sh_landmarks (anp_rows = 0) or the packed wire format of
+    sh_set_record_rows(anp_rows): the fields in front of anp_points, the six trailing int32 fields, then anp_rows point rows."""
+    if anp_rows <= 0:
+        return LANDMARKS_DTYPE
+    names = list(LANDMARKS_DTYPE.names)
+    k = names.index("anp_points")
+    fields = [(n, LANDMARKS_DTYPE.fields[n][0]) for n in names[:k] + names[k + 1:]] + [("anp_points", "<f8", (int(anp_rows), 3))]
+    return np.dtype(fields)
+
+
 class Params(ctypes.Structure):
     _fields_ = [("canal_cutoff", ctypes.c_double * 2), ("groove_cutoff", ctypes.c_double * 2),
                 ("groove_deg_window", ctypes.c_double), ("unet_dtype", ctypes.c_int32), ("bone_kind", ctypes.c_int32)]
@@ -66,7 +77,7 @@ EXPORTS = ["sh_ctx_create", "sh_ctx_destroy", "sh_last_error", "sh_default_param
            "sh_load_unet", "sh_param_block", "sh_upload_meshes", "sh_synth_batch", "sh_batch_size", "sh_run",
            "sh_landmarks_device", "sh_affine_apply", "sh_mesh_transformed", "sh_transform_points", "sh_section_plane", "sh_buffer_info", "sh_fetch", "sh_store",
            "sh_kernel_time_ms", "sh_enable_timing", "sh_set_overlap", "sh_discard_prepared", "sh_unet_infer", "sh_host_alloc", "sh_host_free", "sh_upload_stl", "sh_submit", "sh_collect",
-           "sh_stage_meshes", "sh_stage_stl", "sh_commit_staged", "sh_staged",
+           "sh_stage_meshes", "sh_stage_stl", "sh_commit_staged", "sh_staged", "sh_set_record_rows", "sh_record_bytes", "sh_anp_points",
            "sh_slice_mesh_planes", "sh_set_unet_turns", "sh_get_params", "sh_buffer_device", "sh_param_block_commit", "sh_set_hull_mode", "sh_get_hull_mode", "sh_ring"]
 
 _lib = None
@@ -140,6 +151,10 @@ def load(build_if_missing=True):
     L.sh_stage_stl.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int]
     L.sh_commit_staged.argtypes = [vp, vp, vp]
     L.sh_staged.argtypes = [vp]
+    L.sh_set_record_rows.argtypes = [vp, ctypes.c_int]
+    L.sh_record_bytes.argtypes = [ctypes.c_int]
+    L.sh_record_bytes.restype = ctypes.c_size_t
+    L.sh_anp_points.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.sh_unet_infer.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     _lib = L
     return L

@@ -24,7 +24,8 @@ namespace sh {
 #define SH_HV 16384
 #define SH_HF 32768
 #define SH_HE 49152
-#define SH_ENDCAP 8192      // crossing points of an end section (mesh.py:91-107); ~330 at the fixture resolution, ~1 300 on a 519 k-triangle mesh
+#define SH_ENDCAP 8192      // crossing points of an end section (mesh.py:91-107) a context starts with; ~330 at the fixture resolution, ~1 300 on a 519 k-triangle mesh.
+                            // A run that meets more records how many (overflow counter word 7) and sh_collect grows the buffer and runs the batch again
 
 __device__ inline void obb_basis(const double* n, double* u, double* v) { plane_basis(n, u, v); }
 
@@ -65,12 +66,17 @@ k_obb_face_area2(const double* __restrict__ hv, const double* __restrict__ norma
 __global__ void __launch_bounds__(SH_OBB_BND_THREADS)
 k_obb_bounds(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
              const double* __restrict__ area2, double* __restrict__ lb_out /*[B][SH_HF]*/, unsigned long long* __restrict__ lbmin_enc /*[B], ~0*/,
-             double* __restrict__ cand_vol, int* __restrict__ cand_edge) {
+             double* __restrict__ cand_vol, int* __restrict__ cand_edge, int ntiles, int B) {
   constexpr int S = SH_OBB_BND_SPLIT;
   __shared__ double s_mn[S][2][64], s_mx[S][2][64], s_s[S][2][64];
-  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware order as in k_obb_candidates: linear id L -> humerus 8 * chunk + L % 8, so all tiles of a humerus read its hull
+  // record through ONE XCD's L2 (round 3's counters: 128 MB from the fabric for 7.7 MB of records -- every XCD fetched every record)
+  const int Lid = blockIdx.x, chunk = Lid / (8 * ntiles), rr = Lid - chunk * 8 * ntiles;
+  const int b = chunk * 8 + (rr & 7), tile = rr >> 3;
+  if (b >= B) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nv = nv_[b], nf = nf_[b];
-  if (blockIdx.x * SH_OBB_BND_DIRS >= nf) return;
+  if (tile * SH_OBB_BND_DIRS >= nf) return;
   const double* P = hv + (size_t)b * SH_HV * 3;
   const double* NN = normals + (size_t)b * SH_HF * 3;
   const double* A2 = area2 + (size_t)b * SH_HF;
@@ -78,7 +84,7 @@ k_obb_bounds(const double* __restrict__ hv, const int* __restrict__ nv_, const d
   double n[2][3];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
-    jd[d] = blockIdx.x * SH_OBB_BND_DIRS + d * 64 + lane;
+    jd[d] = tile * SH_OBB_BND_DIRS + d * 64 + lane;
     const int jc = jd[d] < nf ? jd[d] : nf - 1;
     n[d][0] = NN[3 * jc]; n[d][1] = NN[3 * jc + 1]; n[d][2] = NN[3 * jc + 2];
   }
@@ -122,7 +128,7 @@ k_obb_bounds(const double* __restrict__ hv, const int* __restrict__ nv_, const d
   for (int d = 0; d < 2; ++d) { s_mn[wave][d][lane] = mn[d]; s_mx[wave][d][lane] = mx[d]; s_s[wave][d][lane] = s[d]; }
   __syncthreads();
   if (wave >= 2) return;
-  const int d = wave, j = blockIdx.x * SH_OBB_BND_DIRS + d * 64 + lane;      // waves 0 and 1 finish one direction set each
+  const int d = wave, j = tile * SH_OBB_BND_DIRS + d * 64 + lane;      // waves 0 and 1 finish one direction set each
   double fmn = s_mn[0][d][lane], fmx = s_mx[0][d][lane], fs = s_s[0][d][lane];
 #pragma unroll
   for (int w = 1; w < S; ++w) { fmn = fmin(fmn, s_mn[w][d][lane]); fmx = fmax(fmx, s_mx[w][d][lane]); fs += s_s[w][d][lane]; }
@@ -515,7 +521,7 @@ k_obb_pick(const double* __restrict__ hv, const double* __restrict__ normals, co
 // crossing points of the two end sections (z = 0.95*zmin, 0.95*zmax in the raw box frame)
 __global__ void k_obb_end_points(const float* __restrict__ verts, const int* __restrict__ faces, const long long* __restrict__ voff,
                                  const long long* __restrict__ foff, const double* __restrict__ T_pre, const double* __restrict__ zb_pre,
-                                 double* __restrict__ endpts /*[B][2][ENDCAP][2]*/, int* __restrict__ endcnt /*[B][2]*/) {
+                                 double* __restrict__ endpts /*[B][2][cap][2]*/, int* __restrict__ endcnt /*[B][2]*/, int cap) {
   int b = blockIdx.y;
   const double* T = T_pre + 16 * b;
   const float* V = verts + 3 * voff[b];
@@ -541,8 +547,8 @@ __global__ void k_obb_end_points(const float* __restrict__ verts, const int* __r
       int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
       double t = d[l] / (d[l] - d[h]);
       int slot = atomicAdd(&endcnt[2 * b + e], 1);
-      if (slot < SH_ENDCAP) {
-        double* p = endpts + (((size_t)b * 2 + e) * SH_ENDCAP + slot) * 2;
+      if (slot < cap) {
+        double* p = endpts + (((size_t)b * 2 + e) * cap + slot) * 2;
         p[0] = X[l] + t * (X[h] - X[l]);
         p[1] = Y[l] + t * (Y[h] - Y[l]);
       }
@@ -605,14 +611,15 @@ __device__ inline double wave_circle_fit_residual(const double* xy, int n) {
 // one workgroup of 128 lanes per humerus: wave 0 = zmin end, wave 1 = zmax end
 __global__ void __launch_bounds__(128)
 k_obb_ends(const double* __restrict__ endpts, const int* __restrict__ endcnt, const double* __restrict__ T_pre,
-           double* __restrict__ resid /*[B][2]*/, double* __restrict__ T_obb, int* __restrict__ flipped, int* __restrict__ err, int B) {
+           double* __restrict__ resid /*[B][2]*/, double* __restrict__ T_obb, int* __restrict__ flipped, int* __restrict__ err, int B, int cap,
+           unsigned long long* __restrict__ need /*high-water mark of the points an end section asked for*/) {
   __shared__ double res[2];
   const int b = blockIdx.x, e = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int n = endcnt[2 * b + e];
   double r;
-  if (n > SH_ENDCAP) { if (lane == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); n = SH_ENDCAP; }
+  if (n > cap) { if (lane == 0) { atomicExch(&err[b], SH_ERR_CAPACITY_DEV); atomicMax(need, (unsigned long long)n); } n = cap; }
   if (n < 3) { if (lane == 0) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); r = 1e300; }
-  else r = wave_circle_fit_residual(endpts + ((size_t)b * 2 + e) * SH_ENDCAP * 2, n);
+  else r = wave_circle_fit_residual(endpts + ((size_t)b * 2 + e) * cap * 2, n);
   if (lane == 0) { res[e] = r; resid[2 * b + e] = r; }
   __syncthreads();
   if (threadIdx.x == 0) {

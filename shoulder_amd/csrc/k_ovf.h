@@ -28,7 +28,7 @@ struct OvfPools {
 };
 
 // per-set plan arrays, one entry per (humerus, plane): ranges in the pools (-1: not an overflow plane)
-struct OvfSet { long long* soff; long long* roff; long long* woff; int* fill; int* list; int* nlist; };
+struct OvfSet { long long* soff; long long* roff; long long* woff; int* fill; int* list; int* nlist /*[0] listed planes, [1] planes with many loops*/; int* list2; };
 
 __host__ __device__ inline unsigned ovf_hash_size(int n) { unsigned h = 64; while (h < 2u * (unsigned)n) h <<= 1; return h; }
 // join workspace of a plane with n segments (bytes, 16-aligned): skey, labA, labB (u64) | rx, ry (f64) | table (int, hash size) |
@@ -114,16 +114,46 @@ k_slice_emit_ovf(const double* __restrict__ vobb, const int* __restrict__ faces,
   }
 }
 
+// Planes the LDS joins handed over because they have more than SH_MAXLOOPS loops (k_slices.h ManyLoops): pool ranges like
+// k_ovf_plan's, their segments copied from the fixed slots into the segment pool, an entry in the set's list -- k_slice_link_huge
+// joins them next, their consumers read the ring from the pool.
+__global__ void __launch_bounds__(256)
+k_ovf_plan_loops(int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs /*fixed slots*/, OvfPools P, OvfSet S, int* __restrict__ err) {
+  __shared__ long long so, ro, wo;
+  const int n2 = S.nlist[1];
+  for (int i = blockIdx.x; i < n2; i += gridDim.x) {
+    const int pl = S.list2[i];
+    const int cnt = seg_count[pl];
+    if (threadIdx.x == 0) {
+      const unsigned long long wb = ovf_work_bytes(cnt);
+      const unsigned long long s = atomicAdd(&P.ctr[0], (unsigned long long)cnt);
+      const unsigned long long r = atomicAdd(&P.ctr[1], (unsigned long long)cnt + 1ull);
+      const unsigned long long w = atomicAdd(&P.ctr[2], wb);
+      atomicMax(&P.ctr[3], s + cnt); atomicMax(&P.ctr[4], r + cnt + 1ull); atomicMax(&P.ctr[5], w + wb);
+      if (s + cnt > P.seg_cap || r + cnt + 1ull > P.ring_cap || w + wb > P.work_cap) { atomicExch(&err[pl / N], SH_ERR_CAPACITY_DEV); so = -1; }
+      else { so = (long long)s; ro = (long long)r; wo = (long long)w; }
+    }
+    __syncthreads();
+    if (so >= 0) {
+      const Seg* src = segs + (size_t)pl * SH_MAXSEG;
+      for (int j = threadIdx.x; j < cnt; j += 256) P.segs[so + j] = src[j];
+      if (threadIdx.x == 0) { S.soff[pl] = so; S.roff[pl] = ro; S.woff[pl] = wo; S.fill[pl] = cnt; S.list[atomicAdd(&S.nlist[0], 1)] = pl; }
+    }
+    __syncthreads();
+  }
+}
+
 #define SH_HUGE_THREADS 1024
+#define SH_MAXLOOPS_G 1024      // loops per plane in the overflow tier's join (the LDS tiers: SH_MAXLOOPS = 32, more go here)
 
 // slice_link_plane (k_slices.h) with its arrays in the plane's workspace; every step in the same order with the same arithmetic
 __device__ inline void slice_link_plane_g(const int pl, int N, const int* __restrict__ seg_count, const Seg* __restrict__ sp, unsigned char* __restrict__ wk,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring_out /*nullable*/,
              int select, int* __restrict__ err, double* __restrict__ areas_total) {
   constexpr int T = SH_HUGE_THREADS;
-  __shared__ unsigned long long l_key[SH_MAXLOOPS];
-  __shared__ int l_start[SH_MAXLOOPS], l_len[SH_MAXLOOPS], l_off[SH_MAXLOOPS];
-  __shared__ double l_area[SH_MAXLOOPS], l_sel[SH_MAXLOOPS];
+  __shared__ unsigned long long l_key[SH_MAXLOOPS_G];
+  __shared__ int l_start[SH_MAXLOOPS_G], l_len[SH_MAXLOOPS_G], l_off[SH_MAXLOOPS_G];
+  __shared__ double l_area[SH_MAXLOOPS_G], l_sel[SH_MAXLOOPS_G];
   __shared__ int n_loops, bad;
   __shared__ double bbw[T / 64][4];
   const int b = pl / N, tid = threadIdx.x;
@@ -185,12 +215,12 @@ __device__ inline void slice_link_plane_g(const int pl, int N, const int* __rest
   for (int i = tid; i < n; i += T)
     if (ra[i] == 0) {
       const int l = atomicAdd(&n_loops, 1);
-      if (l < SH_MAXLOOPS) l_start[l] = i;
+      if (l < SH_MAXLOOPS_G) l_start[l] = i;
     }
   __syncthreads();
-  const int nl = n_loops > SH_MAXLOOPS ? SH_MAXLOOPS : n_loops;
+  const int nl = n_loops > SH_MAXLOOPS_G ? SH_MAXLOOPS_G : n_loops;
   if (tid == 0) {
-    if (n_loops > SH_MAXLOOPS) atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
+    if (n_loops > SH_MAXLOOPS_G) atomicExch(&err[b], SH_ERR_CAPACITY_DEV);      // (more than 1 024 closed loops in one section)
     for (int a = 1; a < nl; ++a) {      // canonical loop order: ascending start key
       const int v = l_start[a]; int c = a - 1;
       while (c >= 0 && skey[l_start[c]] > skey[v]) { l_start[c + 1] = l_start[c]; --c; }

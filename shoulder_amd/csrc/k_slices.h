@@ -105,7 +105,7 @@ __global__ void k_make_planes(int kind, int N, const double* __restrict__ zb /*[
   for (int k = threadIdx.x; k < N; k += blockDim.x) A.seg_count[(size_t)b * N + k] = 0;
   if (b == 0 && threadIdx.x == 0) {
     *A.nlarge = 0;
-    if (A.ovf_nlist) { *A.ovf_nlist = 0; A.ovf_ctr[0] = 0ull; A.ovf_ctr[2] = 0ull; }
+    if (A.ovf_nlist) { A.ovf_nlist[0] = 0; A.ovf_nlist[1] = 0 /*planes with many loops*/; A.ovf_ctr[0] = 0ull; A.ovf_ctr[2] = 0ull; }
   }
   if (kind == 3) {   // one plane at neck_z: `mesh.section(plane_origin=[0,0,neck_z])` (surgical_neck.py:37-39)
     if (threadIdx.x == 0) { zs[b] = neck_z[b]; zeff[b] = neck_z[b]; }
@@ -237,11 +237,16 @@ __device__ inline uint32_t hash_key64(unsigned long long k) {
 // Two instantiations share the grid: CAP = SH_SMALLSEG (17.5 KB of LDS, 8 workgroups = every wave slot of a CU) takes the planes
 // with up to 384 segments -- every section of a humerus at the fixture resolution -- and CAP = SH_MAXSEG (46 KB) the rest; the
 // other tier's planes exit at once.
+// A plane with more than SH_MAXLOOPS closed loops (a mesh with dozens of components in one section: fragments, trabecular
+// cavities) is handed to the overflow tier's join (k_ovf.h: loop tables of 1 024 entries): listed here, given pool ranges by
+// k_ovf_plan_loops.  With that tier skipped for a resident batch (no list): `missed` tells sh_collect to run again with it.
+struct ManyLoops { int* list; int* n; unsigned long long* missed; };
+
 template <int CAP>
 __device__ inline void slice_link_plane(const int pl, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops,
              int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err,
-             double* __restrict__ areas_total /*nullable: |sum of the signed loop areas| = Path2D.area*/, int* __restrict__ nlarge = nullptr) {
+             double* __restrict__ areas_total /*nullable: |sum of the signed loop areas| = Path2D.area*/, ManyLoops many, int* __restrict__ nlarge = nullptr) {
   // LDS per plane decides how many planes a CU joins at once (the join is a chain of short dependent steps): 44 bytes per
   // segment.  bufB holds the hash table until the label ping-pong starts; the crossing points stay in HBM (read twice, L2 hits).
   constexpr int HASH = CAP <= 384 ? 512 : 2048;
@@ -341,9 +346,16 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
       if (l < SH_MAXLOOPS) l_start[l] = i;
     }
   __syncthreads();
-  const int nl = n_loops > SH_MAXLOOPS ? SH_MAXLOOPS : n_loops;
+  if (n_loops > SH_MAXLOOPS) {      // (uniform: every lane leaves; nothing of this plane has been written yet)
+    if (tid == 0) {
+      if (many.list) many.list[atomicAdd(many.n, 1)] = pl;
+      else if (many.missed) atomicExch(many.missed, 1ull);
+      else atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
+    }
+    return;
+  }
+  const int nl = n_loops;
   if (tid == 0) {
-    if (n_loops > SH_MAXLOOPS) atomicExch(&err[b], SH_ERR_CAPACITY_DEV);
     // canonical loop order: ascending start key
     for (int a = 1; a < nl; ++a) {
       int v = l_start[a]; int c = a - 1;
@@ -471,13 +483,13 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
 __global__ void __launch_bounds__(SH_LINK_THREADS)
 k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs, double* __restrict__ centroids, double* __restrict__ areas,
              int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total,
-             int* __restrict__ nlarge /*zero at launch: planes left to the large tier*/) {
-  slice_link_plane<SH_SMALLSEG>(blockIdx.x, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total, nlarge);
+             int* __restrict__ nlarge /*zero at launch: planes left to the large tier*/, ManyLoops many) {
+  slice_link_plane<SH_SMALLSEG>(blockIdx.x, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total, many, nlarge);
 }
 __global__ void __launch_bounds__(SH_LINK_THREADS)
 k_slice_link_large(int nplanes, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs, double* __restrict__ centroids, double* __restrict__ areas,
                    int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total,
-                   const int* __restrict__ nlarge, unsigned long long* __restrict__ ovf_missed /*null while the overflow tier runs*/) {
+                   const int* __restrict__ nlarge, unsigned long long* __restrict__ ovf_missed /*null while the overflow tier runs*/, ManyLoops many) {
   if (*nlarge == 0) return;      // (the usual case: the sweep below is ~75 dependent loads per workgroup for nothing)
   for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
     // An overflow plane belongs to k_slice_link_huge (k_ovf.h).  When the host skipped that tier for a resident batch "known" to need
@@ -485,7 +497,7 @@ k_slice_link_large(int nplanes, int N, const int* __restrict__ seg_count, const 
     // batch again with the tier on instead of handing out the previous run's section.
     if (seg_count[pl] > SH_MAXSEG && ovf_missed && threadIdx.x == 0) atomicExch(ovf_missed, 1ull);
     if (seg_count[pl] <= SH_SMALLSEG || seg_count[pl] > SH_MAXSEG) continue;
-    slice_link_plane<SH_MAXSEG>(pl, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total);
+    slice_link_plane<SH_MAXSEG>(pl, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total, many);
     __syncthreads();
   }
 }

@@ -274,7 +274,9 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
             float va = acc[2 * mp][2 * h + (r >> 2)][r & 3], vb = acc[2 * mp + 1][2 * h + (r >> 2)][r & 3];
+#ifndef UL_PKRELU
             if (relu) { va = fmaxf(va, 0.0f); vb = fmaxf(vb, 0.0f); }
+#endif
             oa[r] = (ET)va; ob8[r] = (ET)vb;
             if (FUSE & UF_POOL) {      // (rounding to ET and the ReLU are monotonic: the same value as pooling first)
               float vp = fmaxf(va, vb);
@@ -282,6 +284,18 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
               op[r] = (ET)vp;
             }
           }
+#ifdef UL_PKRELU
+          // ReLU on the rounded 16-bit values, two per instruction: a negative bf16 / f16 is a negative int16 (sign bit), so max(bits, 0)
+          // as packed int16 is max(x, +0.0) -- rounding is monotonic and keeps the sign, -0.0 becomes +0.0 either way: the same bits as
+          // fmaxf on the f32 accumulators followed by the conversion (NaN aside, which no layer produces from finite input)
+          if (relu) {
+            typedef short s8 __attribute__((ext_vector_type(8)));
+            const s8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            oa = __builtin_bit_cast(v8, __builtin_elementwise_max(__builtin_bit_cast(s8, oa), z));
+            ob8 = __builtin_bit_cast(v8, __builtin_elementwise_max(__builtin_bit_cast(s8, ob8), z));
+            if (FUSE & UF_POOL) op = __builtin_bit_cast(v8, __builtin_elementwise_max(__builtin_bit_cast(s8, op), z));
+          }
+#endif
           *(v8*)(ob + (lo + (unsigned)((2 * mp) * W * 32 + 8 * h))) = oa;
           *(v8*)(ob + (lo + (unsigned)((2 * mp + 1) * W * 32 + 8 * h))) = ob8;
           if (FUSE & UF_POOL) {

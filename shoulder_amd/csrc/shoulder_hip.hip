@@ -77,6 +77,7 @@ struct sh_ctx {
   std::map<std::string, ULayer> ulayers;
   size_t unet_floats = 0;
   bool obb_injected = false;
+  int rec_rows = 0;                          // sh_set_record_rows: 0 = full sh_landmarks records, R > 0 = packed records with R anatomic-neck rows
   bool bounds_cleared = false;               // run_obb's first fill of this window covered zb_enc / anp.mm_enc (run_window skips its own)
   // hull of SH_STAGE_OBB: 1 = on the device (k_hull.h), 0 = host quickhull (sh_hull.h).  sh_set_hull_mode / SHOULDER_HULL=host|device|auto.
   // A humerus the device hull gives up (pinched horizon on nearly coplanar clouds, capacities) is re-done ALONE by sh_collect:
@@ -91,6 +92,7 @@ struct sh_ctx {
   // a run of the resident batch that planned no overflow plane in any set (ctr[4] == 0 at collect) lets later runs of the SAME batch
   // and parameters skip the overflow tier's launches (they would all return at once: ~17 launches, ~60 us per step)
   unsigned long long ovf_none_gen = ~0ull;
+  int end_cap = SH_ENDCAP;                   // points per end section "obb.endpts" holds (grown by sh_collect like the pools)
   bool redo_records = false;               // run_obb: the hull records of the window are in place already (redo_given_up)
   int redo_nf = 0;
   std::vector<float> h_verts;                // host copy of the vertices (hull stage)
@@ -139,7 +141,7 @@ struct sh_ctx {
   hipEvent_t obb_done_ev = nullptr;      // recorded after the last kernel of a run that reads the hull.* device buffers
   // sh_submit / sh_collect: up to two runs in flight (the second one is enqueued while the first still executes)
   struct Ticket { hipEvent_t ev = nullptr; int* h_err = nullptr; int* h_fail = nullptr; unsigned long long* h_ovf = nullptr; int cap = 0, B = 0; bool pending = false; sh_landmarks* host_out = nullptr;
-                  uint32_t mask = 0; sh_landmarks* out_arg = nullptr; bool dev_hull = false; unsigned long long gen = 0; };
+                  uint32_t mask = 0; sh_landmarks* out_arg = nullptr; bool dev_hull = false; unsigned long long gen = 0; size_t rec = sizeof(sh_landmarks); int rows = 0; };
   Ticket tickets[2];
   int t_head = 0, t_tail = 0, n_pending = 0;
   hipStream_t out_stream = nullptr;      // sh_collect copies the records / status words of a finished run to the host on this stream
@@ -559,7 +561,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("obb.seeded", (size_t)B * SH_HF, 1);
   ENS("obb.T_pre", (size_t)B * 16 * 8, 8);
   ENS("obb.zb_pre", (size_t)B * 2 * 8, 8);
-  ENS("obb.endpts", (size_t)B * 2 * SH_ENDCAP * 2 * 8, 8);
+  ENS("obb.endpts", (size_t)B * 2 * c->end_cap * 2 * 8, 8);
   ENS("obb.endcnt", (size_t)B * 2 * 4, 4);
   ENS("obb.resid", (size_t)B * 2 * 8, 8);
 #undef ENS
@@ -1563,7 +1565,7 @@ static int ovf_pools(sh_ctx* c, OvfPools* P) {
 static int ovf_set(sh_ctx* c, const std::string& pfx, int N, OvfSet* S) {
   const size_t B = (size_t)c->B;
   int rc;
-  struct A { const char* suffix; size_t elem; } arr[5] = {{".ovf_soff", 8}, {".ovf_roff", 8}, {".ovf_woff", 8}, {".ovf_fill", 4}, {".ovf_list", 4}};
+  struct A { const char* suffix; size_t elem; } arr[6] = {{".ovf_soff", 8}, {".ovf_roff", 8}, {".ovf_woff", 8}, {".ovf_fill", 4}, {".ovf_list", 4}, {".ovf_list2", 4}};
   for (const A& a : arr) {
     const std::string nm = pfx + a.suffix;
     const bool fresh = c->bufs.find(nm) == c->bufs.end() || c->bufs[nm].bytes < B * N * a.elem;
@@ -1575,7 +1577,7 @@ static int ovf_set(sh_ctx* c, const std::string& pfx, int N, OvfSet* S) {
   c->bufs[pfx + ".ovf_nlist"].per_mesh = 0;
   S->soff = buf<long long>(c, (pfx + ".ovf_soff").c_str()); S->roff = buf<long long>(c, (pfx + ".ovf_roff").c_str());
   S->woff = buf<long long>(c, (pfx + ".ovf_woff").c_str()); S->fill = buf<int>(c, (pfx + ".ovf_fill").c_str());
-  S->list = buf<int>(c, (pfx + ".ovf_list").c_str()); S->nlist = (int*)c->bufs[pfx + ".ovf_nlist"].p;
+  S->list = buf<int>(c, (pfx + ".ovf_list").c_str()); S->nlist = (int*)c->bufs[pfx + ".ovf_nlist"].p; S->list2 = buf<int>(c, (pfx + ".ovf_list2").c_str());
   return SH_OK;
 }
 
@@ -1610,12 +1612,15 @@ static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring,
   // two capacity tiers share the grid (k_slices.h): the planes of the other tier exit at once
   int* rn = buf<int>(c, (p + ".ring_n").c_str());
   double* rg = ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr;
+  // planes with more than SH_MAXLOOPS loops: listed for the overflow tier's join (tier skipped: flagged, sh_collect runs again with it)
+  const ManyLoops many{ovf_on ? OS.list2 : (int*)nullptr, ovf_on ? OS.nlist + 1 : (int*)nullptr, ovf_on ? (unsigned long long*)nullptr : OP.ctr + 6};
   LAUNCH(c, "k_slice_link", k_slice_link, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
-         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, nlarge);
+         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, nlarge, many);
   LAUNCH(c, "k_slice_link_large", k_slice_link_large, dim3(std::min(B * N, 512)), dim3(SH_LINK_THREADS), B * N, N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
          buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, (const int*)nlarge,
-         ovf_on ? (unsigned long long*)nullptr : OP.ctr + 6);
+         ovf_on ? (unsigned long long*)nullptr : OP.ctr + 6, many);
   if (ovf_on) {
+    LAUNCH(c, "k_ovf_plan_loops", k_ovf_plan_loops, dim3(16), dim3(256), N, (const int*)cnt, (const Seg*)segs, OP, OS, buf<int>(c, "err"));
     LAUNCH(c, "k_slice_link_huge", k_slice_link_huge, dim3(64), dim3(SH_HUGE_THREADS), N, (const int*)cnt, OP, OS, buf<double>(c, (p + ".centroids").c_str()),
            buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, ring ? 1 : 0, select, buf<int>(c, "err"), atot);
   }
@@ -1930,9 +1935,10 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
     const int nemax = 3 * nfmax / 2 + 3;      // (a closed triangulated surface: 2 E = 3 F)
     LAUNCH(c, "k_obb_face_area2", k_obb_face_area2, dim3((unsigned)((std::min(nemax, SH_HE) + 255) / 256), (unsigned)B), dim3(256), buf<double>(c, "hull.hv"),
            buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.area2"));
-    LAUNCH(c, "k_obb_bounds", k_obb_bounds, dim3((unsigned)((nfmax + SH_OBB_BND_DIRS - 1) / SH_OBB_BND_DIRS), (unsigned)B), dim3(SH_OBB_BND_THREADS),
+    const int bnd_tiles = (nfmax + SH_OBB_BND_DIRS - 1) / SH_OBB_BND_DIRS;
+    LAUNCH(c, "k_obb_bounds", k_obb_bounds, dim3((unsigned)(bnd_tiles * ((B + 7) / 8) * 8)), dim3(SH_OBB_BND_THREADS),
            buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<double>(c, "obb.area2"), buf<double>(c, "obb.lb"),
-           buf<unsigned long long>(c, "obb.lbmin_enc"), buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"));
+           buf<unsigned long long>(c, "obb.lbmin_enc"), buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), bnd_tiles, B);
     // capacity tier of k_obb_candidates (k_obb.h): the small one unless a hull of this launch has more than 8 192 faces
     const bool big = nfmax > 8192;
     const int TT = big ? 8 : SH_OBB_TILE;
@@ -1977,9 +1983,10 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   }
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 1024), (unsigned)B);
   LAUNCH(c, "k_obb_end_points", k_obb_end_points, g, dim3(256), buf<float>(c, "verts"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
-         buf<long long>(c, "foff"), buf<double>(c, "obb.T_pre"), buf<double>(c, "obb.zb_pre"), buf<double>(c, "obb.endpts"), buf<int>(c, "obb.endcnt"));
+         buf<long long>(c, "foff"), buf<double>(c, "obb.T_pre"), buf<double>(c, "obb.zb_pre"), buf<double>(c, "obb.endpts"), buf<int>(c, "obb.endcnt"), c->end_cap);
   LAUNCH(c, "k_obb_ends", k_obb_ends, dim3(B), dim3(128), buf<double>(c, "obb.endpts"), buf<int>(c, "obb.endcnt"),
-         buf<double>(c, "obb.T_pre"), buf<double>(c, "obb.resid"), buf<double>(c, "obb_transform"), buf<int>(c, "flipped"), buf<int>(c, "err"), B);
+         buf<double>(c, "obb.T_pre"), buf<double>(c, "obb.resid"), buf<double>(c, "obb_transform"), buf<int>(c, "flipped"), buf<int>(c, "err"), B, c->end_cap,
+         (unsigned long long*)c->bufs["ovf.ctr"].p + 7);
   c->obb_injected = true;
   return SH_OK;
 }
@@ -2225,6 +2232,46 @@ int sh_discard_prepared(sh_ctx* c) {
   (void)join_prepared(c);
   c->prep.gen = ~0ull;
   return SH_OK;
+}
+
+// ---- records on the wire ------------------------------------------------------------------------------------------------------
+// A full record is 104 KB, 96 KB of it the padded anatomic-neck point list (4 096 rows; a humerus has ~1 000).  With
+// sh_set_record_rows(R) the records a run hands out (`out` of sh_run / sh_submit: host memory or a gather's device send buffer)
+// are PACKED: [the bytes of sh_landmarks in front of anp_points][its six trailing int32 fields][R rows of anp_points] -- the
+// first min(n_anp, R) rows, zeros behind them; n_anp keeps the true count, sh_anp_points returns every row.
+#define SH_REC_HEAD offsetof(sh_landmarks, anp_points)
+#define SH_REC_TAIL (sizeof(sh_landmarks) - SH_REC_HEAD - sizeof(((sh_landmarks*)0)->anp_points))
+static inline size_t rec_bytes_rows(int rows) { return rows > 0 ? SH_REC_HEAD + SH_REC_TAIL + (size_t)rows * 24 : sizeof(sh_landmarks); }
+
+__global__ void __launch_bounds__(256)
+k_wire_records(const sh_landmarks* __restrict__ lm, unsigned char* __restrict__ dst, int R, size_t rec) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const unsigned long long* src = (const unsigned long long*)(lm + b);
+  unsigned long long* d = (unsigned long long*)(dst + (size_t)b * rec);
+  constexpr int HEAD = (int)(SH_REC_HEAD / 8), TAIL = (int)(SH_REC_TAIL / 8), PTS = (int)(sizeof(((sh_landmarks*)0)->anp_points) / 8);
+  for (int i = tid; i < HEAD; i += 256) d[i] = src[i];
+  for (int i = tid; i < TAIL; i += 256) d[HEAD + i] = src[HEAD + PTS + i];
+  int n = lm[b].n_anp;
+  n = n < 0 ? 0 : (n > R ? R : n);
+  for (int i = tid; i < 3 * R; i += 256) d[HEAD + TAIL + i] = i < 3 * n ? src[HEAD + i] : 0ull;
+}
+
+// records [b0, b0 + n) of the run just enqueued -> dst (device memory, record b at dst + b * rec) on the context's stream
+static int emit_records(sh_ctx* c, void* dst, int b0, int n, int rows, size_t rec) {
+  const sh_landmarks* src = (const sh_landmarks*)c->bufs["landmarks"].p + b0;
+  if (rows <= 0) { HIPCHK(c, hipMemcpyAsync((char*)dst + (size_t)b0 * rec, src, (size_t)n * rec, hipMemcpyDeviceToDevice, c->stream)); return SH_OK; }
+  LAUNCH(c, "k_wire_records", k_wire_records, dim3(n), dim3(256), src, (unsigned char*)dst + (size_t)b0 * rec, rows, rec);
+  return SH_OK;
+}
+
+// every anatomic-neck point of humerus b (CT) of the last run: the rows a packed record cut off, or all of them
+__global__ void k_anp_points_ct(const double* __restrict__ pts_obb, const double* __restrict__ T_obb, int b, int n, double* __restrict__ out) {
+  double Ti[16];
+  inv_transform(T_obb + 16 * b, Ti);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double* p = pts_obb + ((size_t)b * SH_ANP_CAP + i) * 3;
+    xform_pt(Ti, p[0], p[1], p[2], out + 3 * (size_t)i);
+  }
 }
 
 // ---- the staging side of the mesh slot: a stream of NEW batches at the resident rate -------------------------------------------
@@ -2672,8 +2719,9 @@ static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot
     if (rc != SH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
     // the record and the status word of this humerus -> where the run's results were parked (or the caller's device buffer)
     const sh_landmarks* src = buf<sh_landmarks>(c, "landmarks") + b;
-    if (tk.host_out) HIPCHK(c, hipMemcpyAsync((sh_landmarks*)c->bufs["out.landmarks" + tslot].p + b, src, sizeof(sh_landmarks), hipMemcpyDeviceToDevice, c->stream));
-    else if (tk.out_arg) HIPCHK(c, hipMemcpyAsync(tk.out_arg + b, src, sizeof(sh_landmarks), hipMemcpyDeviceToDevice, c->stream));
+    (void)src;
+    if (tk.host_out) { int erc = emit_records(c, c->bufs["out.landmarks" + tslot].p, b, 1, tk.rows, tk.rec); if (erc != SH_OK) return erc; }
+    else if (tk.out_arg) { int erc = emit_records(c, tk.out_arg, b, 1, tk.rows, tk.rec); if (erc != SH_OK) return erc; }
     HIPCHK(c, hipMemcpyAsync((int*)c->bufs["out.err" + tslot].p + b, buf<int>(c, "err") + b, 4, hipMemcpyDeviceToDevice, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2691,7 +2739,7 @@ static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot
     }
   }
   if (tk.host_out)
-    HIPCHK(c, hipMemcpyAsync(tk.host_out, c->bufs["out.landmarks" + tslot].p, (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->out_stream));
+    HIPCHK(c, hipMemcpyAsync(tk.host_out, c->bufs["out.landmarks" + tslot].p, (size_t)B * tk.rec, hipMemcpyDeviceToHost, c->out_stream));
   HIPCHK(c, hipMemcpyAsync(tk.h_err, c->bufs["out.err" + tslot].p, (size_t)B * 4, hipMemcpyDeviceToHost, c->out_stream));
   HIPCHK(c, hipStreamSynchronize(c->out_stream));
   return SH_OK;
@@ -2739,7 +2787,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     if (!to.pending) {
       if (int e = ensure(c, ("out.err" + oslot).c_str(), status_bytes(B), 4)) return e;
       if (out) { hipPointerAttribute_t at{}; const bool dev = hipPointerGetAttributes(&at, out) == hipSuccess && at.type == hipMemoryTypeDevice; (void)hipGetLastError();
-                 if (!dev) { if (int e = ensure(c, ("out.landmarks" + oslot).c_str(), (size_t)B * sizeof(sh_landmarks), 1)) return e; } }
+                 if (!dev) { if (int e = ensure(c, ("out.landmarks" + oslot).c_str(), (size_t)B * rec_bytes_rows(c->rec_rows), 1)) return e; } }
     }
   }
   if (!c->out_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
@@ -2802,11 +2850,12 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   void *lm_stage = nullptr, *err_stage = nullptr;
   if (int e = ensure(c, ("out.err" + tslot).c_str(), status_bytes(B), 4, &err_stage)) return e;      // (the whole status block: the status words lead it)
   tk.host_out = nullptr;
+  tk.rows = c->rec_rows; tk.rec = rec_bytes_rows(c->rec_rows);
   if (out_on_device) {
-    HIPCHK(c, hipMemcpyAsync(out, buf<sh_landmarks>(c, "landmarks"), (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToDevice, c->stream));
+    if (int e = emit_records(c, out, 0, B, tk.rows, tk.rec)) return e;
   } else if (out) {
-    if (int e = ensure(c, ("out.landmarks" + tslot).c_str(), (size_t)B * sizeof(sh_landmarks), 1, &lm_stage)) return e;
-    HIPCHK(c, hipMemcpyAsync(lm_stage, buf<sh_landmarks>(c, "landmarks"), (size_t)B * sizeof(sh_landmarks), hipMemcpyDeviceToDevice, c->stream));
+    if (int e = ensure(c, ("out.landmarks" + tslot).c_str(), (size_t)B * tk.rec, 1, &lm_stage)) return e;
+    if (int e = emit_records(c, lm_stage, 0, B, tk.rows, tk.rec)) return e;
     tk.host_out = out;
   }
   // status words, what the run asked of the overflow pools (k_ovf.h: sh_collect grows them and runs again if it was more than they
@@ -2828,7 +2877,7 @@ int sh_collect(sh_ctx* c) {
   c->t_tail ^= 1; --c->n_pending; tk.pending = false;
   HIPCHK(c, hipEventSynchronize(tk.ev));
   if (tk.host_out)
-    HIPCHK(c, hipMemcpyAsync(tk.host_out, buf<char>(c, ("out.landmarks" + tslot).c_str()), (size_t)tk.B * sizeof(sh_landmarks), hipMemcpyDeviceToHost, c->out_stream));
+    HIPCHK(c, hipMemcpyAsync(tk.host_out, buf<char>(c, ("out.landmarks" + tslot).c_str()), (size_t)tk.B * tk.rec, hipMemcpyDeviceToHost, c->out_stream));
   HIPCHK(c, hipMemcpyAsync(tk.h_err, buf<char>(c, ("out.err" + tslot).c_str()), status_bytes(tk.B), hipMemcpyDeviceToHost, c->out_stream));      // status, pool counters, give-up words
   HIPCHK(c, hipStreamSynchronize(c->out_stream));
   {
@@ -2853,7 +2902,8 @@ int sh_collect(sh_ctx* c) {
       return sh_collect(c);
     }
     if (getenv("SH_DEBUG")) fprintf(stderr, "[sh] collect: ovf need %llu %llu %llu cap %llu %llu %llu err0 %d\n", need_s, need_r, need_w, c->ovf_seg_cap, c->ovf_ring_cap, c->ovf_work_cap, tk.h_err[0]);
-    if (need_s > c->ovf_seg_cap || need_r > c->ovf_ring_cap || need_w > c->ovf_work_cap) {
+    const unsigned long long need_e = tk.h_ovf[7];
+    if (need_s > c->ovf_seg_cap || need_r > c->ovf_ring_cap || need_w > c->ovf_work_cap || need_e > (unsigned long long)c->end_cap) {
       // The batch has more overflow planes than the pools hold (a first dense mesh): grow them to what the run asked for,
       // with headroom, and run the batch again -- here, synchronously, when nothing else is in flight.
       if (c->n_pending != 0)
@@ -2862,6 +2912,13 @@ int sh_collect(sh_ctx* c) {
       c->ovf_seg_cap = std::max(c->ovf_seg_cap, need_s + need_s / 4);
       c->ovf_ring_cap = std::max(c->ovf_ring_cap, need_r + need_r / 4);
       c->ovf_work_cap = std::max(c->ovf_work_cap, need_w + need_w / 4);
+      if (need_e > (unsigned long long)c->end_cap) {      // an end section of the box with more crossing points than "obb.endpts" holds (a very dense mesh)
+        if (need_e > (1ull << 26)) return fail(c, SH_ERR_CAPACITY, "an end section has more than 2^26 crossing points");
+        c->end_cap = (int)(need_e + need_e / 4);
+        const size_t eb = (size_t)c->B * 2 * c->end_cap * 2 * 8;
+        if (int e = ensure(c, "obb.endpts", eb, 8)) return e;
+        c->bufs["obb.endpts"].per_mesh = eb / (size_t)c->B;
+      }
       const uint32_t mask = tk.mask; sh_landmarks* out = tk.out_arg;
       int rc2 = sh_submit(c, mask, out);
       if (rc2 != SH_OK) return rc2;
@@ -2921,6 +2978,38 @@ int sh_host_alloc(sh_ctx* c, size_t nbytes, void** out) {
 int sh_host_free(sh_ctx* c, void* p) {
   if (!c) return SH_ERR_ARG;
   if (p) HIPCHK(c, hipHostFree(p));
+  return SH_OK;
+}
+
+int sh_set_record_rows(sh_ctx* c, int anp_rows) {
+  if (!c || anp_rows < 0 || anp_rows > SH_ANP_MAX_PTS) return fail(c, SH_ERR_ARG, "sh_set_record_rows: 0 (full records) .. 4096 rows");
+  if (c->n_pending != 0) return fail(c, SH_ERR_STATE, "sh_set_record_rows: runs are in flight");
+  c->rec_rows = anp_rows;
+  return SH_OK;
+}
+
+size_t sh_record_bytes(int anp_rows) { return rec_bytes_rows(anp_rows); }
+
+int sh_anp_points(sh_ctx* c, int b, double* out, int cap, int* n_out) {
+  if (!c || !n_out || b < 0 || b >= c->B || cap < 0 || (cap > 0 && !out)) return fail(c, SH_ERR_ARG, "sh_anp_points: bad argument");
+  if (c->n_pending != 0) return fail(c, SH_ERR_STATE, "sh_anp_points: runs are in flight (sh_collect them first)");
+  if (c->bufs.find("anp.counts") == c->bufs.end()) return fail(c, SH_ERR_STATE, "sh_anp_points: no run yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->b0 = 0; c->Bwin = c->B;
+  int cnt[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(cnt, buf<int>(c, "anp.counts") + 2 * b, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int n = std::min(cnt[0], (int)SH_ANP_CAP);
+  *n_out = n;
+  n = std::min(n, cap);
+  if (n <= 0) return SH_OK;
+  int rc = ensure(c, "anp.points_ct_one", (size_t)SH_ANP_CAP * 24, 8);
+  if (rc != SH_OK) return rc;
+  c->bufs["anp.points_ct_one"].per_mesh = 0;
+  double* d = (double*)c->bufs["anp.points_ct_one"].p;
+  LAUNCH(c, "k_anp_points_ct", k_anp_points_ct, dim3((unsigned)((n + 255) / 256)), dim3(256), (const double*)buf<double>(c, "anp.points_obb"), (const double*)buf<double>(c, "obb_transform"), b, n, d);
+  HIPCHK(c, hipMemcpyAsync(out, d, (size_t)n * 24, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return SH_OK;
 }
 

@@ -224,6 +224,27 @@ class Engine:
     def B(self):
         return self.L.sh_batch_size(self.h)
 
+    # ---- record format ------------------------------------------------------------------------------
+    def set_record_rows(self, anp_rows=0):
+        """sh_set_record_rows: 0 = full 104 KB records, R > 0 = packed records carrying R anatomic-neck rows (n_anp keeps the
+        true count; anp_points(b) fetches every row).  run / submit / collect then return arrays of _lib.record_dtype(R)."""
+        self._chk(self.L.sh_set_record_rows(self.h, int(anp_rows)))
+        if int(anp_rows) != getattr(self, "_rec_rows", 0):
+            self._free_pinned()
+        self._rec_rows = int(anp_rows)
+
+    @property
+    def record_dtype(self):
+        return _lib.record_dtype(getattr(self, "_rec_rows", 0))
+
+    def anp_points(self, b):
+        """Every anatomic-neck point (CT) of humerus b of the last run (sh_anp_points)."""
+        n = ctypes.c_int()
+        self._chk(self.L.sh_anp_points(self.h, int(b), None, 0, ctypes.byref(n)))
+        out = np.empty((max(1, n.value), 3), dtype=np.float64)
+        self._chk(self.L.sh_anp_points(self.h, int(b), _ptr(out), len(out), ctypes.byref(n)))
+        return out[: n.value]
+
     # ---- run ---------------------------------------------------------------------------------------
     def run(self, stages=_lib.STAGE_ALL, fetch=True):
         """One sh_run over the resident batch.  fetch=True: a fresh record array; fetch="view": the engine's page-locked
@@ -231,7 +252,7 @@ class Engine:
         if fetch == "view":
             out = self._pinned_records()
         else:
-            out = np.zeros(self.B, dtype=LANDMARKS_DTYPE) if fetch else None
+            out = np.zeros(self.B, dtype=self.record_dtype) if fetch else None
         self._chk(self.L.sh_run(self.h, int(stages), _ptr(out) if out is not None else None))
         return out
 
@@ -269,9 +290,10 @@ class Engine:
             if ent is not None:
                 self.L.sh_host_free(self.h, ent[0])
             p = ctypes.c_void_p()
-            nbytes = self.B * LANDMARKS_DTYPE.itemsize
+            dt = self.record_dtype
+            nbytes = self.B * dt.itemsize
             self._chk(self.L.sh_host_alloc(self.h, nbytes, ctypes.byref(p)))
-            arr = np.frombuffer((ctypes.c_char * nbytes).from_address(p.value), dtype=LANDMARKS_DTYPE)
+            arr = np.frombuffer((ctypes.c_char * nbytes).from_address(p.value), dtype=dt)
             ent = pins[slot] = (p, self.B, arr)
         return ent[2][: self.B]
 

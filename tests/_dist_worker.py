@@ -7,7 +7,7 @@ import numpy as np
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from shoulder_amd._lib import LANDMARKS_DTYPE  # noqa: E402
+from shoulder_amd._lib import LANDMARKS_DTYPE, record_dtype  # noqa: E402
 from shoulder_amd import dist as shd  # noqa: E402
 from shoulder_amd import synth  # noqa: E402
 
@@ -32,12 +32,23 @@ for i in range(count):
     rec["canal_axis"][i] = T_mine[i][:2, :3]
     rec["n_anp"][i] = 1000 + start + i
 out = shd.gather_records(rec, LANDMARKS_DTYPE, dst=0)
+# the packed wire format (sh_set_record_rows: 8 680 + 24 R bytes per record instead of 104 KB) gathers the same way
+PK = record_dtype(1536)
+recp = np.zeros(count, dtype=PK)
+for i in range(count):
+    recp["neck_index"][i] = start + i
+    recp["n_anp"][i] = 1000 + start + i
+    recp["anp_points"][i, :5] = start + i + np.arange(15).reshape(5, 3)
+outp = shd.gather_records(recp, PK, dst=0)
 if rank == 0:
     assert len(out) == per_rank * world
     np.testing.assert_array_equal(out["neck_index"], np.arange(per_rank * world))
     np.testing.assert_array_equal(out["canal_axis"], T_all[:, :2, :3])
     np.testing.assert_array_equal(out["n_anp"], 1000 + np.arange(per_rank * world))
+    assert len(outp) == per_rank * world and outp.dtype.itemsize == 8680 + 24 * 1536
+    np.testing.assert_array_equal(outp["n_anp"], 1000 + np.arange(per_rank * world))
+    np.testing.assert_array_equal(outp["anp_points"][:, 4, 2], np.arange(per_rank * world) + 14)
     print("DIST_OK")
 else:
-    assert out is None
+    assert out is None and outp is None
 dist.destroy_process_group()

@@ -44,3 +44,22 @@ def test_ctx_create_fails_loudly_without_gpu():
     h = ctypes.c_void_p()
     rc = L.sh_ctx_create(9999, None, ctypes.byref(h))
     assert rc != 0 and not h.value
+
+
+def test_packed_record_layout():
+    """sh_set_record_rows(R): the NumPy mirror of the packed wire record has the library's size and keeps the field order of the
+    full record around the point list (head | six trailing int32 | R rows)."""
+    L = ctypes.CDLL(_lib.lib_path()) if os.path.exists(_lib.lib_path()) else _lib.load()
+    L.sh_record_bytes.restype = ctypes.c_size_t
+    L.sh_record_bytes.argtypes = [ctypes.c_int]
+    full = _lib.LANDMARKS_DTYPE
+    assert L.sh_record_bytes(0) == full.itemsize
+    for R in (1, 1024, 1536, 4096):
+        dt = _lib.record_dtype(R)
+        assert dt.itemsize == L.sh_record_bytes(R) == 8680 + 24 * R
+        for name in full.names:
+            if name == "anp_points":
+                continue
+            off = full.fields[name][1]
+            assert dt.fields[name][1] == (off if off < full.fields["anp_points"][1] else off - 4096 * 24), name
+        assert dt.fields["anp_points"][1] == 8680 and dt["anp_points"].shape == (R, 3)

@@ -388,3 +388,42 @@ def test_contexts_driven_from_different_host_threads(oracle_bones):
     finally:
         for e in engs:
             e.close()
+
+
+def test_packed_records_carry_the_full_records_fields(engine, oracle_bones):
+    """the wire format of sh_set_record_rows(R) -- 8 680 + 24 R bytes instead of 104 KB per humerus -- holds
+    every field of the full record and the first min(n_anp, R) anatomic-neck rows; sh_anp_points returns all of them; the same
+    through sh_submit / sh_collect and into a device buffer (a gather's send buffer)."""
+    hs = [oracle_bones(n) for n in ("humerus_left", "humerus_right", "humerus_left_trab")]
+    engine.reset_params()
+    engine.set_params(unet_dtype=_lib.UNET_F32)
+    engine.upload([(h.verts, h.faces) for h in hs])
+    try:
+        engine.set_record_rows(0)
+        full = engine.run(_lib.STAGE_ALL).copy()
+        n = full["n_anp"]
+        assert (full["status"] == 0).all() and (n > 600).all()
+        for R in (2560, 512):
+            engine.set_record_rows(R)
+            pk = engine.run(_lib.STAGE_ALL).copy()
+            assert pk.dtype == _lib.record_dtype(R) and pk.dtype.itemsize == 8680 + 24 * R
+            for name in full.dtype.names:
+                if name != "anp_points":
+                    np.testing.assert_array_equal(pk[name], full[name], err_msg=name)
+            for b in range(3):
+                k = min(int(n[b]), R)
+                np.testing.assert_array_equal(pk["anp_points"][b, :k], full["anp_points"][b, :k])
+                assert not pk["anp_points"][b, k:].any()
+                np.testing.assert_array_equal(engine.anp_points(b), full["anp_points"][b, : int(n[b])])
+            engine.submit(_lib.STAGE_ALL)                                     # page-locked host view
+            assert engine.collect().tobytes() == pk.tobytes()
+            # device memory as `out` (the send buffer of a gather): a scratch buffer of the engine that the run is done with when the
+            # records are written (the network's input image)
+            ptr, nbytes = engine.buffer_device("anp.image")
+            assert nbytes >= 3 * pk.dtype.itemsize
+            engine.submit(_lib.STAGE_ALL, fetch=False, out_ptr=ptr)
+            engine.collect()
+            assert engine.fetch("anp.image", np.uint8, (3 * pk.dtype.itemsize,)).tobytes() == pk.tobytes()
+        assert (n > 512).all() and (n > 2560).any() and (n <= 2560).any()     # 512 rows cut every list, 2 560 one of the three
+    finally:
+        engine.set_record_rows(0)
