@@ -103,10 +103,18 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   const int wlane = (wlow ? -11 : -10) * wtap_stride + wch * 32 + q8;
 
   int i_g, i_tx, i_ty, i_img;      // item being staged
+  const bool gmajor = (relu & 2) != 0;      // experiment (SHOULDER_GMAJOR=1): cout group slowest -- all tiles of a group before the next group
+  relu &= 1;
   auto decode = [&](int w) {
-    i_g = w % ngroups; w /= ngroups;
-    i_tx = w % tiles_x; w /= tiles_x;
-    i_ty = w % tiles_y; i_img = w / tiles_y;
+    if (gmajor) {
+      i_tx = w % tiles_x; w /= tiles_x;
+      i_ty = w % tiles_y; w /= tiles_y;
+      i_img = w % nimg; i_g = w / nimg;
+    } else {
+      i_g = w % ngroups; w /= ngroups;
+      i_tx = w % tiles_x; w /= tiles_x;
+      i_ty = w % tiles_y; i_img = w / tiles_y;
+    }
   };
   decode(w_begin);
   int pixoff[NHALO];
@@ -189,7 +197,8 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
       if (n_cc < nchunk) {
       } else if (w + 1 < w_end) {
         ++w;
-        if (++i_g == ngroups) { i_g = 0; if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; ++i_img; } } }
+        if (gmajor) { if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; if (++i_img == nimg) { i_img = 0; ++i_g; } } } }
+        else if (++i_g == ngroups) { i_g = 0; if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; ++i_img; } } }
         n_cc = 0; new_item = true;
       } else if (dyn) {      // next ticket: its id was written before this step's barrier; the slot it frees is refilled for the one after
         const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);

@@ -1332,10 +1332,11 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     const bool ldr = dma64 && sched == 1 && !(getenv("SHOULDER_DMA_LDR") && getenv("SHOULDER_DMA_LDR")[0] == '0');
     if (ldr) {
       u16* pl = fuse == UF_POOL ? (u16*)fz.pooled : (u16*)nullptr;
-      if (fuse == UF_POOL && wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
-      else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
-      else if (wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
-      else { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
+      const int gm = (getenv("SHOULDER_GMAJOR") && getenv("SHOULDER_GMAJOR")[0] == '1' && L.cout / 64 > 1) ? 2 : 0;
+      if (fuse == UF_POOL && wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk); }
+      else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk); }
+      else if (wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk); }
+      else { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk); }
     } else if (dma64) {
       if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
       else DMA_LAUNCH(0, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
