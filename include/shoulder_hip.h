@@ -163,7 +163,9 @@ int  sh_upload_stl(sh_ctx*, const void* const* files, const size_t* nbytes, int 
  *     idle (sh_collect every run first).  Reports what sh_upload_* would have reported for a bad batch (SH_ERR_ARG; the resident
  *     batch stays).  The next sh_submit / sh_run finds the hulls prepared.  v_off_out / f_off_out (B+1 each, nullable): offsets.
  * A run submitted between stage and commit belongs to the resident batch and voids the staged batch's prepared hulls (they are
- * computed again by its first run).  Records are identical to sh_upload_* followed by the same runs. */
+ * computed again by its first run).  Keep sh_set_overlap off on a context that streams: a batch that runs once needs no hulls
+ * prepared for a second run, and the staging call would wait for that preparation.  Records are identical to sh_upload_*
+ * followed by the same runs. */
 int  sh_stage_meshes(sh_ctx*, const float* verts, const int32_t* faces, const int64_t* v_off, const int64_t* f_off, int B);
 int  sh_stage_stl(sh_ctx*, const void* const* files, const size_t* nbytes, int B);
 int  sh_commit_staged(sh_ctx*, int64_t* v_off_out, int64_t* f_off_out);

@@ -98,14 +98,33 @@ struct PlaneAux {
   int* seg_count; int* nlarge;                           // [B][N] crossing counters of this set; its large-tier counter
   int* ovf_nlist; unsigned long long* ovf_ctr;           // nullable: overflow tier (k_ovf.h): list length of the set, pool counters [0] and [2]
 };
-__global__ void k_make_planes(int kind, int N, const double* __restrict__ zb /*[B][2]*/, const double* __restrict__ neck_z,
-                              double* __restrict__ zs, double* __restrict__ zeff, int B, PlaneAux A) {
+// Up to two slice sets that hang on the same inputs go through the set's launches TOGETHER (round 4: full + distal behind the box
+// frame, neck contour + proximal behind neck_z; they were four launch groups per step): one launch for their plane heights, one
+// pass over the mesh for their sections, one grid for their joins.  Per set nothing changes.
+struct ManyLoops { int* list; int* n; unsigned long long* missed; };      // planes with more than SH_MAXLOOPS loops: see slice_link_plane
+struct SliceSetDev {
+  int N, kind, select;
+  const double* zb;                                      // [B][2] z bounds the heights are taken from (kind 4: the raw box's)
+  double* zs; double* zeff;                              // [B][N]
+  int* seg_count; Seg* segs;                             // [B][N], [B][N][SH_MAXSEG]
+  double* centroids; double* areas; int* nloops; int* ring_n; double* ring /*nullable*/; double* areas_total /*nullable*/;
+  int* nlarge; ManyLoops many; unsigned long long* ovf_missed;
+  PlaneAux aux;
+};
+struct SliceSets { SliceSetDev s[2]; int n; };
+
+__global__ void k_make_planes(SliceSets sets, const double* __restrict__ neck_z, int B) {
+  const SliceSetDev& S = sets.s[blockIdx.y];
+  const int kind = S.kind, N = S.N;
+  const double* zb = S.zb;
+  double* zs = S.zs; double* zeff = S.zeff;
+  const PlaneAux A = S.aux;
   int b = blockIdx.x;
   if (b >= B) return;
   for (int k = threadIdx.x; k < N; k += blockDim.x) A.seg_count[(size_t)b * N + k] = 0;
   if (b == 0 && threadIdx.x == 0) {
     *A.nlarge = 0;
-    if (A.ovf_nlist) { A.ovf_nlist[0] = 0; A.ovf_nlist[1] = 0 /*planes with many loops*/; A.ovf_ctr[0] = 0ull; A.ovf_ctr[2] = 0ull; }
+    if (A.ovf_nlist) { A.ovf_nlist[0] = 0; A.ovf_nlist[1] = 0 /*planes with many loops*/; if (A.ovf_ctr) { A.ovf_ctr[0] = 0ull; A.ovf_ctr[2] = 0ull; } }
   }
   if (kind == 3) {   // one plane at neck_z: `mesh.section(plane_origin=[0,0,neck_z])` (surgical_neck.py:37-39)
     if (threadIdx.x == 0) { zs[b] = neck_z[b]; zeff[b] = neck_z[b]; }
@@ -143,18 +162,14 @@ __global__ void k_make_planes(int kind, int N, const double* __restrict__ zb /*[
 #define SH_EMIT_MAXN 640      // planes per set (SH_NPROX = 600 is the largest)
 __global__ void __launch_bounds__(256)
 k_slice_emit(const double* __restrict__ vobb, const int* __restrict__ faces,
-             const long long* __restrict__ voff, const long long* __restrict__ foff,
-             const double* __restrict__ zeff, int N, int* __restrict__ seg_count,
-             Seg* __restrict__ segs) {
-  __shared__ int hist[SH_EMIT_MAXN];
+             const long long* __restrict__ voff, const long long* __restrict__ foff, SliceSets sets) {
+  __shared__ int hist[SH_EMIT_MAXN];      // the planes of set 0, then those of set 1 (host: N0 + N1 <= SH_EMIT_MAXN)
   int b = blockIdx.y;
   long long f0 = foff[b], nf = foff[b + 1] - f0;
   const double* vb = vobb + 3 * voff[b];
-  const double* zp = zeff + (size_t)b * N;
-  double z_first = zp[0], z_last = zp[N - 1];
-  double inv_step = (double)(N - 1) / (z_last - z_first);
+  const int nsets = sets.n, Ntot = sets.s[0].N + (nsets > 1 ? sets.s[1].N : 0);
   for (long long f_base = blockIdx.x * (long long)blockDim.x; f_base < nf; f_base += (long long)gridDim.x * blockDim.x) {
-    for (int k = threadIdx.x; k < N; k += blockDim.x) hist[k] = 0;
+    for (int k = threadIdx.x; k < Ntot; k += blockDim.x) hist[k] = 0;
     const long long fi = f_base + threadIdx.x;
     const bool live = fi < nf;
     const int* f = faces + 3 * (f0 + (live ? fi : 0));
@@ -162,58 +177,78 @@ k_slice_emit(const double* __restrict__ vobb, const int* __restrict__ faces,
     double X[3], Y[3], Z[3];
     for (int k = 0; k < 3; ++k) { X[k] = vb[3 * (size_t)id[k]]; Y[k] = vb[3 * (size_t)id[k] + 1]; Z[k] = vb[3 * (size_t)id[k] + 2]; }
     double fzmin = fmin(Z[0], fmin(Z[1], Z[2])), fzmax = fmax(Z[0], fmax(Z[1], Z[2]));
-    double ka = (fzmin - z_first) * inv_step, kb = (fzmax - z_first) * inv_step;
-    double klo = fmin(ka, kb), khi = fmax(ka, kb);
-    int lo = 1, hi = 0;      // empty range: a lane without a triangle or without planes
-    if (live && !(khi < -1.0 || klo > (double)N)) {
-      lo = (int)floor(fmax(klo, 0.0)) - 1; hi = (int)ceil(fmin(khi, (double)(N - 1))) + 1;
-      lo = lo < 0 ? 0 : lo;
-      hi = hi > N - 1 ? N - 1 : hi;
-      if (N == 1) { lo = 0; hi = 0; }
+    int lo_[2] = {1, 1}, hi_[2] = {0, 0};      // empty range: a lane without a triangle or without planes
+    for (int si = 0; si < nsets; ++si) {
+      const int N = sets.s[si].N;
+      const double* zp = sets.s[si].zeff + (size_t)b * N;
+      const double z_first = zp[0], z_last = zp[N - 1];
+      const double inv_step = (double)(N - 1) / (z_last - z_first);
+      double ka = (fzmin - z_first) * inv_step, kb = (fzmax - z_first) * inv_step;
+      double klo = fmin(ka, kb), khi = fmax(ka, kb);
+      int lo = 1, hi = 0;
+      if (live && !(khi < -1.0 || klo > (double)N)) {
+        lo = (int)floor(fmax(klo, 0.0)) - 1; hi = (int)ceil(fmin(khi, (double)(N - 1))) + 1;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > N - 1 ? N - 1 : hi;
+      }
+      if (live && N == 1) { lo = 0; hi = 0; }
+      lo_[si] = lo; hi_[si] = hi;
     }
     __syncthreads();
     // pass A: crossings per plane of this workgroup's triangles
-    for (int k = lo; k <= hi; ++k) {
-      const double z = zp[k];
-      const int s0 = Z[0] - z < -SH_SECTION_TOL ? -1 : 1, s1 = Z[1] - z < -SH_SECTION_TOL ? -1 : 1, s2 = Z[2] - z < -SH_SECTION_TOL ? -1 : 1;
-      if (!(s0 == s1 && s1 == s2)) atomicAdd(&hist[k], 1);
+    for (int si = 0; si < nsets; ++si) {
+      const int N = sets.s[si].N, hoff = si ? sets.s[0].N : 0;
+      const double* zp = sets.s[si].zeff + (size_t)b * N;
+      for (int k = lo_[si]; k <= hi_[si]; ++k) {
+        const double z = zp[k];
+        const int s0 = Z[0] - z < -SH_SECTION_TOL ? -1 : 1, s1 = Z[1] - z < -SH_SECTION_TOL ? -1 : 1, s2 = Z[2] - z < -SH_SECTION_TOL ? -1 : 1;
+        if (!(s0 == s1 && s1 == s2)) atomicAdd(&hist[hoff + k], 1);
+      }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    for (int k = threadIdx.x; k < Ntot; k += blockDim.x) {
       const int n = hist[k];
-      if (n > 0) hist[k] = atomicAdd(&seg_count[(size_t)b * N + k], n);      // first slot of this workgroup's range
+      if (n > 0) {      // first slot of this workgroup's range
+        const int si = k >= sets.s[0].N ? 1 : 0, kk = si ? k - sets.s[0].N : k;
+        hist[k] = atomicAdd(&sets.s[si].seg_count[(size_t)b * sets.s[si].N + kk], n);
+      }
     }
     __syncthreads();
     // pass B: the segments, slots handed out from LDS
-    for (int k = lo; k <= hi; ++k) {
-      const double z = zp[k];
-      double d[3];
-      int s[3];
-      for (int j = 0; j < 3; ++j) { d[j] = Z[j] - z; s[j] = d[j] < -SH_SECTION_TOL ? -1 : 1; }
-      if (s[0] == s[1] && s[1] == s[2]) continue;
-      const int slot = atomicAdd(&hist[k], 1);
-      int up = 0, dn = 0;
-      for (int j = 0; j < 3; ++j) {
-        int jn = (j + 1) % 3;
-        if (s[j] == -1 && s[jn] == 1) up = j;
-        if (s[j] == 1 && s[jn] == -1) dn = j;
+    for (int si = 0; si < nsets; ++si) {
+      const int N = sets.s[si].N, hoff = si ? sets.s[0].N : 0;
+      const double* zp = sets.s[si].zeff + (size_t)b * N;
+      Seg* segs = sets.s[si].segs;
+      for (int k = lo_[si]; k <= hi_[si]; ++k) {
+        const double z = zp[k];
+        double d[3];
+        int s[3];
+        for (int j = 0; j < 3; ++j) { d[j] = Z[j] - z; s[j] = d[j] < -SH_SECTION_TOL ? -1 : 1; }
+        if (s[0] == s[1] && s[1] == s[2]) continue;
+        const int slot = atomicAdd(&hist[hoff + k], 1);
+        int up = 0, dn = 0;
+        for (int j = 0; j < 3; ++j) {
+          int jn = (j + 1) % 3;
+          if (s[j] == -1 && s[jn] == 1) up = j;
+          if (s[j] == 1 && s[jn] == -1) dn = j;
+        }
+        Seg sg;
+        {  // start = crossing on the edge walked downwards (+ -> -)
+          int a = dn, c = (dn + 1) % 3;
+          int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
+          double t = d[l] / (d[l] - d[h]);
+          sg.s_lo = (uint32_t)id[l]; sg.s_hi = (uint32_t)id[h];
+          sg.px = X[l] + t * (X[h] - X[l]);
+          sg.py = Y[l] + t * (Y[h] - Y[l]);
+        }
+        {
+          int a = up, c = (up + 1) % 3;
+          int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
+          sg.e_lo = (uint32_t)id[l]; sg.e_hi = (uint32_t)id[h];
+        }
+        // a plane with more crossings than slots is an overflow plane: seg_count keeps counting, k_ovf.h sections it again into the pool
+        if (slot < SH_MAXSEG) segs[((size_t)b * N + k) * SH_MAXSEG + slot] = sg;
       }
-      Seg sg;
-      {  // start = crossing on the edge walked downwards (+ -> -)
-        int a = dn, c = (dn + 1) % 3;
-        int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
-        double t = d[l] / (d[l] - d[h]);
-        sg.s_lo = (uint32_t)id[l]; sg.s_hi = (uint32_t)id[h];
-        sg.px = X[l] + t * (X[h] - X[l]);
-        sg.py = Y[l] + t * (Y[h] - Y[l]);
-      }
-      {
-        int a = up, c = (up + 1) % 3;
-        int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
-        sg.e_lo = (uint32_t)id[l]; sg.e_hi = (uint32_t)id[h];
-      }
-      // a plane with more crossings than slots is an overflow plane: seg_count keeps counting, k_ovf.h sections it again into the pool
-      if (slot < SH_MAXSEG) segs[((size_t)b * N + k) * SH_MAXSEG + slot] = sg;
     }
     __syncthreads();      // hist is zeroed again at the top of the next chunk
   }
@@ -238,9 +273,8 @@ __device__ inline uint32_t hash_key64(unsigned long long k) {
 // with up to 384 segments -- every section of a humerus at the fixture resolution -- and CAP = SH_MAXSEG (46 KB) the rest; the
 // other tier's planes exit at once.
 // A plane with more than SH_MAXLOOPS closed loops (a mesh with dozens of components in one section: fragments, trabecular
-// cavities) is handed to the overflow tier's join (k_ovf.h: loop tables of 1 024 entries): listed here, given pool ranges by
+// cavities) is handed to the overflow tier's join (k_ovf.h: loop tables of 1 024 entries): listed (ManyLoops), given pool ranges by
 // k_ovf_plan_loops.  With that tier skipped for a resident batch (no list): `missed` tells sh_collect to run again with it.
-struct ManyLoops { int* list; int* n; unsigned long long* missed; };
 
 template <int CAP>
 __device__ inline void slice_link_plane(const int pl, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
@@ -481,24 +515,29 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
 // small tier: one workgroup per plane.  Large tier: a small grid sweeps all planes and works on the few (usually none)
 // with more than SH_SMALLSEG segments -- a workgroup per plane would pay its 70 KB LDS allocation 40 000 times for nothing.
 __global__ void __launch_bounds__(SH_LINK_THREADS)
-k_slice_link(int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs, double* __restrict__ centroids, double* __restrict__ areas,
-             int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total,
-             int* __restrict__ nlarge /*zero at launch: planes left to the large tier*/, ManyLoops many) {
-  slice_link_plane<SH_SMALLSEG>(blockIdx.x, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total, many, nlarge);
+k_slice_link(SliceSets sets, int B, int* __restrict__ err) {
+  const int n0 = B * sets.s[0].N;
+  const int si = (int)blockIdx.x >= n0 ? 1 : 0;      // grid: the planes of set 0, then those of set 1
+  const SliceSetDev& S = sets.s[si];
+  slice_link_plane<SH_SMALLSEG>((int)blockIdx.x - (si ? n0 : 0), S.N, S.seg_count, S.segs, S.centroids, S.areas, S.nloops, S.ring_n, S.ring, S.select, err, S.areas_total,
+                                S.many, S.nlarge);
 }
 __global__ void __launch_bounds__(SH_LINK_THREADS)
-k_slice_link_large(int nplanes, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs, double* __restrict__ centroids, double* __restrict__ areas,
-                   int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring, int select, int* __restrict__ err, double* __restrict__ areas_total,
-                   const int* __restrict__ nlarge, unsigned long long* __restrict__ ovf_missed /*null while the overflow tier runs*/, ManyLoops many) {
-  if (*nlarge == 0) return;      // (the usual case: the sweep below is ~75 dependent loads per workgroup for nothing)
-  for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
-    // An overflow plane belongs to k_slice_link_huge (k_ovf.h).  When the host skipped that tier for a resident batch "known" to need
-    // none and the planes have moved since (another frame, other parameters), nobody joins this plane: say so, sh_collect runs the
-    // batch again with the tier on instead of handing out the previous run's section.
-    if (seg_count[pl] > SH_MAXSEG && ovf_missed && threadIdx.x == 0) atomicExch(ovf_missed, 1ull);
-    if (seg_count[pl] <= SH_SMALLSEG || seg_count[pl] > SH_MAXSEG) continue;
-    slice_link_plane<SH_MAXSEG>(pl, N, seg_count, segs, centroids, areas, nloops, ring_n, ring, select, err, areas_total, many);
-    __syncthreads();
+k_slice_link_large(SliceSets sets, int B, int* __restrict__ err) {
+  for (int si = 0; si < sets.n; ++si) {
+    const SliceSetDev& S = sets.s[si];
+    if (*S.nlarge == 0) continue;      // (the usual case: the sweep below is ~75 dependent loads per workgroup for nothing)
+    const int nplanes = B * S.N;
+    for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
+      // An overflow plane belongs to k_slice_link_huge (k_ovf.h).  When the host skipped that tier for a resident batch "known" to need
+      // none and the planes have moved since (another frame, other parameters), nobody joins this plane: say so, sh_collect runs the
+      // batch again with the tier on instead of handing out the previous run's section.
+      const int cnt = S.seg_count[pl];
+      if (cnt > SH_MAXSEG && S.ovf_missed && threadIdx.x == 0) atomicExch(S.ovf_missed, 1ull);
+      if (cnt <= SH_SMALLSEG || cnt > SH_MAXSEG) continue;
+      slice_link_plane<SH_MAXSEG>(pl, S.N, S.seg_count, S.segs, S.centroids, S.areas, S.nloops, S.ring_n, S.ring, S.select, err, S.areas_total, S.many);
+      __syncthreads();
+    }
   }
 }
 

@@ -1582,60 +1582,80 @@ static int ovf_set(sh_ctx* c, const std::string& pfx, int N, OvfSet* S) {
   return SH_OK;
 }
 
-static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0, bool total_area = false, bool decode_bounds = false) {
+// One or two slice sets through the set's launches together (k_slices.h SliceSets): plane heights (+ counter clears, bound decode),
+// one pass over the mesh for their sections, one grid for their joins; the overflow tier and the resampling stay per set.
+struct SliceSpec { const char* pfx; int kind, N; bool ring, resample; int select; bool total_area, decode_bounds; };
+static int run_slice_sets(sh_ctx* c, const SliceSpec* specs, int nspec) {
   const int B = c->Bwin;
-  std::string p = pfx;
-  double* zs = buf<double>(c, (p + ".zs").c_str());
-  double* zeff = buf<double>(c, (p + ".zeff").c_str());
-  int* cnt = buf<int>(c, (p + ".seg_count").c_str());
-  Seg* segs = buf<Seg>(c, (p + ".segs").c_str());
-  if (N > SH_EMIT_MAXN) return fail(c, SH_ERR_CAPACITY, "slice set has more planes than k_slice_emit's LDS histogram");
-  double* atot = total_area ? buf<double>(c, (p + ".area_total").c_str()) : (double*)nullptr;
-  int* nlarge = (int*)c->bufs["slices.nlarge"].p + (kind & 7);      // (one counter per kind of set: two sets may run on two streams)
-  // planes with more crossings than slots (k_ovf.h): plan their pool ranges, section them again into the segment pool
-  OvfPools OP; OvfSet OS;
-  { int orc; if ((orc = ovf_pools(c, &OP)) != SH_OK || (orc = ovf_set(c, p, N, &OS)) != SH_OK) return orc; }
+  if (nspec < 1 || nspec > 2) return fail(c, SH_ERR_STATE, "run_slice_sets: one or two sets");
+  int ntot = 0;
+  for (int i = 0; i < nspec; ++i) ntot += specs[i].N;
+  if (ntot > SH_EMIT_MAXN) return fail(c, SH_ERR_CAPACITY, "slice sets have more planes than k_slice_emit's LDS histogram");
+  OvfPools OP; OvfSet OS[2];
+  { int orc; if ((orc = ovf_pools(c, &OP)) != SH_OK) return orc; }
   const bool ovf_on = c->ovf_none_gen != c->batch_gen;      // (known from an earlier run of this batch: no plane overflows)
-  // the plane heights; the same launch zeroes the set's crossing counters and its large-tier counter, resets the overflow tier's
-  // per-set words (segments / workspace used: per set; ring points stay for the run) and, for the first set behind
-  // k_transform_verts, decodes the z bounds (run_window)
-  PlaneAux aux{decode_bounds ? (const unsigned long long*)buf<unsigned long long>(c, "zb_enc") : (const unsigned long long*)nullptr, buf<double>(c, "z_bounds"), cnt, nlarge,
-               ovf_on ? OS.nlist : (int*)nullptr, OP.ctr};
-  LAUNCH(c, "k_make_planes", k_make_planes, dim3(B), dim3(256), kind, N, buf<double>(c, kind == 4 ? "obb.zb_pre" : "z_bounds"), buf<double>(c, "neck_z"), zs, zeff, B, aux);
+  SliceSets sets{};
+  sets.n = nspec;
+  for (int i = 0; i < nspec; ++i) {
+    const SliceSpec& sp = specs[i];
+    const std::string p = sp.pfx;
+    { int orc; if ((orc = ovf_set(c, p, sp.N, &OS[i])) != SH_OK) return orc; }
+    SliceSetDev& S = sets.s[i];
+    S.N = sp.N; S.kind = sp.kind; S.select = sp.select;
+    S.zb = buf<double>(c, sp.kind == 4 ? "obb.zb_pre" : "z_bounds");
+    S.zs = buf<double>(c, (p + ".zs").c_str()); S.zeff = buf<double>(c, (p + ".zeff").c_str());
+    S.seg_count = buf<int>(c, (p + ".seg_count").c_str()); S.segs = buf<Seg>(c, (p + ".segs").c_str());
+    S.centroids = buf<double>(c, (p + ".centroids").c_str()); S.areas = buf<double>(c, (p + ".areas").c_str()); S.nloops = buf<int>(c, (p + ".nloops").c_str());
+    S.ring_n = buf<int>(c, (p + ".ring_n").c_str());
+    S.ring = sp.ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr;
+    S.areas_total = sp.total_area ? buf<double>(c, (p + ".area_total").c_str()) : (double*)nullptr;
+    S.nlarge = (int*)c->bufs["slices.nlarge"].p + (sp.kind & 7);      // (one counter per kind of set)
+    // planes with more than SH_MAXLOOPS loops: listed for the overflow tier's join (tier skipped: flagged, sh_collect runs again with it)
+    S.many = ManyLoops{ovf_on ? OS[i].list2 : (int*)nullptr, ovf_on ? OS[i].nlist + 1 : (int*)nullptr, ovf_on ? (unsigned long long*)nullptr : OP.ctr + 6};
+    S.ovf_missed = ovf_on ? (unsigned long long*)nullptr : OP.ctr + 6;
+    // the plane-height launch also zeroes the set's crossing counters and its large-tier counter, resets the overflow tier's words
+    // (segments / workspace used: per launch group, by its first set; ring points stay for the run) and, for the first set behind
+    // k_transform_verts, decodes the z bounds (run_window)
+    S.aux = PlaneAux{sp.decode_bounds ? (const unsigned long long*)buf<unsigned long long>(c, "zb_enc") : (const unsigned long long*)nullptr, buf<double>(c, "z_bounds"), S.seg_count, S.nlarge,
+                     ovf_on ? OS[i].nlist : (int*)nullptr, i == 0 ? OP.ctr : (unsigned long long*)nullptr};
+  }
+  LAUNCH(c, "k_make_planes", k_make_planes, dim3(B, nspec), dim3(256), sets, (const double*)buf<double>(c, "neck_z"), B);
   dim3 g((unsigned)std::min<long long>((c->maxF + 255) / 256, 4096), (unsigned)B);
-  LAUNCH(c, "k_slice_emit", k_slice_emit, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
-         buf<long long>(c, "foff"), zeff, N, cnt, segs);
-  if (ovf_on) {
-    LAUNCH(c, "k_ovf_plan", k_ovf_plan, dim3((unsigned)((B * N + 255) / 256)), dim3(256), N, B * N, (const int*)cnt, OP, OS, buf<int>(c, "err"));
-    LAUNCH(c, "k_slice_emit_ovf", k_slice_emit_ovf, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
-           buf<long long>(c, "foff"), zeff, N, OP, OS);
-  }
+  LAUNCH(c, "k_slice_emit", k_slice_emit, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"), buf<long long>(c, "foff"), sets);
+  if (ovf_on)      // planes with more crossings than slots (k_ovf.h): plan their pool ranges, section them again into the segment pool
+    for (int i = 0; i < nspec; ++i) {
+      const SliceSetDev& S = sets.s[i];
+      LAUNCH(c, "k_ovf_plan", k_ovf_plan, dim3((unsigned)((B * S.N + 255) / 256)), dim3(256), S.N, B * S.N, (const int*)S.seg_count, OP, OS[i], buf<int>(c, "err"));
+      LAUNCH(c, "k_slice_emit_ovf", k_slice_emit_ovf, g, dim3(256), buf<double>(c, "verts_obb"), buf<int>(c, "faces"), buf<long long>(c, "voff"),
+             buf<long long>(c, "foff"), (const double*)S.zeff, S.N, OP, OS[i]);
+    }
   // two capacity tiers share the grid (k_slices.h): the planes of the other tier exit at once
-  int* rn = buf<int>(c, (p + ".ring_n").c_str());
-  double* rg = ring ? buf<double>(c, (p + ".ring").c_str()) : (double*)nullptr;
-  // planes with more than SH_MAXLOOPS loops: listed for the overflow tier's join (tier skipped: flagged, sh_collect runs again with it)
-  const ManyLoops many{ovf_on ? OS.list2 : (int*)nullptr, ovf_on ? OS.nlist + 1 : (int*)nullptr, ovf_on ? (unsigned long long*)nullptr : OP.ctr + 6};
-  LAUNCH(c, "k_slice_link", k_slice_link, dim3(B * N), dim3(SH_LINK_THREADS), N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
-         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, nlarge, many);
-  LAUNCH(c, "k_slice_link_large", k_slice_link_large, dim3(std::min(B * N, 512)), dim3(SH_LINK_THREADS), B * N, N, cnt, segs, buf<double>(c, (p + ".centroids").c_str()),
-         buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, rg, select, buf<int>(c, "err"), atot, (const int*)nlarge,
-         ovf_on ? (unsigned long long*)nullptr : OP.ctr + 6, many);
-  if (ovf_on) {
-    LAUNCH(c, "k_ovf_plan_loops", k_ovf_plan_loops, dim3(16), dim3(256), N, (const int*)cnt, (const Seg*)segs, OP, OS, buf<int>(c, "err"));
-    LAUNCH(c, "k_slice_link_huge", k_slice_link_huge, dim3(64), dim3(SH_HUGE_THREADS), N, (const int*)cnt, OP, OS, buf<double>(c, (p + ".centroids").c_str()),
-           buf<double>(c, (p + ".areas").c_str()), buf<int>(c, (p + ".nloops").c_str()), rn, ring ? 1 : 0, select, buf<int>(c, "err"), atot);
-  }
-  if (resample) {
-    LAUNCH(c, "k_resample_polar", k_resample_polar, dim3(B * N), dim3(SH_RS_THREADS), N, SH_MPROX, rn, rg,
-           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const long long*)OS.roff);
-    LAUNCH(c, "k_resample_polar_large", k_resample_polar_large, dim3(std::min(B * N, 512)), dim3(SH_RS_THREADS), B * N, N, SH_MPROX, rn, rg,
-           buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const int*)nlarge, (const long long*)OS.roff);
+  LAUNCH(c, "k_slice_link", k_slice_link, dim3(B * ntot), dim3(SH_LINK_THREADS), sets, B, buf<int>(c, "err"));
+  LAUNCH(c, "k_slice_link_large", k_slice_link_large, dim3(std::min(B * ntot, 512)), dim3(SH_LINK_THREADS), sets, B, buf<int>(c, "err"));
+  for (int i = 0; i < nspec; ++i) {
+    const SliceSpec& sp = specs[i];
+    const SliceSetDev& S = sets.s[i];
     if (ovf_on) {
-      LAUNCH(c, "k_resample_polar_huge", k_resample_polar_huge, dim3(64), dim3(SH_RS_THREADS), N, SH_MPROX, (const int*)rn, OP, OS,
-             buf<double>(c, (p + ".centroids").c_str()), buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
+      LAUNCH(c, "k_ovf_plan_loops", k_ovf_plan_loops, dim3(16), dim3(256), S.N, (const int*)S.seg_count, (const Seg*)S.segs, OP, OS[i], buf<int>(c, "err"));
+      LAUNCH(c, "k_slice_link_huge", k_slice_link_huge, dim3(64), dim3(SH_HUGE_THREADS), S.N, (const int*)S.seg_count, OP, OS[i], S.centroids, S.areas, S.nloops, S.ring_n,
+             sp.ring ? 1 : 0, S.select, buf<int>(c, "err"), S.areas_total);
+    }
+    if (sp.resample) {
+      LAUNCH(c, "k_resample_polar", k_resample_polar, dim3(B * S.N), dim3(SH_RS_THREADS), S.N, SH_MPROX, S.ring_n, S.ring,
+             S.centroids, buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const long long*)OS[i].roff);
+      LAUNCH(c, "k_resample_polar_large", k_resample_polar_large, dim3(std::min(B * S.N, 512)), dim3(SH_RS_THREADS), B * S.N, S.N, SH_MPROX, S.ring_n, S.ring,
+             S.centroids, buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const int*)S.nlarge, (const long long*)OS[i].roff);
+      if (ovf_on) {
+        LAUNCH(c, "k_resample_polar_huge", k_resample_polar_huge, dim3(64), dim3(SH_RS_THREADS), S.N, SH_MPROX, (const int*)S.ring_n, OP, OS[i],
+               S.centroids, buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
+      }
     }
   }
   return SH_OK;
+}
+static int run_slice_set(sh_ctx* c, const char* pfx, int kind, int N, bool ring, bool resample, int select = 0, bool total_area = false, bool decode_bounds = false) {
+  const SliceSpec sp{pfx, kind, N, ring, resample, select, total_area, decode_bounds};
+  return run_slice_sets(c, &sp, 1);
 }
 
 // The hull's input points.  Host-provided batch: the caller's vertices.  Device-generated batch: the prefilter
@@ -2032,8 +2052,10 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     if (!(mask & SH_STAGE_FULL))      // (with the full set in the run its k_make_planes decodes them)
       LAUNCH(c, "k_decode_bounds", k_decode_bounds, dim3((2 * B + 63) / 64), dim3(64), buf<unsigned long long>(c, "zb_enc"), buf<double>(c, "z_bounds"), B);
   }
-  if (mask & SH_STAGE_FULL)
-    if ((rc = run_slice_set(c, "full", 0, SH_NFULL, false, false, 0, false, transformed)) != SH_OK) return rc;
+  // Slice sets that hang on the same inputs share their launches (run_slice_sets): full + distal behind the box frame, neck contour +
+  // proximal behind neck_z -- 8 launches and two passes over the mesh less per step; same sections (SHOULDER_SLICE_MERGE=0: one
+  // set per launch group, the A/B of tests/test_gpu_slices.py)
+  const bool merge_env = !(getenv("SHOULDER_SLICE_MERGE") && getenv("SHOULDER_SLICE_MERGE")[0] == '0');      // (read per run: the tests switch it in-process)
   // The distal set and the first part of the trans-epicondylar stage (the rectangles of its rows, the ends of the widest one) need
   // nothing but the box frame.  Small batches (up to 16 humeri: one humerus gains 4 %, 6.01 -> 5.78 ms per run; at B = 64 two streams'
   // kernels just share the CUs and one lane LOSES 8 %): the whole branch runs on the side stream beside the full -> neck -> canal ->
@@ -2051,6 +2073,15 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   const bool te_early = can_fork && !side && te_early_env && (mask & SH_STAGE_TE) && (mask & SH_STAGE_ANP);
   bool te_rows_done = false;
   c->side_pending = false;
+  const bool merge_fd = merge_env && (mask & SH_STAGE_FULL) && (mask & SH_STAGE_DISTAL) && !side;
+  if (merge_fd) {
+    // (both sets decode the z bounds themselves: their plane heights are made by ONE launch, the distal workgroups cannot wait for the
+    //  full set's to write "z_bounds")
+    const SliceSpec sp[2] = {{"full", 0, SH_NFULL, false, false, 0, false, transformed}, {"distal", 2, SH_NDIST, true, false, 0, false, transformed}};
+    if ((rc = run_slice_sets(c, sp, 2)) != SH_OK) return rc;
+  } else if (mask & SH_STAGE_FULL) {
+    if ((rc = run_slice_set(c, "full", 0, SH_NFULL, false, false, 0, false, transformed)) != SH_OK) return rc;
+  }
   if (mask & SH_STAGE_DISTAL) {
     hipStream_t main_stream = c->stream;
     auto fork = [&]() -> int {
@@ -2062,7 +2093,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
       return SH_OK;
     };
     if (side && (rc = fork()) != SH_OK) return rc;
-    rc = run_slice_set(c, "distal", 2, SH_NDIST, true, false);
+    rc = merge_fd ? SH_OK : run_slice_set(c, "distal", 2, SH_NDIST, true, false);
     if (rc == SH_OK && te_early) rc = fork();
     // ... and by default it simply runs HERE, in the chain in front of the UNet pass instead of behind it: the same kernels on the same
     // stream, but the part of the step that follows the UNet -- what stands between the pass and the lane's next step -- is 0.3 ms
@@ -2085,8 +2116,12 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
       LAUNCH(c, "k_neck", k_neck<false>, dim3(B), dim3(64), buf<double>(c, "full.areas"), buf<double>(c, "full.zs"),
              buf<double>(c, "neck_z"), buf<int>(c, "neck_index"), B, 0.70, 0.99, (double*)nullptr);
     }
-    // surgical_neck.py:37-54: the contour at neck_z (loop whose vertex mean is nearest the origin)
-    if ((rc = run_slice_set(c, "neckc", 3, 1, true, false, 1)) != SH_OK) return rc;
+    // surgical_neck.py:37-54: the contour at neck_z (loop whose vertex mean is nearest the origin) -- with the proximal set (which
+    // starts from neck_z as well) in the same launches when both stages run
+    if (merge_env && (mask & SH_STAGE_PROXIMAL)) {
+      const SliceSpec sp[2] = {{"neckc", 3, 1, true, false, 1, false, false}, {"prox", 1, SH_NPROX, true, true, 0, false, false}};
+      if ((rc = run_slice_sets(c, sp, 2)) != SH_OK) return rc;
+    } else if ((rc = run_slice_set(c, "neckc", 3, 1, true, false, 1)) != SH_OK) return rc;
   }
   if (mask & SH_STAGE_CANAL) {
     LAUNCH(c, "k_canal", k_canal, dim3(B), dim3(64), buf<double>(c, "full.centroids"), buf<double>(c, "full.zs"),
@@ -2094,7 +2129,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            c->params.bone_kind == SH_BONE_PROXIMAL ? buf<double>(c, "pobb.cutoff") : (const double*)nullptr,
            buf<double>(c, "canal.points_obb"), buf<double>(c, "canal.axis_obb"), buf<double>(c, "canal.axis_ct"), buf<int>(c, "err"));
   }
-  if (mask & SH_STAGE_PROXIMAL)
+  if ((mask & SH_STAGE_PROXIMAL) && !(merge_env && (mask & SH_STAGE_NECK)))
     if ((rc = run_slice_set(c, "prox", 1, SH_NPROX, true, true)) != SH_OK) return rc;
   if (mask & SH_STAGE_GROOVE) {
     if (!c->have_rfc) return fail(c, SH_ERR_STATE, "sh_run: groove stage needs sh_load_rfc first");

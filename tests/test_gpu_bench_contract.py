@@ -48,7 +48,8 @@ def test_bench_line():
     # geometry table: per STEP (every launch of a kernel name in one step), algorithmic and SURVEY bytes, PMC bytes or null
     gk = d["geometry_kernels"]
     row = gk["k_slice_link"]
-    assert row["launches_per_step"] == 4 and row["ms_per_step"] > 0 and row["algorithmic_mb_per_step"] > 0 and "pmc_mb_per_step" in row
+    assert row["launches_per_step"] == 2 and row["ms_per_step"] > 0      # (full + distal, neck contour + proximal: two join grids per step since round 4)
+    assert row["ms_per_step"] > 0 and row["algorithmic_mb_per_step"] > 0 and "pmc_mb_per_step" in row
     assert abs(row["frac_of_hbm_peak"] - row["algorithmic_mb_per_step"] / row["ms_per_step"] / 8000.0) < 2e-3
     assert "k_slice_link_large" not in gk or gk["k_slice_link_large"]["algorithmic_mb_per_step"] == 0      # (own timer name: not averaged into the row above)
     assert gk["k_resample_polar"]["launches_per_step"] == 1 and gk["k_resample_polar"]["survey_mb_per_step"] > 0

@@ -85,3 +85,42 @@ def test_neck_and_canal(engine, ran):
         assert nz[b] == pytest.approx(h.neck["neck_z"], abs=1e-12)
         np.testing.assert_allclose(pts[b], h.canal["points_obb"], rtol=0, atol=TOL)
         np.testing.assert_allclose(ax[b], h.canal["axis_ct"], rtol=0, atol=1e-8)
+
+
+def test_merged_slice_sets_equal_separate_launches(engine, oracle_bones, monkeypatch):
+    """Round 4: full + distal and neck contour + proximal go through the set launches together (one plane-height launch, one pass
+    over the mesh, one join grid per pair).  Against one launch group per set (SHOULDER_SLICE_MERGE=0): the same records and the
+    same slice-layer buffers byte for byte, for a batch and for a single humerus (which keeps the distal set on its side stream)."""
+    names = ["humerus_left", "humerus_left_flipped", "humerus_left_trab", "humerus_right"]
+    hs = [oracle_bones(n) for n in names]
+    engine.reset_params()
+    engine.set_params(unet_dtype=_lib.UNET_BF16)
+    try:
+        for meshes in ([(h.verts, h.faces) for h in hs] * 5, [(hs[2].verts, hs[2].faces)]):      # 20 humeri (> 16: merged), one humerus
+            B = len(meshes)
+            engine.upload(meshes)
+            out = {}
+            for mode in ("1", "0", "1"):
+                monkeypatch.setenv("SHOULDER_SLICE_MERGE", mode)
+                lm = engine.run(_lib.STAGE_ALL).copy()
+                bufs = {k: engine.fetch(k, dt, shp).copy() for k, dt, shp in (
+                    ("full.areas", np.float64, (B, 200)), ("full.centroids", np.float64, (B, 200, 2)), ("distal.ring_n", np.int32, (B, 200)),
+                    ("distal.ring", np.float64, (B, 200, 1025, 2)), ("prox.seg_count", np.int32, (B, 600)), ("prox.itr_start", np.float64, (B, 600, 2, 512)),
+                    ("neckc.ring_n", np.int32, (B, 1)), ("neckc.centroids", np.float64, (B, 1, 2)))}
+                if mode in out:
+                    assert out[mode][0].tobytes() == lm.tobytes()
+                out[mode] = (lm, bufs)
+            assert (out["1"][0]["status"] == 0).all()
+            assert out["1"][0].tobytes() == out["0"][0].tobytes()
+            for k in out["1"][1]:
+                rn = out["1"][1].get("distal.ring_n") if k == "distal.ring" else None
+                if rn is None:
+                    np.testing.assert_array_equal(out["1"][1][k], out["0"][1][k], err_msg=k)
+                else:      # (ring slots behind a ring's end keep whatever an earlier run left there)
+                    for b in range(B):
+                        for p in range(0, 200, 9):
+                            n = int(rn[b, p]) + 1
+                            np.testing.assert_array_equal(out["1"][1][k][b, p, :n], out["0"][1][k][b, p, :n])
+    finally:
+        monkeypatch.delenv("SHOULDER_SLICE_MERGE", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)
