@@ -52,13 +52,42 @@ __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][51
   double* o_t = shft_theta + (size_t)gid * M;
   double lo = 1e300, hi = -1e300;      // the row's share of the image's minimum / maximum (MinMaxScaler, :56-58): a separate pass read the image again
   if (!s_unsorted) {
-    for (int j = lane; j < M; j += 64) {
-      double t = linspace_at(t0, t1, M, j);
-      int jg = 0;
-      double v = np_interp_step(t, s_t, s_r, M - 1, &jg);
+    // On a sorted xp np.interp's search returns the largest index with xp[i] <= x whatever its guess: the lane's eight samples take
+    // that index by a fixed-length branch-free search side by side (nine LDS reads deep in all, where eight guessed searches one
+    // after the other were ~12 dependent reads each: the row's latency is what the chain pays for beside a UNet pass), then the
+    // arithmetic of np_interp_step.
+    constexpr int NS = SH_MPROX / 64, LEN = SH_MPROX - 1;
+    double t[NS];
+    int pos[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) { t[u] = linspace_at(t0, t1, M, lane + 64 * u); pos[u] = 0; }
+#pragma unroll
+    for (int stp = 256; stp >= 1; stp >>= 1) {
+#pragma unroll
+      for (int u = 0; u < NS; ++u) { const int q = pos[u] + stp; if (q < LEN && s_t[q] <= t[u]) pos[u] = q; }
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int j = lane + 64 * u;
+      const double x = t[u];
+      int i = pos[u];
+      if (x > s_t[LEN - 1]) i = LEN; else if (x < s_t[0]) i = -1;
+      double v;
+      if (i == -1) v = s_r[0];
+      else if (i == LEN) v = s_r[LEN - 1];
+      else if (i == LEN - 1) v = s_r[i];
+      else if (s_t[i] == x) v = s_r[i];
+      else {
+        const double slope = (s_r[i + 1] - s_r[i]) / (s_t[i + 1] - s_t[i]);
+        v = slope * (x - s_t[i]) + s_r[i];
+        if (v != v) {      // NaN: NumPy retries from the right neighbour
+          v = slope * (x - s_t[i + 1]) + s_r[i + 1];
+          if (v != v && s_r[i] == s_r[i + 1]) v = s_r[i];
+        }
+      }
       int dst = j - kbest; if (dst < 0) dst += M;
       o_r[dst] = v;
-      o_t[dst] = t;
+      o_t[dst] = x;
       lo = fmin(lo, v); hi = fmax(hi, v);
     }
   } else if (lane == 0) {

@@ -618,27 +618,57 @@ SH_HD void unitxyz_to_spherical_deg(const double* v, double* theta, double* phi)
 // relative to the neck-plane point (any shift near the data keeps the normal equations well conditioned; the
 // fit itself is shift invariant).  partial[b][part][14] = sum q q^T (6), |q|^2, q|q|^2 (3), q (3), count.
 #define SH_SPH_PARTS 16
+// Round 4: the points' angles are the rows of a uniform theta grid (k_anp_rows: t_j = linspace(t0, t1, 512)[j], stored rolled by the
+// row's `roll`), so a wave that owns a row takes ONE sincos per lane (its first column) and walks its other seven columns by a
+// rotation of 64 grid steps (or 64 - 512 steps where the column index wraps) -- it took a cos and a sin per mask pixel, and behind a
+// UNet pass on the 32 reserved CUs that was 0.33 ms of f64 range reduction on the lane's critical path.  Angle error after seven
+// rotations ~1e-15 (radius_curvature is held to 1e-6 mm against the oracle).  32 rows per workgroup, 8 per wave.
 __global__ void __launch_bounds__(256)
-k_sphere_partial(const float* __restrict__ logits, const double* __restrict__ raw, const double* __restrict__ shft_theta,
-                 const double* __restrict__ prox_zs, const double* __restrict__ plane, double* __restrict__ partial) {
+k_sphere_partial(const float* __restrict__ logits, const double* __restrict__ raw, const double* __restrict__ itr_start /*[B][600][2][512]: the rows' theta*/,
+                 const int* __restrict__ roll /*[B][512]*/, const double* __restrict__ prox_zs, const double* __restrict__ plane, double* __restrict__ partial) {
   __shared__ double sh[14 * 4];
-  const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+  constexpr int M = SH_MPROX, RPW = SH_ANP_ROWS / SH_SPH_PARTS;      // 32 rows per workgroup
+  const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* lg = logits + (size_t)b * SH_IMG;
   const double* rr = raw + (size_t)b * SH_IMG;
-  const double* tt = shft_theta + (size_t)b * SH_IMG;
   const double* zz = prox_zs + (size_t)b * SH_NPROX + SH_ANP_ROW0;
   const double m[3] = {plane[6 * b], plane[6 * b + 1], plane[6 * b + 2]};
   double a[14];
   for (int k = 0; k < 14; ++k) a[k] = 0.0;
-  const int chunk = SH_IMG / SH_SPH_PARTS;
-  for (int i = part * chunk + tid; i < (part + 1) * chunk; i += 256)
-    if (lg[i] > 0.0f) {
-      double r = rr[i], t = tt[i];
-      double q[3] = {r * cos(t) - m[0], r * sin(t) - m[1], zz[i / SH_MPROX] - m[2]};
-      double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
-      a[0] += q[0] * q[0]; a[1] += q[0] * q[1]; a[2] += q[0] * q[2]; a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
-      a[6] += q2; a[7] += q[0] * q2; a[8] += q[1] * q2; a[9] += q[2] * q2; a[10] += q[0]; a[11] += q[1]; a[12] += q[2]; a[13] += 1.0;
+  for (int rw = wave; rw < RPW; rw += 4) {
+    const int row = part * RPW + rw;
+    const double* th = itr_start + ((size_t)b * SH_NPROX + SH_ANP_ROW0 + row) * 2 * M;
+    const double t0 = th[0], t1 = th[M - 2];                           // the grid of k_anp_rows
+    const int kbest = roll[(size_t)b * SH_ANP_ROWS + row];
+    const double step = (t1 - t0) / (double)(M - 1);
+    int j = lane + kbest; if (j >= M) j -= M;                          // grid index of storage column `lane`
+    // lanes 0 / 1 also take the two rotation angles; every lane its own first angle
+    const double ang = lane == 0 ? 64.0 * step : (lane == 1 ? (double)(64 - M) * step : 0.0);
+    double sa, ca;
+    sincos(ang, &sa, &ca);
+    const double c64 = __shfl(ca, 0), s64 = __shfl(sa, 0), cw = __shfl(ca, 1), sw = __shfl(sa, 1);
+    double sn, cs;
+    sincos(linspace_at(t0, t1, M, j), &sn, &cs);
+    const double z = zz[row] - m[2];
+    const size_t base = (size_t)row * M + lane;
+#pragma unroll
+    for (int k = 0; k < M / 64; ++k) {
+      if (lg[base + 64 * k] > 0.0f) {
+        const double r = rr[base + 64 * k];
+        const double q[3] = {r * cs - m[0], r * sn - m[1], z};
+        const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];
+        a[0] += q[0] * q[0]; a[1] += q[0] * q[1]; a[2] += q[0] * q[2]; a[3] += q[1] * q[1]; a[4] += q[1] * q[2]; a[5] += q[2] * q[2];
+        a[6] += q2; a[7] += q[0] * q2; a[8] += q[1] * q2; a[9] += q[2] * q2; a[10] += q[0]; a[11] += q[1]; a[12] += q[2]; a[13] += 1.0;
+      }
+      j += 64;
+      const bool wrap = j >= M;
+      if (wrap) j -= M;
+      const double cr = wrap ? cw : c64, sr = wrap ? sw : s64;
+      const double cn = cs * cr - sn * sr;
+      sn = sn * cr + cs * sr;
+      cs = cn;
     }
+  }
   block_sum<14>(a, sh, tid, 4);
   if (tid < 14) partial[((size_t)b * SH_SPH_PARTS + part) * 14 + tid] = a[tid];
 }

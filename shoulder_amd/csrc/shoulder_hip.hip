@@ -2186,7 +2186,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   const bool metrics = (mask & need) == need;
   if (metrics)
     LAUNCH(c, "k_sphere_partial", k_sphere_partial, dim3(SH_SPH_PARTS, B), dim3(256), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
-           buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.plane"), buf<double>(c, "metrics.partial"));
+           buf<double>(c, "prox.itr_start"), buf<int>(c, "anp.roll"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.plane"), buf<double>(c, "metrics.partial"));
   {      // ray points -> trans-epicondylar order -> record -> metrics: one launch, one workgroup per humerus (k_tail, k_te.h)
     PackArgs A{};
     A.lm = buf<sh_landmarks>(c, "landmarks"); A.T_obb = buf<double>(c, "obb_transform"); A.zb = buf<double>(c, "z_bounds"); A.neck_z = buf<double>(c, "neck_z");
