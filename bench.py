@@ -907,6 +907,17 @@ def single_humerus_leg(device, weights, verts, faces, reps=10):
         t0 = time.perf_counter()
         lm = e.run(_lib.STAGE_ALL)
         walls.append(1e3 * (time.perf_counter() - t0))
+    # the same humerus with SH_UNET_F32X (mask identical to the exact path's on every image compared so far; not the facade's default:
+    # only the exact f32 chain is GUARANTEED to give the oracle's mask)
+    e.set_params(unet_dtype=_lib.UNET_F32X)
+    e.run(_lib.STAGE_ALL)
+    walls_x = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        lmx = e.run(_lib.STAGE_ALL)
+        walls_x.append(1e3 * (time.perf_counter() - t0))
+    same_x = bool(lmx.tobytes() == lm.tobytes())
+    e.set_params(unet_dtype=_lib.UNET_F32)
     e.enable_timing(1)
     e.reset_timers()
     e.run(_lib.STAGE_ALL)
@@ -937,6 +948,7 @@ def single_humerus_leg(device, weights, verts, faces, reps=10):
     med = lambda a: float(sorted(a)[len(a) // 2])
     return {"workload": "BASELINE configs[1]: single humerus (humerus_left.stl, 16 222 vertices), full landmark set, f32 UNet, 1 GPU",
             "engine_run_ms": round(med(walls), 3), "engine_run_ms_min": round(min(walls), 3), "reps": reps, "status_ok": ok,
+            "engine_run_ms_f32x": round(med(walls_x), 3), "f32x_record_equal_to_f32": same_x,
             "device_ms_by_stage": {k: round(v, 3) for k, v in sorted(stages.items())}, "device_ms_total": round(sum(v for k, v in stages.items() if not k.endswith(".host")), 3),
             "facade_readme_flow_ms": round(med(fw), 3), "facade_readme_flow_ms_min": round(min(fw), 3),
             "facade_flow": "Humerus(stl) -> apply_csys_canal_transepiconylar() -> canal.axis(), trans_epiconylar.axis(), anatomic_neck.points(), bicipital_groove.axis(); file read + parse included",
