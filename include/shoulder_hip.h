@@ -196,6 +196,24 @@ int  sh_submit(sh_ctx*, uint32_t stage_mask, sh_landmarks* out /* B, host, nulla
 int  sh_collect(sh_ctx*);
 /* Device address of the B result structs of the last sh_run (for a collective gather). */
 int  sh_landmarks_device(sh_ctx*, void** dev_ptr, size_t* nbytes);
+/* ---- several GPUs from ONE host process (a host in C, C++ or any FFI that does not launch one process per GPU) ----
+ * One sh_ctx per device; the humeri of a cohort are sharded over the contexts (independent units of work: the reference runs one
+ * `Humerus(stl)` at a time, bone.py:110-131), each context runs its shard (sh_submit on every context, then sh_collect), and
+ * the records come together at ctxs[0].  What crosses the xGMI links: the parameter block once (the reference loads the same
+ * pickled forest / ONNX blob in every process: bicipital_groove.py:21-25, anatomic_neck.py:56-60) and the records once per step
+ * -- no exchange inside the path.  RCCL is loaded at run time by sh_comm_init_all (librccl.so.1, or the path in SHOULDER_RCCL_LIB);
+ * nothing else in the library needs it.  Errors of these three calls are left on ctxs[0] (sh_last_error).  The multi-process
+ * launch (bench.py --gpus N, one rank per GPU under torch.distributed) does the same transfers in shoulder_amd/dist.py.
+ *   sh_comm_init_all     ncclCommInitAll over the contexts' devices (distinct devices); rank i = ctxs[i].  A context leaves its group
+ *                        when it is destroyed or put into another.
+ *   sh_bcast_weights     the parameter block of ctxs[root] (layout of sh_param_block) to every context; each has loaded a network
+ *                        and a forest of the same shape before (any values); receivers validate the block like sh_param_block_commit.
+ *   sh_gather_landmarks  the records of every context's last run, rank order, to host memory at ctxs[0]: sum of the batch sizes
+ *                        records of sh_record_bytes(rows) bytes each, `rows` = the record format all contexts are set to
+ *                        (sh_set_record_rows; 0 = full sh_landmarks). */
+int  sh_comm_init_all(sh_ctx** ctxs, int n);
+int  sh_bcast_weights(sh_ctx** ctxs, int n, int root);
+int  sh_gather_landmarks(sh_ctx** ctxs, int n, sh_landmarks* out_root /* host */);
 /* Page-locked host memory for the `out` array of sh_run when it is reused from run to run (the reference returns fresh
  * NumPy arrays from every accessor; a streaming caller keeps one record buffer): direct D2H, no page faults. */
 int  sh_host_alloc(sh_ctx*, size_t nbytes, void** out);

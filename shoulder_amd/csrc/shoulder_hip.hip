@@ -41,6 +41,8 @@
 #include <functional>
 #include <thread>
 #include <sched.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types for sh_comm.h; librccl itself is bound at run time
 
 using namespace sh;
 
@@ -77,6 +79,8 @@ struct sh_ctx {
   std::map<std::string, ULayer> ulayers;
   size_t unet_floats = 0;
   bool obb_injected = false;
+  void* comm = nullptr;                      // sh_comm_init_all: this context's RCCL communicator (sh_comm.h), its rank and the group's size
+  int comm_rank = -1, comm_n = 0;
   int rec_rows = 0;                          // sh_set_record_rows: 0 = full sh_landmarks records, R > 0 = packed records with R anatomic-neck rows
   bool bounds_cleared = false;               // run_obb's first fill of this window covered zb_enc / anp.mm_enc (run_window skips its own)
   // hull of SH_STAGE_OBB: 1 = on the device (k_hull.h), 0 = host quickhull (sh_hull.h).  sh_set_hull_mode / SHOULDER_HULL=host|device|auto.
@@ -369,12 +373,14 @@ int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
 }
 
 static void unet_turn_forget(sh_ctx* c);
+static void comm_forget(sh_ctx* c);
 
 void sh_ctx_destroy(sh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->prep.active && c->prep.th.joinable()) c->prep.th.join();
   (void)hipStreamSynchronize(c->stream);
+  comm_forget(c);
   unet_turn_forget(c);
   if (c->unet_done_ev) (void)hipEventDestroy(c->unet_done_ev);
   drain_timers(c);
@@ -3213,5 +3219,7 @@ int sh_param_block(sh_ctx* c, void** p, size_t* n) {
   *n = c->unet_floats * 4 + c->h_feat.size() * 20 + c->h_roots.size() * 4;
   return SH_OK;
 }
+
+#include "sh_comm.h"
 
 }  // extern "C"

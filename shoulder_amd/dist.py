@@ -49,3 +49,35 @@ def gather_records(block, record_dtype, dst=0, device=None):
         return None
     out = torch.cat(bufs).cpu().numpy()
     return out.view(record_dtype)
+
+
+class LocalGroup:
+    """Several GPUs driven from THIS process: one Engine per device, the library's own RCCL entry points (sh_comm_init_all /
+    sh_bcast_weights / sh_gather_landmarks, include/shoulder_hip.h) instead of torch.distributed.  What a host without a
+    process launcher (C, C++, an FFI binding) would do, spelled in Python; INTEGRATION.md section 4.3.
+
+        g = LocalGroup([Engine(0), Engine(1)])       # rank i = engines[i]
+        g.bcast_weights(root=0)                      # every engine has loaded parameters of the same shape before
+        for e, shard in zip(g.engines, shards): e.upload(shard)
+        for e in g.engines: e.submit(fetch=False)
+        for e in g.engines: e.collect()
+        records = g.gather_landmarks()               # rank order, at engines[0]
+    """
+
+    def __init__(self, engines):
+        import ctypes
+        if not engines:
+            raise ValueError("LocalGroup needs at least one engine")
+        self.engines = list(engines)
+        self.L = self.engines[0].L
+        self._arr = (ctypes.c_void_p * len(self.engines))(*[e.h for e in self.engines])
+        self.engines[0]._chk(self.L.sh_comm_init_all(self._arr, len(self.engines)))
+
+    def bcast_weights(self, root=0):
+        self.engines[0]._chk(self.L.sh_bcast_weights(self._arr, len(self.engines), int(root)))
+
+    def gather_landmarks(self):
+        e0 = self.engines[0]
+        out = np.zeros(sum(e.B for e in self.engines), e0.record_dtype)
+        e0._chk(self.L.sh_gather_landmarks(self._arr, len(self.engines), out.ctypes.data))
+        return out

@@ -46,6 +46,16 @@ def test_ctx_create_fails_loudly_without_gpu():
     assert rc != 0 and not h.value
 
 
+def test_collective_entry_points_check_their_arguments_without_a_gpu():
+    """sh_comm_init_all / sh_bcast_weights / sh_gather_landmarks: exported, and an empty group is an argument error
+    (RCCL itself is only loaded once a group of real contexts asks for it)."""
+    L = _lib.load()
+    assert L.sh_comm_init_all(None, 0) == -1 and L.sh_bcast_weights(None, 0, 0) == -1 and L.sh_gather_landmarks(None, 0, None) == -1
+    import subprocess
+    deps = subprocess.run(["ldd", _lib.lib_path()], capture_output=True, text=True).stdout
+    assert "rccl" not in deps
+
+
 def test_packed_record_layout():
     """sh_set_record_rows(R): the NumPy mirror of the packed wire record has the library's size and keeps the field order of the
     full record around the point list (head | six trailing int32 | R rows)."""
