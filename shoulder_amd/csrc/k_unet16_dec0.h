@@ -36,7 +36,7 @@ k_dec0a_up16(const u16* __restrict__ skip_ /*[img][H W][32]*/, const u16* __rest
              const u16* __restrict__ wgt_ /*dec0a packed [9][2][32][32]*/, const float* __restrict__ bias,
              const u16* __restrict__ wup_ /*up0 packed [4][2][32][32]*/, const float* __restrict__ upb,
              u16* __restrict__ dst_ /*[img][H W][32]*/, int H, int W, int nimg, const u16* __restrict__ zero_page_,
-             unsigned* __restrict__ ticket, const int* __restrict__ tk_tab, int ntk) {
+             unsigned* __restrict__ ticket, const int* __restrict__ tk_tab, int ntk, YieldArg yl) {
   using ET = typename EKT<EK>::type;
   using v8 = typename E16<ET>::v8;
   const ET* skip = (const ET*)skip_;
@@ -55,7 +55,7 @@ k_dec0a_up16(const u16* __restrict__ skip_ /*[img][H W][32]*/, const u16* __rest
   const int tiles_x = W / 32, tiles_y = H / 16;
   const int total = nimg * tiles_x * tiles_y;
   const bool dyn = ticket != nullptr;
-  if (dyn && tid == 0) { s_q[0] = (int)atomicAdd(ticket, 1u); s_q[1] = (int)atomicAdd(ticket, 1u); }
+  if (dyn && tid == 0) { s_q[0] = ud_take_ticket(ticket, ntk, yl); s_q[1] = ud_take_ticket(ticket, ntk, yl); }
 
   // ---- once per workgroup: both weight sets and the biases -> LDS
   {
@@ -233,7 +233,7 @@ k_dec0a_up16(const u16* __restrict__ skip_ /*[img][H W][32]*/, const u16* __rest
     else if (dyn) {
       const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);
       if (nt < ntk) {
-        if (tid == 0) s_q[qk ^ 1] = (int)atomicAdd(ticket, 1u);
+        if (tid == 0) s_q[qk ^ 1] = ud_take_ticket(ticket, ntk, yl);
         qk ^= 1;
         w = tk_tab[nt]; w_end = tk_tab[nt + 1];
         decode(w);
@@ -260,7 +260,7 @@ k_dec0a_up16(const u16* __restrict__ skip_ /*[img][H W][32]*/, const u16* __rest
     else if (dyn) {
       const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);
       if (nt < ntk) {
-        if (tid == 0) s_q[qk ^ 1] = (int)atomicAdd(ticket, 1u);
+        if (tid == 0) s_q[qk ^ 1] = ud_take_ticket(ticket, ntk, yl);
         qk ^= 1;
         w = tk_tab[nt]; w_end = tk_tab[nt + 1];
         decode(w);

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(UD_THREADS)
 k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int C0, int C1,
               const u16* __restrict__ wgt_, const float* __restrict__ bias, u16* __restrict__ dst_,
               int H, int W, int Cout, int relu, int nimg, const u16* __restrict__ zero_page_, u16* __restrict__ pooled_,
-              unsigned* __restrict__ ticket /*zero at launch; nullptr: fixed equal shares*/, const int* __restrict__ tk_tab /*[ntk + 1] item bounds*/, int ntk) {
+              unsigned* __restrict__ ticket /*zero at launch; nullptr: fixed equal shares*/, const int* __restrict__ tk_tab /*[ntk + 1] item bounds*/, int ntk, YieldArg yl) {
   using ET = typename EKT<EK>::type;
   const ET* src0 = (const ET*)src0_;
   const ET* src1 = (const ET*)src1_;
@@ -59,7 +59,7 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   const int tiles_x = W / 32, tiles_y = H / 16, ngroups = Cout / WR;
   const int total = nimg * tiles_x * tiles_y * ngroups;
   const bool dyn = ticket != nullptr;
-  if (dyn && tid == UL_LTHREADS) { s_q[0] = (int)atomicAdd(ticket, 1u); s_q[1] = (int)atomicAdd(ticket, 1u); }
+  if (dyn && tid == UL_LTHREADS) { s_q[0] = ud_take_ticket(ticket, ntk, yl); s_q[1] = ud_take_ticket(ticket, ntk, yl); }
 
   float* s_bias = (float*)(smem + UD_BIAS_OFF);
   for (int i = tid; i < Cout; i += UD_THREADS) s_bias[i] = bias[i];
@@ -203,7 +203,7 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
       } else if (dyn) {      // next ticket: its id was written before this step's barrier; the slot it frees is refilled for the one after
         const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);
         if (nt < ntk) {
-          if (tid == UL_LTHREADS) s_q[qk ^ 1] = (int)atomicAdd(ticket, 1u);
+          if (tid == UL_LTHREADS) s_q[qk ^ 1] = ud_take_ticket(ticket, ntk, yl);
           qk ^= 1;
           w = tk_tab[nt]; w_end = tk_tab[nt + 1];
           decode(w);

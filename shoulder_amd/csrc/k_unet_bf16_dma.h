@@ -57,6 +57,23 @@ template <int N> __device__ inline void ud_wait_vm() {      // s_waitcnt takes a
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Yielding the reserve (sh_ctx: persistent_grid / lane_busy).  Beside another lane a persistent launch leaves SHOULDER_CU_RESERVE CUs
+// to that lane's geometry chain -- but the chain is in flight for only part of a pass (5.2 of 7.8 ms on the two-lane headline).
+// With a YieldArg the launch covers the whole chip and its LAST `nres` workgroups ask, whenever they would take a work ticket,
+// whether any OTHER lane of the device has its busy word up (one word per lane, written on the lane's stream around its chain):
+// if so they take no (further) ticket and leave their CU.  Only those workgroups ever yield, so every ticket is always taken.
+#define SH_YIELD_SLOTS 16
+struct YieldArg { const int* flags; int self; int nres; };
+__device__ inline int ud_take_ticket(unsigned* ticket, int ntk, const YieldArg& y) {      // (called by one lane of the workgroup)
+  if (y.flags != nullptr && (int)blockIdx.x >= (int)gridDim.x - y.nres) {
+    int busy = 0;
+#pragma unroll
+    for (int j = 0; j < SH_YIELD_SLOTS; ++j) busy |= (j != y.self) ? __hip_atomic_load(y.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    if (busy) return ntk;      // "no ticket left" for this workgroup
+  }
+  return (int)atomicAdd(ticket, 1u);
+}
+
 // FUSE: 0, UF_POOL (2x2 max pool written beside the output) or UF_HEAD (1x1 head: only the logits leave the kernel).
 // NN: 16-cout tiles per item: 4 (64-cout groups) or 2 (the 32-channel level: 288 weight rows, 8 DMA pieces per step).
 // Output channels of an item are dealt to the accumulator tiles so that a lane ends up with CONSECUTIVE channels: weight
@@ -81,7 +98,8 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
               const u16* __restrict__ wgt_, const float* __restrict__ bias, u16* __restrict__ dst_,
               int H, int W, int Cout, int relu, int nimg, const u16* __restrict__ zero_page_, u16* __restrict__ pooled_,
               const float* __restrict__ head_w, const float* __restrict__ head_b, float* __restrict__ logits,
-              unsigned* __restrict__ ticket /*zero at launch; nullptr: fixed equal shares*/, const int* __restrict__ tk_tab /*[ntk + 1] item bounds*/, int ntk) {
+              unsigned* __restrict__ ticket /*zero at launch; nullptr: fixed equal shares*/, const int* __restrict__ tk_tab /*[ntk + 1] item bounds*/, int ntk,
+              YieldArg yl) {
   using ET = typename EKT<EK>::type;
   const ET* src0 = (const ET*)src0_;
   const ET* src1 = (const ET*)src1_;
@@ -115,7 +133,7 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   // current one is always already in LDS (fetched one ticket ahead by lane 0 of wave 0): no step waits for the counter.
   __shared__ int s_q[2];
   const bool dyn = ticket != nullptr;
-  if (dyn && tid == 0) { s_q[0] = (int)atomicAdd(ticket, 1u); s_q[1] = (int)atomicAdd(ticket, 1u); }
+  if (dyn && tid == 0) { s_q[0] = ud_take_ticket(ticket, ntk, yl); s_q[1] = ud_take_ticket(ticket, ntk, yl); }
 #ifdef SH_DMA_PRIO_HALF
   if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);      // experiment: static priority for the younger half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
 #endif
@@ -263,7 +281,7 @@ k_conv3_dma16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
       } else if (dyn) {      // next ticket: its id was written before this step's barrier; the slot it frees is refilled for the one after
         const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);
         if (nt < ntk) {
-          if (tid == 0) s_q[qk ^ 1] = (int)atomicAdd(ticket, 1u);
+          if (tid == 0) s_q[qk ^ 1] = ud_take_ticket(ticket, ntk, yl);
           qk ^= 1;
           w = tk_tab[nt]; w_end = tk_tab[nt + 1];
           decode(w);

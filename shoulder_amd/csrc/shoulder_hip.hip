@@ -150,6 +150,7 @@ struct sh_ctx {
   int t_head = 0, t_tail = 0, n_pending = 0;
   hipStream_t out_stream = nullptr;      // sh_collect copies the records / status words of a finished run to the host on this stream
   bool overlap = false;
+  int yield_slot = -1;                   // this lane's busy word among the device's (lane_busy / yield_arg); -1: none
   bool unet_turn = false;                // sh_set_unet_turns: UNet passes of the contexts of one device run one after another
   hipEvent_t unet_done_ev = nullptr;
   unsigned long long batch_gen = 0;
@@ -373,6 +374,7 @@ int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
 }
 
 static void unet_turn_forget(sh_ctx* c);
+static void yield_leave(sh_ctx* c);
 static void comm_forget(sh_ctx* c);
 
 void sh_ctx_destroy(sh_ctx* c) {
@@ -382,6 +384,7 @@ void sh_ctx_destroy(sh_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   comm_forget(c);
   unet_turn_forget(c);
+  yield_leave(c);
   if (c->unet_done_ev) (void)hipEventDestroy(c->unet_done_ev);
   drain_timers(c);
   if (c->stl_counted_ev) (void)hipEventDestroy(c->stl_counted_ev);
@@ -1136,6 +1139,46 @@ static void unet_turn_forget(sh_ctx* c) {
   if (c->device >= 0 && c->device < 64 && g_turn_owner[c->device] == c) { g_turn_last[c->device] = nullptr; g_turn_owner[c->device] = nullptr; }
 }
 
+// ---- yielding the CU reserve (k_unet_bf16_dma.h, YieldArg) ----------------------------------------------------------------
+// One busy word per lane of a device, in uncached device memory shared by the contexts of the process: a lane raises its word
+// on its stream in front of its geometry chain and behind its UNet pass and lowers it in front of the pass and behind the run
+// (hipStreamWriteValue32: no launch).  OFF by default (SHOULDER_CU_YIELD=1 switches it on): measured on the two-lane headline the
+// pass keeps its 7.74 ms -- the chain is in flight for 6 of them, and what the pass gains in the rest the chain loses waiting for
+// yielding workgroups (geometry 5.2 -> 5.9 ms, the wait for the turn 1.3 -> 0.4): 7.95 vs 7.97 ms per step.
+static int* g_yield_flags[64] = {};
+static unsigned g_yield_used[64] = {};
+static bool yield_enabled() {
+  static const bool on = getenv("SHOULDER_CU_YIELD") && getenv("SHOULDER_CU_YIELD")[0] == '1';
+  return on;
+}
+static void yield_join(sh_ctx* c) {
+  if (!yield_enabled() || c->yield_slot >= 0 || c->device < 0 || c->device >= 64) return;
+  std::lock_guard<std::mutex> lk(g_turn_mu);
+  if (!g_yield_flags[c->device]) {
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, SH_YIELD_SLOTS * 4, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipMemset(p, 0, SH_YIELD_SLOTS * 4) != hipSuccess) { (void)hipFree(p); return; }
+    g_yield_flags[c->device] = (int*)p;
+  }
+  for (int j = 0; j < SH_YIELD_SLOTS; ++j)
+    if (!(g_yield_used[c->device] >> j & 1u)) { g_yield_used[c->device] |= 1u << j; c->yield_slot = j; break; }
+}
+static void yield_leave(sh_ctx* c) {
+  if (c->yield_slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_turn_mu);
+  (void)hipStreamSynchronize(c->stream);
+  const int zero = 0;
+  (void)hipMemcpy(g_yield_flags[c->device] + c->yield_slot, &zero, 4, hipMemcpyHostToDevice);
+  g_yield_used[c->device] &= ~(1u << c->yield_slot);
+  c->yield_slot = -1;
+}
+// the lane's busy word <- v, in stream order
+static void lane_busy(sh_ctx* c, unsigned v) {
+  if (c->yield_slot < 0 || !c->unet_turn) return;
+  if (hipStreamWriteValue32(c->stream, g_yield_flags[c->device] + c->yield_slot, v, 0) != hipSuccess) (void)hipGetLastError();
+}
+static YieldArg yield_arg(const sh_ctx* c);
+
 static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
   const int D = c->unet_depth, base = c->unet_base;
   if ((H >> D) % 16 || (W >> D) % 16) return fail(c, SH_ERR_ARG, "unet: input size must be a multiple of 16 << depth");
@@ -1252,10 +1295,20 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
 // (sh_set_unet_turns: there IS another lane) therefore leave SHOULDER_CU_RESERVE CUs (default 32 = 4 per XCD) out of the grid;
 // the work tickets spread the items over whatever grid there is.  Measured on the two-lane headline: 0 / 8 / 16 / 32 / 48 / 64 / 96
 // reserved -> 8.72 / 8.80 / 8.73 / 8.27 / 8.54 / 8.56 / 9.35 ms per step.
-static int persistent_grid(const sh_ctx* c) {
+static int cu_reserve() {
   static const int reserve = getenv("SHOULDER_CU_RESERVE") ? std::max(0, atoi(getenv("SHOULDER_CU_RESERVE"))) : 32;
-  return c->unet_turn ? std::max(8, c->num_cus - reserve) : c->num_cus;
+  return reserve;
 }
+static int persistent_grid(const sh_ctx* c) {
+  return c->unet_turn ? std::max(8, c->num_cus - cu_reserve()) : c->num_cus;
+}
+// ... and for the launches that hand their items out in tickets: the whole chip, the last `reserve` workgroups yielding to another
+// lane's chain when one is in flight (k_unet_bf16_dma.h, YieldArg)
+static YieldArg yield_arg(const sh_ctx* c) {
+  if (!c->unet_turn || c->yield_slot < 0 || c->num_cus - cu_reserve() < 8) return YieldArg{nullptr, 0, 0};
+  return YieldArg{g_yield_flags[c->device], c->yield_slot, cu_reserve()};
+}
+static int ticket_grid(const sh_ctx* c, const YieldArg& y) { return y.flags ? c->num_cus : persistent_grid(c); }
 
 static int dma_tickets(sh_ctx* c, int total, int nwg, int ngrp, unsigned** tk, const int** tk_tab, int* ntk) {
   *tk = nullptr; *tk_tab = nullptr; *ntk = 0;
@@ -1316,7 +1369,10 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     // SHOULDER_DMA_GRIDMUL workgroups per CU (default 1): with more, shorter work ranges the hardware dispatcher balances the
     // launch over the CUs another lane's kernels leave free (a workgroup takes a whole CU's LDS, so it waits for a free CU)
     static const int gridmul = getenv("SHOULDER_DMA_GRIDMUL") ? std::max(1, atoi(getenv("SHOULDER_DMA_GRIDMUL"))) : 1;
-    const dim3 g((unsigned)std::min(total, persistent_grid(c) * gridmul));
+    const bool tickets_on = !(getenv("SHOULDER_DMA_TICKETS") && getenv("SHOULDER_DMA_TICKETS")[0] == '0');
+    YieldArg yl = (tickets_on && gridmul == 1) ? yield_arg(c) : YieldArg{nullptr, 0, 0};
+    if (total < c->num_cus) yl = YieldArg{nullptr, 0, 0};
+    const dim3 g((unsigned)std::min(total, (yl.flags ? ticket_grid(c, yl) : persistent_grid(c)) * gridmul));
     unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
     { int rct; if ((rct = dma_tickets(c, total, (int)g.x, L.cout / (dma64 ? 64 : 32), &tk, &tk_tab, &ntk)) != SH_OK) return rct; }
     const u16* zp = (const u16*)c->bufs["unet16.zero"].p;
@@ -1339,14 +1395,14 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     if (ldr) {
       u16* pl = fuse == UF_POOL ? (u16*)fz.pooled : (u16*)nullptr;
       const int gm = (getenv("SHOULDER_GMAJOR") && getenv("SHOULDER_GMAJOR")[0] == '1' && L.cout / 64 > 1) ? 2 : 0;
-      if (fuse == UF_POOL && wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk); }
-      else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk); }
-      else if (wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk); }
-      else { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk); }
+      if (fuse == UF_POOL && wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk, yl); }
+      else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk, yl); }
+      else if (wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk, yl); }
+      else { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk, yl); }
     } else if (dma64) {
-      if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
-      else DMA_LAUNCH(0, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
-    } else if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
+      if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk, yl);
+      else DMA_LAUNCH(0, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk, yl);
+    } else if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk, yl);
     else if (fuse == UF_HEAD) {
       // SHOULDER_DEC0B_OCC=1: dec0b + head as small workgroups that share a CU (k_unet16_occ.h; bit-identical, measured 4 % slower)
       const bool occ = C0 == 32 && C1 == 0 && L.cout == 32 && relu && H % SH_OCC_TR == 0 && getenv("SHOULDER_DEC0B_OCC") && getenv("SHOULDER_DEC0B_OCC")[0] == '1';
@@ -1356,9 +1412,9 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
         const int ntiles = nimg * (W / 32) * (H / SH_OCC_TR), ntko = (ntiles + SH_OCC_TK - 1) / SH_OCC_TK;
         static const int occ_mul = getenv("SHOULDER_OCC_MUL") ? std::max(1, atoi(getenv("SHOULDER_OCC_MUL"))) : 2;      // workgroups per CU
         LAUNCH(c, lname, (k_dec0b_head_occ<EK>), dim3((unsigned)std::min(ntko, persistent_grid(c) * occ_mul)), dim3(SH_OCC_THREADS), src0, w, b, fz.head_w, fz.head_b, fz.logits, H, W, nimg, zp, tko);
-      } else DMA_LAUNCH(UF_HEAD, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits, tk, tk_tab, ntk);
+      } else DMA_LAUNCH(UF_HEAD, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits, tk, tk_tab, ntk, yl);
     }
-    else DMA_LAUNCH(0, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk);
+    else DMA_LAUNCH(0, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk, yl);
 #undef DMA_LAUNCH
   } else if (L.taps == 9 && L.cout % 64 == 0) {
     const dim3 g(tiles, L.cout / 64, nimg);
@@ -1492,11 +1548,13 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
       if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
       if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
       const int total = nimg * (w / 32) * (h / 16);
-      const dim3 g((unsigned)std::min(total, persistent_grid(c)));
+      const bool tickets_on = !(getenv("SHOULDER_DMA_TICKETS") && getenv("SHOULDER_DMA_TICKETS")[0] == '0');
+      const YieldArg yl = (tickets_on && total >= c->num_cus) ? yield_arg(c) : YieldArg{nullptr, 0, 0};
+      const dim3 g((unsigned)std::min(total, ticket_grid(c, yl)));
       unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
       if ((rc = dma_tickets(c, total, (int)g.x, 1, &tk, &tk_tab, &ntk)) != SH_OK) return rc;
       LAUNCH(c, "unet.dec0a", (k_dec0a_up16<EK>), g, dim3(UD_THREADS), skip[0], x, PW + la.w_off, P + la.b_off, PW + lu.w_off, P + lu.b_off, y, h, w, nimg,
-             (const u16*)c->bufs["unet16.zero"].p, tk, tk_tab, ntk);
+             (const u16*)c->bufs["unet16.zero"].p, tk, tk_tab, ntk, yl);
       const sh_ctx::ULayer& l = L("head");
       ConvFuse fz{};
       fz.head_w = P + l.w_off; fz.head_b = P + l.b_off; fz.logits = logits;
@@ -2169,9 +2227,11 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<double>(c, "groove.bg_theta"), buf<double>(c, "anp.raw"), buf<double>(c, "anp.shft_theta"), buf<int>(c, "anp.roll"), B,
            buf<unsigned long long>(c, "anp.mm_enc"));      // (+ the image's minimum / maximum: no second pass over it)
     LAUNCH(c, "k_anp_scale", k_anp_scale, dim3(64, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"), buf<float>(c, "anp.image"));
+    lane_busy(c, 0);      // (this lane's chain rests until its pass is through: the other lane's pass may have the reserve)
     if ((rc = unet_turn_enter(c)) != SH_OK) return rc;
     rc = unet_dispatch(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
     (void)unet_turn_leave(c);      // also after a failed pass: whatever was enqueued is what the next context waits for
+    lane_busy(c, 1);
     if (rc != SH_OK) return rc;
     LAUNCH(c, "k_anp_edge_count", k_anp_edge_count, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<float>(c, "anp.logits"), buf<int>(c, "anp.rowcnt"));
     LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
@@ -2265,7 +2325,8 @@ int sh_set_overlap(sh_ctx* c, int on) {
 int sh_set_unet_turns(sh_ctx* c, int on) {
   if (!c) return SH_ERR_ARG;
   c->unet_turn = on != 0;
-  if (!c->unet_turn) unet_turn_forget(c);
+  if (c->unet_turn) { (void)hipSetDevice(c->device); yield_join(c); }
+  else { unet_turn_forget(c); yield_leave(c); }
   return SH_OK;
 }
 
@@ -2870,10 +2931,12 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     if (c->timing && !c->h_verts_valid) { KTimer& a = c->timers["host.verts_d2h"]; a.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); a.n += 1; }
   }
   int rc = SH_OK, widx = 0;
+  lane_busy(c, 1);      // this lane's chain is in flight from here (k_unet_bf16_dma.h, YieldArg) ...
   for (int b0 = 0; b0 < B && rc == SH_OK; b0 += win, ++widx) {
     c->b0 = b0; c->Bwin = std::min(win, B - b0);
     rc = run_window(c, mask, widx == 0 ? prepared : -1);
   }
+  if (rc != SH_OK) lane_busy(c, 0);
   // everything of this run is enqueued: the host is free until the device is done -> hulls of the next run
   if (rc == SH_OK && c->overlap && (mask & SH_STAGE_OBB) && win == B && !dev_hull && !c->stg.active) start_prepare(c);
   c->b0 = 0; c->Bwin = B;
@@ -2904,6 +2967,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   // hold) and which humeri the device hull gave up (its own word per humerus: the status word can be overwritten by a later stage)
   LAUNCH(c, "k_stage_status", k_stage_status, dim3((unsigned)((std::max(B, 8) + 255) / 256)), dim3(256), (const int*)buf<int>(c, "err"), (const unsigned long long*)c->bufs["ovf.ctr"].p,
          dev_hull ? (const int*)buf<int>(c, "hulld.fail") : (const int*)nullptr, (char*)err_stage, B, status_ovf_off(B));
+  lane_busy(c, 0);      // ... to here
   HIPCHK(c, hipEventRecord(tk.ev, c->stream));
   tk.B = B; tk.pending = true; tk.mask = mask; tk.out_arg = out; tk.dev_hull = dev_hull; tk.gen = c->batch_gen;
   c->t_head ^= 1; ++c->n_pending;
