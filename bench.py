@@ -400,7 +400,7 @@ def main():
             e.param_block_commit()      # host mirrors follow the device block (a later sh_load_* re-uploads from them)
     for e in engs:
         e.set_hull_mode(eng.hull_mode)
-        e.set_unet_turns(lanes > 1 and os.environ.get("SH_BENCH_NO_TURNS") != "1")
+        e.set_unet_turns((lanes > 1 and os.environ.get("SH_BENCH_NO_TURNS") != "1") or os.environ.get("SH_BENCH_FORCE_TURNS") == "1")      # (FORCE_TURNS: a single lane on the two-lane grid, i.e. without the CU reserve)
 
     T = synth.similarity_transforms(B, verts, seed=1234, start=rank * B)
     host_batch = None
