@@ -114,8 +114,9 @@ def geom_bytes(B, V, F):
         # segments read; closed rings written for the distal / proximal / neck sets
         "k_slice_link": (B * (seg * S + 16 * (s_dist + s_prox + s_neck)), B * 16 * S),
         "k_slice_link_large": (0, None),
-        # proximal rings read, resampled contour + two polar images written (3 x 2 x 512 f64 per plane)
-        "k_resample_polar": (B * (16 * s_prox + 600 * 3 * 2 * 512 * 8), B * (600 * 512 * 2 * 4 * 3)),
+        # proximal rings read; written: the polar rows the later stages read (about the origin from plane 88 on, centred ones in the groove's
+        # 330-plane range; round 3 wrote contour + both images of all 600 planes: 944 MB at B = 64) -- k_slices.h, RsWant
+        "k_resample_polar": (B * (16 * s_prox + (512 + 330) * 2 * 512 * 8), B * (600 * 512 * 2 * 4 * 3)),
         "k_resample_polar_large": (0, None),
         "k_groove_rows": (B * 330 * (2 * 512 * 8 + 512 * 8), B * 330 * 2 * 512 * 4),
         "k_anp_rows": (B * 512 * (2 * 512 * 8 + 2 * 512 * 8), B * 512 * 2 * 512 * 4 * 2),
@@ -400,6 +401,8 @@ def main():
             e.param_block_commit()      # host mirrors follow the device block (a later sh_load_* re-uploads from them)
     for e in engs:
         e.set_hull_mode(eng.hull_mode)
+        if os.environ.get("SH_BENCH_KEEP_PRODUCTS") == "1":      # A/B: every proximal plane's resampled contour and polar rows written (round 3's traffic)
+            e.set_keep_products(True)
         e.set_unet_turns((lanes > 1 and os.environ.get("SH_BENCH_NO_TURNS") != "1") or os.environ.get("SH_BENCH_FORCE_TURNS") == "1")      # (FORCE_TURNS: a single lane on the two-lane grid, i.e. without the CU reserve)
 
     T = synth.similarity_transforms(B, verts, seed=1234, start=rank * B)

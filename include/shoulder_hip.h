@@ -175,6 +175,15 @@ int  sh_staged(const sh_ctx*);      /* 1 while a staged batch waits for its comm
 int  sh_synth_batch(sh_ctx*, const double* T /* B x 16 */, int B);
 int  sh_batch_size(const sh_ctx*);
 
+/* The proximal slice set's resampling (slice.py:65-147, 166-206) makes three arrays per plane -- the 512-sample contour ("prox.ixy")
+ * and its polar rows about the origin / about the centroid ("prox.itr_start" / "prox.itr_centered_start") -- 24 KB per plane, 944 MB
+ * per batch of 64.  The stages behind read part of them only (polar rows about the origin from plane 88 on: anatomic_neck.py:34;
+ * centred rows inside the groove's cut-off range: bicipital_groove.py:63-67; the contour never), and that is what a run writes.
+ * sh_set_keep_products(ctx, 1): every plane's three arrays are written (for sh_fetch: the reference keeps them as
+ * `Slices.ixy / itr_start / itr_centered_start`).  A run of SH_STAGE_GROOVE without SH_STAGE_PROXIMAL after groove_cutoff changed
+ * returns SH_ERR_STATE: the rows it needs were not written. */
+int  sh_set_keep_products(sh_ctx*, int on);
+
 /* Records on the wire.  A full sh_landmarks record is 104 KB, 96 KB of it the padded anatomic-neck point list (4 096 rows; a
  * humerus has about a thousand).  sh_set_record_rows(R), R > 0: every record a run hands out through `out` of sh_run /
  * sh_submit (host memory or a gather's device send buffer) is PACKED to sh_record_bytes(R) = 8 680 + 24 R bytes:

@@ -329,7 +329,7 @@ k_slice_link_huge(int N, const int* __restrict__ seg_count, OvfPools P, OvfSet S
 // resample_polar_plane (k_slices.h) for a listed plane: ring from the pool, cumulative lengths in the plane's workspace
 __global__ void __launch_bounds__(SH_RS_THREADS)
 k_resample_polar_huge(int N, int M, const int* __restrict__ ring_n, OvfPools P, OvfSet S, const double* __restrict__ centroids,
-                      double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs) {
+                      double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs, const RsWant W) {
   constexpr int NS = SH_MPROX / SH_RS_THREADS;
   __shared__ int amin_idx;
   __shared__ double wmin[SH_RS_THREADS / 64];
@@ -337,6 +337,9 @@ k_resample_polar_huge(int N, int M, const int* __restrict__ ring_n, OvfPools P, 
   const int nlist = *S.nlist, tid = threadIdx.x;
   for (int it = blockIdx.x; it < nlist; it += gridDim.x) {
     const int pl = S.list[it];
+    const int kpl = pl % N;
+    const bool want_st = W.keep_all || kpl >= W.st_lo, want_cs = W.keep_all || (kpl >= W.cs_lo && kpl < W.cs_hi);      // (k_slices.h, RsWant)
+    if (!want_st && !want_cs) continue;
     const int L = ring_n[pl];
     const double* rp = P.ring + 2 * S.roff[pl];
     double* d = (double*)(P.work + S.woff[pl]);
@@ -372,11 +375,14 @@ k_resample_polar_huge(int N, int M, const int* __restrict__ ring_n, OvfPools P, 
         }
       }
     }
-    double* oxy = ixy + (size_t)pl * 2 * M;
+    if (W.keep_all) {
+      double* oxy = ixy + (size_t)pl * 2 * M;
 #pragma unroll
-    for (int u = 0; u < NS; ++u) { const int j = tid + u * SH_RS_THREADS; oxy[j] = sx[u]; oxy[M + j] = sy[u]; }
+      for (int u = 0; u < NS; ++u) { const int j = tid + u * SH_RS_THREADS; oxy[j] = sx[u]; oxy[M + j] = sy[u]; }
+    }
     const double cx = centroids[2 * (size_t)pl], cy = centroids[2 * (size_t)pl + 1];
     for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 0 ? !want_st : !want_cs) continue;
       const double ox = pass ? cx : 0.0, oy = pass ? cy : 0.0;
       double best = 1e300;
       int bi = 0x7fffffff;

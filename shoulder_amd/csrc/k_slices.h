@@ -548,10 +548,16 @@ k_slice_link_large(SliceSets sets, int B, int* __restrict__ err) {
 // Round 2: the samples stay in registers (four per lane; M = 512, 128 lanes) -- 9 KB of LDS per plane instead of 25 KB, so a CU
 // works on eight planes at once; np.cumsum's running sum (one lane, order kept) loads eight lengths at a time instead of
 // paying an LDS round trip per element (it was half of a plane's latency); x and y share one search per sample.
+// Which of a plane's three products leave the kernel.  They are 24 KB per plane -- 944 MB per step at B = 64, the largest stream of
+// the geometry chain, and beside another lane's UNet pass every GB of the chain's traffic costs that pass ~0.28 ms (DESIGN.md
+// section 6) -- and the stages behind read a part of them only: the polar rows about the origin (itr_start) from plane SH_ANP_ROW0
+// on (k_anp_rows, k_sphere_partial), the centred ones (itr_cs) inside the groove's cut-off range (k_groove_rows, k_groove_tail),
+// the resampled contour (ixy) never.  keep_all (sh_set_keep_products: the slice layer's parity tests fetch every plane): all of it.
+struct RsWant { int keep_all, st_lo, cs_lo, cs_hi; };
 template <int CAP>
 __device__ inline void resample_polar_plane(const int pl, int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring,
                  const double* __restrict__ centroids, double* __restrict__ ixy,
-                 double* __restrict__ itr_start, double* __restrict__ itr_cs, const long long* __restrict__ ovf_roff) {
+                 double* __restrict__ itr_start, double* __restrict__ itr_cs, const long long* __restrict__ ovf_roff, const RsWant W) {
   static_assert(SH_MPROX % SH_RS_THREADS == 0, "whole samples per lane");
   constexpr int NS = SH_MPROX / SH_RS_THREADS;      // samples per lane
   __shared__ double rx[CAP + 1], ry[CAP + 1], d[CAP + 1];
@@ -562,6 +568,9 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
   const int L = ring_n[pl];
   if (CAP == SH_SMALLSEG ? L > SH_SMALLSEG : L <= SH_SMALLSEG) return;      // the other tier's plane
   if (ovf_roff[pl] >= 0) return;                                           // ring in the overflow pool: k_resample_polar_huge (k_ovf.h)
+  const int kpl = pl % N;
+  const bool want_st = W.keep_all || kpl >= W.st_lo, want_cs = W.keep_all || (kpl >= W.cs_lo && kpl < W.cs_hi);
+  if (!want_st && !want_cs) return;                                        // (the same for every lane of the workgroup)
   const double* rp = ring + (size_t)pl * (SH_MAXSEG + 1) * 2;
   for (int q = tid; q <= L; q += SH_RS_THREADS) { rx[q] = rp[2 * q]; ry[q] = rp[2 * q + 1]; }
   __syncthreads();
@@ -612,9 +621,11 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
       }
     }
   }
-  double* oxy = ixy + (size_t)pl * 2 * M;
+  if (W.keep_all) {
+    double* oxy = ixy + (size_t)pl * 2 * M;
 #pragma unroll
-  for (int u = 0; u < NS; ++u) { const int j = tid + u * SH_RS_THREADS; oxy[j] = sx[u]; oxy[M + j] = sy[u]; }
+    for (int u = 0; u < NS; ++u) { const int j = tid + u * SH_RS_THREADS; oxy[j] = sx[u]; oxy[M + j] = sy[u]; }
+  }
 #if defined(SH_ABL_RS) && SH_ABL_RS == 3
   return;
 #endif
@@ -623,6 +634,7 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
 #if defined(SH_ABL_RS) && SH_ABL_RS == 4
     if (pass == 1) return;
 #endif
+    if (pass == 0 ? !want_st : !want_cs) continue;
     const double ox = pass ? cx : 0.0, oy = pass ? cy : 0.0;
     double best = 1e300;
     int bi = 0x7fffffff;
@@ -668,17 +680,17 @@ __device__ inline void resample_polar_plane(const int pl, int N, int M, const in
 
 __global__ void __launch_bounds__(SH_RS_THREADS)
 k_resample_polar(int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring, const double* __restrict__ centroids,
-                 double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs, const long long* __restrict__ ovf_roff) {
-  resample_polar_plane<SH_SMALLSEG>(blockIdx.x, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs, ovf_roff);
+                 double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs, const long long* __restrict__ ovf_roff, const RsWant W) {
+  resample_polar_plane<SH_SMALLSEG>(blockIdx.x, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs, ovf_roff, W);
 }
 __global__ void __launch_bounds__(SH_RS_THREADS)
 k_resample_polar_large(int nplanes, int N, int M, const int* __restrict__ ring_n, const double* __restrict__ ring, const double* __restrict__ centroids,
                        double* __restrict__ ixy, double* __restrict__ itr_start, double* __restrict__ itr_cs, const int* __restrict__ nlarge,
-                       const long long* __restrict__ ovf_roff) {
+                       const long long* __restrict__ ovf_roff, const RsWant W) {
   if (*nlarge == 0) return;      // no plane with more than SH_SMALLSEG segments, hence no ring that long
   for (int pl = blockIdx.x; pl < nplanes; pl += gridDim.x) {
     if (ring_n[pl] <= SH_SMALLSEG || ovf_roff[pl] >= 0) continue;
-    resample_polar_plane<SH_MAXSEG>(pl, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs, ovf_roff);
+    resample_polar_plane<SH_MAXSEG>(pl, N, M, ring_n, ring, centroids, ixy, itr_start, itr_cs, ovf_roff, W);
     __syncthreads();
   }
 }

@@ -81,6 +81,12 @@ struct sh_ctx {
   bool obb_injected = false;
   void* comm = nullptr;                      // sh_comm_init_all: this context's RCCL communicator (sh_comm.h), its rank and the group's size
   int comm_rank = -1, comm_n = 0;
+  // sh_set_keep_products: every plane's resampled contour and polar rows leave k_resample_polar (k_slices.h, RsWant); off: the rows
+  // the later stages read.  rs_*: what the last SH_STAGE_PROXIMAL run of the resident batch wrote (SH_STAGE_GROOVE checks it covers its rows)
+  bool keep_products = false;
+  int rs_cs_lo = 0, rs_cs_hi = 0;
+  bool rs_all = false;
+  unsigned long long rs_gen = ~0ull;
   int rec_rows = 0;                          // sh_set_record_rows: 0 = full sh_landmarks records, R > 0 = packed records with R anatomic-neck rows
   bool bounds_cleared = false;               // run_obb's first fill of this window covered zb_enc / anp.mm_enc (run_window skips its own)
   // hull of SH_STAGE_OBB: 1 = on the device (k_hull.h), 0 = host quickhull (sh_hull.h).  sh_set_hull_mode / SHOULDER_HULL=host|device|auto.
@@ -1705,13 +1711,16 @@ static int run_slice_sets(sh_ctx* c, const SliceSpec* specs, int nspec) {
              sp.ring ? 1 : 0, S.select, buf<int>(c, "err"), S.areas_total);
     }
     if (sp.resample) {
+      RsWant want{c->keep_products ? 1 : 0, SH_ANP_ROW0, 0, 0};
+      cutoff_range(SH_NPROX, c->params.groove_cutoff[0], c->params.groove_cutoff[1], &want.cs_lo, &want.cs_hi);
+      if (c->b0 == 0) { c->rs_cs_lo = want.cs_lo; c->rs_cs_hi = want.cs_hi; c->rs_all = c->keep_products; c->rs_gen = c->batch_gen; }
       LAUNCH(c, "k_resample_polar", k_resample_polar, dim3(B * S.N), dim3(SH_RS_THREADS), S.N, SH_MPROX, S.ring_n, S.ring,
-             S.centroids, buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const long long*)OS[i].roff);
+             S.centroids, buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const long long*)OS[i].roff, want);
       LAUNCH(c, "k_resample_polar_large", k_resample_polar_large, dim3(std::min(B * S.N, 512)), dim3(SH_RS_THREADS), B * S.N, S.N, SH_MPROX, S.ring_n, S.ring,
-             S.centroids, buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const int*)S.nlarge, (const long long*)OS[i].roff);
+             S.centroids, buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), (const int*)S.nlarge, (const long long*)OS[i].roff, want);
       if (ovf_on) {
         LAUNCH(c, "k_resample_polar_huge", k_resample_polar_huge, dim3(64), dim3(SH_RS_THREADS), S.N, SH_MPROX, (const int*)S.ring_n, OP, OS[i],
-               S.centroids, buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"));
+               S.centroids, buf<double>(c, "prox.ixy"), buf<double>(c, "prox.itr_start"), buf<double>(c, "prox.itr_centered_start"), want);
       }
     }
   }
@@ -2199,6 +2208,9 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     if (!c->have_rfc) return fail(c, SH_ERR_STATE, "sh_run: groove stage needs sh_load_rfc first");
     int ga, gb;
     cutoff_range(SH_NPROX, c->params.groove_cutoff[0], c->params.groove_cutoff[1], &ga, &gb);
+    // the centred polar rows [ga, gb) come from the proximal set's resampling, which writes the rows of ITS run's cut-off range (RsWant)
+    if (!(mask & SH_STAGE_PROXIMAL) && !(c->rs_gen == c->batch_gen && (c->rs_all || (ga >= c->rs_cs_lo && gb <= c->rs_cs_hi))))
+      return fail(c, SH_ERR_STATE, "sh_run: SH_STAGE_GROOVE without SH_STAGE_PROXIMAL, and the proximal slices of this batch were not made for this groove_cutoff (run SH_STAGE_PROXIMAL again)");
     const char* pp = buf<char>(c, "params") + c->unet_floats * 4;
     const size_t N = c->h_feat.size();
     const int* feat = (const int*)pp; const float* thr = (const float*)(pp + N * 4); const int* ti = (const int*)(pp + N * 8);
@@ -3084,6 +3096,13 @@ int sh_host_alloc(sh_ctx* c, size_t nbytes, void** out) {
 int sh_host_free(sh_ctx* c, void* p) {
   if (!c) return SH_ERR_ARG;
   if (p) HIPCHK(c, hipHostFree(p));
+  return SH_OK;
+}
+
+int sh_set_keep_products(sh_ctx* c, int on) {
+  if (!c) return SH_ERR_ARG;
+  if (c->n_pending != 0) return fail(c, SH_ERR_STATE, "sh_set_keep_products: runs are in flight");
+  c->keep_products = on != 0;
   return SH_OK;
 }
 

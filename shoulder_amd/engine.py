@@ -224,6 +224,11 @@ class Engine:
     def B(self):
         return self.L.sh_batch_size(self.h)
 
+    def set_keep_products(self, on=True):
+        """Every proximal plane's resampled contour and polar rows are written (sh_set_keep_products): for fetch("prox.ixy") etc.;
+        off (the default) a run writes the rows its later stages read."""
+        self._chk(self.L.sh_set_keep_products(self.h, int(bool(on))))
+
     # ---- record format ------------------------------------------------------------------------------
     def set_record_rows(self, anp_rows=0):
         """sh_set_record_rows: 0 = full 104 KB records, R > 0 = packed records carrying R anatomic-neck rows (n_anp keeps the

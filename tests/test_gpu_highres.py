@@ -92,7 +92,9 @@ def test_overflow_planes_slice_layer_matches_oracle(engine, dense16):
     engine.reset_params()
     engine.upload([(v3, f3)])
     engine.store("obb_transform", h.T_obb[None])
+    engine.set_keep_products(True)
     engine.run(_lib.STAGE_FULL | _lib.STAGE_DISTAL | _lib.STAGE_NECK | _lib.STAGE_CANAL | _lib.STAGE_PROXIMAL, fetch=False)
+    engine.set_keep_products(False)
     for pfx, attr, N in (("full", "full", 200), ("distal", "distal", 200), ("prox", "proximal", 600)):
         s = getattr(h, attr)
         cnt = engine.fetch(pfx + ".seg_count", np.int32, (1, N))[0]

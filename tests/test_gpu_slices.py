@@ -17,7 +17,9 @@ def ran(engine, oracle_bones):
     hs = [oracle_bones(n) for n in NAMES]
     engine.upload([(h.verts, h.faces) for h in hs])
     engine.store("obb_transform", np.stack([h.T_obb for h in hs]))
+    engine.set_keep_products(True)      # every plane's resampled contour and polar rows (a production run writes the rows its later stages read)
     engine.run(_lib.STAGE_FULL | _lib.STAGE_DISTAL | _lib.STAGE_NECK | _lib.STAGE_CANAL | _lib.STAGE_PROXIMAL, fetch=False)
+    engine.set_keep_products(False)
     return hs
 
 
@@ -114,7 +116,9 @@ def test_merged_slice_sets_equal_separate_launches(engine, oracle_bones, monkeyp
             assert out["1"][0].tobytes() == out["0"][0].tobytes()
             for k in out["1"][1]:
                 rn = out["1"][1].get("distal.ring_n") if k == "distal.ring" else None
-                if rn is None:
+                if k == "prox.itr_start":      # (a run writes the rows its later stages read: from plane 88 on)
+                    np.testing.assert_array_equal(out["1"][1][k][:, 88:], out["0"][1][k][:, 88:], err_msg=k)
+                elif rn is None:
                     np.testing.assert_array_equal(out["1"][1][k], out["0"][1][k], err_msg=k)
                 else:      # (ring slots behind a ring's end keep whatever an earlier run left there)
                     for b in range(B):
@@ -124,3 +128,35 @@ def test_merged_slice_sets_equal_separate_launches(engine, oracle_bones, monkeyp
     finally:
         monkeypatch.delenv("SHOULDER_SLICE_MERGE", raising=False)
         engine.set_params(unet_dtype=_lib.UNET_F32)
+
+
+def test_a_run_writes_the_polar_rows_its_stages_read(engine, oracle_bones):
+    """k_resample_polar (RsWant): by default the polar rows about the origin leave the kernel from plane 88 on, the centred ones inside
+    the groove's cut-off range, the resampled contour not at all -- bit for bit the rows of a run that keeps everything, and the same
+    records.  SH_STAGE_GROOVE alone after the cut-off moved is refused (its rows were not written)."""
+    from shoulder_amd.engine import ShoulderHipError
+    h = oracle_bones(NAMES[0])
+    engine.reset_params()
+    engine.upload([(h.verts, h.faces)])
+    engine.set_keep_products(True)
+    lm_all = engine.run(_lib.STAGE_ALL).copy()
+    keep = {k: engine.fetch(k, np.float64, (1, 600, 2, 512)).copy() for k in ("prox.ixy", "prox.itr_start", "prox.itr_centered_start")}
+    engine.set_keep_products(False)
+    for k in keep:
+        engine.store(k, np.full((1, 600, 2, 512), -7.0))
+    lm = engine.run(_lib.STAGE_ALL).copy()
+    assert lm.tobytes() == lm_all.tobytes()
+    got = {k: engine.fetch(k, np.float64, (1, 600, 2, 512)) for k in keep}
+    assert (got["prox.ixy"] == -7.0).all()
+    assert (got["prox.itr_start"][:, :88] == -7.0).all()
+    np.testing.assert_array_equal(got["prox.itr_start"][:, 88:], keep["prox.itr_start"][:, 88:])
+    cs = got["prox.itr_centered_start"][0]
+    written = np.flatnonzero((cs != -7.0).any(axis=(1, 2)))
+    assert len(written) == 330 and written[-1] - written[0] == 329
+    np.testing.assert_array_equal(cs[written], keep["prox.itr_centered_start"][0][written])
+    # another cut-off range: the groove stage alone has no rows to read
+    engine.set_params(groove_cutoff=(0.3, 0.85))
+    with pytest.raises(ShoulderHipError, match="SH_STAGE_PROXIMAL"):
+        engine.run(_lib.STAGE_GROOVE)
+    engine.run(_lib.STAGE_PROXIMAL | _lib.STAGE_GROOVE)
+    engine.reset_params()
