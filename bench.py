@@ -119,7 +119,7 @@ def geom_bytes(B, V, F):
         "k_resample_polar": (B * (16 * s_prox + (512 + 330) * 2 * 512 * 8), B * (600 * 512 * 2 * 4 * 3)),
         "k_resample_polar_large": (0, None),
         "k_groove_rows": (B * 330 * (2 * 512 * 8 + 512 * 8), B * 330 * 2 * 512 * 4),
-        "k_anp_rows": (B * 512 * (2 * 512 * 8 + 2 * 512 * 8), B * 512 * 2 * 512 * 4 * 2),
+        "k_anp_rows": (B * 512 * (2 * 512 * 8 + 512 * 8), B * 512 * 2 * 512 * 4 * 2),      # (theta, r) rows read, the raw image written (round 3: + the shifted-theta image)
         "k_anp_scale": (B * 512 * 512 * (8 + 4), B * 512 * 512 * 4),
         "k_anp_edge_count": (B * 512 * 512 * 4, None),
         "k_anp_edges": (B * 512 * 512 * 4, B * 512 * 512 * 4),

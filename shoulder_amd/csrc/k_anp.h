@@ -16,7 +16,9 @@ namespace sh {
 #define SH_IMG (SH_ANP_ROWS * SH_MPROX)
 
 __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][512]*/, const double* __restrict__ bg_theta,
-                           double* __restrict__ raw, double* __restrict__ shft_theta, int* __restrict__ roll, int B,
+                           double* __restrict__ raw, double* __restrict__ t01 /*[B][rows][2]: the ends of the row's sampling grid.  The shifted
+                           theta image of anatomic_neck.py:44-52 is linspace(t0, t1, 512) rolled by `roll`: k_anp_edges evaluates it at the
+                           edge pixels instead of reading a 134 MB image back*/, int* __restrict__ roll, int B,
                            unsigned long long* __restrict__ mm_enc /*[B][2]: minimum / maximum of the humerus' image, order-preserving encoding, the maximum complemented (both words all ones before this launch)*/) {
   // One wave per image row, the (theta, r) row in LDS.  np.interp's search carries the previous index as a
   // guess; on a sorted xp the answer does not depend on the guess, so when theta[:-1] is non-decreasing every
@@ -46,10 +48,9 @@ __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][51
     if (od < dbest || (od == dbest && ok < kb)) { dbest = od; kb = ok; }
   }
   const int kbest = __shfl(kb, 0);
-  if (lane == 0) roll[gid] = kbest;
+  if (lane == 0) { roll[gid] = kbest; t01[2 * (size_t)gid] = t0; t01[2 * (size_t)gid + 1] = t1; }
   __syncthreads();
   double* o_r = raw + (size_t)gid * M;
-  double* o_t = shft_theta + (size_t)gid * M;
   double lo = 1e300, hi = -1e300;      // the row's share of the image's minimum / maximum (MinMaxScaler, :56-58): a separate pass read the image again
   if (!s_unsorted) {
     // On a sorted xp np.interp's search returns the largest index with xp[i] <= x whatever its guess: the lane's eight samples take
@@ -87,7 +88,6 @@ __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][51
       }
       int dst = j - kbest; if (dst < 0) dst += M;
       o_r[dst] = v;
-      o_t[dst] = x;
       lo = fmin(lo, v); hi = fmax(hi, v);
     }
   } else if (lane == 0) {
@@ -97,7 +97,6 @@ __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][51
       double v = np_interp_step(t, s_t, s_r, M - 1, &jg);
       int dst = j - kbest; if (dst < 0) dst += M;
       o_r[dst] = v;
-      o_t[dst] = t;
       lo = fmin(lo, v); hi = fmax(hi, v);
     }
   }
@@ -145,7 +144,7 @@ k_anp_edge_count(const float* __restrict__ logits, int* __restrict__ rowcnt /*[B
 }
 
 __global__ void __launch_bounds__(512)
-k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, const double* __restrict__ shft_theta,
+k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, const double* __restrict__ t01, const int* __restrict__ roll,
             const double* __restrict__ prox_zs, const int* __restrict__ rowcnt, double* __restrict__ pts_obb, int* __restrict__ counts,
             int* __restrict__ err) {
   static_assert(SH_ANP_ROWS == 512, "8 row counts per lane");
@@ -169,7 +168,8 @@ k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, co
   }
   // the edge pixels as points (r cos t, r sin t, z), in row-major order
   const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
-  const double* t = shft_theta + ((size_t)b * SH_ANP_ROWS + i) * M;
+  const double t0 = t01[2 * ((size_t)b * SH_ANP_ROWS + i)], t1 = t01[2 * ((size_t)b * SH_ANP_ROWS + i) + 1];
+  const int kroll = roll[(size_t)b * SH_ANP_ROWS + i];
   const double* r = raw + ((size_t)b * SH_ANP_ROWS + i) * M;
   const double z = prox_zs[(size_t)b * SH_NPROX + SH_ANP_ROW0 + i];
   int o = before, carry = 0;
@@ -187,8 +187,10 @@ k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, co
       const int pos = o + __popcll(eb & ((1ull << lane) - 1ull));
       if (pos < SH_ANP_CAP) {
         double* p = pts_obb + ((size_t)b * SH_ANP_CAP + pos) * 3;
-        p[0] = r[j] * cos(t[j]);
-        p[1] = r[j] * sin(t[j]);
+        int js = j + kroll; if (js >= M) js -= M;      // pixel j of the rolled row is sample js of the row's grid (k_anp_rows)
+        const double tj = linspace_at(t0, t1, M, js);
+        p[0] = r[j] * cos(tj);
+        p[1] = r[j] * sin(tj);
         p[2] = z;
       }
     }

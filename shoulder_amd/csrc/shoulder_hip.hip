@@ -515,7 +515,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("groove.axis_ct", (size_t)B * 6 * 8, 8);
   // anatomic neck
   ENS("anp.raw", (size_t)B * SH_IMG * 8, 8);
-  ENS("anp.shft_theta", (size_t)B * SH_IMG * 8, 8);
+  ENS("anp.t01", (size_t)B * SH_ANP_ROWS * 2 * 8, 8);
   ENS("anp.roll", (size_t)B * SH_ANP_ROWS * 4, 4);
   ENS("anp.mm_enc", (size_t)B * 2 * 8, 8);
   ENS("metrics.partial", (size_t)B * SH_SPH_PARTS * 14 * 8, 8);
@@ -2236,7 +2236,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   if (mask & SH_STAGE_ANP) {
     if (!c->have_unet) return fail(c, SH_ERR_STATE, "sh_run: anatomic-neck stage needs sh_load_unet first");
     LAUNCH(c, "k_anp_rows", k_anp_rows, dim3(B * SH_ANP_ROWS), dim3(64), buf<double>(c, "prox.itr_start"),
-           buf<double>(c, "groove.bg_theta"), buf<double>(c, "anp.raw"), buf<double>(c, "anp.shft_theta"), buf<int>(c, "anp.roll"), B,
+           buf<double>(c, "groove.bg_theta"), buf<double>(c, "anp.raw"), buf<double>(c, "anp.t01"), buf<int>(c, "anp.roll"), B,
            buf<unsigned long long>(c, "anp.mm_enc"));      // (+ the image's minimum / maximum: no second pass over it)
     LAUNCH(c, "k_anp_scale", k_anp_scale, dim3(64, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"), buf<float>(c, "anp.image"));
     lane_busy(c, 0);      // (this lane's chain rests until its pass is through: the other lane's pass may have the reserve)
@@ -2247,7 +2247,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     if (rc != SH_OK) return rc;
     LAUNCH(c, "k_anp_edge_count", k_anp_edge_count, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<float>(c, "anp.logits"), buf<int>(c, "anp.rowcnt"));
     LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
-           buf<double>(c, "anp.shft_theta"), buf<double>(c, "prox.zs"), buf<int>(c, "anp.rowcnt"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
+           buf<double>(c, "anp.t01"), buf<int>(c, "anp.roll"), buf<double>(c, "prox.zs"), buf<int>(c, "anp.rowcnt"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
            buf<int>(c, "err"));
     LAUNCH(c, "k_anp_plane", k_anp_plane, dim3(B), dim3(256), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
            buf<double>(c, "anp.plane"), buf<int>(c, "err"), buf<unsigned long long>(c, "anp.ray_t"));      // (+ "no hit yet" for the rays)
