@@ -42,7 +42,11 @@ template <int EK>
 __global__ void __launch_bounds__(L0_THREADS)
 k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[9][32] f32*/, const float* __restrict__ b0 /*[32]*/,
                const u16* __restrict__ wgt_ /*enc0b, packed [9][1][32][32]*/, const float* __restrict__ bias /*[32]*/,
-               u16* __restrict__ skip_, u16* __restrict__ pooled_, int H, int W, int nimg) {
+               u16* __restrict__ skip_, u16* __restrict__ pooled_, int H, int W, int nimg,
+               const double* __restrict__ raw /*nullable: the UNSCALED image [nimg][H][W] f64 and ...*/,
+               const unsigned long long* __restrict__ mm_enc /*... its minimum / complemented maximum per image, encoded (k_anp_rows): the MinMaxScaler
+               arithmetic of k_anp_scale is then applied where the patch is read, and the f32 image (a 201 MB pass of its own at B = 64)
+               is never made*/) {
   using ET = typename EKT<EK>::type;
   using v8 = typename E16<ET>::v8;
   const ET* wgt = (const ET*)wgt_;
@@ -102,28 +106,52 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
     const int ty = w % tiles_y; img = w / tiles_y;
     x0 = tx * 32; y0 = ty * 16;
   };
-  // image patch of an item: rows y0-2 .. y0+17, columns x0-2 .. x0+33 (zero outside the image), 720 values e[row * 36 + col]
-  auto patch_load = [&](int w, float (&r)[2]) {
+  // image patch of an item: rows y0-2 .. y0+17, columns x0-2 .. x0+33 (zero outside the image), 720 values e[row * 36 + col].
+  // From the unscaled image the values stay doubles while the loads are in flight; patch_store applies X * scale_ + min_
+  // (k_anp_scale's expression, so the same float) when it splits them.
+  struct Patch { float f[2]; double d[2]; double sc, mn; unsigned ok; };
+  auto patch_load = [&](int w, Patch& r) {
     int img, x0, y0;
     item_coords(w, img, x0, y0);
+    r.ok = 0u;
+    if (raw != nullptr) {
+      const unsigned long long elo = mm_enc[2 * img], ehi = ~mm_enc[2 * img + 1];      // order-preserving encoding (k_slices.h: enc_f64 / dec_f64)
+      const double lo = __longlong_as_double((long long)((elo & 0x8000000000000000ull) ? (elo & 0x7FFFFFFFFFFFFFFFull) : ~elo));
+      const double hi = __longlong_as_double((long long)((ehi & 0x8000000000000000ull) ? (ehi & 0x7FFFFFFFFFFFFFFFull) : ~ehi));
+      double rng = hi - lo;
+      if (rng == 0.0) rng = 1.0;
+      r.sc = 1.0 / rng; r.mn = 0.0 - lo * r.sc;
+      const double* im = raw + (size_t)img * H * W;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + k * L0_THREADS;
+        const int py = e / L0_PW, px = e - py * L0_PW;
+        const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+        const bool in = e < 20 * L0_PW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        r.d[k] = in ? im[(size_t)gy * W + gx] : 0.0;
+        r.ok |= in ? 1u << k : 0u;
+      }
+      return;
+    }
     const float* im = image + (size_t)img * H * W;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int e = tid + k * L0_THREADS;
       const int py = e / L0_PW, px = e - py * L0_PW;
       const int gy = y0 - 2 + py, gx = x0 - 2 + px;
-      r[k] = (e < 20 * L0_PW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.0f;
+      r.f[k] = (e < 20 * L0_PW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? im[(size_t)gy * W + gx] : 0.0f;
     }
   };
   // split into high and low parts; copy s holds e[i + s] at index i (i = -s .. 743 - s; the first s entries are padding)
-  auto patch_store = [&](int slot, const float (&r)[2]) {
+  auto patch_store = [&](int slot, const Patch& r) {
     unsigned char* base = smem + L0_IMGOFF + slot * L0_SLOT + L0_CPAD;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int e = tid + k * L0_THREADS;
       if (k == 0 || e < L0_PATCH) {
-        const ET hi = (ET)r[k];
-        const ET lo = (ET)(r[k] - (float)hi);
+        const float val = raw != nullptr ? ((r.ok >> k & 1u) ? (float)(r.d[k] * r.sc + r.mn) : 0.0f) : r.f[k];
+        const ET hi = (ET)val;
+        const ET lo = (ET)(val - (float)hi);
         unsigned char* pe = base + 2 * e;
 #pragma unroll
         for (int sft = 0; sft < 8; ++sft) {
@@ -163,7 +191,7 @@ k_enc0_fused16(const float* __restrict__ image, const float* __restrict__ w0 /*[
   };
 
   // ---- prologue: patch 0 -> LDS, first conv of item 0 into buffer 0, patch 1 -> LDS
-  float pr[2];
+  Patch pr;
   {
     patch_load(w_begin, pr);
     patch_store(0, pr);

@@ -84,6 +84,8 @@ struct sh_ctx {
   // sh_set_keep_products: every plane's resampled contour and polar rows leave k_resample_polar (k_slices.h, RsWant); off: the rows
   // the later stages read.  rs_*: what the last SH_STAGE_PROXIMAL run of the resident batch wrote (SH_STAGE_GROOVE checks it covers its rows)
   bool keep_products = false;
+  const double* unet_raw = nullptr;          // run_window -> unet_forward16: the unscaled image and its encoded range, when the first kernel scales it itself
+  const unsigned long long* unet_mm = nullptr;
   int rs_cs_lo = 0, rs_cs_hi = 0;
   bool rs_all = false;
   unsigned long long rs_gen = ~0ull;
@@ -1451,6 +1453,15 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
 // 4-level double-conv UNet, bf16.  With 32 base channels the memory-bound ends are fused (k_unet_bf16.h): the first
 // conv into the staging of enc0b, every 2x2 max pool into the epilogue of the conv before it, the 1x1 head into the
 // epilogue of dec0b.  SHOULDER_UNET_UNFUSED=1 (or another base width) runs the layer-by-layer form.
+// does the 16-bit forward start with the fused level-0 encoder (k_enc0_fused16)?  (run_window asks: that kernel can read the unscaled image)
+static bool unet16_starts_fused(const sh_ctx* c, int H, int W) {
+  const char* unf = getenv("SHOULDER_UNET_UNFUSED");
+  const char* ff = getenv("SHOULDER_UNET_FUSE_FIRST");
+  const char* l0env = getenv("SHOULDER_UNET_L0");
+  return c->unet_base == 32 && !(unf && unf[0] == '1') && !(ff && ff[0] == '0') && !(l0env && l0env[0] == '0') && W % 32 == 0 && H % 16 == 0 &&
+         (H >> c->unet_depth) % 16 == 0 && (W >> c->unet_depth) % 16 == 0;
+}
+
 template <int EK>
 static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
   const int D = c->unet_depth, base = c->unet_base;
@@ -1507,7 +1518,7 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
     if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
     const int total = nimg * (w / 32) * (h / 16);
     LAUNCH(c, "unet.enc0b", (k_enc0_fused16<EK>), dim3((unsigned)std::min(total, persistent_grid(c))), dim3(L0_THREADS), image, P + la.w_off, P + la.b_off,
-           PW + lb.w_off, P + lb.b_off, skip[0], A, h, w, nimg);
+           PW + lb.w_off, P + lb.b_off, skip[0], A, h, w, nimg, c->unet_raw, c->unet_mm);
   } else if (fused && !(ff && ff[0] == '0')) {
     const sh_ctx::ULayer& l = L("enc0a");
     ConvFuse fz{};
@@ -2238,10 +2249,16 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     LAUNCH(c, "k_anp_rows", k_anp_rows, dim3(B * SH_ANP_ROWS), dim3(64), buf<double>(c, "prox.itr_start"),
            buf<double>(c, "groove.bg_theta"), buf<double>(c, "anp.raw"), buf<double>(c, "anp.t01"), buf<int>(c, "anp.roll"), B,
            buf<unsigned long long>(c, "anp.mm_enc"));      // (+ the image's minimum / maximum: no second pass over it)
-    LAUNCH(c, "k_anp_scale", k_anp_scale, dim3(64, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"), buf<float>(c, "anp.image"));
+    // MinMaxScaler (anatomic_neck.py:56-58): the 16-bit network's first kernel applies it where it reads its patches (k_unet16_l0.h) --
+    // no f32 image, 201 MB less traffic and a launch less per step; the other forms of the network and sh_set_keep_products get "anp.image"
+    const bool scale_in_net = (c->params.unet_dtype == SH_UNET_BF16 || c->params.unet_dtype == SH_UNET_F16) && unet16_starts_fused(c, SH_ANP_ROWS, SH_MPROX);
+    if (!scale_in_net || c->keep_products)
+      LAUNCH(c, "k_anp_scale", k_anp_scale, dim3(64, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"), buf<float>(c, "anp.image"));
     lane_busy(c, 0);      // (this lane's chain rests until its pass is through: the other lane's pass may have the reserve)
     if ((rc = unet_turn_enter(c)) != SH_OK) return rc;
+    if (scale_in_net) { c->unet_raw = buf<double>(c, "anp.raw"); c->unet_mm = buf<unsigned long long>(c, "anp.mm_enc"); }
     rc = unet_dispatch(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
+    c->unet_raw = nullptr; c->unet_mm = nullptr;
     (void)unet_turn_leave(c);      // also after a failed pass: whatever was enqueued is what the next context waits for
     lane_busy(c, 1);
     if (rc != SH_OK) return rc;

@@ -25,7 +25,9 @@ def test_bf16_logits_and_mask(engine, oracle_bones, unet_weights, name):
     lm32 = engine.run(stages)[0].copy()
     try:
         engine.set_params(unet_dtype=dtype)
+        engine.set_keep_products(True)      # (the 16-bit network scales the raw image itself; "anp.image" is written on request)
         lm16 = engine.run(stages)[0].copy()
+        engine.set_keep_products(False)
         img = engine.fetch("anp.image", np.float32, (1, 512, 512))[0]
         lg = engine.fetch("anp.logits", np.float32, (1, 512, 512))[0]
     finally:
@@ -363,3 +365,28 @@ def test_other_widths_and_depths(base, depth, H, W):
             e.load_unet(unet_spec.make_teacher_weights(seed=1, base=288, depth=1), 288, 1)      # above SH_UNET_MAXBASE
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_first_kernel_scales_the_raw_image_itself(engine, oracle_bones, name):
+    """In the 16-bit network k_enc0_fused16 reads the UNSCALED image ("anp.raw", f64) and applies the MinMaxScaler arithmetic of
+    k_anp_scale where it loads its patches (no "anp.image" pass): the logits are those of the same network fed the f32 image, bit
+    for bit, and a run that also writes the image (sh_set_keep_products) gives the same record."""
+    h = oracle_bones("humerus_left_flipped")
+    engine.reset_params()
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        engine.upload([(h.verts, h.faces)])
+        engine.store("anp.image", np.full((1, 512, 512), -3.0, np.float32))
+        lm = engine.run(_lib.STAGE_ALL).copy()
+        assert (engine.fetch("anp.image", np.float32, (1, 512, 512)) == -3.0).all()      # never written ...
+        lg = engine.fetch("anp.logits", np.float32, (1, 512, 512)).copy()
+        engine.set_keep_products(True)
+        lm_keep = engine.run(_lib.STAGE_ALL).copy()
+        img = engine.fetch("anp.image", np.float32, (1, 512, 512)).copy()                   # ... unless asked for
+        assert lm_keep.tobytes() == lm.tobytes() and lm["status"][0] == 0
+        assert 0.0 <= img.min() and img.max() <= 1.0 and img.max() > 0.99
+        np.testing.assert_array_equal(engine.unet_infer(img), lg)
+    finally:
+        engine.set_keep_products(False)
+        engine.reset_params()
