@@ -122,8 +122,9 @@ def geom_bytes(B, V, F):
         "k_anp_rows": (B * 512 * (2 * 512 * 8 + 512 * 8), B * 512 * 2 * 512 * 4 * 2),      # (theta, r) rows read, the raw image written (round 3: + the shifted-theta image)
         "k_anp_scale": (B * 512 * 512 * (8 + 4), B * 512 * 512 * 4),
         "k_anp_edge_count": (B * 512 * 512 * 4, None),
-        "k_anp_edges": (B * 512 * 512 * 4, B * 512 * 512 * 4),
-        "k_sphere_partial": (B * 512 * 512 * 4, None),
+        # the mask as bits (2 MB, written by k_anp_edge_count) instead of the logits again; the radii of the mask's pixels (about 0.6 of the image)
+        "k_anp_edges": (B * 512 * 64, B * 512 * 512 * 4),
+        "k_sphere_partial": (B * (512 * 64 + int(0.6 * 512 * 512) * 8), None),
         "k_rays_hit": (B * (24 * V + 12 * F), B * (12 * V + 12 * F)),      # every triangle once for the four rays
         "k_apply_csys": (B * V * (12 + 24), B * 2 * 12 * V),
         "k_obb_end_points": (B * (12 * V + 12 * F), None),

@@ -123,7 +123,9 @@ k_anp_scale(const double* __restrict__ raw, const unsigned long long* __restrict
 // edges by ballot): counts per row first, then every row finds its place in the row-major point list from the counts of the
 // rows before it (one block per humerus kept 192 CUs idle for 0.3 ms on the critical path behind the network).
 __global__ void __launch_bounds__(512)
-k_anp_edge_count(const float* __restrict__ logits, int* __restrict__ rowcnt /*[B][SH_ANP_ROWS][2]: mask changes, mask pixels*/) {
+k_anp_edge_count(const float* __restrict__ logits, int* __restrict__ rowcnt /*[B][SH_ANP_ROWS][2]: mask changes, mask pixels*/,
+                 unsigned long long* __restrict__ maskbits /*[B][SH_ANP_ROWS][8]: the mask (logit > 0), one bit per pixel -- k_anp_edges and
+                 k_sphere_partial read these 2 MB instead of the 67 MB of logits again*/) {
   const int b = blockIdx.y, lane = threadIdx.x & 63, i = blockIdx.x * 8 + (threadIdx.x >> 6);
   const int M = SH_MPROX;
   const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
@@ -137,14 +139,16 @@ k_anp_edge_count(const float* __restrict__ logits, int* __restrict__ rowcnt /*[B
     int prev = __shfl_up(m, 1);
     if (lane == 0) prev = carry;
     ne += __popcll(__ballot(m != prev));      // np.diff(mask, prepend=0) != 0
-    nm += __popcll(__ballot(m));
+    const unsigned long long bm = __ballot(m);
+    nm += __popcll(bm);
+    if (lane == 0) maskbits[((size_t)b * SH_ANP_ROWS + i) * (SH_MPROX / 64) + c] = bm;
     carry = __shfl(m, 63);
   }
   if (lane == 0) { rowcnt[2 * ((size_t)b * SH_ANP_ROWS + i)] = ne; rowcnt[2 * ((size_t)b * SH_ANP_ROWS + i) + 1] = nm; }
 }
 
 __global__ void __launch_bounds__(512)
-k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, const double* __restrict__ t01, const int* __restrict__ roll,
+k_anp_edges(const unsigned long long* __restrict__ maskbits, const double* __restrict__ raw, const double* __restrict__ t01, const int* __restrict__ roll,
             const double* __restrict__ prox_zs, const int* __restrict__ rowcnt, double* __restrict__ pts_obb, int* __restrict__ counts,
             int* __restrict__ err) {
   static_assert(SH_ANP_ROWS == 512, "8 row counts per lane");
@@ -167,19 +171,19 @@ k_anp_edges(const float* __restrict__ logits, const double* __restrict__ raw, co
     if (tot < 6) atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV);
   }
   // the edge pixels as points (r cos t, r sin t, z), in row-major order
-  const float* lg = logits + ((size_t)b * SH_ANP_ROWS + i) * M;
+  const unsigned long long* mb = maskbits + ((size_t)b * SH_ANP_ROWS + i) * (SH_MPROX / 64);
   const double t0 = t01[2 * ((size_t)b * SH_ANP_ROWS + i)], t1 = t01[2 * ((size_t)b * SH_ANP_ROWS + i) + 1];
   const int kroll = roll[(size_t)b * SH_ANP_ROWS + i];
   const double* r = raw + ((size_t)b * SH_ANP_ROWS + i) * M;
   const double z = prox_zs[(size_t)b * SH_NPROX + SH_ANP_ROW0 + i];
   int o = before, carry = 0;
-  float v[SH_MPROX / 64];
+  unsigned long long v[SH_MPROX / 64];
 #pragma unroll
-  for (int c = 0; c < SH_MPROX / 64; ++c) v[c] = lg[c * 64 + lane];
+  for (int c = 0; c < SH_MPROX / 64; ++c) v[c] = mb[c];
 #pragma unroll
   for (int c = 0; c < SH_MPROX / 64; ++c) {
     const int j = c * 64 + lane;
-    const int m = v[c] > 0.0f ? 1 : 0;
+    const int m = (int)(v[c] >> lane & 1ull);
     int prev = __shfl_up(m, 1);
     if (lane == 0) prev = carry;
     const unsigned long long eb = __ballot(m != prev);

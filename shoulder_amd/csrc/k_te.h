@@ -624,12 +624,12 @@ SH_HD void unitxyz_to_spherical_deg(const double* v, double* theta, double* phi)
 // UNet pass on the 32 reserved CUs that was 0.33 ms of f64 range reduction on the lane's critical path.  Angle error after seven
 // rotations ~1e-15 (radius_curvature is held to 1e-6 mm against the oracle).  32 rows per workgroup, 8 per wave.
 __global__ void __launch_bounds__(256)
-k_sphere_partial(const float* __restrict__ logits, const double* __restrict__ raw, const double* __restrict__ itr_start /*[B][600][2][512]: the rows' theta*/,
+k_sphere_partial(const unsigned long long* __restrict__ maskbits /*[B][512][8]: k_anp_edge_count*/, const double* __restrict__ raw, const double* __restrict__ t01 /*[B][512][2]: the ends of the rows' theta grids (k_anp_rows)*/,
                  const int* __restrict__ roll /*[B][512]*/, const double* __restrict__ prox_zs, const double* __restrict__ plane, double* __restrict__ partial) {
   __shared__ double sh[14 * 4];
   constexpr int M = SH_MPROX, RPW = SH_ANP_ROWS / SH_SPH_PARTS;      // 32 rows per workgroup
   const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* lg = logits + (size_t)b * SH_IMG;
+  const unsigned long long* mbits = maskbits + (size_t)b * SH_ANP_ROWS * (M / 64);
   const double* rr = raw + (size_t)b * SH_IMG;
   const double* zz = prox_zs + (size_t)b * SH_NPROX + SH_ANP_ROW0;
   const double m[3] = {plane[6 * b], plane[6 * b + 1], plane[6 * b + 2]};
@@ -637,8 +637,7 @@ k_sphere_partial(const float* __restrict__ logits, const double* __restrict__ ra
   for (int k = 0; k < 14; ++k) a[k] = 0.0;
   for (int rw = wave; rw < RPW; rw += 4) {
     const int row = part * RPW + rw;
-    const double* th = itr_start + ((size_t)b * SH_NPROX + SH_ANP_ROW0 + row) * 2 * M;
-    const double t0 = th[0], t1 = th[M - 2];                           // the grid of k_anp_rows
+    const double t0 = t01[2 * ((size_t)b * SH_ANP_ROWS + row)], t1 = t01[2 * ((size_t)b * SH_ANP_ROWS + row) + 1];      // the grid of k_anp_rows
     const int kbest = roll[(size_t)b * SH_ANP_ROWS + row];
     const double step = (t1 - t0) / (double)(M - 1);
     int j = lane + kbest; if (j >= M) j -= M;                          // grid index of storage column `lane`
@@ -653,7 +652,7 @@ k_sphere_partial(const float* __restrict__ logits, const double* __restrict__ ra
     const size_t base = (size_t)row * M + lane;
 #pragma unroll
     for (int k = 0; k < M / 64; ++k) {
-      if (lg[base + 64 * k] > 0.0f) {
+      if (mbits[(size_t)row * (M / 64) + k] >> lane & 1ull) {
         const double r = rr[base + 64 * k];
         const double q[3] = {r * cs - m[0], r * sn - m[1], z};
         const double q2 = (q[0] * q[0] + q[1] * q[1]) + q[2] * q[2];

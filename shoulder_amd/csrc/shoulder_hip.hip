@@ -519,6 +519,7 @@ static int alloc_batch(sh_ctx* c) {
   ENS("anp.raw", (size_t)B * SH_IMG * 8, 8);
   ENS("anp.t01", (size_t)B * SH_ANP_ROWS * 2 * 8, 8);
   ENS("anp.roll", (size_t)B * SH_ANP_ROWS * 4, 4);
+  ENS("anp.maskbits", (size_t)B * SH_ANP_ROWS * (SH_MPROX / 64) * 8, 8);
   ENS("anp.mm_enc", (size_t)B * 2 * 8, 8);
   ENS("metrics.partial", (size_t)B * SH_SPH_PARTS * 14 * 8, 8);
   ENS("anp.image", (size_t)B * SH_IMG * 4, 4);
@@ -2262,8 +2263,8 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     (void)unet_turn_leave(c);      // also after a failed pass: whatever was enqueued is what the next context waits for
     lane_busy(c, 1);
     if (rc != SH_OK) return rc;
-    LAUNCH(c, "k_anp_edge_count", k_anp_edge_count, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<float>(c, "anp.logits"), buf<int>(c, "anp.rowcnt"));
-    LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
+    LAUNCH(c, "k_anp_edge_count", k_anp_edge_count, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<float>(c, "anp.logits"), buf<int>(c, "anp.rowcnt"), buf<unsigned long long>(c, "anp.maskbits"));
+    LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<unsigned long long>(c, "anp.maskbits"), buf<double>(c, "anp.raw"),
            buf<double>(c, "anp.t01"), buf<int>(c, "anp.roll"), buf<double>(c, "prox.zs"), buf<int>(c, "anp.rowcnt"), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
            buf<int>(c, "err"));
     LAUNCH(c, "k_anp_plane", k_anp_plane, dim3(B), dim3(256), buf<double>(c, "anp.points_obb"), buf<int>(c, "anp.counts"),
@@ -2280,8 +2281,8 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   const uint32_t need = SH_STAGE_GROOVE | SH_STAGE_ANP | SH_STAGE_CSYS | (c->params.bone_kind == SH_BONE_PROXIMAL ? 0u : (uint32_t)SH_STAGE_TE);
   const bool metrics = (mask & need) == need;
   if (metrics)
-    LAUNCH(c, "k_sphere_partial", k_sphere_partial, dim3(SH_SPH_PARTS, B), dim3(256), buf<float>(c, "anp.logits"), buf<double>(c, "anp.raw"),
-           buf<double>(c, "prox.itr_start"), buf<int>(c, "anp.roll"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.plane"), buf<double>(c, "metrics.partial"));
+    LAUNCH(c, "k_sphere_partial", k_sphere_partial, dim3(SH_SPH_PARTS, B), dim3(256), buf<unsigned long long>(c, "anp.maskbits"), buf<double>(c, "anp.raw"),
+           buf<double>(c, "anp.t01"), buf<int>(c, "anp.roll"), buf<double>(c, "prox.zs"), buf<double>(c, "anp.plane"), buf<double>(c, "metrics.partial"));
   {      // ray points -> trans-epicondylar order -> record -> metrics: one launch, one workgroup per humerus (k_tail, k_te.h)
     PackArgs A{};
     A.lm = buf<sh_landmarks>(c, "landmarks"); A.T_obb = buf<double>(c, "obb_transform"); A.zb = buf<double>(c, "z_bounds"); A.neck_z = buf<double>(c, "neck_z");
