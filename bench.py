@@ -204,6 +204,8 @@ def sym_key(name, unet, cout, fused_net=True):
         wres = int(sched == 1 and os.environ.get("SHOULDER_DMA_WRES") != "0" and cout == grp and (cin // 32) * grp <= 128)
         if wres and grp == 32 and cin == 32 and os.environ.get("SHOULDER_DMA_WREG") != "0":
             wres = 2      # 32 -> 32: the weight fragments stay in registers as well
+        if name == "unet.dec0b" and wres == 2 and fuse == 2 and os.environ.get("SHOULDER_DEC0B3") != "0" and os.environ.get("SHOULDER_DEC0B_OCC") != "1" and os.environ.get("SHOULDER_DMA_TICKETS") != "0":
+            return "k_dec0b_head3<%s>" % unet      # dec0b + head with three halo buffers, two tiles in flight (k_unet16_dec0b3.h)
         if grp == 64 and sched == 1 and fuse in (0, 4) and os.environ.get("SHOULDER_DMA_LDR") != "0":
             return "k_conv3_ldr16<%s,%d,%d>" % (unet, fuse, wres)      # 64-cout items: compute waves + loader waves (k_unet16_ldr.h)
         return "k_conv3_dma16<%s,%d,%d,%d,%d>" % (unet, fuse, nt, sched, wres)

@@ -26,6 +26,7 @@
 #include "k_unet16_l0.h"
 #include "k_unet16_dec0.h"
 #include "k_unet16_occ.h"
+#include "k_unet16_dec0b3.h"
 #include "k_stl.h"
 #include "k_clip.h"
 #include "k_hullpre.h"
@@ -1421,6 +1422,9 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
         const int ntiles = nimg * (W / 32) * (H / SH_OCC_TR), ntko = (ntiles + SH_OCC_TK - 1) / SH_OCC_TK;
         static const int occ_mul = getenv("SHOULDER_OCC_MUL") ? std::max(1, atoi(getenv("SHOULDER_OCC_MUL"))) : 2;      // workgroups per CU
         LAUNCH(c, lname, (k_dec0b_head_occ<EK>), dim3((unsigned)std::min(ntko, persistent_grid(c) * occ_mul)), dim3(SH_OCC_THREADS), src0, w, b, fz.head_w, fz.head_b, fz.logits, H, W, nimg, zp, tko);
+      } else if (C0 == 32 && C1 == 0 && L.cout == 32 && relu && tk != nullptr && !(getenv("SHOULDER_DEC0B3") && getenv("SHOULDER_DEC0B3")[0] == '0')) {
+        // three halo buffers, two tiles in flight (k_unet16_dec0b3.h; bit-identical; SHOULDER_DEC0B3=0: the two-buffer kernel)
+        LAUNCH(c, lname, (k_dec0b_head3<EK>), g, dim3(UD_THREADS), src0, w, b, fz.head_w, fz.head_b, fz.logits, H, W, nimg, zp, tk, tk_tab, ntk, yl);
       } else DMA_LAUNCH(UF_HEAD, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits, tk, tk_tab, ntk, yl);
     }
     else DMA_LAUNCH(0, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk, yl);

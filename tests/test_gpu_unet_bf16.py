@@ -390,3 +390,24 @@ def test_first_kernel_scales_the_raw_image_itself(engine, oracle_bones, name):
     finally:
         engine.set_keep_products(False)
         engine.reset_params()
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_three_buffer_dec0b_bit_identical(engine, monkeypatch, name):
+    """k_dec0b_head3 (k_unet16_dec0b3.h: three halo buffers, the tile two items ahead in flight, counted waits over a fixed number of
+    vector-memory operations per step) against k_conv3_dma16<.., UF_HEAD, 2, 1, 2> (two buffers): the same operations in the same
+    order -> the same logits bit for bit, at both image sizes, batches of one item per workgroup and of many, run after run (a tile
+    read before it landed, or overwritten while it was read, would show as a changing result)."""
+    rng = np.random.default_rng(37)
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        for H, W, n in ((256, 512, 1), (256, 512, 3), (512, 512, 5), (512, 512, 16)):
+            img = rng.random((n, H, W), dtype=np.float32)
+            monkeypatch.setenv("SHOULDER_DEC0B3", "0")
+            a = engine.unet_infer(img)
+            monkeypatch.setenv("SHOULDER_DEC0B3", "1")
+            for _ in range(3):
+                assert np.array_equal(a, engine.unet_infer(img))
+    finally:
+        monkeypatch.delenv("SHOULDER_DEC0B3", raising=False)
+        engine.set_params(unet_dtype=_lib.UNET_F32)

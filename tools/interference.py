@@ -11,7 +11,7 @@ def load(path):
     rows = list(csv.DictReader(open(path)))
     return sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void sh::", "").replace("sh::", "")[:44], r["Queue_Id"]) for r in rows)
 
-is_head = lambda n: "k_head16" in n or "k_conv3_dma16<0, 2, 2, 1, 2>" in n
+is_head = lambda n: "k_head16" in n or "k_dec0b_head3" in n or "k_conv3_dma16<0, 2, 2, 1, 2>" in n
 def passes(ev, skip):
     out = []
     for q in sorted({e[3] for e in ev if "k_enc0_fused16" in e[2]}):

@@ -15,7 +15,7 @@ for q in lanes:
     first = [e for e in L if "k_obb_face_area2" in e[2]]
     scale = [e for e in L if "k_anp_scale" in e[2]]
     enc = [e for e in L if "k_enc0_fused16" in e[2]]
-    head = [e for e in L if "k_head16" in e[2] or "k_conv3_dma16<0, 2, 2, 1, 2>" in e[2]]
+    head = [e for e in L if "k_head16" in e[2] or "k_dec0b_head3" in e[2] or "k_conv3_dma16<0, 2, 2, 1, 2>" in e[2]]
     app = [e for e in L if "k_apply_csys" in e[2]]
     n = min(len(first), len(scale), len(enc), len(head), len(app))
     pre = [round(ms(scale[i][1]) - ms(first[i][0]), 2) for i in range(skip, n)]

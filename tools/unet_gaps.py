@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]) for r in rows)
 short = lambda n: n.split("(")[0].replace("void sh::", "").replace("sh::", "")[:40]
-is_head = lambda n: "k_head16" in n or "k_conv3_dma16<0, 2, 2, 1, 2>" in n or "k_conv3_dma16<1, 2, 2, 1, 2>" in n
+is_head = lambda n: "k_head16" in n or "k_dec0b_head3" in n or "k_conv3_dma16<0, 2, 2, 1, 2>" in n or "k_conv3_dma16<1, 2, 2, 1, 2>" in n
 gaps, sums, spans, durs = {}, [], [], {}
 for q in sorted({e[3] for e in ev if "k_enc0_fused16" in e[2]}):
     L = [e for e in ev if e[3] == q]
