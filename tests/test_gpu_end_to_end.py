@@ -427,3 +427,16 @@ def test_packed_records_carry_the_full_records_fields(engine, oracle_bones):
         assert (n > 512).all() and (n > 2560).any() and (n <= 2560).any()     # 512 rows cut every list, 2 560 one of the three
     finally:
         engine.set_record_rows(0)
+
+
+def test_lanes_that_yield_their_reserve():
+    """SHOULDER_CU_YIELD=1 (off by default, measured neutral: DESIGN.md section 9): the ticketed UNet launches of a lane cover the whole
+    chip and their last workgroups take no ticket while the other lane's busy word is up.  Who computes an item changes, the
+    records do not; no launch is left without workgroups (tests/_yield_worker.py, a process of its own: the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SHOULDER_CU_YIELD="1")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_yield_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "YIELD_OK" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
