@@ -17,10 +17,10 @@
 // 64-image batch stay in the 256 MB Infinity Cache between layers).
 #pragma once
 #include "k_anp.h"
+#include "k_unet16_base.h"
 
 namespace sh {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define UN_TW 16
 #define UN_TH 16

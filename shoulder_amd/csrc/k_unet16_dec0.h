@@ -136,15 +136,16 @@ k_dec0a_up16(const u16* __restrict__ skip_ /*[img][H W][32]*/, const u16* __rest
   };
   // the DMA pieces are issued one at a time between groups of MFMAs (a run of them back to back stalls the wave on the
   // vector-memory issue port while the matrix pipe idles)
+  const unsigned lds_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ud_lptr)smem + (unsigned)(wave * 1024));      // this wave's 1 KB of a piece
   auto skip_piece = [&](int k) {      // piece k of 6 -> halo buffer A (k is a compile-time constant at every call site)
     const ET* simg = skip + (size_t)i_img * H * W * 32;
     const ET* p = pixoff[k] >= 0 ? simg + (unsigned)(pixoff[k] * 32 + q8) : zero_page;
-    if (k < 5 || in5) __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(smem + wave * 1024 + k * 8192), 16, 0, 0);
+    if (k < 5 || in5) ud_dma16(lds_w + k * 8192, p);
   };
   auto low_piece = [&](int k) {      // piece k of 3 -> low tile
     const ET* limg = low + (size_t)i_img * H2 * W2 * 64;
     const ET* p = lowoff[k] >= 0 ? limg + (unsigned)(lowoff[k] + l_src[k]) : zero_page;
-    __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(smem + D0_LOW + wave * 1024 + k * 8192), 16, 0, 0);
+    ud_dma16(lds_w + D0_LOW + k * 8192, p);
   };
   // one conv step: 9 taps x (4 pixel rows x 2 cout tiles) MFMAs on halo buffer `sb`, weight chunk `cc`
   f32x4 acc[4][2];

@@ -1,0 +1,368 @@
+// k_unet16_pp.h -- the full-resolution (32-channel) level of the 16-bit UNet, second generation: the two waves of a SIMD take
+// TURNS on the matrix pipe ("ping-pong").
+//
+// The first generation (k_unet16_l0.h / k_unet16_dec0.h / k_unet16_dec0b3.h) runs 8 waves in lockstep: every wave stages, then
+// every wave multiplies, then every wave runs its epilogue, one s_barrier per tile.  Its counters (profiles/r04_pmc_sq_b64_bf16.json):
+// matrix pipe busy 0.27-0.39, waves parked 0.40-0.46 -- while the 8 waves issue LDS-DMA pieces or convert, round and store a tile,
+// no wave of the CU has an MFMA to issue, and the two waves of a SIMD reach that state together.
+// Here a workgroup is two GROUPS of four waves (waves w and w + 4 share a SIMD: one wave of each group per SIMD) that run half a
+// period apart.  In phase p group (p & 1) is ON: 144 MFMAs per wave on tile p (8 rows x 16 pixels x 32 couts, the whole 32 x 16
+// tile for the group), nothing else but its 30 fragment reads; the other group is OFF: it issues the LDS-DMA pieces of tile p + 2
+// (the ON group of phase p + 2 is the group that is ON now) and runs the epilogue of the tile it multiplied in phase p - 1.  One
+// s_barrier per phase for the whole workgroup.  Three halo buffers: tile p is read in phase p, tile p + 1 has landed, tile p + 2 is
+// in flight.  A wave's vector-memory operations are, per OFF phase and in this order, its pieces and then its epilogue stores, so the
+// counted wait in front of the barrier that ends its next ON phase -- vmcnt(number of stores) -- retires exactly the pieces.
+//
+// Vector work is kept off the matrix waves' issue slots: ReLU is an integer max on the f32 bits (fmaxf is two v_max_f32: it
+// quiets NaNs first), conversions are packed (v_cvt_pk_bf16_f32 on pairs), the head's sum over the four lane groups is a
+// reduce-scatter on v_permlane16_swap / v_permlane32_swap (6 swaps + 6 adds per 8 rows instead of 16 ds_bpermute + 16 adds, and
+// two store instructions per tile instead of eight), interior tiles stage from one scalar base + per-lane offsets computed once.
+//
+// Work items, tickets, LDS image of a halo tile (648 rows of 64 B at pitch 36, XOR slot swizzle on the DMA's source address and on
+// the fragment read), channel dealing and the order of every sum are those of the first generation: dec0b + head returns the
+// same logits bit for bit (tests/test_gpu_unet_bf16.py).
+#pragma once
+#include <type_traits>
+#include "k_unet16_base.h"
+
+namespace sh {
+
+#define PP_THREADS 512
+#define PP_GTHREADS 256                      // lanes of a group (4 waves)
+#define PP_NPIECE 11                         // LDS-DMA pieces per staging wave and tile: 256 lanes x 11 = 2816 slots of 16 B >= 648 rows x 4
+#define PP_BUFB (PP_NPIECE * 4096)           // 45 056 bytes per halo buffer: piece k of staging wave v at k * 4096 + v * 1024
+#ifndef PP_K1
+#define PP_K1 11                             // pieces 0 .. PP_K1 - 1 of a tile are issued by the OFF group, the rest by the ON group behind its MFMAs
+#endif
+#ifndef PP_OFFPRIO
+#define PP_OFFPRIO 0                         // s_setprio of a wave in its OFF phase
+#endif
+
+template <int N> __device__ inline void pp_wait_vm() {      // s_waitcnt takes an immediate
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  else static_assert(N < 0, "pp_wait_vm: add the immediate");
+}
+// wait until at most nb + ns of this wave's vector-memory operations are outstanding (nb in {0, NB}, ns in {0, NS})
+template <int NB, int NS> __device__ inline void pp_wait_vm2(bool b, bool s) {
+  if (b) { if (s) pp_wait_vm<NB + NS>(); else pp_wait_vm<NB>(); }
+  else { if (s) pp_wait_vm<NS>(); else pp_wait_vm<0>(); }
+}
+
+__device__ inline float pp_relu(float x) {      // max(x, +0) for every x that is not a NaN: one v_max_i32 (negative floats are negative ints)
+  const int i = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+// x' = [x0 y0 x2 y2], y' = [x1 y1 x3 y3] by 16-lane rows; returns x' + y': rows 0 and 2 hold x summed over the row pairs (0,1) / (2,3), rows 1 and 3 hold y
+__device__ inline float pp_swap16_add(float x, float y) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  return x + y;
+}
+// x' = [x.lo y.lo], y' = [x.hi y.hi] by 32-lane halves; returns x' + y': the low half holds x summed over both halves, the high half y
+__device__ inline float pp_swap32_add(float x, float y) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  return x + y;
+}
+
+// Diagnostic build (-DPP_STAMP; never the product): cycles a wave spends per part of a phase, summed per workgroup and wave into
+// pp_stamp[blockIdx][wave][part] (s_memtime ticks = shader cycles; cdna_hip_programming.md section 7, in-kernel stamps).
+#ifdef PP_STAMP
+#define PP_NSTAMP 8      // 0 ON multiply, 1 ON vm wait, 2 ON barrier, 3 OFF stage, 4 OFF epilogue, 5 OFF barrier, 6 phases, 7 whole loop
+__device__ unsigned long long pp_stamp[256 * 8 * PP_NSTAMP];
+#define PP_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define PP_ADD(i, a, b) st_[i] += (b) - (a)
+#else
+#define PP_T(v)
+#define PP_ADD(i, a, b)
+#endif
+
+// the next work ticket: the returning atomic and its wait as ONE statement inside the caller's branch (left to the compiler, the wait
+// for the returned value moves behind the branch's join, where every wave of the workgroup drains its LDS-DMA queue for it)
+__device__ inline int pp_take_ticket(unsigned* ticket) {
+  unsigned t;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(ticket), "v"(1u) : "memory");
+  return (int)t;
+}
+// a value loaded from global memory in front of the main loop is USED here, so the compiler's wait for it stands here and not at
+// its first use inside the loop (where it would be a vmcnt(0) behind the loop's own LDS-DMA pieces)
+template <typename T> __device__ inline void pp_settle(T& v) { asm volatile("" : "+v"(v)); }
+
+// the tile cursor every wave of a workgroup keeps in step: items of the current ticket, the next ticket's id one ticket ahead in LDS
+struct PpCursor {
+  int w, wend, tx, ty, img, qk;
+  bool live;
+};
+
+// dec0b (32 -> 32 channels, 3x3, ReLU) + the 1x1 head: only the logits leave the kernel (anatomic_neck.py:67-76, the network's last two layers)
+template <int EK>
+__global__ void __launch_bounds__(PP_THREADS)
+k_dec0b_head_pp(const u16* __restrict__ src_ /*[img][H W][32]*/, const u16* __restrict__ wgt_ /*packed [9][1][32][32]*/, const float* __restrict__ bias,
+                const float* __restrict__ head_w, const float* __restrict__ head_b, float* __restrict__ logits, int H, int W, int nimg,
+                const u16* __restrict__ zero_page_, unsigned* __restrict__ ticket, const int* __restrict__ tk_tab, int ntk) {
+  using ET = typename EKT<EK>::type;
+  using v8 = typename E16<ET>::v8;
+  const ET* src = (const ET*)src_;
+  const ET* wgt = (const ET*)wgt_;
+  const ET* zero_page = (const ET*)zero_page_;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[3 * PP_BUFB];
+  __shared__ int s_q[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wv = wave & 3;
+  const int xh = wv & 1, rg8 = wv >> 1;
+  const int tiles_x = W / 32, tiles_y = H / 16;
+  if (tid == 0) { s_q[0] = pp_take_ticket(ticket); s_q[1] = pp_take_ticket(ticket); }
+
+  // ---- once per workgroup: the weight fragments of this lane (row dealing and slot swizzle of k_conv3_dma16, NN = 2) through buffer 2
+  for (int e = tid; e < 9 * 32 * 4; e += PP_THREADS) {
+    const int row = e >> 2, q = e & 3;
+    const int tap = row >> 5, j = row & 31;
+    const int ch = 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);
+    *(u32x4*)(smem + 2 * PP_BUFB + e * 16) = *(const u32x4*)(wgt + (size_t)(tap * 32 + ch) * 32 + ((q ^ ((row >> 1) & 2)) << 3));
+  }
+  f32x4 bv[2];
+  float hw[8];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bv[n][r] = bias[8 * lk + 4 * n + r]; hw[4 * n + r] = head_w[8 * lk + 4 * n + r]; }
+  float hb = head_b[0];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) pp_settle(bv[n]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pp_settle(hw[i]);
+  pp_settle(hb);
+  __syncthreads();
+  const int t0 = __builtin_amdgcn_readfirstlane(s_q[0]);      // (read in front of the next barrier: lane 0 refills this slot in its first advance())
+  v8 wreg[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) wreg[tap][n] = *(const v8*)(smem + 2 * PP_BUFB + (tap * 32 + n * 16) * 64 + UB_OFF(li, lk) * 2);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();      // every wave holds its fragments: buffer 2 is free; every ordinary load is retired before the first LDS-DMA
+
+  PpCursor cu;
+  {
+    if (t0 >= ntk) return;
+    cu.w = tk_tab[t0]; cu.wend = tk_tab[t0 + 1]; cu.qk = 1; cu.live = true;
+    int w = cu.w;
+    cu.tx = w % tiles_x; w /= tiles_x; cu.ty = w % tiles_y; cu.img = w / tiles_y;
+  }
+  // to the next item of the ticket, or the first of the next ticket (its id was written at least a barrier ago).  `fetcher`: the lane
+  // that refills the freed slot -- lane 0 of the first wave of the group that is ON (its vector-memory queue is all but empty at the
+  // end of an ON phase; an OFF wave would wait for the pieces it has just issued)
+  auto advance = [&](const bool fetcher) {
+    if (cu.w + 1 < cu.wend) { ++cu.w; if (++cu.tx == tiles_x) { cu.tx = 0; if (++cu.ty == tiles_y) { cu.ty = 0; ++cu.img; } } return; }
+    const int nt = __builtin_amdgcn_readfirstlane(s_q[cu.qk]);
+    if (nt < ntk) {
+      if (fetcher) s_q[cu.qk ^ 1] = pp_take_ticket(ticket);
+      cu.qk ^= 1;
+      cu.w = tk_tab[nt]; cu.wend = tk_tab[nt + 1];
+      int w = cu.w;
+      cu.tx = w % tiles_x; w /= tiles_x; cu.ty = w % tiles_y; cu.img = w / tiles_y;
+    } else cu.live = false;
+  };
+
+  // ---- staging plan of a group: slot e_k = ltid + 256 k -> LDS row (ltid >> 2) + 64 k (row = py * 36 + px), 16-byte slot ltid & 3.
+  // The swizzle bit (bit 2 of the row) is the same for every k.  voff[k]: byte offset of the slot's source from the tile's halo
+  // origin (pixel (y0 - 1, x0 - 1)); slots behind the halo rows and the two padding columns re-read the origin pixel (never read back).
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ud_lptr)smem);
+  const unsigned wv1024 = __builtin_amdgcn_readfirstlane((unsigned)(wv * 1024));
+  const int ltid = tid & (PP_GTHREADS - 1);
+  const int r0 = ltid >> 2;
+  const int q8 = ((ltid & 3) ^ ((r0 >> 1) & 2)) * 8;
+  int voff[PP_NPIECE];
+#pragma unroll
+  for (int k = 0; k < PP_NPIECE; ++k) {
+    const int r = r0 + 64 * k, py = r / UD_PW, px = r - py * UD_PW;
+    voff[k] = (r < UD_INROWS && px < 34) ? ((py * W + px) * 32 + q8) * 2 : ((W + 1) * 32 + q8) * 2;
+  }
+  auto stage = [&](int bf, auto KB, auto KE) {      // pieces KB .. KE - 1 of the cursor's tile -> buffer bf; the four waves of the calling group
+    constexpr int kb = decltype(KB)::value, ke = decltype(KE)::value;
+#if defined(PP_ABL) && (PP_ABL & 2)      // diagnostic (wrong results): no LDS-DMA
+    return;
+#endif
+    const ET* simg = src + (size_t)cu.img * H * W * 32;
+    const unsigned lb = lds0 + (unsigned)(bf * PP_BUFB) + wv1024;
+    if (cu.tx > 0 && cu.tx + 1 < tiles_x && cu.ty > 0 && cu.ty + 1 < tiles_y) {      // interior tile: every halo pixel is inside the image
+      const ET* base = simg + ((size_t)(cu.ty * 16 - 1) * W + (cu.tx * 32 - 1)) * 32;
+#pragma unroll
+      for (int k = kb; k < ke; ++k) ud_dma16_s(lb + k * 4096, (unsigned)voff[k], base);
+    } else {
+#pragma unroll
+      for (int k = kb; k < ke; ++k) {
+        const int r = r0 + 64 * k, py = r / UD_PW, px = r - py * UD_PW;
+        const int gx = cu.tx * 32 + px - 1, gy = cu.ty * 16 + py - 1;
+        const bool ok = r < UD_INROWS && px < 34 && gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const ET* p = ok ? simg + (unsigned)((gy * W + gx) * 32 + q8) : zero_page;
+        ud_dma16(lb + k * 4096, p);
+      }
+    }
+  };
+  // fragment read offsets (bytes inside a buffer): rows rg8 * 8 + s (s = 0..9), pixel xh * 16 + li + dx
+  int xoff[2][3];
+  {
+    const int rowbase = rg8 * 8 * UD_PW + xh * 16 + li;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) xoff[sp][dx] = UB_OFF(rowbase + sp * UD_PW + dx, lk) * 2;
+  }
+  // the two logit stores of a tile: lane group lk holds rows lk and lk + 4 of its 8 after the reduce-scatter
+  const unsigned soff0 = (unsigned)(((rg8 * 8 + lk) * W + xh * 16 + li) * 4), soff1 = soff0 + (unsigned)(4 * W * 4);
+
+  // ---- prologue: group 1 stages item 0 (its "phase -2"), group 0 item 1; every wave walks the cursor
+  int ax0 = 0, ay0 = 0, aimg = 0;      // item p - 1 (the epilogue of the OFF group)
+  int bx0, by0, bimg; bool blive;      // item p
+  int cx0, cy0, cimg; bool clive;      // item p + 1
+  bool alive = false;
+  bx0 = cu.tx * 32; by0 = cu.ty * 16; bimg = cu.img; blive = true;
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, PP_K1>;
+  using KN = std::integral_constant<int, PP_NPIECE>;
+  if (grp == 1) stage(0, K0{}, KN{});
+  advance(tid == 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();      // (a ticket id is read a barrier after it was written)
+  cx0 = cu.tx * 32; cy0 = cu.ty * 16; cimg = cu.img; clive = cu.live;
+  if (grp == 0 && cu.live) stage(1, K0{}, KN{});
+  if (cu.live) advance(tid == 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 acc[8][2];
+#ifdef PP_STAMP
+  unsigned long long st_[PP_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+  PP_T(tl0_);
+#endif
+  bool had_stores = false;      // this wave's most recent OFF phase ended with its two logit stores ...
+  bool had_off = false;         // ... and began with its PP_K1 pieces
+  int bf = 0;                          // buffer of item p
+  // one phase of a wave; ON: multiply item p; OFF: stage item p + 2, finish item p - 1.  Returns false when the workgroup is done.
+  auto phase = [&](const bool on) -> bool {
+    if (!blive && !alive) return false;
+    const int bf2 = bf == 0 ? 2 : bf - 1;      // (p + 2) % 3
+    PP_T(ta_);
+    if (on) {
+#if defined(PP_ABL) && (PP_ABL & 1)      // diagnostic (wrong results): no fragment reads, no MFMAs
+      if (false) {
+#else
+      if (blive) {
+#endif
+        const unsigned char* sb = smem + bf * PP_BUFB;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int m = 0; m < 8; ++m) acc[m][n] = bv[n];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          v8 xq[10];
+#pragma unroll
+          for (int s = 0; s < 10; ++s) xq[s] = *(const v8*)(sb + xoff[s & 1][dx] + (s & ~1) * UD_PW * 64);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+              for (int n = 0; n < 2; ++n) acc[m][n] = E16<ET>::mfma(wreg[dy * 3 + dx][n], xq[m + dy], acc[m][n]);
+        }
+      }
+      // this wave's pieces of item p + 1 (issued one phase ago in its OFF phase, in front of its stores) have landed
+#ifdef PP_STAMP
+      asm volatile("" :: "v"(acc[7][1]), "v"(acc[0][0]));
+#endif
+      PP_T(tb_);
+      pp_wait_vm2<0, 2>(false, had_stores);
+      if (PP_K1 < PP_NPIECE && cu.live) stage(bf2, K1{}, KN{});      // the ON group's share of item p + 2, behind its MFMAs
+      PP_T(tc_);
+      PP_ADD(0, ta_, tb_); PP_ADD(1, tb_, tc_);
+    } else {
+      if (PP_OFFPRIO) __builtin_amdgcn_s_setprio(PP_OFFPRIO);
+      had_off = cu.live;
+      if (cu.live) stage(bf2, K0{}, K1{});
+      PP_T(tb_);
+      PP_ADD(3, ta_, tb_);
+      had_stores = false;
+#if defined(PP_ABL) && (PP_ABL & 4)      // diagnostic (wrong results): no epilogue
+      asm volatile("" :: "v"(acc[0][0]), "v"(acc[7][1]));
+      if (false) {
+#else
+      if (alive) {
+#endif
+        // logit = head_b + sum over the 32 channels of relu(conv) * head_w: 8 in the lane (the fma chain of k_conv3_dma16), then
+        // (lane groups 0 + 1) + (lane groups 2 + 3) as a reduce-scatter
+        // (the eight rows' chains side by side: hipcc keeps the source order, and one chain alone is 16 dependent instructions)
+        float t[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) t[m] = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) t[m] = __builtin_fmaf(pp_relu(acc[m][n][r]), hw[4 * n + r], t[m]);
+        float u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = pp_swap16_add(t[2 * j], t[2 * j + 1]);      // lane groups with bit 0 clear: row 2 j, set: row 2 j + 1
+        const float w0 = pp_swap32_add(u[0], u[1]);      // row 2 (lk >> 1) + (lk & 1) = lk
+        const float w1 = pp_swap32_add(u[2], u[3]);      // row 4 + lk
+        float* lo = logits + ((size_t)aimg * H + ay0) * W + ax0;
+        ud_store4((float*)((char*)lo + soff0), hb + w0);
+        ud_store4((float*)((char*)lo + soff1), hb + w1);
+        had_stores = true;
+      }
+      // the pieces this wave issued behind its MFMAs one phase ago (item p + 1) have landed: younger are this phase's pieces and stores
+      if (PP_K1 < PP_NPIECE) pp_wait_vm2<PP_K1, 2>(had_off, had_stores);
+      if (PP_OFFPRIO) __builtin_amdgcn_s_setprio(0);
+      PP_T(tc_);
+      PP_ADD(4, tb_, tc_);
+    }
+    PP_T(td_);
+    // every wave: the cursor's item becomes item p + 2
+    ax0 = bx0; ay0 = by0; aimg = bimg; alive = blive;
+    bx0 = cx0; by0 = cy0; bimg = cimg; blive = clive;
+    cx0 = cu.tx * 32; cy0 = cu.ty * 16; cimg = cu.img; clive = cu.live;
+    if (cu.live) advance(on && ltid == 0);
+    bf = bf == 2 ? 0 : bf + 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    PP_T(te_);
+    PP_ADD(on ? 2 : 5, td_, te_);
+#ifdef PP_STAMP
+    st_[6] += 1;
+#endif
+    return true;
+  };
+  // (the roles run separate loops: in one shared body hipcc keeps one role's registers alive through the other's branch)
+  if (grp == 0) {
+#pragma unroll 1
+    for (;;) { if (!phase(true)) break; if (!phase(false)) break; }
+  } else {
+#pragma unroll 1
+    for (;;) { if (!phase(false)) break; if (!phase(true)) break; }
+  }
+#ifdef PP_STAMP
+  {
+    PP_T(tl1_);
+    st_[7] = tl1_ - tl0_;
+    if (lane == 0 && blockIdx.x < 256)
+      for (int i = 0; i < PP_NSTAMP; ++i) pp_stamp[(blockIdx.x * 8 + wave) * PP_NSTAMP + i] = st_[i];
+  }
+#endif
+}
+
+}  // namespace sh

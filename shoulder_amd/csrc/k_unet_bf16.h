@@ -21,41 +21,6 @@
 
 namespace sh {
 
-// Activation layout: channel-blocked "NC/32HW32" -- per image, 32-channel planes of [H][W][32] bf16 (64 B per pixel and
-// plane).  A 32-channel chunk of a tile row is then one contiguous run (full 128-B lines for the staging loads and the
-// LDS-DMA), where the plain NHWC form made every staging step touch half of each pixel's line and fetched most lines twice
-// (PMC: 1.34 GB per launch against 0.65 GB algorithmic).  A 32-channel tensor is plain NHWC either way.
-__device__ __host__ inline size_t act_off(size_t HW, size_t pix, int c) { return ((size_t)(c >> 5) * HW + pix) * 32 + (size_t)(c & 31); }
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// Kernels are templates on an element-KIND integer (EK: 0 = __bf16, 1 = _Float16) and take their 16-bit tensors as
-// `const u16*`: with the element TYPE in the template arguments or the parameter list (mangled DF16b / DF16_) rocprofv3's
-// demangler prints the symbols half mangled, and profiles/ is keyed by kernel name.
-typedef unsigned short u16;
-template <int EK> struct EKT;
-template <> struct EKT<0> { typedef __bf16 type; };
-template <> struct EKT<1> { typedef _Float16 type; };
-
-// element-type trait: vector types and the 16x16x32 MFMA (A = 8 k-values of 16 rows, B = 8 k-values of 16 columns)
-template <typename ET> struct E16;
-template <> struct E16<__bf16> {
-  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
-  typedef __bf16 v4 __attribute__((ext_vector_type(4)));
-  static __device__ inline f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct E16<_Float16> {
-  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
-  typedef _Float16 v4 __attribute__((ext_vector_type(4)));
-  static __device__ inline f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-
-#define UB_PSTR 32      // bf16 elements per LDS row: 32 channels = 64 B = four 16-B slots, unpadded
-// XOR swizzle of the 16-B slot inside a row: slot' = slot ^ ((row >> 1) & 2).  With it the 16 lanes of every
-// ds_read_b128 lane group (rows p0 + (lane & 15), slot lane >> 4) hit 16 distinct slots of the 256-B bank row for
-// every p0 (checked exhaustively), so fragment reads are bank-conflict free without padding.
-#define UB_OFF(row, slot) ((row) * UB_PSTR + (((slot) ^ (((row) >> 1) & 2)) << 3))
-
 // Fusions at the memory-bound ends of the network (the 32-channel level moves 1.07 GB per tensor at B = 64):
 //   UF_FIRST  the layer's input is the 1-channel image: the 32-channel activations of the first conv (enc0a) are
 //             computed into the halo tile on the matrix cores instead of being read from HBM -- one MFMA per 16

@@ -19,32 +19,12 @@
 namespace sh {
 
 #define UD_THREADS 512
-#define UD_PW 36
-#define UD_INROWS (18 * UD_PW)              // 648
 #define UD_ROWS (UD_INROWS + 576)           // 1224
 #define UD_BUF (UD_ROWS * 64)               // 78336
 #define UD_SLOTS (UD_ROWS * 4)              // 4896
 #define UD_BIAS_OFF (2 * UD_BUF)
 #define UD_SMEM (2 * UD_BUF + 2048)         // 158720
 
-typedef const __attribute__((address_space(1))) void* ud_gptr;
-typedef __attribute__((address_space(3))) void* ud_lptr;
-
-template <typename ET, typename V4>
-__device__ inline void ud_store8(ET* p, V4 v) {      // exactly one vector-memory instruction (counted by s_waitcnt vmcnt)
-  asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(__builtin_bit_cast(unsigned long long, v)) : "memory");
-}
-template <typename ET, typename V8>
-__device__ inline void ud_store16(ET* p, V8 v) {      // one dwordx4 store: 8 consecutive channels of a pixel
-  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-  // s_nop 1 inside the string: hipcc pads nothing around an asm statement, and a store of more than 64 bits must not have
-  // its data registers overwritten in the next two issue slots (cdna_hip_programming.md 5.7; without it the later lanes
-  // of the wave stored the NEXT tile's values)
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(u4, v)) : "memory");
-}
-__device__ inline void ud_store4(float* p, float v) {
-  asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
-}
 template <int N> __device__ inline void ud_wait_vm() {      // s_waitcnt takes an immediate
   if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");

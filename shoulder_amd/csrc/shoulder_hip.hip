@@ -27,6 +27,7 @@
 #include "k_unet16_dec0.h"
 #include "k_unet16_occ.h"
 #include "k_unet16_dec0b3.h"
+#include "unet16_pp.h"
 #include "k_stl.h"
 #include "k_clip.h"
 #include "k_hullpre.h"
@@ -241,6 +242,23 @@ static inline bool timed_launch(const sh_ctx* c, const char* name) {
       (void)hipEventRecord(e0_, (ctx)->stream);                                             \
     }                                                                                       \
     hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);                 \
+    if (timed_) {                                                                           \
+      (void)hipEventRecord(e1_, (ctx)->stream);                                             \
+      (ctx)->pending.emplace_back(name, e0_, e1_);                                          \
+    }                                                                                       \
+    HIPCHK(ctx, hipGetLastError());                                                         \
+  } while (0)
+
+// the same bookkeeping around a launcher function of another translation unit (unet16_pp.h)
+#define LAUNCH_FN(ctx, name, call)                                                           \
+  do {                                                                                      \
+    hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                \
+    const bool timed_ = timed_launch(ctx, name);                                            \
+    if (timed_) {                                                                           \
+      (void)hipEventCreate(&e0_); (void)hipEventCreate(&e1_);                               \
+      (void)hipEventRecord(e0_, (ctx)->stream);                                             \
+    }                                                                                       \
+    call;                                                                                   \
     if (timed_) {                                                                           \
       (void)hipEventRecord(e1_, (ctx)->stream);                                             \
       (ctx)->pending.emplace_back(name, e0_, e1_);                                          \
@@ -1422,6 +1440,9 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
         const int ntiles = nimg * (W / 32) * (H / SH_OCC_TR), ntko = (ntiles + SH_OCC_TK - 1) / SH_OCC_TK;
         static const int occ_mul = getenv("SHOULDER_OCC_MUL") ? std::max(1, atoi(getenv("SHOULDER_OCC_MUL"))) : 2;      // workgroups per CU
         LAUNCH(c, lname, (k_dec0b_head_occ<EK>), dim3((unsigned)std::min(ntko, persistent_grid(c) * occ_mul)), dim3(SH_OCC_THREADS), src0, w, b, fz.head_w, fz.head_b, fz.logits, H, W, nimg, zp, tko);
+      } else if (C0 == 32 && C1 == 0 && L.cout == 32 && relu && tk != nullptr && !yl.flags && !(getenv("SHOULDER_L0_PP") && getenv("SHOULDER_L0_PP")[0] == '0')) {
+        // the two waves of a SIMD take turns on the matrix pipe (k_unet16_pp.h; same logits bit for bit)
+        LAUNCH_FN(c, lname, launch_dec0b_head_pp(EK, g.x, c->stream, src0, w, b, fz.head_w, fz.head_b, fz.logits, H, W, nimg, zp, tk, tk_tab, ntk));
       } else if (C0 == 32 && C1 == 0 && L.cout == 32 && relu && tk != nullptr && !(getenv("SHOULDER_DEC0B3") && getenv("SHOULDER_DEC0B3")[0] == '0')) {
         // three halo buffers, two tiles in flight (k_unet16_dec0b3.h; bit-identical; SHOULDER_DEC0B3=0: the two-buffer kernel)
         LAUNCH(c, lname, (k_dec0b_head3<EK>), g, dim3(UD_THREADS), src0, w, b, fz.head_w, fz.head_b, fz.logits, H, W, nimg, zp, tk, tk_tab, ntk, yl);

@@ -1,0 +1,12 @@
+// unet16_pp.h -- host-side launchers of the kernels in k_unet16_pp.h (their translation unit: unet16_pp.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sh {
+
+// dec0b + head on the ping-pong kernel; ek: 0 = bf16, 1 = f16.  grid = persistent workgroups (one per CU).
+void launch_dec0b_head_pp(int ek, unsigned grid, hipStream_t st, const unsigned short* src, const unsigned short* wgt, const float* bias,
+                          const float* head_w, const float* head_b, float* logits, int H, int W, int nimg, const unsigned short* zero_page,
+                          unsigned* ticket, const int* tk_tab, int ntk);
+
+}  // namespace sh
