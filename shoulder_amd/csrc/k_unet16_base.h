@@ -71,10 +71,11 @@ __device__ inline void ud_store4(float* p, float v) {
 // before it reads a fragment of the tile that landed long ago.  As assembly the transfers are the kernel's own business: its
 // counted waits and barriers order them; the `memory` clobber keeps the compiler's loads and stores on their side of every wait.
 __device__ inline void ud_dma16(unsigned lds_dst /*wave-uniform LDS byte address*/, const void* p) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_dst), "v"(p) : "memory");
+  // (readfirstlane: the "s" constraint alone does not make hipcc keep a value it takes for divergent in a scalar register)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "v"(p) : "memory");
 }
 __device__ inline void ud_dma16_s(unsigned lds_dst /*wave-uniform*/, unsigned voff, const void* sbase /*wave-uniform*/) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "v"(voff), "s"(sbase) : "memory");
 }
 
 }  // namespace sh

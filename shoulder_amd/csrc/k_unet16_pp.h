@@ -80,7 +80,7 @@ __device__ inline float pp_swap32_add(float x, float y) {
 // pp_stamp[blockIdx][wave][part] (s_memtime ticks = shader cycles; cdna_hip_programming.md section 7, in-kernel stamps).
 #ifdef PP_STAMP
 #define PP_NSTAMP 8      // 0 ON multiply, 1 ON vm wait, 2 ON barrier, 3 OFF stage, 4 OFF epilogue, 5 OFF barrier, 6 phases, 7 whole loop
-__device__ unsigned long long pp_stamp[256 * 8 * PP_NSTAMP];
+__device__ unsigned long long pp_stamp[2 * 256 * 8 * PP_NSTAMP];      // [kernel: 0 dec0b + head, 1 enc0][workgroup][wave][part]
 #define PP_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #define PP_ADD(i, a, b) st_[i] += (b) - (a)
 #else
@@ -98,6 +98,31 @@ __device__ inline int pp_take_ticket(unsigned* ticket) {
 // a value loaded from global memory in front of the main loop is USED here, so the compiler's wait for it stands here and not at
 // its first use inside the loop (where it would be a vmcnt(0) behind the loop's own LDS-DMA pieces)
 template <typename T> __device__ inline void pp_settle(T& v) { asm volatile("" : "+v"(v)); }
+
+// max of two packed pairs of non-negative 16-bit floats (they order like int16), and the same against the lane that holds the
+// neighbouring pixel (lane ^ 1): as assembly -- written with __builtin_amdgcn_mov_dpp in a loop over the four dwords of a pixel,
+// hipcc (ROCm 7.2) emitted ONE swap and stored its result four times
+__device__ inline unsigned pp_pkmax(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline unsigned pp_pkmax_lane1(unsigned a) {
+  unsigned t, r;
+  asm("s_nop 1\n\tv_mov_b32_dpp %0, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\tv_pk_max_i16 %1, %2, %0" : "=&v"(t), "=&v"(r) : "v"(a));
+  return r;
+}
+// the same for N dwords at once: all swaps, then all maxima -- the two wait states a DPP read needs behind the write of its source
+// (and a read of a DPP result behind it) are then other members of the batch instead of s_nop
+template <int N> __device__ inline void pp_pkmax_lane1_n(unsigned (&a)[N]) {
+  static_assert(N >= 3, "the batch is its own padding");
+  unsigned t[N];
+  asm volatile("s_nop 1" ::: );
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(t[i]) : "v"(a[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(t[i]));
+}
 
 // the tile cursor every wave of a workgroup keeps in step: items of the current ticket, the next ticket's id one ticket ahead in LDS
 struct PpCursor {
@@ -164,7 +189,7 @@ k_dec0b_head_pp(const u16* __restrict__ src_ /*[img][H W][32]*/, const u16* __re
   // to the next item of the ticket, or the first of the next ticket (its id was written at least a barrier ago).  `fetcher`: the lane
   // that refills the freed slot -- lane 0 of the first wave of the group that is ON (its vector-memory queue is all but empty at the
   // end of an ON phase; an OFF wave would wait for the pieces it has just issued)
-  auto advance = [&](const bool fetcher) {
+  auto advance = [&](const bool fetcher) __attribute__((always_inline)) {
     if (cu.w + 1 < cu.wend) { ++cu.w; if (++cu.tx == tiles_x) { cu.tx = 0; if (++cu.ty == tiles_y) { cu.ty = 0; ++cu.img; } } return; }
     const int nt = __builtin_amdgcn_readfirstlane(s_q[cu.qk]);
     if (nt < ntk) {
@@ -190,7 +215,7 @@ k_dec0b_head_pp(const u16* __restrict__ src_ /*[img][H W][32]*/, const u16* __re
     const int r = r0 + 64 * k, py = r / UD_PW, px = r - py * UD_PW;
     voff[k] = (r < UD_INROWS && px < 34) ? ((py * W + px) * 32 + q8) * 2 : ((W + 1) * 32 + q8) * 2;
   }
-  auto stage = [&](int bf, auto KB, auto KE) {      // pieces KB .. KE - 1 of the cursor's tile -> buffer bf; the four waves of the calling group
+  auto stage = [&](int bf, auto KB, auto KE) __attribute__((always_inline)) {      // pieces KB .. KE - 1 of the cursor's tile -> buffer bf; the four waves of the calling group
     constexpr int kb = decltype(KB)::value, ke = decltype(KE)::value;
 #if defined(PP_ABL) && (PP_ABL & 2)      // diagnostic (wrong results): no LDS-DMA
     return;
@@ -252,7 +277,7 @@ k_dec0b_head_pp(const u16* __restrict__ src_ /*[img][H W][32]*/, const u16* __re
   bool had_off = false;         // ... and began with its PP_K1 pieces
   int bf = 0;                          // buffer of item p
   // one phase of a wave; ON: multiply item p; OFF: stage item p + 2, finish item p - 1.  Returns false when the workgroup is done.
-  auto phase = [&](const bool on) -> bool {
+  auto phase = [&](const bool on) __attribute__((always_inline)) -> bool {
     if (!blive && !alive) return false;
     const int bf2 = bf == 0 ? 2 : bf - 1;      // (p + 2) % 3
     PP_T(ta_);
@@ -361,6 +386,369 @@ k_dec0b_head_pp(const u16* __restrict__ src_ /*[img][H W][32]*/, const u16* __re
     st_[7] = tl1_ - tl0_;
     if (lane == 0 && blockIdx.x < 256)
       for (int i = 0; i < PP_NSTAMP; ++i) pp_stamp[(blockIdx.x * 8 + wave) * PP_NSTAMP + i] = st_[i];
+  }
+#endif
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// enc0: image -> [enc0a: 1 -> 32, 3x3, ReLU] -> LDS -> [enc0b: 32 -> 32, 3x3, ReLU] -> skip0 (+ 2x2 max pool -> level 1), ping-pong.
+//   ON  (group p & 1):  enc0b on the halo tile h(p) of tile p: 144 MFMAs per wave, 30 pixel + 18 weight fragment reads
+//   OFF (other group):  the patch loads of tile p + 2 are issued; enc0a of tile p + 1 on the matrix cores (patch(p + 1) -> h(p + 1),
+//                       ~10 groups of 16 halo pixels per wave); the epilogue of tile p - 1 (rounded, ReLU'd, stored; pooled); the
+//                       patch of tile p + 2 is scaled, split and written to LDS
+// Two halo buffers, two patch slots, one s_barrier per phase.  No LDS-DMA here (the input is 4 bytes per pixel): the kernel's
+// vector-memory operations are the patch loads and the epilogue's stores.
+//
+// First conv on the matrix cores: a patch value v is split into its ET high part and ET low part (v - hi); K layout of the MFMA:
+// lane group lk = patch row ty (0..2; lk = 3 has zero weights), element j = column offset tx for the high parts (j = 0..2) and
+// 4 + tx for the low parts, so ONE MFMA per 16 pixels x 16 channels does what k_enc0_fused16 needed two for.  The 4 + 4 consecutive
+// patch values a lane needs are two aligned ds_read_b64 from copy (q & 3) of the high / low patch (4 shifted copies each, where
+// k_enc0_fused16 kept 8 + 8 for its ds_read_b128).  Image precision ~2^-17, ET-rounded weights, f32 accumulate from the bias.
+#define E0_HB (UD_INROWS * 64)              // 41 472: a halo buffer
+#define E0_CS 1472                          // bytes between two shifted copies of a patch part (8 of front padding + 2 x 728, rounded up)
+#define E0_PSLOT (8 * E0_CS)                // 11 776: 4 copies of the high part, 4 of the low part
+#define E0_POFF (2 * E0_HB)                 // 82 944
+#define E0_WOFF (E0_POFF + 2 * E0_PSLOT)    // 106 496: enc0b weights [9 taps][32 rows] of 64 B (in LDS: the OFF phase needs the registers)
+#define E0_SMEM (E0_WOFF + 9 * 32 * 64)     // 124 928
+#ifndef E0_OFFPRIO
+#define E0_OFFPRIO 1                        // s_setprio of a wave in its OFF phase: the OFF side (~500 instructions) is this kernel's critical path (measured: 0.398 -> 0.383 ms)
+#endif
+#define E0_NGRP 41                          // groups of 16 halo rows (648 = 40.5 x 16)
+
+// groups T0 .. T1 - 1 of a wave's share of the first conv (k_enc0_pp): all fragment reads of the batch, then its MFMAs, then its
+// conversions and writes -- one group after the other is one LDS latency + one MFMA latency per group
+template <typename ET, int T0, int T1>
+__device__ __forceinline__ void e0_first_conv_batch(const unsigned char* fp, unsigned char* op, const typename E16<ET>::v8 (&wA)[2], const f32x4 (&b0v)[2],
+                                                     bool interior, int p0 /*16 wv + li*/, int x0, int y0, int H, int W, bool low8 /*li < 8*/) {
+  using v8 = typename E16<ET>::v8;
+  using v2 = typename E16<ET>::v2;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  constexpr int N = T1 - T0;
+  u32x2 fh[N], fl[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { fh[i] = *(const u32x2*)(fp + 128 * (T0 + i)); fl[i] = *(const u32x2*)(fp + 128 * (T0 + i) + 4 * E0_CS); }
+  f32x4 a[N][2];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const u32x4 fq = {fh[i][0], fh[i][1], fl[i][0], fl[i][1]};
+#pragma unroll
+    for (int n = 0; n < 2; ++n) a[i][n] = E16<ET>::mfma(wA[n], __builtin_bit_cast(v8, fq), b0v[n]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    u32x4 o;
+    const s16x2 z = {0, 0};      // ReLU on the rounded values: a negative ET is a negative int16
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const f32x2 a01 = {a[i][n][0], a[i][n][1]}, a23 = {a[i][n][2], a[i][n][3]};
+      o[2 * n] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(a01, v2)), z));
+      o[2 * n + 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(a23, v2)), z));
+    }
+    if (!interior) {      // outside the image: the second conv's zero padding
+      const int p = p0 + 64 * (T0 + i), py = p / UD_PW, px = p - py * UD_PW;
+      const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+      if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) o = u32x4{0u, 0u, 0u, 0u};
+    }
+    if (T0 + i < 10 || low8) *(u32x4*)(op + 4096 * (T0 + i)) = o;
+  }
+}
+
+template <int EK, bool RAW /*the input is the unscaled f64 image + its bounds*/>
+__global__ void __launch_bounds__(PP_THREADS)
+k_enc0_pp(const float* __restrict__ image, const float* __restrict__ w0 /*[9][32] f32*/, const float* __restrict__ b0 /*[32]*/,
+          const u16* __restrict__ wgt_ /*enc0b, packed [9][1][32][32]*/, const float* __restrict__ bias /*[32]*/,
+          u16* __restrict__ skip_, u16* __restrict__ pooled_, int H, int W, int nimg,
+          const double* __restrict__ raw /*nullable: the UNSCALED image [nimg][H][W] f64 and ...*/,
+          const unsigned long long* __restrict__ mm_enc /*... its minimum / complemented maximum per image, encoded (k_anp_rows)*/,
+          unsigned* __restrict__ ticket, const int* __restrict__ tk_tab, int ntk) {
+  using ET = typename EKT<EK>::type;
+  using v8 = typename E16<ET>::v8;
+  using v2 = typename E16<ET>::v2;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const ET* wgt = (const ET*)wgt_;
+  ET* skip = (ET*)skip_;
+  ET* pooled = (ET*)pooled_;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[E0_SMEM];
+  __shared__ int s_q[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wv = __builtin_amdgcn_readfirstlane(wave & 3);
+  const int xh = wv & 1, rg8 = wv >> 1;
+  const int ltid = tid & (PP_GTHREADS - 1);
+  const int tiles_x = W / 32, tiles_y = H / 16;
+  if (tid == 0) { s_q[0] = pp_take_ticket(ticket); s_q[1] = pp_take_ticket(ticket); }
+
+  // ---- once per workgroup: enc0b weights -> LDS (row dealing and slot swizzle of k_conv3_dma16, NN = 2), biases, first-conv weights
+  for (int e = tid; e < 9 * 32 * 4; e += PP_THREADS) {
+    const int row = e >> 2, q = e & 3;
+    const int tap = row >> 5, j = row & 31;
+    const int ch = 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);
+    *(u32x4*)(smem + E0_WOFF + e * 16) = *(const u32x4*)(wgt + (size_t)(tap * 32 + ch) * 32 + ((q ^ ((row >> 1) & 2)) << 3));
+  }
+  f32x4 bv[2], b0v[2];
+  v8 wA[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bv[n][r] = bias[8 * lk + 4 * n + r]; b0v[n][r] = b0[8 * lk + 4 * n + r]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {      // MFMA row li of tile n = channel 8 (li >> 2) + 4 n + (li & 3): lane group lk of the result owns channels 8 lk .. 8 lk + 7
+      const float wv0 = w0[(min(lk, 2) * 3 + min(j & 3, 2)) * 32 + 8 * (li >> 2) + 4 * n + (li & 3)];
+      wA[n][j] = (lk < 3 && (j & 3) < 3) ? (ET)wv0 : (ET)0.0f;
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    pp_settle(bv[n]); pp_settle(b0v[n]);
+    u32x4 t = __builtin_bit_cast(u32x4, wA[n]);
+    pp_settle(t);
+    wA[n] = __builtin_bit_cast(v8, t);
+  }
+  __syncthreads();
+  const int t0 = __builtin_amdgcn_readfirstlane(s_q[0]);
+  __syncthreads();
+  // the patch slots start as zeros: a patch writes elements 0 .. 719 of every copy; the last rows' fragments also read the few
+  // elements behind them (against zero weights: they must be finite)
+  for (int e = tid; e < 2 * E0_PSLOT / 16; e += PP_THREADS) *(u32x4*)(smem + E0_POFF + e * 16) = u32x4{0u, 0u, 0u, 0u};
+
+  PpCursor cu;
+  if (t0 >= ntk) return;
+  {
+    cu.w = tk_tab[t0]; cu.wend = tk_tab[t0 + 1]; cu.qk = 1; cu.live = true;
+    int w = cu.w;
+    cu.tx = w % tiles_x; w /= tiles_x; cu.ty = w % tiles_y; cu.img = w / tiles_y;
+  }
+  auto advance = [&](const bool fetcher) __attribute__((always_inline)) {
+    if (cu.w + 1 < cu.wend) { ++cu.w; if (++cu.tx == tiles_x) { cu.tx = 0; if (++cu.ty == tiles_y) { cu.ty = 0; ++cu.img; } } return; }
+    const int nt = __builtin_amdgcn_readfirstlane(s_q[cu.qk]);
+    if (nt < ntk) {
+      if (fetcher) s_q[cu.qk ^ 1] = pp_take_ticket(ticket);
+      cu.qk ^= 1;
+      cu.w = tk_tab[nt]; cu.wend = tk_tab[nt + 1];
+      int w = cu.w;
+      cu.tx = w % tiles_x; w /= tiles_x; cu.ty = w % tiles_y; cu.img = w / tiles_y;
+    } else cu.live = false;
+  };
+
+  // ---- the image patch of a tile: rows y0 - 2 .. y0 + 17, columns x0 - 2 .. x0 + 33 (zero outside the image): 720 values
+  // e[row * 36 + col], three per lane of the loading group (e = ltid + 256 k).  From the unscaled image the values stay doubles while
+  // the loads are in flight; patch_store applies X * scale_ + min_ (k_anp_scale's expression, so the same float) when it splits them.
+  // Loads are unconditional (coordinates clamped into the image, the value zeroed when it is split): a load inside a branch makes
+  // hipcc wait for it at the branch's join -- the whole memory latency, in front of everything else the phase has to do.
+  struct Patch { float f[3]; double d[3]; unsigned ok; };
+  double sc = 1.0, mn = 0.0;
+  int sc_img = -1;
+  int pe_row[3], pe_col[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const int e = ltid + 256 * k; pe_row[k] = e / UD_PW; pe_col[k] = e - pe_row[k] * UD_PW; }
+  auto patch_load = [&](Patch& r) __attribute__((always_inline)) {      // the cursor's tile
+    const int x0 = cu.tx * 32, y0 = cu.ty * 16;
+    r.ok = 0u;
+    if (RAW && cu.img != sc_img) {      // (per image, not per tile: the reciprocal is a division)
+      const unsigned long long elo = mm_enc[2 * cu.img], ehi = ~mm_enc[2 * cu.img + 1];      // order-preserving encoding (k_slices.h: enc_f64 / dec_f64)
+      const double lo = __longlong_as_double((long long)((elo & 0x8000000000000000ull) ? (elo & 0x7FFFFFFFFFFFFFFFull) : ~elo));
+      const double hi = __longlong_as_double((long long)((ehi & 0x8000000000000000ull) ? (ehi & 0x7FFFFFFFFFFFFFFFull) : ~ehi));
+      double rng = hi - lo;
+      if (rng == 0.0) rng = 1.0;
+      sc = 1.0 / rng; mn = 0.0 - lo * sc;
+      sc_img = cu.img;
+    }
+    const size_t ibase = (size_t)cu.img * H * W;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int gy = y0 - 2 + pe_row[k], gx = x0 - 2 + pe_col[k];
+      const bool in = pe_row[k] < 20 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const unsigned off = (unsigned)(min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1));
+      if (RAW) r.d[k] = raw[ibase + off];
+      else r.f[k] = image[ibase + off];
+      r.ok |= in ? 1u << k : 0u;
+    }
+  };
+  // split into high and low parts; copy s of a part holds e[i + s] at index i (i = -s .. 727 - s; 8 bytes of padding in front of index 0)
+  auto patch_store = [&](int slot, const Patch& r) __attribute__((always_inline)) {
+    unsigned char* base = smem + E0_POFF + slot * E0_PSLOT + 8;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int e = ltid + 256 * k;
+      if (k < 2 || e < 720) {
+        const float val = (r.ok >> k & 1u) ? (RAW ? (float)(r.d[k] * sc + mn) : r.f[k]) : 0.0f;
+        const ET hi = (ET)val;
+        const ET lo = (ET)(val - (float)hi);
+        unsigned char* pe = base + 2 * e;
+#pragma unroll
+        for (int sft = 0; sft < 4; ++sft) {
+          *(ET*)(pe + sft * (E0_CS - 2)) = hi;                       // copy sft, index e - sft
+          *(ET*)(pe + sft * (E0_CS - 2) + 4 * E0_CS) = lo;
+        }
+      }
+    }
+  };
+  // ---- first conv: group g (16 halo rows p = 16 g + li) of a tile; wave wv of the OFF group takes g = wv + 4 t.
+  // Fragment of lane (li, lk): patch values e[q .. q + 3], q = p + 36 min(lk, 2) (lk = 3 multiplies zero weights: any finite values),
+  // from copy q & 3 = li & 3 at index q - (q & 3): byte address = lane constant + 32 g.  Output: halo row p, 16-byte slot lk.
+  const int qlane = li + UD_PW * min(lk, 2);
+  const int fr_lane = E0_POFF + 8 + (li & 3) * E0_CS + 2 * (qlane - (li & 3));      // + slot * E0_PSLOT + 32 g (+ 4 E0_CS: the low part)
+  const int out_lane = UB_OFF(li, lk) * 2;                                            // + buffer + 1024 g  (bit 2 of p = bit 2 of li)
+  auto enc0a = [&](int slot, int hb, int x0, int y0) __attribute__((always_inline)) {      // the tile at (x0, y0): patch slot -> halo buffer hb
+    const bool interior = x0 > 0 && x0 + 32 < W && y0 > 0 && y0 + 16 < H;
+    const unsigned char* fp = smem + fr_lane + slot * E0_PSLOT + 32 * wv;
+    unsigned char* op = smem + hb * E0_HB + out_lane + 1024 * wv;
+    const int p0 = 16 * wv + li;
+    e0_first_conv_batch<ET, 0, 5>(fp, op, wA, b0v, interior, p0, x0, y0, H, W, li < 8);
+    e0_first_conv_batch<ET, 5, 10>(fp, op, wA, b0v, interior, p0, x0, y0, H, W, li < 8);
+    if (wv == 0) e0_first_conv_batch<ET, 10, 11>(fp, op, wA, b0v, interior, p0, x0, y0, H, W, li < 8);      // group 40 (rows 640 .. 655: the first eight exist)
+  };
+  // fragment read offsets of the second conv (bytes inside a halo buffer): rows rg8 * 8 + s (s = 0..9), pixel xh * 16 + li + dx
+  int xoff[2][3];
+  {
+    const int rowbase = rg8 * 8 * UD_PW + xh * 16 + li;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) xoff[sp][dx] = UB_OFF(rowbase + sp * UD_PW + dx, lk) * 2;
+  }
+  // output offsets of this lane inside a tile (elements): skip0 row m of its 8, the pooled row pair
+  const unsigned so_lane = (unsigned)(((rg8 * 8) * W + xh * 16 + li) * 32 + 8 * lk);
+  const unsigned po_lane = (unsigned)(((rg8 * 4) * (W / 2) + (xh * 16 + li) / 2) * 32 + 8 * lk);
+
+  // ---- prologue: patches of items 0 and 1 -> LDS, first conv of item 0 -> halo buffer 0 (both groups share the work of these)
+  int ax0 = 0, ay0 = 0, aimg = 0;      // item p - 1
+  int bx0, by0, bimg; bool blive;      // item p
+  int cx0, cy0, cimg; bool clive;      // item p + 1
+  bool alive = false;
+  Patch pr;
+  bx0 = cu.tx * 32; by0 = cu.ty * 16; bimg = cu.img; blive = true;
+  if (grp == 0) patch_load(pr);
+  advance(tid == 0);
+  if (grp == 0) patch_store(0, pr);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  cx0 = cu.tx * 32; cy0 = cu.ty * 16; cimg = cu.img; clive = cu.live;
+  if (grp == 1) enc0a(0, 0, bx0, by0);
+  if (grp == 0 && cu.live) { patch_load(pr); patch_store(1, pr); }
+  if (cu.live) advance(tid == 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  f32x4 acc[8][2];
+#ifdef PP_STAMP      // 0 ON multiply, 1 OFF first conv, 2 ON barrier, 3 OFF patch loads issued, 4 OFF patch store + epilogue, 5 OFF barrier, 6 phases, 7 loop
+  unsigned long long st_[PP_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+  PP_T(tl0_);
+#endif
+  int bf = 0;                          // halo buffer / patch slot of item p: p & 1
+  auto phase = [&](const bool on) __attribute__((always_inline)) -> bool {
+    if (!blive && !alive) return false;
+    PP_T(ta_);
+    if (on) {
+      if (blive) {
+        const unsigned char* sb = smem + bf * E0_HB;
+        const unsigned char* wbp = smem + E0_WOFF + UB_OFF(li, lk) * 2;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int m = 0; m < 8; ++m) acc[m][n] = bv[n];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          v8 xq[10];
+#pragma unroll
+          for (int s = 0; s < 10; ++s) xq[s] = *(const v8*)(sb + xoff[s & 1][dx] + (s & ~1) * UD_PW * 64);
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            v8 wf[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) wf[n] = *(const v8*)(wbp + ((dy * 3 + dx) * 32 + n * 16) * 64);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+              for (int n = 0; n < 2; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xq[m + dy], acc[m][n]);
+          }
+        }
+      }
+#ifdef PP_STAMP
+      asm volatile("" :: "v"(acc[7][1]), "v"(acc[0][0]));
+#endif
+      PP_T(tb_);
+      PP_ADD(0, ta_, tb_);
+    } else {
+      // item p + 2 (the cursor): its patch loads are in flight during the rest of the phase
+      const bool stage2 = cu.live;
+      if (E0_OFFPRIO) __builtin_amdgcn_s_setprio(E0_OFFPRIO);
+      if (stage2) patch_load(pr);
+      PP_T(tb_);
+      if (clive) enc0a(bf ^ 1, bf ^ 1, cx0, cy0);      // item p + 1: patch slot and halo buffer (p + 1) & 1
+      PP_T(tc_);
+      PP_ADD(3, ta_, tb_); PP_ADD(1, tb_, tc_);
+      // (in front of the epilogue: the compiler's wait for the patch loads then does not include the epilogue's stores)
+      if (stage2) patch_store(bf, pr);      // slot (p + 2) & 1 = p & 1: its last reader was enc0a of item p, one barrier ago
+      if (alive) {
+        // epilogue of item p - 1: rounded, ReLU'd on the rounded values, 16 bytes (8 consecutive channels) per pixel and lane
+        ET* out = skip + ((size_t)aimg * H * W + (size_t)ay0 * W + ax0) * 32 + so_lane;
+        u32x4 o[8];
+        const s16x2 z = {0, 0};
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const f32x2 a01 = {acc[m][n][0], acc[m][n][1]}, a23 = {acc[m][n][2], acc[m][n][3]};
+            o[m][2 * n] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(a01, v2)), z));
+            o[m][2 * n + 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(a23, v2)), z));
+          }
+          ud_store16(out + (size_t)m * W * 32, o[m]);
+        }
+        // 2x2 max pool on the rounded values (non-negative ETs order like int16): rows pair inside the lane, columns with lane li ^ 1
+        ET* po = pooled + ((size_t)aimg * (H / 2) * (W / 2) + (size_t)(ay0 / 2) * (W / 2) + ax0 / 2) * 32 + po_lane;
+        unsigned pv[16];
+#pragma unroll
+        for (int mp = 0; mp < 4; ++mp)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pv[4 * mp + i] = pp_pkmax(o[2 * mp][i], o[2 * mp + 1][i]);
+        pp_pkmax_lane1_n(pv);
+#pragma unroll
+        for (int mp = 0; mp < 4; ++mp) {
+          const u32x4 v = {pv[4 * mp], pv[4 * mp + 1], pv[4 * mp + 2], pv[4 * mp + 3]};
+          if ((li & 1) == 0) ud_store16(po + (size_t)mp * (W / 2) * 32, v);
+        }
+      }
+      if (E0_OFFPRIO) __builtin_amdgcn_s_setprio(0);
+      PP_T(tf_);
+      PP_ADD(4, tc_, tf_);
+    }
+    PP_T(td_);
+    ax0 = bx0; ay0 = by0; aimg = bimg; alive = blive;
+    bx0 = cx0; by0 = cy0; bimg = cimg; blive = clive;
+    cx0 = cu.tx * 32; cy0 = cu.ty * 16; cimg = cu.img; clive = cu.live;
+    if (cu.live) advance(on && ltid == 0);
+    bf ^= 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    PP_T(te_);
+    PP_ADD(on ? 2 : 5, td_, te_);
+#ifdef PP_STAMP
+    st_[6] += 1;
+#endif
+    return true;
+  };
+  if (grp == 0) {
+#pragma unroll 1
+    for (;;) { if (!phase(true)) break; if (!phase(false)) break; }
+  } else {
+#pragma unroll 1
+    for (;;) { if (!phase(false)) break; if (!phase(true)) break; }
+  }
+#ifdef PP_STAMP
+  {
+    PP_T(tl1_);
+    st_[7] = tl1_ - tl0_;
+    if (lane == 0 && blockIdx.x < 256)
+      for (int i = 0; i < PP_NSTAMP; ++i) pp_stamp[(256 * 8 + blockIdx.x * 8 + wave) * PP_NSTAMP + i] = st_[i];
   }
 #endif
 }

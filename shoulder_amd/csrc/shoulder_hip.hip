@@ -1543,8 +1543,17 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
     const sh_ctx::ULayer& lb = L("enc0b");
     if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
     const int total = nimg * (w / 32) * (h / 16);
-    LAUNCH(c, "unet.enc0b", (k_enc0_fused16<EK>), dim3((unsigned)std::min(total, persistent_grid(c))), dim3(L0_THREADS), image, P + la.w_off, P + la.b_off,
-           PW + lb.w_off, P + lb.b_off, skip[0], A, h, w, nimg, c->unet_raw, c->unet_mm);
+    const unsigned grid = (unsigned)std::min(total, persistent_grid(c));
+    unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
+    if ((rc = dma_tickets(c, total, (int)grid, 1, &tk, &tk_tab, &ntk)) != SH_OK) return rc;
+    if (tk != nullptr && !(getenv("SHOULDER_L0_PP") && getenv("SHOULDER_L0_PP")[0] == '0') && !(getenv("SHOULDER_ENC0_PP") && getenv("SHOULDER_ENC0_PP")[0] == '0')) {
+      // the two waves of a SIMD take turns on the matrix pipe (k_unet16_pp.h)
+      LAUNCH_FN(c, "unet.enc0b", launch_enc0_pp(EK, grid, c->stream, image, P + la.w_off, P + la.b_off, PW + lb.w_off, P + lb.b_off, skip[0], A, h, w, nimg,
+                                                c->unet_raw, c->unet_mm, tk, tk_tab, ntk));
+    } else {
+      LAUNCH(c, "unet.enc0b", (k_enc0_fused16<EK>), dim3(grid), dim3(L0_THREADS), image, P + la.w_off, P + la.b_off,
+             PW + lb.w_off, P + lb.b_off, skip[0], A, h, w, nimg, c->unet_raw, c->unet_mm);
+    }
   } else if (fused && !(ff && ff[0] == '0')) {
     const sh_ctx::ULayer& l = L("enc0a");
     ConvFuse fz{};

@@ -9,4 +9,9 @@ void launch_dec0b_head_pp(int ek, unsigned grid, hipStream_t st, const unsigned 
                           const float* head_w, const float* head_b, float* logits, int H, int W, int nimg, const unsigned short* zero_page,
                           unsigned* ticket, const int* tk_tab, int ntk);
 
+// enc0a + enc0b + pool on the ping-pong kernel (image: f32 [nimg][H][W], or raw + mm: the unscaled f64 image and its encoded bounds)
+void launch_enc0_pp(int ek, unsigned grid, hipStream_t st, const float* image, const float* w0, const float* b0, const unsigned short* wgt,
+                    const float* bias, unsigned short* skip, unsigned short* pooled, int H, int W, int nimg, const double* raw,
+                    const unsigned long long* mm, unsigned* ticket, const int* tk_tab, int ntk);
+
 }  // namespace sh

@@ -12,11 +12,20 @@ void launch_dec0b_head_pp(int ek, unsigned grid, hipStream_t st, const unsigned 
   else hipLaunchKernelGGL((k_dec0b_head_pp<1>), dim3(grid), dim3(PP_THREADS), 0, st, src, wgt, bias, head_w, head_b, logits, H, W, nimg, zero_page, ticket, tk_tab, ntk);
 }
 
+void launch_enc0_pp(int ek, unsigned grid, hipStream_t st, const float* image, const float* w0, const float* b0, const unsigned short* wgt,
+                    const float* bias, unsigned short* skip, unsigned short* pooled, int H, int W, int nimg, const double* raw,
+                    const unsigned long long* mm, unsigned* ticket, const int* tk_tab, int ntk) {
+#define E0_GO(EK, RAW) hipLaunchKernelGGL((k_enc0_pp<EK, RAW>), dim3(grid), dim3(PP_THREADS), 0, st, image, w0, b0, wgt, bias, skip, pooled, H, W, nimg, raw, mm, ticket, tk_tab, ntk)
+  if (ek == 0) { if (raw) E0_GO(0, true); else E0_GO(0, false); }
+  else { if (raw) E0_GO(1, true); else E0_GO(1, false); }
+#undef E0_GO
+}
+
 }  // namespace sh
 
 #ifdef PP_STAMP
-// diagnostic build only: the stamps of the most recent stamped launch -> out[256][8][PP_NSTAMP]
+// diagnostic build only: the stamps of the most recent stamped launch -> out[2][256][8][PP_NSTAMP]
 extern "C" int sh_lab_pp_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sh::pp_stamp), sizeof(unsigned long long) * 256 * 8 * PP_NSTAMP);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sh::pp_stamp), sizeof(unsigned long long) * 2 * 256 * 8 * PP_NSTAMP);
 }
 #endif
