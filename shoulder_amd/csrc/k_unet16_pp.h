@@ -34,6 +34,9 @@ namespace sh {
 #ifndef PP_K1
 #define PP_K1 11                             // pieces 0 .. PP_K1 - 1 of a tile are issued by the OFF group, the rest by the ON group behind its MFMAs
 #endif
+#ifndef PP_G1PRIO
+#define PP_G1PRIO 0                          // static s_setprio of the second-dispatched group (waves 4 .. 7: the loser of every age-based arbitration)
+#endif
 #ifndef PP_OFFPRIO
 #define PP_OFFPRIO 0                         // s_setprio of a wave in its OFF phase
 #endif
@@ -80,7 +83,7 @@ __device__ inline float pp_swap32_add(float x, float y) {
 // pp_stamp[blockIdx][wave][part] (s_memtime ticks = shader cycles; cdna_hip_programming.md section 7, in-kernel stamps).
 #ifdef PP_STAMP
 #define PP_NSTAMP 8      // 0 ON multiply, 1 ON vm wait, 2 ON barrier, 3 OFF stage, 4 OFF epilogue, 5 OFF barrier, 6 phases, 7 whole loop
-__device__ unsigned long long pp_stamp[2 * 256 * 8 * PP_NSTAMP];      // [kernel: 0 dec0b + head, 1 enc0][workgroup][wave][part]
+__device__ unsigned long long pp_stamp[3 * 256 * 8 * PP_NSTAMP];      // [kernel: 0 dec0b + head, 1 enc0, 2 dec0a][workgroup][wave][part]
 #define PP_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #define PP_ADD(i, a, b) st_[i] += (b) - (a)
 #else
@@ -373,6 +376,7 @@ k_dec0b_head_pp(const u16* __restrict__ src_ /*[img][H W][32]*/, const u16* __re
     return true;
   };
   // (the roles run separate loops: in one shared body hipcc keeps one role's registers alive through the other's branch)
+  if (PP_G1PRIO && grp == 1) __builtin_amdgcn_s_setprio(PP_G1PRIO);
   if (grp == 0) {
 #pragma unroll 1
     for (;;) { if (!phase(true)) break; if (!phase(false)) break; }
@@ -736,6 +740,7 @@ k_enc0_pp(const float* __restrict__ image, const float* __restrict__ w0 /*[9][32
 #endif
     return true;
   };
+  if (PP_G1PRIO && grp == 1) __builtin_amdgcn_s_setprio(PP_G1PRIO);
   if (grp == 0) {
 #pragma unroll 1
     for (;;) { if (!phase(true)) break; if (!phase(false)) break; }
@@ -749,6 +754,365 @@ k_enc0_pp(const float* __restrict__ image, const float* __restrict__ w0 /*[9][32
     st_[7] = tl1_ - tl0_;
     if (lane == 0 && blockIdx.x < 256)
       for (int i = 0; i < PP_NSTAMP; ++i) pp_stamp[(256 * 8 + blockIdx.x * 8 + wave) * PP_NSTAMP + i] = st_[i];
+  }
+#endif
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// dec0a with its up-convolution:  dec0a( concat( skip0 [32 ch, H x W],  up0( low [64 ch, H/2 x W/2] ) ) ) -> 32 ch, H x W, ping-pong.
+// Tiles are 32 x 8 pixels (two sets of every buffer fit beside the conv's weights: 2 x (skip halo 23 040 + up halo 23 040 + low tile
+// 13 824) + 36 864 = 156 672 bytes), walked down the image columns (ty fastest: the two halo rows a tile shares with the tile above
+// were fetched one phase ago).
+//   ON  (group p & 1):  the conv of tile p, both 32-channel chunks: skip(p) then up(p); 144 MFMAs per wave (4 rows x 16 pixels x 32 couts)
+//   OFF (other group):  LDS-DMA of skip(p + 1) and of low(p + 2); up-conv of tile p + 1 on the matrix cores (low(p + 1) -> up(p + 1): a wave
+//                       owns one of the four output phases, its four weight fragments stay in registers); epilogue of tile p - 1;
+//                       counted wait: the pieces have landed (the epilogue's four stores may still be in flight)
+// Same arithmetic in the same order as k_dec0a_up16 (and so as k_upconv16 + k_conv3_dma16): the same tensor bit for bit.
+#define DA_ROWS (10 * UD_PW)                 // 360 halo rows of 64 B: 10 x 34 pixels at pitch 36
+#define DA_HB (DA_ROWS * 64)                 // 23 040
+#define DA_LROWS 108                         // 6 x 18 low-resolution pixels per 32-channel chunk
+#define DA_LB (2 * DA_LROWS * 64)            // 13 824
+#define DA_UP (2 * DA_HB)                    // 46 080
+#define DA_LOW (4 * DA_HB)                   // 92 160
+#define DA_W (DA_LOW + 2 * DA_LB)            // 119 808: dec0a weights [2 chunks][9 taps][32 rows] of 64 B
+#define DA_SMEM (DA_W + 2 * 9 * 32 * 64)     // 156 672
+#define DA_NSP 6                             // LDS-DMA pieces per staging wave: skip halo (1 440 slots of 16 B) ...
+#define DA_NLP 4                             // ... and low tile (864 slots)
+
+template <int EK>
+__global__ void __launch_bounds__(PP_THREADS)
+k_dec0a_up_pp(const u16* __restrict__ skip_ /*[img][H W][32]*/, const u16* __restrict__ low_ /*[img][2][H/2 W/2][32]*/,
+              const u16* __restrict__ wgt_ /*dec0a packed [9][2][32][32]*/, const float* __restrict__ bias,
+              const u16* __restrict__ wup_ /*up0 packed [4][2][32][32]*/, const float* __restrict__ upb,
+              u16* __restrict__ dst_ /*[img][H W][32]*/, int H, int W, int nimg, const u16* __restrict__ zero_page_,
+              unsigned* __restrict__ ticket, const int* __restrict__ tk_tab, int ntk) {
+  using ET = typename EKT<EK>::type;
+  using v8 = typename E16<ET>::v8;
+  using v2 = typename E16<ET>::v2;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const ET* skip = (const ET*)skip_;
+  const ET* low = (const ET*)low_;
+  const ET* wgt = (const ET*)wgt_;
+  const ET* wup = (const ET*)wup_;
+  ET* dst = (ET*)dst_;
+  const ET* zero_page = (const ET*)zero_page_;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[DA_SMEM];
+  __shared__ int s_q[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wv = __builtin_amdgcn_readfirstlane(wave & 3);
+  const int xh = wv & 1, rg4 = wv >> 1;
+  const int ltid = tid & (PP_GTHREADS - 1);
+  const int H2 = H >> 1, W2 = W >> 1;
+  const int tiles_x = W / 32, tiles_y = H / 8;
+  if (tid == 0) { s_q[0] = pp_take_ticket(ticket); s_q[1] = pp_take_ticket(ticket); }
+
+  // ---- once per workgroup: the conv's weights -> LDS; this wave's up-conv fragments and the biases -> registers
+  // dec0a: LDS row (chunk, tap, 16 n + i) <- packed row (tap, chunk, channel 8 (i >> 2) + 4 n + (i & 3)); slot swizzle on the source
+  for (int e = tid; e < 2 * 9 * 32 * 4; e += PP_THREADS) {
+    const int row = e >> 2, q = e & 3;
+    const int cc = row / 288, rem = row - cc * 288, tap = rem >> 5, j = rem & 31;
+    const int ch = 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);
+    *(u32x4*)(smem + DA_W + e * 16) = *(const u32x4*)(wgt + (size_t)((tap * 2 + cc) * 32 + ch) * 32 + ((q ^ ((row >> 1) & 2)) << 3));
+  }
+  // up0: phase wv, chunk kc, cout tile n: MFMA row li = channel 8 (li >> 2) + 4 n + (li & 3), k = 8 lk .. 8 lk + 7
+  v8 uw[2][2];
+  f32x4 bv[2], ub[2];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      u32x4 t = *(const u32x4*)(wup + (size_t)((wv * 2 + kc) * 32 + 8 * (li >> 2) + 4 * n + (li & 3)) * 32 + 8 * lk);
+      pp_settle(t);
+      uw[kc][n] = __builtin_bit_cast(v8, t);
+    }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bv[n][r] = bias[8 * lk + 4 * n + r]; ub[n][r] = upb[8 * lk + 4 * n + r]; }
+    pp_settle(bv[n]); pp_settle(ub[n]);
+  }
+  __syncthreads();
+  const int t0 = __builtin_amdgcn_readfirstlane(s_q[0]);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  PpCursor cu;
+  if (t0 >= ntk) return;
+  auto decode = [&](int w) __attribute__((always_inline)) { cu.ty = w % tiles_y; w /= tiles_y; cu.tx = w % tiles_x; cu.img = w / tiles_x; };
+  cu.w = tk_tab[t0]; cu.wend = tk_tab[t0 + 1]; cu.qk = 1; cu.live = true;
+  decode(cu.w);
+  auto advance = [&](const bool fetcher) __attribute__((always_inline)) {
+    if (cu.w + 1 < cu.wend) { ++cu.w; if (++cu.ty == tiles_y) { cu.ty = 0; if (++cu.tx == tiles_x) { cu.tx = 0; ++cu.img; } } return; }
+    const int nt = __builtin_amdgcn_readfirstlane(s_q[cu.qk]);
+    if (nt < ntk) {
+      if (fetcher) s_q[cu.qk ^ 1] = pp_take_ticket(ticket);
+      cu.qk ^= 1;
+      cu.w = tk_tab[nt]; cu.wend = tk_tab[nt + 1];
+      decode(cu.w);
+    } else cu.live = false;
+  };
+
+  // ---- staging plans of a group (lane constants).  Skip halo: slot e = ltid + 256 k -> row e >> 2 = py * 36 + px; low tile: slot e ->
+  // chunk e / 432, row (e % 432) >> 2 = a * 18 + b.  The 16-byte slot of a row is XOR-swizzled on the source address (bit 2 of the row).
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ud_lptr)smem);
+  const unsigned wv1024 = (unsigned)(wv * 1024);
+  int svoff[DA_NSP], lvoff[DA_NLP];
+  const int sq8 = ((ltid & 3) ^ (((ltid >> 2) >> 1) & 2)) * 8;
+#pragma unroll
+  for (int k = 0; k < DA_NSP; ++k) {
+    const int r = (ltid >> 2) + 64 * k, py = r / UD_PW, px = r - py * UD_PW;
+    svoff[k] = (r < DA_ROWS && px < 34) ? ((py * W + px) * 32 + sq8) * 2 : ((W + 1) * 32 + sq8) * 2;
+  }
+#pragma unroll
+  for (int k = 0; k < DA_NLP; ++k) {
+    const int e = ltid + 256 * k, c = e >= 4 * DA_LROWS ? 1 : 0, rem = e - c * 4 * DA_LROWS, lr = rem >> 2;
+    const int a = lr / 18, b = lr - a * 18;
+    lvoff[k] = (c * (H2 * W2) + a * W2 + b) * 64 + (((rem & 3) ^ ((lr >> 1) & 2)) << 4);
+  }
+  const bool s5 = (ltid >> 2) + 64 * 5 < DA_ROWS, l3 = ltid + 256 * 3 < 2 * 4 * DA_LROWS;      // the lanes of the last, partial pieces
+  auto stage_skip = [&](int bf) __attribute__((always_inline)) {      // the cursor's tile -> skip buffer bf
+    const ET* simg = skip + (size_t)cu.img * H * W * 32;
+    const unsigned lb = lds0 + (unsigned)(bf * DA_HB) + wv1024;
+    if (cu.tx > 0 && cu.tx + 1 < tiles_x && cu.ty > 0 && cu.ty + 1 < tiles_y) {      // interior: every halo pixel is inside the image
+      const ET* base = simg + ((size_t)(cu.ty * 8 - 1) * W + (cu.tx * 32 - 1)) * 32;
+#pragma unroll
+      for (int k = 0; k < DA_NSP; ++k)
+        if (k < DA_NSP - 1 || s5) ud_dma16_s(lb + k * 4096, (unsigned)svoff[k], base);
+    } else {
+#pragma unroll
+      for (int k = 0; k < DA_NSP; ++k) {
+        const int r = (ltid >> 2) + 64 * k, py = r / UD_PW, px = r - py * UD_PW;
+        const int gx = cu.tx * 32 + px - 1, gy = cu.ty * 8 + py - 1;
+        const bool ok = px < 34 && gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const ET* p = ok ? simg + (unsigned)((gy * W + gx) * 32 + sq8) : zero_page;
+        if (k < DA_NSP - 1 || s5) ud_dma16(lb + k * 4096, p);
+      }
+    }
+  };
+  auto stage_low = [&](int bf) __attribute__((always_inline)) {      // the cursor's tile -> low buffer bf
+    const ET* limg = low + (size_t)cu.img * H2 * W2 * 64;
+    const unsigned lb = lds0 + (unsigned)(DA_LOW + bf * DA_LB) + wv1024;
+    if (cu.tx > 0 && cu.tx + 1 < tiles_x && cu.ty > 0 && cu.ty + 1 < tiles_y) {
+      const ET* base = limg + ((size_t)(cu.ty * 4 - 1) * W2 + (cu.tx * 16 - 1)) * 32;
+#pragma unroll
+      for (int k = 0; k < DA_NLP; ++k)
+        if (k < DA_NLP - 1 || l3) ud_dma16_s(lb + k * 4096, (unsigned)lvoff[k], base);
+    } else {
+#pragma unroll
+      for (int k = 0; k < DA_NLP; ++k) {
+        const int e = ltid + 256 * k, c = e >= 4 * DA_LROWS ? 1 : 0, rem = e - c * 4 * DA_LROWS, lr = rem >> 2;
+        const int a = lr / 18, b = lr - a * 18;
+        const int ly = cu.ty * 4 - 1 + a, lx = cu.tx * 16 - 1 + b;
+        const bool ok = ly >= 0 && ly < H2 && lx >= 0 && lx < W2;
+        const ET* p = ok ? limg + (size_t)c * H2 * W2 * 32 + (unsigned)((ly * W2 + lx) * 32 + (((rem & 3) ^ ((lr >> 1) & 2)) << 3)) : zero_page;
+        if (k < DA_NLP - 1 || l3) ud_dma16(lb + k * 4096, p);
+      }
+    }
+  };
+  // ---- the up-conv half of a halo tile: phase (pdy, pdx) = (wv >> 1, wv & 1) of this wave: 5 x 17 pixels, six groups of 16
+  const int pdy = wv >> 1, pdx = wv & 1;
+  int u_low[6], u_out[6];      // byte offsets: the low pixel's row in a chunk of the low tile, the halo row in the up buffer (-1: no pixel)
+#pragma unroll
+  for (int g = 0; g < 6; ++g) {
+    const int t = 16 * g + li;
+    const bool valid = t < 85;
+    const int a = valid ? t / 17 : 0, bc = valid ? t - a * 17 : 0;
+    const int lowrow = (a + (pdy == 0 ? 1 : 0)) * 18 + bc + (pdx == 0 ? 1 : 0);
+    const int py = 2 * a + (pdy == 0 ? 1 : 0), px = 2 * bc + (pdx == 0 ? 1 : 0);
+    u_low[g] = UB_OFF(lowrow, lk) * 2;
+    u_out[g] = valid ? UB_OFF(py * UD_PW + px, lk) * 2 : -1;
+  }
+  auto upconv = [&](int lb, int ub_, int x0, int y0) __attribute__((always_inline)) {      // low buffer lb -> up buffer ub_, the tile at (x0, y0)
+    const bool interior = x0 > 0 && x0 + 32 < W && y0 > 0 && y0 + 8 < H;
+    const unsigned char* lp = smem + DA_LOW + lb * DA_LB;
+    unsigned char* op = smem + DA_UP + ub_ * DA_HB;
+#pragma unroll
+    for (int g0 = 0; g0 < 6; g0 += 3) {      // (two batches of three groups: reads, MFMAs, conversions and writes of a batch together)
+      v8 xf[3][2];
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) xf[g][kc] = *(const v8*)(lp + kc * (DA_LROWS * 64) + u_low[g0 + g]);
+      f32x4 ua[3][2];
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          ua[g][n] = ub[n];
+#pragma unroll
+          for (int kc = 0; kc < 2; ++kc) ua[g][n] = E16<ET>::mfma(uw[kc][n], xf[g][kc], ua[g][n]);
+        }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        u32x4 o;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const f32x2 a01 = {ua[g][n][0], ua[g][n][1]}, a23 = {ua[g][n][2], ua[g][n][3]};
+          o[2 * n] = __builtin_bit_cast(unsigned, __builtin_convertvector(a01, v2));
+          o[2 * n + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(a23, v2));
+        }
+        if (!interior) {      // outside the image: the conv's zero padding
+          const int t = 16 * (g0 + g) + li, a = t / 17, bc = t - a * 17;
+          const int gy = y0 - 1 + 2 * a + (pdy == 0 ? 1 : 0), gx = x0 - 1 + 2 * bc + (pdx == 0 ? 1 : 0);
+          if (!(gy >= 0 && gy < H && gx >= 0 && gx < W)) o = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (u_out[g0 + g] >= 0) *(u32x4*)(op + u_out[g0 + g]) = o;
+      }
+    }
+  };
+  // fragment read offsets of the conv (bytes inside a halo buffer): rows rg4 * 4 + s (s = 0..5), pixel xh * 16 + li + dx
+  int xoff[2][3];
+  {
+    const int rowbase = rg4 * 4 * UD_PW + xh * 16 + li;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) xoff[sp][dx] = UB_OFF(rowbase + sp * UD_PW + dx, lk) * 2;
+  }
+  const int woff = UB_OFF(li, lk) * 2;
+  const unsigned so_lane = (unsigned)(((rg4 * 4) * W + xh * 16 + li) * 32 + 8 * lk);
+
+  // ---- prologue: low(0), skip(0), low(1) land; up(0) is computed
+  int ax0 = 0, ay0 = 0, aimg = 0;      // item p - 1
+  int bx0, by0, bimg; bool blive;      // item p
+  int cx0, cy0, cimg; bool clive;      // item p + 1
+  bool alive = false;
+  bx0 = cu.tx * 32; by0 = cu.ty * 8; bimg = cu.img; blive = true;
+  if (grp == 0) stage_low(0); else stage_skip(0);
+  advance(tid == 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  cx0 = cu.tx * 32; cy0 = cu.ty * 8; cimg = cu.img; clive = cu.live;
+  if (grp == 0 && cu.live) stage_low(1);
+  if (grp == 1) upconv(0, 0, bx0, by0);
+  if (cu.live) advance(tid == 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  f32x4 acc[4][2];
+#ifdef PP_STAMP      // 0 ON multiply, 1 OFF up-conv, 2 ON barrier, 3 OFF pieces issued, 4 OFF epilogue + vm wait, 5 OFF barrier, 6 phases, 7 loop
+  unsigned long long st_[PP_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
+  PP_T(tl0_);
+#endif
+  int bf = 0;                          // buffers of item p: p & 1
+  auto phase = [&](const bool on) __attribute__((always_inline)) -> bool {
+    if (!blive && !alive) return false;
+    PP_T(ta_);
+    if (on) {
+      if (blive) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[m][n] = bv[n];
+        // Six groups (chunk, dx) of three taps.  The pixel rows of the next group and the (up chunk's) weight fragments of the next tap
+        // are requested before the MFMAs of this tap: hipcc otherwise reads a fragment right in front of its first use, one exposed
+        // LDS latency per four MFMAs (measured: 4 000 - 4 800 cycles for the 144 MFMAs of a phase).
+        const unsigned char* sb0 = smem + bf * DA_HB;
+        const unsigned char* sb1 = smem + DA_UP + bf * DA_HB;
+        const unsigned char* wbp = smem + DA_W + woff;
+        v8 xq[2][6], wf[3][2];
+        auto tap_of = [](int t) { const int g = t / 3, dy = t % 3; return (g / 3) * 9 + dy * 3 + g % 3; };      // t = 3 (3 chunk + dx) + dy -> packed tap row block
+#pragma unroll
+        for (int s = 0; s < 6; ++s) xq[0][s] = *(const v8*)(sb0 + xoff[s & 1][0] + (s & ~1) * UD_PW * 64);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) wf[t][n] = *(const v8*)(wbp + (tap_of(t) * 32 + n * 16) * 64);
+#pragma unroll
+        for (int t = 0; t < 18; ++t) {
+          const int g = t / 3, dy = t % 3;
+          if (dy == 0 && g + 1 < 6) {      // the next group's six pixel rows
+            const unsigned char* sbn = (g + 1) / 3 == 0 ? sb0 : sb1;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) xq[(g + 1) & 1][s] = *(const v8*)(sbn + xoff[s & 1][(g + 1) % 3] + (s & ~1) * UD_PW * 64);
+          }
+          if (t + 2 < 18) {      // the weight fragments of the tap after the next
+#pragma unroll
+            for (int n = 0; n < 2; ++n) wf[(t + 2) % 3][n] = *(const v8*)(wbp + (tap_of(t + 2) * 32 + n * 16) * 64);
+          }
+          __builtin_amdgcn_sched_barrier(0);      // (requests in front of this tap's MFMAs, MFMAs in front of the next requests)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = E16<ET>::mfma(wf[t % 3][n], xq[g & 1][m + dy], acc[m][n]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#ifdef PP_STAMP
+      asm volatile("" :: "v"(acc[3][1]), "v"(acc[0][0]));
+#endif
+      PP_T(tb_);
+      PP_ADD(0, ta_, tb_);
+    } else {
+      // item p + 1 (c): its skip tile; item p + 2 (the cursor): its low tile -- both land during this phase
+      bool had_stores = false;
+      if (clive) {
+        const PpCursor keep = cu;
+        cu.tx = cx0 >> 5; cu.ty = cy0 >> 3; cu.img = cimg;
+        stage_skip(bf ^ 1);
+        cu = keep;
+      }
+      if (cu.live) stage_low(bf);
+      PP_T(tb_);
+      if (clive) upconv(bf ^ 1, bf ^ 1, cx0, cy0);
+      PP_T(tc_);
+      PP_ADD(3, ta_, tb_); PP_ADD(1, tb_, tc_);
+      if (alive) {
+        ET* out = dst + ((size_t)aimg * H * W + (size_t)ay0 * W + ax0) * 32 + so_lane;
+        const s16x2 z = {0, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          u32x4 o;
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const f32x2 a01 = {acc[m][n][0], acc[m][n][1]}, a23 = {acc[m][n][2], acc[m][n][3]};
+            o[2 * n] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(a01, v2)), z));
+            o[2 * n + 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, __builtin_convertvector(a23, v2)), z));
+          }
+          ud_store16(out + (size_t)m * W * 32, o);
+        }
+        had_stores = true;
+      }
+      // the pieces have landed (they are older than the stores)
+      if (had_stores) pp_wait_vm<4>(); else pp_wait_vm<0>();
+      PP_T(tf_);
+      PP_ADD(4, tc_, tf_);
+    }
+    PP_T(td_);
+    ax0 = bx0; ay0 = by0; aimg = bimg; alive = blive;
+    bx0 = cx0; by0 = cy0; bimg = cimg; blive = clive;
+    cx0 = cu.tx * 32; cy0 = cu.ty * 8; cimg = cu.img; clive = cu.live;
+    if (cu.live) advance(on && ltid == 0);
+    bf ^= 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    PP_T(te_);
+    PP_ADD(on ? 2 : 5, td_, te_);
+#ifdef PP_STAMP
+    st_[6] += 1;
+#endif
+    return true;
+  };
+  if (PP_G1PRIO && grp == 1) __builtin_amdgcn_s_setprio(PP_G1PRIO);
+  if (grp == 0) {
+#pragma unroll 1
+    for (;;) { if (!phase(true)) break; if (!phase(false)) break; }
+  } else {
+#pragma unroll 1
+    for (;;) { if (!phase(false)) break; if (!phase(true)) break; }
+  }
+#ifdef PP_STAMP
+  {
+    PP_T(tl1_);
+    st_[7] = tl1_ - tl0_;
+    if (lane == 0 && blockIdx.x < 256)
+      for (int i = 0; i < PP_NSTAMP; ++i) pp_stamp[(2 * 256 * 8 + blockIdx.x * 8 + wave) * PP_NSTAMP + i] = st_[i];
   }
 #endif
 }

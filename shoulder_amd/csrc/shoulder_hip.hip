@@ -1599,6 +1599,21 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
       if ((rc = ensure(c, "unet16.zero", 256, 2)) != SH_OK) return rc;
       if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
       if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
+      const sh_ctx::ULayer& lh = L("head");
+      if (h % 8 == 0 && !(getenv("SHOULDER_L0_PP") && getenv("SHOULDER_L0_PP")[0] == '0') && !(getenv("SHOULDER_DEC0A_PP") && getenv("SHOULDER_DEC0A_PP")[0] == '0')) {
+        // the two waves of a SIMD take turns on the matrix pipe (k_unet16_pp.h: 32 x 8 tiles; the same tensor bit for bit)
+        const int total8 = nimg * (w / 32) * (h / 8);
+        const unsigned g8 = (unsigned)std::min(total8, persistent_grid(c));
+        unsigned* tk8 = nullptr; const int* tk_tab8 = nullptr; int ntk8 = 0;
+        if ((rc = dma_tickets(c, total8, (int)g8, 1, &tk8, &tk_tab8, &ntk8)) != SH_OK) return rc;
+        if (tk8 != nullptr) {
+          LAUNCH_FN(c, "unet.dec0a", launch_dec0a_up_pp(EK, g8, c->stream, skip[0], x, PW + la.w_off, P + la.b_off, PW + lu.w_off, P + lu.b_off, y, h, w, nimg,
+                                                        (const u16*)c->bufs["unet16.zero"].p, tk8, tk_tab8, ntk8));
+          ConvFuse fz{};
+          fz.head_w = P + lh.w_off; fz.head_b = P + lh.b_off; fz.logits = logits;
+          return conv_layer16<EK>(c, ("unet." + nb).c_str(), L(nb), y, nullptr, ch, 0, x, h, w, nimg, 1, UF_HEAD, fz);
+        }
+      }
       const int total = nimg * (w / 32) * (h / 16);
       const bool tickets_on = !(getenv("SHOULDER_DMA_TICKETS") && getenv("SHOULDER_DMA_TICKETS")[0] == '0');
       const YieldArg yl = (tickets_on && total >= c->num_cus) ? yield_arg(c) : YieldArg{nullptr, 0, 0};

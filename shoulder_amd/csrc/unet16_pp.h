@@ -14,4 +14,9 @@ void launch_enc0_pp(int ek, unsigned grid, hipStream_t st, const float* image, c
                     const float* bias, unsigned short* skip, unsigned short* pooled, int H, int W, int nimg, const double* raw,
                     const unsigned long long* mm, unsigned* ticket, const int* tk_tab, int ntk);
 
+// up0 + dec0a on the ping-pong kernel (32 x 8 tiles: tk_tab over nimg * (W / 32) * (H / 8) items)
+void launch_dec0a_up_pp(int ek, unsigned grid, hipStream_t st, const unsigned short* skip, const unsigned short* low, const unsigned short* wgt,
+                        const float* bias, const unsigned short* wup, const float* upb, unsigned short* dst, int H, int W, int nimg,
+                        const unsigned short* zero_page, unsigned* ticket, const int* tk_tab, int ntk);
+
 }  // namespace sh

@@ -23,9 +23,18 @@ void launch_enc0_pp(int ek, unsigned grid, hipStream_t st, const float* image, c
 
 }  // namespace sh
 
+namespace sh {
+void launch_dec0a_up_pp(int ek, unsigned grid, hipStream_t st, const unsigned short* skip, const unsigned short* low, const unsigned short* wgt,
+                        const float* bias, const unsigned short* wup, const float* upb, unsigned short* dst, int H, int W, int nimg,
+                        const unsigned short* zero_page, unsigned* ticket, const int* tk_tab, int ntk) {
+  if (ek == 0) hipLaunchKernelGGL((k_dec0a_up_pp<0>), dim3(grid), dim3(PP_THREADS), 0, st, skip, low, wgt, bias, wup, upb, dst, H, W, nimg, zero_page, ticket, tk_tab, ntk);
+  else hipLaunchKernelGGL((k_dec0a_up_pp<1>), dim3(grid), dim3(PP_THREADS), 0, st, skip, low, wgt, bias, wup, upb, dst, H, W, nimg, zero_page, ticket, tk_tab, ntk);
+}
+}  // namespace sh
+
 #ifdef PP_STAMP
-// diagnostic build only: the stamps of the most recent stamped launch -> out[2][256][8][PP_NSTAMP]
+// diagnostic build only: the stamps of the most recent stamped launch -> out[3][256][8][PP_NSTAMP]
 extern "C" int sh_lab_pp_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sh::pp_stamp), sizeof(unsigned long long) * 2 * 256 * 8 * PP_NSTAMP);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sh::pp_stamp), sizeof(unsigned long long) * 3 * 256 * 8 * PP_NSTAMP);
 }
 #endif

@@ -15,14 +15,15 @@ img = np.random.default_rng(1).random((64, 512, 512), dtype=np.float32)
 for _ in range(3): eng.unet_infer(img)
 L = ctypes.CDLL(os.environ["SHOULDER_LIB"])
 NS = 8
-out = (ctypes.c_ulonglong * (2 * 256 * 8 * NS))()
+out = (ctypes.c_ulonglong * (3 * 256 * 8 * NS))()
 rc = L.sh_lab_pp_stamps(out)
-both = np.frombuffer(out, dtype=np.uint64).reshape(2, 256, 8, NS).astype(np.float64)
+both = np.frombuffer(out, dtype=np.uint64).reshape(3, 256, 8, NS).astype(np.float64)
 which = int(os.environ.get("PP_KERNEL", "0"))      # 0 dec0b + head, 1 enc0 (its parts: see k_enc0_pp)
 a = both[which]
 if which == 1: names_override = ["ON multiply", "OFF 1st conv", "ON barrier", "OFF patch ld", "OFF store+epi", "OFF barrier", "phases", "whole loop"]
 names = ["ON multiply", "ON vm wait", "ON barrier", "OFF stage", "OFF epilogue", "OFF barrier", "phases", "whole loop"]
 if which == 1: names = names_override
+if which == 2: names = ["ON multiply", "OFF up-conv", "ON barrier", "OFF pieces", "OFF epi+vmwait", "OFF barrier", "phases", "whole loop"]
 print("rc", rc, "phases per wave: mean", a[:, :, 6].mean(), "loop cycles mean", a[:, :, 7].mean(), "max", a[:, :, 7].max())
 ph = a[:, :, 6].mean()
 for i in range(6):
