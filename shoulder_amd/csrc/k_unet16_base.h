@@ -78,4 +78,30 @@ __device__ inline void ud_dma16_s(unsigned lds_dst /*wave-uniform*/, unsigned vo
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "v"(voff), "s"(sbase) : "memory");
 }
 
+// max of two packed pairs of non-negative 16-bit floats (they order like int16), and the same against the lane that holds the
+// neighbouring pixel (lane ^ 1): as assembly -- written with __builtin_amdgcn_mov_dpp in a loop over the four dwords of a pixel,
+// hipcc (ROCm 7.2) emitted ONE swap and stored its result four times
+__device__ inline unsigned pp_pkmax(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline unsigned pp_pkmax_lane1(unsigned a) {
+  unsigned t, r;
+  asm("s_nop 1\n\tv_mov_b32_dpp %0, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\tv_pk_max_i16 %1, %2, %0" : "=&v"(t), "=&v"(r) : "v"(a));
+  return r;
+}
+// the same for N dwords at once: all swaps, then all maxima -- the two wait states a DPP read needs behind the write of its source
+// (and a read of a DPP result behind it) are then other members of the batch instead of s_nop
+template <int N> __device__ inline void pp_pkmax_lane1_n(unsigned (&a)[N]) {
+  static_assert(N >= 3, "the batch is its own padding");
+  unsigned t[N];
+  asm volatile("s_nop 1" ::: );
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(t[i]) : "v"(a[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(t[i]));
+}
+
+
 }  // namespace sh

@@ -432,6 +432,12 @@ k_upconv16r(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed 
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) xf[m][cc] = *(const v8*)(in + ((size_t)cc * H * W + (size_t)(y0 + m) * W + x0) * 32 + 8 * lk);
+  // the pixel fragments are USED here, so hipcc's waits for them stand in front of the slice loop: inside it they were counted waits
+  // that ended in s_waitcnt vmcnt(0) in the middle of every slice -- the slice's own weight prefetch and the previous slice's stores
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) { u32x4 t = __builtin_bit_cast(u32x4, xf[m][cc]); asm volatile("" : "+v"(t)); xf[m][cc] = __builtin_bit_cast(v8, t); }
   put_slice(0);
   __syncthreads();
 

@@ -90,6 +90,7 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   // (row = py * 36 + px), rows 648 + 64 tap + j weight row j of tap `tap`.  The swizzle bit (bit 2 of the row) is the same
   // for every k.
   const int ltid = tid - UL_LTHREADS, lw = wave - UL_NCW;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ud_lptr)smem);
   const int r0 = (ltid >> 2) & 63;
   const int q8 = ((ltid & 3) ^ ((r0 >> 1) & 2)) * 8;
   int hpy[NHALO], hpx[NHALO];                                       // halo pixel of piece k (px >= 34: padding column)
@@ -133,24 +134,24 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     const int cb = ((first ? c0 : c0 - C0) >> 5) * (H * W);      // pixel offset of this chunk's 32-channel plane (channel-blocked activations)
     const ET* simg = (first ? src0 : src1) + (size_t)i_img * H * W * Cs;
     const ET* wbase = wgt + ((size_t)cc * Cout + i_g * WR) * 32;
-    unsigned char* lbase = smem + buf * BUFB + lw * 1024;
+    const unsigned lbase = lds0 + (unsigned)(buf * BUFB + lw * 1024);      // (LDS byte address: the pieces are inline assembly, k_unet16_base.h)
 #pragma unroll
     for (int k = 0; k < NPIECE; ++k) {
       if (k < NHALO - 1) {
         const ET* p = pixoff[k] >= 0 ? simg + (unsigned)((cb + pixoff[k]) * 32 + q8) : zero_page;
-        __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(lbase + k * 4096), 16, 0, 0);
+        ud_dma16(lbase + k * 4096, p);
       } else if (k == NHALO - 1) {      // rows 640..703: 8 halo rows, then the first 56 weight rows
         const ET* pi = pixoff[k] >= 0 ? simg + (unsigned)((cb + pixoff[k]) * 32 + q8) : zero_page;
         if constexpr (WRES != 0) {
-          if (wlow) __builtin_amdgcn_global_load_lds((ud_gptr)pi, (ud_lptr)(lbase + k * 4096), 16, 0, 0);
+          if (wlow) ud_dma16(lbase + k * 4096, pi);
         } else {
           const ET* p = wlow ? pi : wbase + (wlane + k * wtap_stride);
-          __builtin_amdgcn_global_load_lds((ud_gptr)p, (ud_lptr)(lbase + k * 4096), 16, 0, 0);
+          ud_dma16(lbase + k * 4096, p);
         }
       } else if (k < NPIECE - 1) {
-        __builtin_amdgcn_global_load_lds((ud_gptr)(wbase + (wlane + k * wtap_stride)), (ud_lptr)(lbase + k * 4096), 16, 0, 0);
+        ud_dma16(lbase + k * 4096, (wbase + (wlane + k * wtap_stride)));
       } else {                          // the last piece: rows 1216..1223 only (tap 8, rows 56..63)
-        if (wlow) __builtin_amdgcn_global_load_lds((ud_gptr)(wbase + (wlane + k * wtap_stride)), (ud_lptr)(lbase + k * 4096), 16, 0, 0);
+        if (wlow) ud_dma16(lbase + k * 4096, (wbase + (wlane + k * wtap_stride)));
       }
     }
   };
@@ -279,35 +280,42 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
       for (int mp = 0; mp < 4; ++mp)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          v8 oa, ob8, op;
+          // Rounded in pairs (one v_cvt_pk per two values), then ReLU on the rounded 16-bit values, two per instruction: a negative
+          // bf16 / f16 is a negative int16 (sign bit), so max(bits, 0) as packed int16 is max(x, +0.0) -- rounding is monotonic and keeps
+          // the sign, -0.0 becomes +0.0 either way: the same bits as fmaxf on the f32 accumulators followed by the conversion (NaN aside,
+          // which no layer produces from finite input).  Without ReLU the max is against the smallest int16: the identity.  (fmaxf is two
+          // v_max_f32 per value -- it quiets NaNs first -- and a `relu` flag tested per value a select: 380 instead of 128 instructions.)
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          using v2 = typename E16<ET>::v2;
+          const unsigned zsel = relu ? 0u : 0x80008000u;
+          u32x4 ua, ub;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            float va = acc[2 * mp][2 * h + (r >> 2)][r & 3], vb = acc[2 * mp + 1][2 * h + (r >> 2)][r & 3];
-#ifndef UL_PKRELU
-            if (relu) { va = fmaxf(va, 0.0f); vb = fmaxf(vb, 0.0f); }
-#endif
-            oa[r] = (ET)va; ob8[r] = (ET)vb;
-            if (FUSE & UF_POOL) {      // (rounding to ET and the ReLU are monotonic: the same value as pooling first)
-              float vp = fmaxf(va, vb);
-              vp = fmaxf(vp, __shfl_xor(vp, 1));
-              op[r] = (ET)vp;
-            }
+          for (int i = 0; i < 4; ++i) {
+            const f32x4& ra = acc[2 * mp][2 * h + (i >> 1)];
+            const f32x4& rb = acc[2 * mp + 1][2 * h + (i >> 1)];
+            const f32x2 pa = {ra[2 * (i & 1)], ra[2 * (i & 1) + 1]}, pb2 = {rb[2 * (i & 1)], rb[2 * (i & 1) + 1]};
+            ua[i] = pp_pkmax(__builtin_bit_cast(unsigned, __builtin_convertvector(pa, v2)), zsel);
+            ub[i] = pp_pkmax(__builtin_bit_cast(unsigned, __builtin_convertvector(pb2, v2)), zsel);
           }
-#ifdef UL_PKRELU
-          // ReLU on the rounded 16-bit values, two per instruction: a negative bf16 / f16 is a negative int16 (sign bit), so max(bits, 0)
-          // as packed int16 is max(x, +0.0) -- rounding is monotonic and keeps the sign, -0.0 becomes +0.0 either way: the same bits as
-          // fmaxf on the f32 accumulators followed by the conversion (NaN aside, which no layer produces from finite input)
-          if (relu) {
-            typedef short s8 __attribute__((ext_vector_type(8)));
-            const s8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            oa = __builtin_bit_cast(v8, __builtin_elementwise_max(__builtin_bit_cast(s8, oa), z));
-            ob8 = __builtin_bit_cast(v8, __builtin_elementwise_max(__builtin_bit_cast(s8, ob8), z));
-            if (FUSE & UF_POOL) op = __builtin_bit_cast(v8, __builtin_elementwise_max(__builtin_bit_cast(s8, op), z));
-          }
-#endif
+          const v8 oa = __builtin_bit_cast(v8, ua), ob8 = __builtin_bit_cast(v8, ub);
           *(v8*)(ob + (lo + (unsigned)((2 * mp) * W * 32 + 8 * h))) = oa;
           *(v8*)(ob + (lo + (unsigned)((2 * mp + 1) * W * 32 + 8 * h))) = ob8;
           if (FUSE & UF_POOL) {
+            v8 op;
+            if (relu) {      // 2x2 max on the rounded non-negative values (they order like int16): rows inside the lane, columns with lane ^ 1
+              unsigned pv[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) pv[i] = pp_pkmax(ua[i], ub[i]);
+              pp_pkmax_lane1_n(pv);
+              op = __builtin_bit_cast(v8, u32x4{pv[0], pv[1], pv[2], pv[3]});
+            } else {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) {      // (rounding to ET is monotonic: the same value as pooling first)
+                float vp = fmaxf(acc[2 * mp][2 * h + (r >> 2)][r & 3], acc[2 * mp + 1][2 * h + (r >> 2)][r & 3]);
+                vp = fmaxf(vp, __shfl_xor(vp, 1));
+                op[r] = (ET)vp;
+              }
+            }
             if (!(li & 1)) *(v8*)(pb + (plo + (unsigned)(mp * (W >> 1) * 32 + 8 * h))) = op;
           }
         }
