@@ -165,57 +165,45 @@ PARITY_NOTE = {
 UNET_ENUM = {"f32": 0, "bf16": 1, "f16": 2, "f32x": 3}
 
 
-def sym_key(name, unet, cout, fused_net=True):
+def sym_key(name, unet, cout, fused_net=True, raw_image=True):
     """Kernel symbol (as rocprofv3 --stats groups launches) of UNet layer `name`; element type spelled bf16 / f16 / f32."""
     if name in ("unet.head", "unet.enc0a", "unet.pool"):
         return name
     nt = 4 if cout % 64 == 0 else 2
     up = name.startswith("unet.up")
+    from shoulder_amd import unet_spec
+    cin = unet_cins(unet_spec.BASE, unet_spec.DEPTH).get(name, 0)
     if unet == "f32":
         return "k_conv_mfma_f32<%d,%d>" % (1 if up else 9, nt)
     if unet == "f32x":
-        if up and os.environ.get("SHOULDER_X3_UPREG") != "0":
-            from shoulder_amd import unet_spec
-            cin = unet_cins(unet_spec.BASE, unet_spec.DEPTH)[name]
-            if cin in (64, 128, 256, 512):      # source pixels resident in registers (k_unet_x3.h)
-                return "k_upconv_x3r<%d,%d>" % (cin // 32, {64: 4, 128: 4, 256: 2, 512: 1}[cin])
+        if up and cin in (64, 128, 256, 512):      # source pixels resident in registers (k_unet_x3.h)
+            return "k_upconv_x3r<%d,%d>" % (cin // 32, {64: 4, 128: 4, 256: 2, 512: 1}[cin])
         fuse = 4 if name in ("unet.enc0b", "unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
         return "k_conv_mfma_x3<%d,%d,%d>" % (1 if up else 9, nt, fuse)
-    # third template argument = fused ends (k_unet_bf16.h): UF_FIRST 1, UF_HEAD 2, UF_POOL 4
-    fuse = 5 if name == "unet.enc0b" else 2 if name == "unet.dec0b" else 4 if name in ("unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
-    if not fused_net:
-        fuse = 0
-    if name == "unet.enc0b" and fused_net and os.environ.get("SHOULDER_UNET_L0") != "0" and os.environ.get("SHOULDER_UNET_FUSE_FIRST") != "0":
-        return "k_enc0_fused16<%s>" % unet      # level-0 encoder as one persistent kernel (k_unet16_l0.h)
-    if name == "unet.dec0a" and fused_net and os.environ.get("SHOULDER_UNET_DEC0") != "0":
-        return "k_dec0a_up16<%s>" % unet      # dec0a with up0 computed inside (k_unet16_dec0.h); no unet.up0 launch then
-    if up and os.environ.get("SHOULDER_UNET_UPCONV") != "0":
-        from shoulder_amd import unet_spec
-        cin = unet_cins(unet_spec.BASE, unet_spec.DEPTH)[name]
-        if cin in (128, 256, 512) and os.environ.get("SHOULDER_UPCONV_REG") != "0":
-            return "k_upconv16r<%s,%d,%d>" % (unet, cin // 32, 2 if cin == 512 else 4)      # source pixels resident in MFMA fragments (k_unet16_l0.h)
-        return "k_upconv16<%s>" % unet                           # 2x2 transposed conv, both column phases per workgroup (k_unet16_l0.h)
-    dma = (not up and not (fuse & 1) and os.environ.get("SHOULDER_UNET_DMA") != "0" and (cout % 64 == 0 or os.environ.get("SHOULDER_UNET_DMA32") != "0"))
-    if dma:      # persistent LDS-DMA form of the 3x3 layers (k_unet_bf16_dma.h); last arguments = tap order (SCHED), weights resident (WRES)
-        sched = 0 if os.environ.get("SHOULDER_DMA_SCHED") == "0" else 1
-        grp = 64 if cout % 64 == 0 else 32
-        from shoulder_amd import unet_spec
-        cin = unet_cins(unet_spec.BASE, unet_spec.DEPTH)[name]
-        wres = int(sched == 1 and os.environ.get("SHOULDER_DMA_WRES") != "0" and cout == grp and (cin // 32) * grp <= 128)
-        if wres and grp == 32 and cin == 32 and os.environ.get("SHOULDER_DMA_WREG") != "0":
-            wres = 2      # 32 -> 32: the weight fragments stay in registers as well
-        if name == "unet.dec0b" and wres == 2 and fuse == 2 and os.environ.get("SHOULDER_DEC0B3") != "0" and os.environ.get("SHOULDER_DEC0B_OCC") != "1" and os.environ.get("SHOULDER_DMA_TICKETS") != "0":
-            return "k_dec0b_head3<%s>" % unet      # dec0b + head with three halo buffers, two tiles in flight (k_unet16_dec0b3.h)
-        if grp == 64 and sched == 1 and fuse in (0, 4) and os.environ.get("SHOULDER_DMA_LDR") != "0":
-            return "k_conv3_ldr16<%s,%d,%d>" % (unet, fuse, wres)      # 64-cout items: compute waves + loader waves (k_unet16_ldr.h)
-        return "k_conv3_dma16<%s,%d,%d,%d,%d>" % (unet, fuse, nt, sched, wres)
-    return "k_conv_mfma16<%s,%d,%d,%d>" % (unet, 1 if up else 9, nt, fuse)
+    if fused_net:      # the production 16-bit network (shoulder_hip.hip: unet_forward16)
+        if name == "unet.enc0b":
+            return "k_enc0_pp<%s,%s>" % (unet, "true" if raw_image else "false")      # image -> enc0a -> enc0b -> skip0 + pool (k_unet16_pp.h)
+        if name == "unet.dec0a":
+            return "k_dec0a_up_pp<%s>" % unet      # up0 computed inside dec0a; no unet.up0 launch
+        if name == "unet.dec0b":
+            return "k_dec0b_head_pp<%s>" % unet      # dec0b + head: only the logits leave the kernel
+        if up:
+            if cin in (128, 256):
+                return "k_upconv16r<%s,%d,4>" % (unet, cin // 32)      # source pixels resident in MFMA fragments (k_unet16_up.h)
+            return "k_upconv16<%s>" % unet                           # 2x2 transposed conv, both column phases per workgroup
+        if cout % 64 == 0:      # persistent LDS-DMA conv with loader waves (k_unet16_ldr.h): <EK, FUSE (UF_POOL = 4), weights resident>
+            fuse = 4 if name in ("unet.enc1b", "unet.enc2b", "unet.enc3b") else 0
+            wres = int(cout == 64 and (cin // 32) * 64 <= 128)
+            return "k_conv3_ldr16<%s,%d,%d>" % (unet, fuse, wres)
+    if up:
+        return "k_conv_mfma16<%s,1,%d,0>" % (unet, nt)
+    return "k_conv_mfma16<%s,9,%d,0>" % (unet, nt)
 
 
 def rocprof_name(key):
     """bench symbol key -> the kernel name rocprofv3 prints (profiles/*.json are keyed by it).  The 16-bit kernels are
     templates on an element-kind integer (k_unet_bf16.h: 0 = __bf16, 1 = _Float16), spelled bf16 / f16 in bench keys."""
-    return "sh::" + key.replace("<bf16", "<0").replace("<f16", "<1").replace(",", ", ")
+    return "sh::" + key.replace("<bf16", "<0").replace("<f16", "<1").replace(",", ", ")      # (bool template arguments print as true / false)
 
 
 def host_info():

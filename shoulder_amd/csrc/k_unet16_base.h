@@ -104,4 +104,12 @@ template <int N> __device__ inline void pp_pkmax_lane1_n(unsigned (&a)[N]) {
 }
 
 
+// the next work ticket: the returning atomic and its wait as ONE statement inside the caller's branch (left to the compiler, the wait
+// for the returned value moves behind the branch's join, where every wave of the workgroup drains its LDS-DMA queue for it)
+__device__ inline int ud_take_ticket(unsigned* ticket) {
+  unsigned t;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(ticket), "v"(1u) : "memory");
+  return (int)t;
+}
+
 }  // namespace sh

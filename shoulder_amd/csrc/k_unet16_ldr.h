@@ -1,30 +1,37 @@
-// k_unet16_ldr.h -- 3x3 conv, 16-bit, 64-cout items: the persistent LDS-DMA conv of k_unet_bf16_dma.h with the two jobs of a
+// k_unet16_ldr.h -- 3x3 conv, 16-bit, for the layers with >= 64 output channels: persistent workgroups (one per CU, 512 lanes,
+// 155 KB of LDS) that walk (image, 32x16-pixel tile, 64-cout group) items handed out in work tickets, with the two jobs of a
 // workgroup given to different waves.
 //
-// k_conv3_dma16 lets each of its 8 waves do both: 144 MFMAs of a step and 10 of the step's 80 LDS-DMA pieces, issued between
-// its MFMA groups.  Its counters (profiles/r02_pmc_sq_b64_bf16.json) say the matrix pipe idles 40 % of the cycles, and its
-// ablation builds price the pieces at 24-37 % of a layer: a `global_load_lds_dwordx4` holds the issuing wave for 100-185
-// cycles (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), 20 of them per SIMD and step beside 4 608 cycles of MFMA, and
-// the two waves of a SIMD run the same program in lockstep, so they issue their pieces -- and read their fragments -- at
-// the same moments.  Moving the pieces around inside the step changes nothing (round 3: SH_DMA_EARLY / _UNCOND / _PRIO_HALF).
-//
-// Here a workgroup is 4 COMPUTE waves + 4 LOADER waves (one of each per SIMD):
+// A workgroup is 4 COMPUTE waves + 4 LOADER waves (one of each per SIMD):
 //   compute wave (cw = 0..3): 8 rows x 16 pixels x 64 couts of the 32 x 16 tile = 128 accumulator registers, 288 MFMAs per
-//     step and nothing else but the fragment reads -- 66 `ds_read_b128` per step (per column offset dx: 10 pixel-row
-//     fragments that serve its three dy taps + 12 weight fragments) where the 8-wave form reads 2 x 54 for the same MFMAs;
-//     no vector-memory instruction except the epilogue stores, no vmcnt wait, no address arithmetic per step;
+//     32-channel step and nothing else but the fragment reads -- 66 `ds_read_b128` per step (per column offset dx: 10 pixel-row
+//     fragments that serve its three dy taps + 12 weight fragments); no vector-memory instruction except the epilogue stores,
+//     no vmcnt wait, no address arithmetic per step;
 //   loader wave (lw = 0..3): decodes the next step, issues ALL its LDS-DMA pieces (20, or 11 with resident weights) right
 //     after the step barrier, waits for them (vmcnt(0)) and joins the next barrier: a step's data has a whole step to land,
 //     and the wave is parked -- it takes no issue slot from the compute wave of its SIMD -- for most of it.
-// One raw s_barrier per step for the whole workgroup, as before.  Same LDS image (two 78 KB buffers: 18 x 36 halo rows +
-// 576 weight rows of 64 B, XOR slot swizzle on the DMA's source and on the read), same work items and tickets, same
-// channel dealing, same tap order (dx major) and chunk order per output element: results are bit-identical to
-// k_conv3_dma16 (tests/test_gpu_unet_bf16.py::test_loader_wave_conv_bit_identical).
+// One raw s_barrier per step for the whole workgroup.  LDS image per buffer (two of them): 18 x 36 halo-pixel rows (pitch 36:
+// the swizzle bit of a fragment row then depends only on row parity, dx and the lane), then 576 weight rows ([tap][64 couts]);
+// 32 channels = 64 B per row, XOR slot swizzle applied on the DMA's SOURCE address (the DMA writes lane-linear) and on the
+// fragment read.  Out-of-image halo pixels read a 64-byte page of zeros.  Output channels of an item are dealt to the
+// accumulator tiles so that a lane ends up with CONSECUTIVE channels (weight row 16 n + i of the LDS image holds channel
+// 16 (i >> 2) + 4 n + (i & 3) of the group): the epilogue stores 16 bytes per instruction.
+// The pieces are inline assembly (k_unet16_base.h): through the builtin hipcc drains every vector-memory operation of a wave in
+// front of its first LDS read -- for a compute wave the stores of the item it has just finished.
+// Work tickets: runs of items of DECREASING length (tk_tab, built on the host) are handed out by a global counter, so a workgroup
+// that starts late -- its CU was still held by a kernel of the engine's other lane -- takes less and the layer ends when the chip
+// runs out of work; the id of the ticket after the current one is always already in LDS (fetched one ticket ahead).
 #pragma once
-#include "k_unet_bf16_dma.h"
+#include "k_unet_bf16.h"
 
 namespace sh {
 
+#define UD_THREADS 512
+#define UD_ROWS (UD_INROWS + 576)           // 1224 LDS rows of 64 B per buffer: 648 halo rows + [9 taps][64 couts] weight rows
+#define UD_BUF (UD_ROWS * 64)               // 78336
+#define UD_SLOTS (UD_ROWS * 4)              // 4896
+#define UD_BIAS_OFF (2 * UD_BUF)
+#define UD_SMEM (2 * UD_BUF + 2048)         // 158720
 #define UL_NCW 4                          // compute waves; waves UL_NCW .. 7 load
 #define UL_LTHREADS 256                   // lanes of the loader half
 
@@ -35,7 +42,7 @@ __global__ void __launch_bounds__(UD_THREADS)
 k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int C0, int C1,
               const u16* __restrict__ wgt_, const float* __restrict__ bias, u16* __restrict__ dst_,
               int H, int W, int Cout, int relu, int nimg, const u16* __restrict__ zero_page_, u16* __restrict__ pooled_,
-              unsigned* __restrict__ ticket /*zero at launch; nullptr: fixed equal shares*/, const int* __restrict__ tk_tab /*[ntk + 1] item bounds*/, int ntk, YieldArg yl) {
+              unsigned* __restrict__ ticket /*zero at launch*/, const int* __restrict__ tk_tab /*[ntk + 1] item bounds*/, int ntk) {
   using ET = typename EKT<EK>::type;
   const ET* src0 = (const ET*)src0_;
   const ET* src1 = (const ET*)src1_;
@@ -57,9 +64,7 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   const int li = lane & 15, lk = lane >> 4;
   const int Cin = C0 + C1, nchunk = Cin >> 5;
   const int tiles_x = W / 32, tiles_y = H / 16, ngroups = Cout / WR;
-  const int total = nimg * tiles_x * tiles_y * ngroups;
-  const bool dyn = ticket != nullptr;
-  if (dyn && tid == UL_LTHREADS) { s_q[0] = ud_take_ticket(ticket, ntk, yl); s_q[1] = ud_take_ticket(ticket, ntk, yl); }
+  if (tid == UL_LTHREADS) { s_q[0] = ud_take_ticket(ticket); s_q[1] = ud_take_ticket(ticket); }
 
   float* s_bias = (float*)(smem + UD_BIAS_OFF);
   for (int i = tid; i < Cout; i += UD_THREADS) s_bias[i] = bias[i];
@@ -76,14 +81,10 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   __syncthreads();       // every ordinary load is retired before the first LDS-DMA is issued
   int qk = 1;
   int w_begin, w_end;
-  if (dyn) {
+  {
     const int t0 = __builtin_amdgcn_readfirstlane(s_q[0]);
     if (t0 >= ntk) return;
     w_begin = tk_tab[t0]; w_end = tk_tab[t0 + 1];
-  } else {
-    const int per = (total + gridDim.x - 1) / gridDim.x;
-    w_begin = blockIdx.x * per; w_end = min(total, w_begin + per);
-    if (w_begin >= w_end) return;
   }
 
   // ---- loader lanes: staging plan.  Slot e_k = ltid + 256 k -> LDS row r_k = (ltid >> 2) + 64 k; rows < 648 are halo pixels
@@ -104,18 +105,10 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   const int wlane = (wlow ? -11 : -10) * wtap_stride + wch * 32 + q8;
 
   int i_g, i_tx, i_ty, i_img;      // item being staged
-  const bool gmajor = (relu & 2) != 0;      // experiment (SHOULDER_GMAJOR=1): cout group slowest -- all tiles of a group before the next group
-  relu &= 1;
-  auto decode = [&](int w) {
-    if (gmajor) {
-      i_tx = w % tiles_x; w /= tiles_x;
-      i_ty = w % tiles_y; w /= tiles_y;
-      i_img = w % nimg; i_g = w / nimg;
-    } else {
-      i_g = w % ngroups; w /= ngroups;
-      i_tx = w % tiles_x; w /= tiles_x;
-      i_ty = w % tiles_y; i_img = w / tiles_y;
-    }
+  auto decode = [&](int w) {      // cout groups of one tile are neighbours: their input tile stays in L2
+    i_g = w % ngroups; w /= ngroups;
+    i_tx = w % tiles_x; w /= tiles_x;
+    i_ty = w % tiles_y; i_img = w / tiles_y;
   };
   decode(w_begin);
   int pixoff[NHALO];
@@ -172,9 +165,6 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     item_lane_setup();
     stage(0, 0);
   }
-#ifdef UL_PRIO
-  else __builtin_amdgcn_s_setprio(UL_PRIO);      // experiment: the compute wave wins the issue arbitration against its SIMD's loader wave
-#endif
   int buf = 0;
   for (int w = w_begin;;) {
     bool more = true;
@@ -198,49 +188,27 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
       if (n_cc < nchunk) {
       } else if (w + 1 < w_end) {
         ++w;
-        if (gmajor) { if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; if (++i_img == nimg) { i_img = 0; ++i_g; } } } }
-        else if (++i_g == ngroups) { i_g = 0; if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; ++i_img; } } }
+        if (++i_g == ngroups) { i_g = 0; if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; ++i_img; } } }
         n_cc = 0; new_item = true;
-      } else if (dyn) {      // next ticket: its id was written before this step's barrier; the slot it frees is refilled for the one after
+      } else {      // next ticket: its id was written before this step's barrier; the slot it frees is refilled for the one after
         const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);
         if (nt < ntk) {
-          if (tid == UL_LTHREADS) s_q[qk ^ 1] = ud_take_ticket(ticket, ntk, yl);
+          if (tid == UL_LTHREADS) s_q[qk ^ 1] = ud_take_ticket(ticket);
           qk ^= 1;
           w = tk_tab[nt]; w_end = tk_tab[nt + 1];
           decode(w);
           n_cc = 0; new_item = true;
         } else { has_next = false; more = false; }
-      } else { has_next = false; more = false; }
+      }
       if (loader) {
-#if !(defined(UL_ABL) && (UL_ABL == 1 || UL_ABL == 4))      // ablation 1 (wrong results): no DMA at all -> what the compute waves need on their own
         if (has_next) {
           if (new_item) item_lane_setup();
           stage(n_cc, buf ^ 1);
         }
-#endif
       } else {
-#if defined(UL_ABL) && UL_ABL == 2      // ablation 2 (wrong results): no fragment reads, no MFMAs -> what staging alone takes
-        asm volatile("" :: "v"(acc[0][0]));
-        if (false)
-#endif
         {
         const unsigned char* sb = smem + buf * BUFB;
         const unsigned char* wbp = WRES ? smem + WRES_OFF + cc * 9 * WR * 64 + (woff - UD_INROWS * 64) : sb + woff;
-#if defined(UL_ABL) && (UL_ABL == 3 || UL_ABL == 4)      // ablation 3 (wrong results): the 288 MFMAs of a step on fragments read once -> the bare matrix stream + barrier
-        {
-          v8 xq[10], wf[4];
-#pragma unroll
-          for (int s = 0; s < 10; ++s) xq[s] = *(const v8*)(sb + xoff[s & 1][0] + (s & ~1) * UD_PW * 64);
-#pragma unroll
-          for (int n = 0; n < 4; ++n) wf[n] = *(const v8*)(wbp + (n * 16) * 64);
-#pragma unroll
-          for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-#pragma unroll
-              for (int n = 0; n < 4; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xq[m + t % 3], acc[m][n]);
-        }
-#else
         // compiler-scheduled form: per column offset the 10 pixel rows, per tap the 4 weight fragments
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
@@ -259,7 +227,6 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
               for (int n = 0; n < 4; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xq[m + dy], acc[m][n]);
           }
         }
-#endif
         }
       }
       buf ^= 1;
@@ -324,16 +291,5 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// NOT kept (round 3, measured at B = 64, 512 x 512, bf16; layer dec0b + head = k_conv3_dma16<.., UF_HEAD, 2, 1, 2>, 0.46 ms):
-// the same role split for the 32 -> 32 layer with the fused head, in three forms, each bit-identical to the 8-wave kernel:
-//   two halo buffers, epilogue in the compute wave                                      0.45 ms (without its MFMAs: 0.25)
-//   epilogue handed to the loader waves through a 64 KB LDS exchange area               0.48 ms (one tile's staging in flight)
-//   three halo buffers + weights in LDS, the epilogue of tile i - 1 spread behind the
-//   taps of tile i in the compute wave (two accumulator sets)                           0.48 ms (without epilogue 0.30,
-//                                                                                        without MFMAs 0.23 = the HBM time)
-// A tile of this layer is 144 MFMAs per compute wave and an epilogue of ~200 vector instructions; one wave per SIMD cannot
-// overlap the two, and the 8-wave kernel's second wave per SIMD does exactly that.  The layer stays on k_conv3_dma16.
 
 }  // namespace sh

@@ -91,13 +91,6 @@ __device__ unsigned long long pp_stamp[3 * 256 * 8 * PP_NSTAMP];      // [kernel
 #define PP_ADD(i, a, b)
 #endif
 
-// the next work ticket: the returning atomic and its wait as ONE statement inside the caller's branch (left to the compiler, the wait
-// for the returned value moves behind the branch's join, where every wave of the workgroup drains its LDS-DMA queue for it)
-__device__ inline int pp_take_ticket(unsigned* ticket) {
-  unsigned t;
-  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(t) : "v"(ticket), "v"(1u) : "memory");
-  return (int)t;
-}
 // a value loaded from global memory in front of the main loop is USED here, so the compiler's wait for it stands here and not at
 // its first use inside the loop (where it would be a vmcnt(0) behind the loop's own LDS-DMA pieces)
 template <typename T> __device__ inline void pp_settle(T& v) { asm volatile("" : "+v"(v)); }
@@ -126,7 +119,7 @@ k_dec0b_head_pp(const u16* __restrict__ src_ /*[img][H W][32]*/, const u16* __re
   const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), wv = wave & 3;
   const int xh = wv & 1, rg8 = wv >> 1;
   const int tiles_x = W / 32, tiles_y = H / 16;
-  if (tid == 0) { s_q[0] = pp_take_ticket(ticket); s_q[1] = pp_take_ticket(ticket); }
+  if (tid == 0) { s_q[0] = ud_take_ticket(ticket); s_q[1] = ud_take_ticket(ticket); }
 
   // ---- once per workgroup: the weight fragments of this lane (row dealing and slot swizzle of k_conv3_dma16, NN = 2) through buffer 2
   for (int e = tid; e < 9 * 32 * 4; e += PP_THREADS) {
@@ -171,7 +164,7 @@ k_dec0b_head_pp(const u16* __restrict__ src_ /*[img][H W][32]*/, const u16* __re
     if (cu.w + 1 < cu.wend) { ++cu.w; if (++cu.tx == tiles_x) { cu.tx = 0; if (++cu.ty == tiles_y) { cu.ty = 0; ++cu.img; } } return; }
     const int nt = __builtin_amdgcn_readfirstlane(s_q[cu.qk]);
     if (nt < ntk) {
-      if (fetcher) s_q[cu.qk ^ 1] = pp_take_ticket(ticket);
+      if (fetcher) s_q[cu.qk ^ 1] = ud_take_ticket(ticket);
       cu.qk ^= 1;
       cu.w = tk_tab[nt]; cu.wend = tk_tab[nt + 1];
       int w = cu.w;
@@ -460,7 +453,7 @@ k_enc0_pp(const float* __restrict__ image, const float* __restrict__ w0 /*[9][32
   const int xh = wv & 1, rg8 = wv >> 1;
   const int ltid = tid & (PP_GTHREADS - 1);
   const int tiles_x = W / 32, tiles_y = H / 16;
-  if (tid == 0) { s_q[0] = pp_take_ticket(ticket); s_q[1] = pp_take_ticket(ticket); }
+  if (tid == 0) { s_q[0] = ud_take_ticket(ticket); s_q[1] = ud_take_ticket(ticket); }
 
   // ---- once per workgroup: enc0b weights -> LDS (row dealing and slot swizzle of k_conv3_dma16, NN = 2), biases, first-conv weights
   for (int e = tid; e < 9 * 32 * 4; e += PP_THREADS) {
@@ -506,7 +499,7 @@ k_enc0_pp(const float* __restrict__ image, const float* __restrict__ w0 /*[9][32
     if (cu.w + 1 < cu.wend) { ++cu.w; if (++cu.tx == tiles_x) { cu.tx = 0; if (++cu.ty == tiles_y) { cu.ty = 0; ++cu.img; } } return; }
     const int nt = __builtin_amdgcn_readfirstlane(s_q[cu.qk]);
     if (nt < ntk) {
-      if (fetcher) s_q[cu.qk ^ 1] = pp_take_ticket(ticket);
+      if (fetcher) s_q[cu.qk ^ 1] = ud_take_ticket(ticket);
       cu.qk ^= 1;
       cu.w = tk_tab[nt]; cu.wend = tk_tab[nt + 1];
       int w = cu.w;
@@ -782,7 +775,7 @@ k_dec0a_up_pp(const u16* __restrict__ skip_ /*[img][H W][32]*/, const u16* __res
   const int ltid = tid & (PP_GTHREADS - 1);
   const int H2 = H >> 1, W2 = W >> 1;
   const int tiles_x = W / 32, tiles_y = H / 8;
-  if (tid == 0) { s_q[0] = pp_take_ticket(ticket); s_q[1] = pp_take_ticket(ticket); }
+  if (tid == 0) { s_q[0] = ud_take_ticket(ticket); s_q[1] = ud_take_ticket(ticket); }
 
   // ---- once per workgroup: the conv's weights -> LDS; this wave's up-conv fragments and the biases -> registers
   // dec0a: LDS row (chunk, tap, 16 n + i) <- packed row (tap, chunk, channel 8 (i >> 2) + 4 n + (i & 3)); slot swizzle on the source
@@ -823,7 +816,7 @@ k_dec0a_up_pp(const u16* __restrict__ skip_ /*[img][H W][32]*/, const u16* __res
     if (cu.w + 1 < cu.wend) { ++cu.w; if (++cu.ty == tiles_y) { cu.ty = 0; if (++cu.tx == tiles_x) { cu.tx = 0; ++cu.img; } } return; }
     const int nt = __builtin_amdgcn_readfirstlane(s_q[cu.qk]);
     if (nt < ntk) {
-      if (fetcher) s_q[cu.qk ^ 1] = pp_take_ticket(ticket);
+      if (fetcher) s_q[cu.qk ^ 1] = ud_take_ticket(ticket);
       cu.qk ^= 1;
       cu.w = tk_tab[nt]; cu.wend = tk_tab[nt + 1];
       decode(cu.w);

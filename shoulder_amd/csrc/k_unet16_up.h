@@ -1,0 +1,214 @@
+// k_unet16_up.h -- 2x2 stride-2 transposed convolutions (the decoder's up-sampling) of the 16-bit UNet.
+#pragma once
+#include "k_unet_bf16.h"
+
+namespace sh {
+
+// ---- 2x2 stride-2 transposed convolution (the decoder's up-sampling), both column phases of an output row per workgroup --
+// out[2y + dy][2x + dx][co] = b[co] + sum_ci in[y][x][ci] * w[dy * 2 + dx][ci][co]: per output pixel one K = Cin product, no
+// spatial reuse -- a memory-bound layer (up0 at B = 64: 0.54 GB in, 1.07 GB out, 0.07 TFLOP).  The two-barrier kernel ran
+// it as one launch of 4 x Cout/64 workgroups per tile: every workgroup re-read the input tile, and the two dx phases of an
+// output row -- the two 64-byte halves of each 128-byte line -- were written by different workgroups.  Here a workgroup
+// (4 waves) owns a 16x16 source tile x 32 output channels x the two dx phases of one row parity dy: the tile is staged
+// once per 32-channel chunk and multiplied against both phases' weights (pixel fragments reused), and both halves of
+// every output line leave the same wave back to back.  Channels are dealt to the MFMA rows as in k_conv3_ldr16 (16-byte stores).
+// A workgroup takes one output-row parity dy (both dx): 32 accumulator tiles for all four phases cost 128 VGPRs and left two
+// workgroups per CU, which made the kernel the slowest one beside another lane's kernels (0.47 ms average in the two-lane
+// bench against 0.27 ms alone); with 16 tiles four to five workgroups fit.
+#define UPC_THREADS 256
+
+template <int EK>
+__global__ void __launch_bounds__(UPC_THREADS)
+k_upconv16(const u16* __restrict__ src_, int Cin, const u16* __restrict__ wgt_ /*packed [4][Cin/32][Cout][32]*/, const float* __restrict__ bias,
+           u16* __restrict__ dst_, int H, int W, int Cout) {
+  using ET = typename EKT<EK>::type;
+  using v8 = typename E16<ET>::v8;
+  const ET* wgt = (const ET*)wgt_;
+  __shared__ __attribute__((aligned(16))) ET s_in[256 * UB_PSTR];
+  __shared__ __attribute__((aligned(16))) ET s_w[64 * UB_PSTR];
+  const int tiles_x = W / 16;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int n0 = blockIdx.y * 32, img = blockIdx.z >> 1, dy = blockIdx.z & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int x0 = tx * 16, y0 = ty * 16;
+  const int nchunk = Cin / 32;
+  const ET* in = (const ET*)src_ + (size_t)img * H * W * Cin;
+
+  // staging plan: 4 input pieces + 1 weight piece of 16 bytes per thread and chunk
+  int in_src[4], in_lds[4], wt_src[1], wt_lds[1];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = tid + k * UPC_THREADS, q = e & 3, p = e >> 2;
+    in_src[k] = ((y0 + (p >> 4)) * W + x0 + (p & 15)) * 32 + q * 8;
+    in_lds[k] = UB_OFF(p, q);
+  }
+  {
+    const int e = tid, q = e & 3, r = e >> 2, dx = r >> 5, j = r & 31;
+    const int ch = 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);      // LDS row 16 n + i of a phase holds channel 8 (i >> 2) + 4 n + (i & 3)
+    wt_src[0] = ((dy * 2 + dx) * nchunk * Cout + n0 + ch) * 32 + q * 8;
+    wt_lds[0] = UB_OFF(r, q);
+  }
+  u32x4 rin[4], rwt[1];
+  auto load_chunk = [&](int cc) {
+    const ET* s = in + (size_t)cc * H * W * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rin[k] = *(const u32x4*)(s + in_src[k]);
+    rwt[0] = *(const u32x4*)(wgt + (size_t)wt_src[0] + (size_t)cc * Cout * 32);
+  };
+
+  f32x4 acc[4][2][2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    f32x4 bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = bias[n0 + 8 * lk + 4 * n + r];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) acc[m][ph][n] = bv;
+  }
+  load_chunk(0);
+  for (int cc = 0; cc < nchunk; ++cc) {
+    __syncthreads();                  // every wave is done reading the previous chunk
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *(u32x4*)(s_in + in_lds[k]) = rin[k];
+    *(u32x4*)(s_w + wt_lds[0]) = rwt[0];
+    __syncthreads();
+    if (cc + 1 < nchunk) load_chunk(cc + 1);      // in flight during the MFMAs below
+    v8 xf[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) xf[m] = *(const v8*)(s_in + UB_OFF((wave * 4 + m) * 16 + li, lk));
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {      // ph = dx
+      v8 wf[2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) wf[n] = *(const v8*)(s_w + UB_OFF(ph * 32 + n * 16 + li, lk));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][ph][n] = E16<ET>::mfma(wf[n], xf[m], acc[m][ph][n]);
+    }
+  }
+  const int OW = 2 * W, OH = 2 * H;
+  ET* out = (ET*)dst_ + (size_t)img * OH * OW * Cout + (size_t)blockIdx.y * OH * OW * 32;      // this group's 32-channel plane
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      const int oy = 2 * (y0 + wave * 4 + m) + dy, ox = 2 * (x0 + li) + ph;
+      v8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = (ET)acc[m][ph][r >> 2][r & 3];
+      *(v8*)(out + ((size_t)oy * OW + ox) * 32 + 8 * lk) = o;
+    }
+}
+
+
+// ---- the same layer with the source pixels held in REGISTERS ---------------------------------------------------------------
+// k_upconv16 stages a 16 x 16 source tile per 32-channel chunk and (row parity, 32-cout group): the tile is read 2 Cout / 32 times
+// from L2, and a chunk is 16 MFMAs per wave between two workgroup barriers (matrix pipe busy 0.19, 0.3-0.4 of the HBM roof).
+// Here a workgroup (8 waves) owns a 32 x 16 source tile for ALL 4 Cout outputs of its pixels: every wave loads its 4 rows x 16
+// pixels x Cin once, straight into the MFMA pixel fragments (4 NCH fragments = 64 / 128 VGPRs for Cin = 128 / 256), and keeps
+// them for the whole launch; only the weights -- one (32-cout group, phase) slice of NCH x 32 rows at a time, 8 / 16 KB -- go through
+// LDS, fetched into registers while the previous slice is multiplied (one barrier per slice of 4 x 2 x NCH MFMAs per wave).
+// Input bytes come from HBM exactly once, the two 64-byte halves of an output line (dx = 0, 1) leave the same wave in
+// consecutive slices.  Same accumulation (bias in the accumulator, chunks in order) and the same channel dealing as
+// k_upconv16: bit-identical results (tests/test_gpu_unet_bf16.py::test_register_resident_upconv_bit_identical).
+// Cin = 512 (up3): 2 rows per wave (MT = 2, 128 fragment registers), a 32 x 8 source tile per workgroup.
+#define UPR_THREADS 512
+
+template <int EK, int NCH, int MT = 4>      // MT: source rows (16-pixel MFMA tiles) per wave; a workgroup owns 4 MT rows x 32 pixels
+__global__ void __launch_bounds__(UPR_THREADS)
+k_upconv16r(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed [4][NCH][Cout][32]*/, const float* __restrict__ bias,
+            u16* __restrict__ dst_, int H, int W, int Cout) {
+  using ET = typename EKT<EK>::type;
+  using v8 = typename E16<ET>::v8;
+  const ET* wgt = (const ET*)wgt_;
+  constexpr int WROWS = NCH * 32;                      // LDS rows of a weight slice: [chunk][16 n + i]
+  constexpr int WPASS = WROWS * 4 / UPR_THREADS;       // 16-byte pieces per thread and slice: 1 / 2
+  static_assert(WROWS * 4 % UPR_THREADS == 0, "whole passes");
+  __shared__ __attribute__((aligned(16))) ET s_w[2][WROWS * UB_PSTR];
+  __shared__ __attribute__((aligned(16))) float s_b[512];
+  const int tiles_x = W / 32;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, img = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < Cout) s_b[tid] = bias[tid];
+  const int li = lane & 15, lk = lane >> 4;
+  const int xh = wave & 1, rg = wave >> 1;
+  const int x0 = tx * 32 + xh * 16 + li, y0 = (ty * 4 + rg) * MT;
+  const ET* in = (const ET*)src_ + (size_t)img * H * W * (NCH * 32);
+  const int groups = Cout >> 5, nslice = groups * 4;
+
+  // weight slice t = (group g = t >> 2, phase ph = t & 3): piece e -> LDS row r = e >> 2 = 32 cc + j, slot q
+  int wt_src[WPASS], wt_lds[WPASS];
+#pragma unroll
+  for (int k = 0; k < WPASS; ++k) {
+    const int e = tid + k * UPR_THREADS, q = e & 3, r = e >> 2, cc = r >> 5, j = r & 31;
+    const int ch = 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);      // LDS row 16 n + i holds channel 8 (i >> 2) + 4 n + (i & 3) of the group
+    wt_src[k] = (cc * Cout + ch) * 32 + q * 8;
+    wt_lds[k] = UB_OFF(r, q);
+  }
+  u32x4 rwt[WPASS];
+  auto load_slice = [&](int t) {
+    const ET* wsl = wgt + ((size_t)(t & 3) * NCH * Cout + (size_t)(t >> 2) * 32) * 32;
+#pragma unroll
+    for (int k = 0; k < WPASS; ++k) rwt[k] = *(const u32x4*)(wsl + wt_src[k]);
+  };
+  auto put_slice = [&](int b) {
+#pragma unroll
+    for (int k = 0; k < WPASS; ++k) *(u32x4*)(s_w[b] + wt_lds[k]) = rwt[k];
+  };
+  load_slice(0);
+  // the wave's pixels: fragment (m, cc) = 8 channels 32 cc + 8 lk .. of pixel (y0 + m, x0)
+  v8 xf[MT][NCH];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) xf[m][cc] = *(const v8*)(in + ((size_t)cc * H * W + (size_t)(y0 + m) * W + x0) * 32 + 8 * lk);
+  // the pixel fragments are USED here, so hipcc's waits for them stand in front of the slice loop: inside it they were counted waits
+  // that ended in s_waitcnt vmcnt(0) in the middle of every slice -- the slice's own weight prefetch and the previous slice's stores
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) { u32x4 t = __builtin_bit_cast(u32x4, xf[m][cc]); asm volatile("" : "+v"(t)); xf[m][cc] = __builtin_bit_cast(v8, t); }
+  put_slice(0);
+  __syncthreads();
+
+  const int OW = 2 * W, OH = 2 * H;
+  ET* out0 = (ET*)dst_ + (size_t)img * OH * OW * Cout;
+  for (int t = 0; t < nslice; ++t) {
+    const int g = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
+    if (t + 1 < nslice) load_slice(t + 1);      // in flight during the MFMAs below
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const f32x4 bv = *(const f32x4*)(s_b + g * 32 + 8 * lk + 4 * n);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m][n] = bv;
+    }
+    const ET* sw = s_w[t & 1];
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) {
+      v8 wf[2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) wf[n] = *(const v8*)(sw + UB_OFF(cc * 32 + n * 16 + li, lk));
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xf[m][cc], acc[m][n]);
+    }
+    ET* out = out0 + (size_t)g * OH * OW * 32;      // this group's 32-channel plane
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      v8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = (ET)acc[m][r >> 2][r & 3];
+      *(v8*)(out + ((size_t)(2 * (y0 + m) + dy) * OW + 2 * x0 + dx) * 32 + 8 * lk) = o;
+    }
+    if (t + 1 < nslice) put_slice((t + 1) & 1);      // its last readers passed the barrier that ended slice t - 1
+    __syncthreads();
+  }
+}
+
+}  // namespace sh

@@ -20,13 +20,9 @@
 #include "k_anp.h"
 #include "k_unet.h"
 #include "k_unet_bf16.h"
-#include "k_unet_bf16_dma.h"
 #include "k_unet16_ldr.h"
 #include "k_unet_x3.h"
-#include "k_unet16_l0.h"
-#include "k_unet16_dec0.h"
-#include "k_unet16_occ.h"
-#include "k_unet16_dec0b3.h"
+#include "k_unet16_up.h"
 #include "unet16_pp.h"
 #include "k_stl.h"
 #include "k_clip.h"
@@ -160,7 +156,6 @@ struct sh_ctx {
   int t_head = 0, t_tail = 0, n_pending = 0;
   hipStream_t out_stream = nullptr;      // sh_collect copies the records / status words of a finished run to the host on this stream
   bool overlap = false;
-  int yield_slot = -1;                   // this lane's busy word among the device's (lane_busy / yield_arg); -1: none
   bool unet_turn = false;                // sh_set_unet_turns: UNet passes of the contexts of one device run one after another
   hipEvent_t unet_done_ev = nullptr;
   unsigned long long batch_gen = 0;
@@ -173,6 +168,17 @@ struct sh_ctx {
   bool side_pending = false;
   // timing
   bool zero_page_ready = false;
+  // Switches of equivalent paths (the A/B arms of tests/), read from the environment ONCE, when the context is created -- no launch
+  // path consults the environment.
+  struct Switches {
+    int window = 0;            // SHOULDER_WINDOW=n: humeri per window of the host-hull walk (0: SH_WINDOW)
+    bool obb_prune = true;     // SHOULDER_OBB_PRUNE=0: every hull-face direction is evaluated
+    bool slice_merge = true;   // SHOULDER_SLICE_MERGE=0: one slice set per launch group
+    bool side_stream = true;   // SHOULDER_SIDE_STREAM=0: small batches keep the distal branch in the chain
+    int te_early = -1;         // SHOULDER_TE_EARLY=1: the trans-epicondylar part forked beside the lane's UNet; 0: behind the UNet; unset: in front of it
+    bool debug = false;        // SH_DEBUG: host-phase timings on stderr
+  } sw;
+  bool unet_reference = false;      // SHOULDER_UNET_REFERENCE=1 at context creation: the 16-bit network layer by layer on the generic kernels
   int ticket_next = 0;              // next free work counter of "unet16.tickets" (one per persistent conv launch of a forward pass)
   std::map<std::tuple<int, int, int>, std::pair<int, int>> tk_tabs;      // (items, workgroups, cout groups) -> (offset, tickets) in "unet16.tk_tab"
   int tk_tab_used = 0;
@@ -390,6 +396,16 @@ int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
   if (!c) return SH_ERR_NOMEM;
   c->device = device;
   c->hull_mode = hull_mode_from(getenv("SHOULDER_HULL"));
+  c->unet_reference = getenv("SHOULDER_UNET_REFERENCE") && getenv("SHOULDER_UNET_REFERENCE")[0] == '1';
+  {
+    auto off = [](const char* n) { const char* e = getenv(n); return e && e[0] == '0'; };
+    if (const char* e = getenv("SHOULDER_WINDOW")) { const int v = atoi(e); if (v > 0) c->sw.window = v; }
+    c->sw.obb_prune = !off("SHOULDER_OBB_PRUNE");
+    c->sw.slice_merge = !off("SHOULDER_SLICE_MERGE");
+    c->sw.side_stream = !off("SHOULDER_SIDE_STREAM");
+    if (const char* e = getenv("SHOULDER_TE_EARLY")) c->sw.te_early = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1);
+    c->sw.debug = getenv("SH_DEBUG") != nullptr;
+  }
   sh_default_params(&c->params);
   if (hip_stream) c->stream = (hipStream_t)hip_stream;
   else {
@@ -401,7 +417,6 @@ int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
 }
 
 static void unet_turn_forget(sh_ctx* c);
-static void yield_leave(sh_ctx* c);
 static void comm_forget(sh_ctx* c);
 
 void sh_ctx_destroy(sh_ctx* c) {
@@ -411,7 +426,6 @@ void sh_ctx_destroy(sh_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   comm_forget(c);
   unet_turn_forget(c);
-  yield_leave(c);
   if (c->unet_done_ev) (void)hipEventDestroy(c->unet_done_ev);
   drain_timers(c);
   if (c->stl_counted_ev) (void)hipEventDestroy(c->stl_counted_ev);
@@ -1098,20 +1112,17 @@ static int conv_layer(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, con
     const u16* wh = buf<u16>(c, "params_x3h") + L.w_off;
     const u16* wl = buf<u16>(c, "params_x3l") + L.w_off;
     float* np_ = nullptr; const float* nf_ = nullptr;
-    const bool db2 = getenv("SHOULDER_X3_DB2") && getenv("SHOULDER_X3_DB2")[0] == '1';      // 32-cout 3x3 layers: double-buffered input too (one workgroup per CU then)
     if (L.taps == 9 && fuse == (UF_FIRST | UF_POOL) && L.cout == 32 && C0 == 32 && C1 == 0) {      // enc0b with enc0a computed while its halo tile is staged
       LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_FIRST | UF_POOL, 0>), dim3(tiles, 1, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_, image, w0, b0);
     }
     else if (L.taps == 9 && fuse == UF_HEAD && L.cout == 32) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_HEAD>), dim3(tiles, 1, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, head_w, head_b, logits, nf_, nf_, nf_); }
     else if (L.taps == 9 && fuse == UF_POOL && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4, UF_POOL>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_, nf_, nf_, nf_); }
-    else if (L.taps == 9 && fuse == UF_POOL && db2) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_POOL, 1>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_, nf_, nf_, nf_); }
     else if (L.taps == 9 && fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, UF_POOL, 0>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, pooled, nf_, nf_, np_, nf_, nf_, nf_); }
     else if (fuse != 0) return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
     else if (L.taps == 9 && L.cout % 64 == 0) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 4>), dim3(tiles, L.cout / 64, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_, nf_, nf_, nf_); }
-    else if (L.taps == 9 && db2) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, 0, 1>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_, nf_, nf_, nf_); }
     else if (L.taps == 9) { LAUNCH(c, lname, (k_conv_mfma_x3<9, 2, 0, 0>), dim3(tiles, L.cout / 32, nimg), dim3(UN_THREADS), src0, src1, C0, C1, wh, wl, b, dst, H, W, L.cout, relu, np_, nf_, nf_, np_, nf_, nf_, nf_); }
-    else if (C1 == 0 && W % 32 == 0 && H % 16 == 0 && (C0 == 64 || C0 == 128 || C0 == 256 || C0 == 512) && !(getenv("SHOULDER_X3_UPREG") && getenv("SHOULDER_X3_UPREG")[0] == '0')) {
-      // up-convolutions with the source pixels resident in registers (k_upconv_x3r; SHOULDER_X3_UPREG=0: the staged form, bit-identical)
+    else if (C1 == 0 && W % 32 == 0 && H % 16 == 0 && (C0 == 64 || C0 == 128 || C0 == 256 || C0 == 512)) {
+      // up-convolutions with the source pixels resident in registers (k_upconv_x3r)
       if (C0 == 64) { LAUNCH(c, lname, (k_upconv_x3r<2, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UXR_THREADS), src0, wh, wl, b, dst, H, W, L.cout); }
       else if (C0 == 128) { LAUNCH(c, lname, (k_upconv_x3r<4, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UXR_THREADS), src0, wh, wl, b, dst, H, W, L.cout); }
       else if (C0 == 256) { LAUNCH(c, lname, (k_upconv_x3r<8, 2>), dim3((W / 32) * (H / 8), nimg), dim3(UXR_THREADS), src0, wh, wl, b, dst, H, W, L.cout); }
@@ -1167,46 +1178,6 @@ static void unet_turn_forget(sh_ctx* c) {
   if (c->device >= 0 && c->device < 64 && g_turn_owner[c->device] == c) { g_turn_last[c->device] = nullptr; g_turn_owner[c->device] = nullptr; }
 }
 
-// ---- yielding the CU reserve (k_unet_bf16_dma.h, YieldArg) ----------------------------------------------------------------
-// One busy word per lane of a device, in uncached device memory shared by the contexts of the process: a lane raises its word
-// on its stream in front of its geometry chain and behind its UNet pass and lowers it in front of the pass and behind the run
-// (hipStreamWriteValue32: no launch).  OFF by default (SHOULDER_CU_YIELD=1 switches it on): measured on the two-lane headline the
-// pass keeps its 7.74 ms -- the chain is in flight for 6 of them, and what the pass gains in the rest the chain loses waiting for
-// yielding workgroups (geometry 5.2 -> 5.9 ms, the wait for the turn 1.3 -> 0.4): 7.95 vs 7.97 ms per step.
-static int* g_yield_flags[64] = {};
-static unsigned g_yield_used[64] = {};
-static bool yield_enabled() {
-  static const bool on = getenv("SHOULDER_CU_YIELD") && getenv("SHOULDER_CU_YIELD")[0] == '1';
-  return on;
-}
-static void yield_join(sh_ctx* c) {
-  if (!yield_enabled() || c->yield_slot >= 0 || c->device < 0 || c->device >= 64) return;
-  std::lock_guard<std::mutex> lk(g_turn_mu);
-  if (!g_yield_flags[c->device]) {
-    void* p = nullptr;
-    if (hipExtMallocWithFlags(&p, SH_YIELD_SLOTS * 4, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (hipMemset(p, 0, SH_YIELD_SLOTS * 4) != hipSuccess) { (void)hipFree(p); return; }
-    g_yield_flags[c->device] = (int*)p;
-  }
-  for (int j = 0; j < SH_YIELD_SLOTS; ++j)
-    if (!(g_yield_used[c->device] >> j & 1u)) { g_yield_used[c->device] |= 1u << j; c->yield_slot = j; break; }
-}
-static void yield_leave(sh_ctx* c) {
-  if (c->yield_slot < 0) return;
-  std::lock_guard<std::mutex> lk(g_turn_mu);
-  (void)hipStreamSynchronize(c->stream);
-  const int zero = 0;
-  (void)hipMemcpy(g_yield_flags[c->device] + c->yield_slot, &zero, 4, hipMemcpyHostToDevice);
-  g_yield_used[c->device] &= ~(1u << c->yield_slot);
-  c->yield_slot = -1;
-}
-// the lane's busy word <- v, in stream order
-static void lane_busy(sh_ctx* c, unsigned v) {
-  if (c->yield_slot < 0 || !c->unet_turn) return;
-  if (hipStreamWriteValue32(c->stream, g_yield_flags[c->device] + c->yield_slot, v, 0) != hipSuccess) (void)hipGetLastError();
-}
-static YieldArg yield_arg(const sh_ctx* c);
-
 static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
   const int D = c->unet_depth, base = c->unet_base;
   if ((H >> D) % 16 || (W >> D) % 16) return fail(c, SH_ERR_ARG, "unet: input size must be a multiple of 16 << depth");
@@ -1258,9 +1229,9 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
   auto L = [&](const std::string& n) -> const sh_ctx::ULayer& { return c->ulayers[n]; };
   int h = H, w = W;
   // SH_UNET_F32X: the 2x2 pools ride in the epilogue of the conv before them (k_unet_x3.h), and with 32 base channels the first
-  // conv is computed inside enc0b's staging (SHOULDER_X3_FIRST=0: as its own launch)
+  // conv is computed inside enc0b's staging
   const bool x3 = c->params.unet_dtype == SH_UNET_F32X && base % 32 == 0;
-  const bool x3_first = x3 && base == 32 && !(getenv("SHOULDER_X3_FIRST") && getenv("SHOULDER_X3_FIRST")[0] == '0');
+  const bool x3_first = x3 && base == 32;
   if (!x3_first) {
     const sh_ctx::ULayer& l = L("enc0a");
     size_t npx = (size_t)nimg * h * w;
@@ -1292,12 +1263,8 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
     if ((rc = conv_layer(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
     h *= 2; w *= 2; ch /= 2;
     if ((rc = conv_layer(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;
-    // (the head stays on k_head: its sequential f32 chain over the channels is the exact path's; fused into dec0b's epilogue
-    //  -- SHOULDER_X3_HEAD=1 -- the logits move by another ~1e-6 and one mask pixel of the 64-humerus bench batch flips)
-    if (x3 && i == 0 && ch == 32 && getenv("SHOULDER_X3_HEAD") && getenv("SHOULDER_X3_HEAD")[0] == '1') {
-      const sh_ctx::ULayer& l = L("head");
-      return conv_layer(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1, UF_HEAD, nullptr, P + l.w_off, P + l.b_off, logits);
-    }
+    // (the head stays on k_head: its sequential f32 chain over the channels is the exact path's; fused into dec0b's epilogue the
+    //  logits move by another ~1e-6 and one mask pixel of the 64-humerus bench batch flips)
     if ((rc = conv_layer(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1)) != SH_OK) return rc;
     std::swap(x, y);
   }
@@ -1315,42 +1282,33 @@ static int unet_forward(sh_ctx* c, const float* image, float* logits, int nimg, 
 // ---- UNet forward (16-bit MFMA paths: EK = 0 __bf16, 1 _Float16; tensors as raw u16) -----------------------------------------
 #define SH_UNET_TICKETS 64
 #define SH_UNET_TKTAB (1 << 18)
-// work tickets of the persistent convs (k_unet_bf16_dma.h; SHOULDER_DMA_TICKETS=0: fixed equal shares): the next free counter
-// of this forward pass and the table of item bounds of decreasing runs for (items, workgroups, cout groups), built once per shape
-// Workgroups of a persistent UNet launch.  Each takes a whole CU (158 KB of LDS, all of its registers), so while one is resident no
-// other kernel can start there: beside the UNet pass of one lane, every launch of the other lane's geometry chain (~100 per step)
+// Workgroups of a persistent UNet launch.  Each takes a whole CU (its LDS, all of its registers), so while one is resident no
+// other kernel can start there: beside the UNet pass of one lane, every launch of the other lane's geometry chain (~40 per step)
 // waited ~50 us for a workgroup to end, and the chain took 7-8 ms instead of 3.2.  Contexts that take turns on a device
-// (sh_set_unet_turns: there IS another lane) therefore leave SHOULDER_CU_RESERVE CUs (default 32 = 4 per XCD) out of the grid;
-// the work tickets spread the items over whatever grid there is.  Measured on the two-lane headline: 0 / 8 / 16 / 32 / 48 / 64 / 96
-// reserved -> 8.72 / 8.80 / 8.73 / 8.27 / 8.54 / 8.56 / 9.35 ms per step.
+// (sh_set_unet_turns: there IS another lane) therefore leave SHOULDER_CU_RESERVE CUs (default 32 = 4 per XCD; read once) out of
+// the grid; the work tickets spread the items over whatever grid there is.  Measured on the two-lane headline: 0 / 8 / 16 / 32 /
+// 48 / 64 / 96 reserved -> 8.72 / 8.80 / 8.73 / 8.27 / 8.54 / 8.56 / 9.35 ms per step.
 static int cu_reserve() {
   static const int reserve = getenv("SHOULDER_CU_RESERVE") ? std::max(0, atoi(getenv("SHOULDER_CU_RESERVE"))) : 32;
   return reserve;
 }
-static int persistent_grid(const sh_ctx* c) {
+static int persistent_grid(sh_ctx* c) {
+  if (c->num_cus <= 0) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) v = 0; c->num_cus = v > 0 ? v : 256; }
   return c->unet_turn ? std::max(8, c->num_cus - cu_reserve()) : c->num_cus;
 }
-// ... and for the launches that hand their items out in tickets: the whole chip, the last `reserve` workgroups yielding to another
-// lane's chain when one is in flight (k_unet_bf16_dma.h, YieldArg)
-static YieldArg yield_arg(const sh_ctx* c) {
-  if (!c->unet_turn || c->yield_slot < 0 || c->num_cus - cu_reserve() < 8) return YieldArg{nullptr, 0, 0};
-  return YieldArg{g_yield_flags[c->device], c->yield_slot, cu_reserve()};
-}
-static int ticket_grid(const sh_ctx* c, const YieldArg& y) { return y.flags ? c->num_cus : persistent_grid(c); }
 
-static int dma_tickets(sh_ctx* c, int total, int nwg, int ngrp, unsigned** tk, const int** tk_tab, int* ntk) {
-  *tk = nullptr; *tk_tab = nullptr; *ntk = 0;
-  const bool tickets_on = !(getenv("SHOULDER_DMA_TICKETS") && getenv("SHOULDER_DMA_TICKETS")[0] == '0');      // (read per launch: the tests switch it in-process)
-  if (!tickets_on) return SH_OK;
+// work tickets of a persistent launch: the next free counter of this forward pass and the table of item bounds of runs of decreasing
+// length for (items, workgroups, cout groups) -- every ticket a third of what would be a fair share of the remaining items, whole
+// cout-group sets of a tile (its input tile comes from HBM once) -- built once per shape
+static int unet_tickets(sh_ctx* c, int total, int nwg, int ngrp, unsigned** tk, const int** tk_tab, int* ntk) {
   const auto key = std::make_tuple(total, nwg, ngrp);
   auto it = c->tk_tabs.find(key);
   if (it == c->tk_tabs.end()) {
     std::vector<int> tab;
     int pos = 0;
     while (pos < total) {
-      static const double tkdiv = getenv("SHOULDER_DMA_TKDIV") ? std::max(1.0, atof(getenv("SHOULDER_DMA_TKDIV"))) : 3.0;
-      int sz = std::max(1, (int)std::ceil((total - pos) / (tkdiv * (double)nwg)));
-      if (sz >= ngrp) sz = sz / ngrp * ngrp;      // whole cout-group sets of a tile: its input tile comes from HBM once
+      int sz = std::max(1, (int)std::ceil((total - pos) / (3.0 * (double)nwg)));
+      if (sz >= ngrp) sz = sz / ngrp * ngrp;
       tab.push_back(pos);
       pos += std::min(sz, total - pos);
     }
@@ -1373,6 +1331,11 @@ static int dma_tickets(sh_ctx* c, int total, int nwg, int ngrp, unsigned** tk, c
   return SH_OK;
 }
 
+// One layer of the 16-bit network.  3x3 convs with a multiple of 64 output channels on 32 x 16-tileable maps run on the persistent
+// LDS-DMA kernel (k_unet16_ldr.h; UF_POOL: the 2x2 max pool written beside the output); 2x2 transposed convs on k_upconv16r /
+// k_upconv16; everything else on the generic two-barrier kernel k_conv_mfma16 (k_unet_bf16.h), which is also the whole of the
+// REFERENCE network (sh_ctx::unet_reference: layer by layer, nothing fused, no persistent kernel -- what the tests hold the
+// production kernels against).
 template <int EK>
 static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const u16* src0, const u16* src1, int C0, int C1,
                            u16* dst, int H, int W, int nimg, int relu, int fuse = 0, ConvFuse fz = ConvFuse{}) {
@@ -1381,75 +1344,24 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
   const float* b = buf<float>(c, "params") + L.b_off;
   const int tiles = (H / UN_TH) * (W / UN_TW);
   const dim3 blk(UN_THREADS);
-  const char* dma_env = getenv("SHOULDER_UNET_DMA");
-  const bool dma_shape = L.taps == 9 && L.cout <= 512 && W % 32 == 0 && H % 16 == 0 && C0 % 32 == 0 && C1 % 32 == 0 && !(dma_env && dma_env[0] == '0');
-  const bool dma64 = dma_shape && L.cout % 64 == 0 && (fuse == 0 || fuse == UF_POOL);
-  // the 32-channel level: 32-cout items (SHOULDER_UNET_DMA32=0 keeps it on the two-barrier kernel)
-  const char* dma32_env = getenv("SHOULDER_UNET_DMA32");
-  const bool dma32 = dma_shape && !dma64 && L.cout % 32 == 0 && (fuse == 0 || fuse == UF_POOL || (fuse == UF_HEAD && L.cout == 32)) && !(dma32_env && dma32_env[0] == '0');
-  if (dma64 || dma32) {
-    // persistent LDS-DMA form (k_unet_bf16_dma.h): one workgroup per CU walks (image, 32x16 tile, 64- or 32-cout group) items
+  const bool ldr = !c->unet_reference && L.taps == 9 && L.cout % 64 == 0 && L.cout <= 512 && W % 32 == 0 && H % 16 == 0 && C0 % 32 == 0 && C1 % 32 == 0 &&
+                   (fuse == 0 || fuse == UF_POOL);
+  if (ldr) {
     int rc0;
     if ((rc0 = ensure(c, "unet16.zero", 256, 2)) != SH_OK) return rc0;
     if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
-    if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
-    const int total = nimg * (W / 32) * (H / 16) * (L.cout / (dma64 ? 64 : 32));
-    // SHOULDER_DMA_GRIDMUL workgroups per CU (default 1): with more, shorter work ranges the hardware dispatcher balances the
-    // launch over the CUs another lane's kernels leave free (a workgroup takes a whole CU's LDS, so it waits for a free CU)
-    static const int gridmul = getenv("SHOULDER_DMA_GRIDMUL") ? std::max(1, atoi(getenv("SHOULDER_DMA_GRIDMUL"))) : 1;
-    const bool tickets_on = !(getenv("SHOULDER_DMA_TICKETS") && getenv("SHOULDER_DMA_TICKETS")[0] == '0');
-    YieldArg yl = (tickets_on && gridmul == 1) ? yield_arg(c) : YieldArg{nullptr, 0, 0};
-    if (total < c->num_cus) yl = YieldArg{nullptr, 0, 0};
-    const dim3 g((unsigned)std::min(total, (yl.flags ? ticket_grid(c, yl) : persistent_grid(c)) * gridmul));
+    const int total = nimg * (W / 32) * (H / 16) * (L.cout / 64);
+    const dim3 g((unsigned)std::min(total, persistent_grid(c)));
     unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
-    { int rct; if ((rct = dma_tickets(c, total, (int)g.x, L.cout / (dma64 ? 64 : 32), &tk, &tk_tab, &ntk)) != SH_OK) return rct; }
+    if ((rc0 = unet_tickets(c, total, (int)g.x, L.cout / 64, &tk, &tk_tab, &ntk)) != SH_OK) return rc0;
     const u16* zp = (const u16*)c->bufs["unet16.zero"].p;
-    const float* nof = nullptr;
-    static const int sched = (getenv("SHOULDER_DMA_SCHED") && getenv("SHOULDER_DMA_SCHED")[0] == '0') ? 0 : 1;      // tap order inside a step (k_unet_bf16_dma.h)
-    // weights resident in LDS (k_unet_bf16_dma.h, WRES): one cout group and nchunk * rows-per-tap <= 128
-    const bool wres_on = !(getenv("SHOULDER_DMA_WRES") && getenv("SHOULDER_DMA_WRES")[0] == '0');
-    const bool wres = wres_on && sched == 1 && L.cout == (dma64 ? 64 : 32) && ((C0 + C1) / 32) * (dma64 ? 64 : 32) <= 128;
-    // 32 -> 32 layers: the weight fragments also stay in registers (SHOULDER_DMA_WREG=0: LDS reads as in the other layers)
-    const bool wreg = wres && !dma64 && C0 + C1 == 32 && !(getenv("SHOULDER_DMA_WREG") && getenv("SHOULDER_DMA_WREG")[0] == '0');
-#define DMA_LAUNCH(F, N, ...)                                                                                                     \
-  do {                                                                                                                            \
-    if (wres && wreg && N == 2) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, 2, 1, 2>), g, dim3(UD_THREADS), __VA_ARGS__); }              \
-    else if (wres) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1, 1>), g, dim3(UD_THREADS), __VA_ARGS__); }                       \
-    else if (sched == 0) { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 0, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                 \
-    else { LAUNCH(c, lname, (k_conv3_dma16<EK, F, N, 1, 0>), g, dim3(UD_THREADS), __VA_ARGS__); }                                 \
-  } while (0)
-    // 64-cout items: compute waves + loader waves (k_unet16_ldr.h); SHOULDER_DMA_LDR=0 keeps the form where every wave does both
-    const bool ldr = dma64 && sched == 1 && !(getenv("SHOULDER_DMA_LDR") && getenv("SHOULDER_DMA_LDR")[0] == '0');
-    if (ldr) {
-      u16* pl = fuse == UF_POOL ? (u16*)fz.pooled : (u16*)nullptr;
-      const int gm = (getenv("SHOULDER_GMAJOR") && getenv("SHOULDER_GMAJOR")[0] == '1' && L.cout / 64 > 1) ? 2 : 0;
-      if (fuse == UF_POOL && wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk, yl); }
-      else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk, yl); }
-      else if (wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk, yl); }
-      else { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu | gm, nimg, zp, pl, tk, tk_tab, ntk, yl); }
-    } else if (dma64) {
-      if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk, yl);
-      else DMA_LAUNCH(0, 4, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk, yl);
-    } else if (fuse == UF_POOL) DMA_LAUNCH(UF_POOL, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)fz.pooled, nof, nof, (float*)nullptr, tk, tk_tab, ntk, yl);
-    else if (fuse == UF_HEAD) {
-      // SHOULDER_DEC0B_OCC=1: dec0b + head as small workgroups that share a CU (k_unet16_occ.h; bit-identical, measured 4 % slower)
-      const bool occ = C0 == 32 && C1 == 0 && L.cout == 32 && relu && H % SH_OCC_TR == 0 && getenv("SHOULDER_DEC0B_OCC") && getenv("SHOULDER_DEC0B_OCC")[0] == '1';
-      if (occ) {
-        if (c->ticket_next >= SH_UNET_TICKETS) return fail(c, SH_ERR_CAPACITY, "unet: out of work counters");
-        unsigned* tko = buf<unsigned>(c, "unet16.tickets") + c->ticket_next++;
-        const int ntiles = nimg * (W / 32) * (H / SH_OCC_TR), ntko = (ntiles + SH_OCC_TK - 1) / SH_OCC_TK;
-        static const int occ_mul = getenv("SHOULDER_OCC_MUL") ? std::max(1, atoi(getenv("SHOULDER_OCC_MUL"))) : 2;      // workgroups per CU
-        LAUNCH(c, lname, (k_dec0b_head_occ<EK>), dim3((unsigned)std::min(ntko, persistent_grid(c) * occ_mul)), dim3(SH_OCC_THREADS), src0, w, b, fz.head_w, fz.head_b, fz.logits, H, W, nimg, zp, tko);
-      } else if (C0 == 32 && C1 == 0 && L.cout == 32 && relu && tk != nullptr && !yl.flags && !(getenv("SHOULDER_L0_PP") && getenv("SHOULDER_L0_PP")[0] == '0')) {
-        // the two waves of a SIMD take turns on the matrix pipe (k_unet16_pp.h; same logits bit for bit)
-        LAUNCH_FN(c, lname, launch_dec0b_head_pp(EK, g.x, c->stream, src0, w, b, fz.head_w, fz.head_b, fz.logits, H, W, nimg, zp, tk, tk_tab, ntk));
-      } else if (C0 == 32 && C1 == 0 && L.cout == 32 && relu && tk != nullptr && !(getenv("SHOULDER_DEC0B3") && getenv("SHOULDER_DEC0B3")[0] == '0')) {
-        // three halo buffers, two tiles in flight (k_unet16_dec0b3.h; bit-identical; SHOULDER_DEC0B3=0: the two-buffer kernel)
-        LAUNCH(c, lname, (k_dec0b_head3<EK>), g, dim3(UD_THREADS), src0, w, b, fz.head_w, fz.head_b, fz.logits, H, W, nimg, zp, tk, tk_tab, ntk, yl);
-      } else DMA_LAUNCH(UF_HEAD, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, fz.head_w, fz.head_b, fz.logits, tk, tk_tab, ntk, yl);
-    }
-    else DMA_LAUNCH(0, 2, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, (u16*)nullptr, nof, nof, (float*)nullptr, tk, tk_tab, ntk, yl);
-#undef DMA_LAUNCH
+    u16* pl = fuse == UF_POOL ? (u16*)fz.pooled : (u16*)nullptr;
+    // weights resident in LDS: one cout group whose packed weights fit behind the two input buffers (32 -> 64 and 64 -> 64 layers)
+    const bool wres = L.cout == 64 && ((C0 + C1) / 32) * 64 <= 128;
+    if (fuse == UF_POOL && wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
+    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
+    else if (wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
+    else { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
   } else if (L.taps == 9 && L.cout % 64 == 0) {
     const dim3 g(tiles, L.cout / 64, nimg);
     if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 4, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
@@ -1458,13 +1370,10 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
   } else if (L.taps == 9) {
     const dim3 g(tiles, L.cout / 32, nimg);
     if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == (UF_FIRST | UF_POOL)) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, UF_FIRST | UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, UF_POOL>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
-    else if (fuse == UF_HEAD) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, UF_HEAD>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
     else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
-  } else if (L.cout % 32 == 0 && C1 == 0 && C0 % 32 == 0 && !(getenv("SHOULDER_UNET_UPCONV") && getenv("SHOULDER_UNET_UPCONV")[0] == '0')) {
-    // 2x2 transposed conv (k_unet16_l0.h): source pixels in registers for Cin = 128 / 256 (SHOULDER_UPCONV_REG=0: the staged form everywhere)
-    const bool upr = W % 32 == 0 && H % 16 == 0 && (C0 == 128 || C0 == 256) && L.cout <= 512 && !(getenv("SHOULDER_UPCONV_REG") && getenv("SHOULDER_UPCONV_REG")[0] == '0');
+  } else if (!c->unet_reference && L.cout % 32 == 0 && C1 == 0 && C0 % 32 == 0) {
+    // 2x2 transposed conv (k_unet16_up.h): source pixels in registers for Cin = 128 / 256, the staged form otherwise
+    const bool upr = W % 32 == 0 && H % 16 == 0 && (C0 == 128 || C0 == 256) && L.cout <= 512;
     if (upr && C0 == 128) { LAUNCH(c, lname, (k_upconv16r<EK, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
     else if (upr) { LAUNCH(c, lname, (k_upconv16r<EK, 8>), dim3((W / 32) * (H / 16), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
     else { LAUNCH(c, lname, (k_upconv16<EK>), dim3(tiles, L.cout / 32, nimg * 2), dim3(UPC_THREADS), src0, C0, w, b, dst, H, W, L.cout); }
@@ -1476,18 +1385,15 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
   return SH_OK;
 }
 
-// 4-level double-conv UNet, bf16.  With 32 base channels the memory-bound ends are fused (k_unet_bf16.h): the first
-// conv into the staging of enc0b, every 2x2 max pool into the epilogue of the conv before it, the 1x1 head into the
-// epilogue of dec0b.  SHOULDER_UNET_UNFUSED=1 (or another base width) runs the layer-by-layer form.
-// does the 16-bit forward start with the fused level-0 encoder (k_enc0_fused16)?  (run_window asks: that kernel can read the unscaled image)
-static bool unet16_starts_fused(const sh_ctx* c, int H, int W) {
-  const char* unf = getenv("SHOULDER_UNET_UNFUSED");
-  const char* ff = getenv("SHOULDER_UNET_FUSE_FIRST");
-  const char* l0env = getenv("SHOULDER_UNET_L0");
-  return c->unet_base == 32 && !(unf && unf[0] == '1') && !(ff && ff[0] == '0') && !(l0env && l0env[0] == '0') && W % 32 == 0 && H % 16 == 0 &&
-         (H >> c->unet_depth) % 16 == 0 && (W >> c->unet_depth) % 16 == 0;
+// does the 16-bit forward run its fused level-0 kernels (k_unet16_pp.h)?  (run_window asks: k_enc0_pp can read the unscaled image)
+static bool unet16_level0_fused(const sh_ctx* c, int H, int W) {
+  return !c->unet_reference && c->unet_base == 32 && c->unet_depth >= 1 && W % 32 == 0 && H % 16 == 0 && (H >> c->unet_depth) % 16 == 0 && (W >> c->unet_depth) % 16 == 0;
 }
+static bool unet16_starts_fused(const sh_ctx* c, int H, int W) { return unet16_level0_fused(c, H, W); }
 
+// Double-conv UNet, 16-bit.  With 32 base channels the full-resolution level runs as three fused ping-pong kernels (k_unet16_pp.h:
+// image -> enc0a -> enc0b -> skip0 + pool; up0 + dec0a; dec0b + head) and every 2x2 max pool rides in the epilogue of the conv before
+// it.  Other widths, maps that do not tile, and the reference network run layer by layer.
 template <int EK>
 static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg, int H, int W) {
   const int D = c->unet_depth, base = c->unet_base;
@@ -1496,8 +1402,7 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
   if ((rc = ensure(c, "params_bf16", c->unet_floats * 2, 2)) != SH_OK) return rc;
   const float* P = buf<float>(c, "params");
   u16* PW = buf<u16>(c, "params_bf16");
-  static const bool repack_always = getenv("SHOULDER_UNET_REPACK") && getenv("SHOULDER_UNET_REPACK")[0] == '1';
-  if (c->packed_kind != EK || repack_always) {     // pack the MFMA layers' weights for this element type: one launch for all layers, once per parameter block
+  if (c->packed_kind != EK) {     // pack the MFMA layers' weights for this element type: one launch for all layers, once per parameter block
     std::vector<PackEntry> tab;
     long long total = 0;
     for (auto& kv : c->ulayers) {
@@ -1519,8 +1424,7 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
   if ((rc = ensure(c, "unet16.tk_tab", SH_UNET_TKTAB * 4, 4)) != SH_OK) return rc;
   FILL(c, {buf<unsigned>(c, "unet16.tickets"), (size_t)SH_UNET_TICKETS * 4, 0});
   c->ticket_next = 0;
-  const char* unf = getenv("SHOULDER_UNET_UNFUSED");
-  const bool fused = base == 32 && !(unf && unf[0] == '1');
+  const bool fused = unet16_level0_fused(c, H, W);      // level 0 on the ping-pong kernels, pools in the conv epilogues
   const size_t full = (size_t)nimg * H * W * base * 2;
   if ((rc = ensure(c, "unet16.a", full, 2)) != SH_OK) return rc;
   if ((rc = ensure(c, "unet16.b", full, 2)) != SH_OK) return rc;
@@ -1533,39 +1437,20 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
   u16* A = buf<u16>(c, "unet16.a");
   u16* Bq = buf<u16>(c, "unet16.b");
   auto L = [&](const std::string& n) -> const sh_ctx::ULayer& { return c->ulayers[n]; };
+  if ((rc = ensure(c, "unet16.zero", 256, 2)) != SH_OK) return rc;
+  if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
+  const u16* zp = (const u16*)c->bufs["unet16.zero"].p;
   int h = H, w = W;
-  const char* ff = getenv("SHOULDER_UNET_FUSE_FIRST");
-  const char* l0env = getenv("SHOULDER_UNET_L0");
-  const bool l0 = fused && !(ff && ff[0] == '0') && !(l0env && l0env[0] == '0') && w % 32 == 0 && h % 16 == 0;
-  if (l0) {
-    // level-0 encoder as one persistent kernel (k_unet16_l0.h): image -> enc0a -> LDS -> enc0b -> skip0 + pooled
+  if (fused) {
+    // level-0 encoder (k_enc0_pp): image -> enc0a -> LDS -> enc0b -> skip0 + pooled
     const sh_ctx::ULayer& la = L("enc0a");
     const sh_ctx::ULayer& lb = L("enc0b");
-    if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
     const int total = nimg * (w / 32) * (h / 16);
     const unsigned grid = (unsigned)std::min(total, persistent_grid(c));
     unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
-    if ((rc = dma_tickets(c, total, (int)grid, 1, &tk, &tk_tab, &ntk)) != SH_OK) return rc;
-    if (tk != nullptr && !(getenv("SHOULDER_L0_PP") && getenv("SHOULDER_L0_PP")[0] == '0') && !(getenv("SHOULDER_ENC0_PP") && getenv("SHOULDER_ENC0_PP")[0] == '0')) {
-      // the two waves of a SIMD take turns on the matrix pipe (k_unet16_pp.h)
-      LAUNCH_FN(c, "unet.enc0b", launch_enc0_pp(EK, grid, c->stream, image, P + la.w_off, P + la.b_off, PW + lb.w_off, P + lb.b_off, skip[0], A, h, w, nimg,
-                                                c->unet_raw, c->unet_mm, tk, tk_tab, ntk));
-    } else {
-      LAUNCH(c, "unet.enc0b", (k_enc0_fused16<EK>), dim3(grid), dim3(L0_THREADS), image, P + la.w_off, P + la.b_off,
-             PW + lb.w_off, P + lb.b_off, skip[0], A, h, w, nimg, c->unet_raw, c->unet_mm);
-    }
-  } else if (fused && !(ff && ff[0] == '0')) {
-    const sh_ctx::ULayer& l = L("enc0a");
-    ConvFuse fz{};
-    fz.image = image; fz.w0 = P + l.w_off; fz.b0 = P + l.b_off; fz.pooled = A;
-    if ((rc = conv_layer16<EK>(c, "unet.enc0b", L("enc0b"), nullptr, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_FIRST | UF_POOL, fz)) != SH_OK) return rc;
-  } else if (fused) {
-    const sh_ctx::ULayer& l = L("enc0a");
-    size_t npx = (size_t)nimg * h * w;
-    LAUNCH(c, "unet.enc0a", k_conv_first16<EK>, dim3((unsigned)std::min<size_t>((npx + 255) / 256, 8192)), dim3(256), image, P + l.w_off, P + l.b_off, Bq, h, w, l.cout, nimg);
-    ConvFuse fz{};
-    fz.pooled = A;
-    if ((rc = conv_layer16<EK>(c, "unet.enc0b", L("enc0b"), Bq, nullptr, base, 0, skip[0], h, w, nimg, 1, UF_POOL, fz)) != SH_OK) return rc;
+    if ((rc = unet_tickets(c, total, (int)grid, 1, &tk, &tk_tab, &ntk)) != SH_OK) return rc;
+    LAUNCH_FN(c, "unet.enc0b", launch_enc0_pp(EK, grid, c->stream, image, P + la.w_off, P + la.b_off, PW + lb.w_off, P + lb.b_off, skip[0], A, h, w, nimg,
+                                              c->unet_raw, c->unet_mm, tk, tk_tab, ntk));
   } else {
     const sh_ctx::ULayer& l = L("enc0a");
     size_t npx = (size_t)nimg * h * w;
@@ -1590,54 +1475,35 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
   u16* x = A; u16* y = Bq;
   for (int i = D - 1; i >= 0; --i) {
     std::string nu = "up" + std::to_string(i), na = "dec" + std::to_string(i) + "a", nb = "dec" + std::to_string(i) + "b";
-    const char* d0env = getenv("SHOULDER_UNET_DEC0");
-    if (fused && i == 0 && ch == 64 && (2 * w) % 32 == 0 && (2 * h) % 16 == 0 && !(d0env && d0env[0] == '0')) {
-      // level 0: the up-convolution computed inside dec0a (k_unet16_dec0.h); x = low-resolution input, y = dec0a's output
+    if (fused && i == 0) {
+      // level 0: the up-convolution computed inside dec0a (k_dec0a_up_pp: x = low-resolution input, y = dec0a's output), then
+      // dec0b with the 1x1 head in its epilogue (k_dec0b_head_pp: only the logits leave the kernel)
       h *= 2; w *= 2; ch /= 2;
       const sh_ctx::ULayer& lu = L(nu);
       const sh_ctx::ULayer& la = L(na);
-      if ((rc = ensure(c, "unet16.zero", 256, 2)) != SH_OK) return rc;
-      if (!c->zero_page_ready) { HIPCHK(c, hipMemsetAsync(buf<char>(c, "unet16.zero"), 0, 256, c->stream)); c->zero_page_ready = true; }
-      if (c->num_cus <= 0) { int v = 0; HIPCHK(c, hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device)); c->num_cus = v > 0 ? v : 256; }
+      const sh_ctx::ULayer& lb = L(nb);
       const sh_ctx::ULayer& lh = L("head");
-      if (h % 8 == 0 && !(getenv("SHOULDER_L0_PP") && getenv("SHOULDER_L0_PP")[0] == '0') && !(getenv("SHOULDER_DEC0A_PP") && getenv("SHOULDER_DEC0A_PP")[0] == '0')) {
-        // the two waves of a SIMD take turns on the matrix pipe (k_unet16_pp.h: 32 x 8 tiles; the same tensor bit for bit)
-        const int total8 = nimg * (w / 32) * (h / 8);
-        const unsigned g8 = (unsigned)std::min(total8, persistent_grid(c));
-        unsigned* tk8 = nullptr; const int* tk_tab8 = nullptr; int ntk8 = 0;
-        if ((rc = dma_tickets(c, total8, (int)g8, 1, &tk8, &tk_tab8, &ntk8)) != SH_OK) return rc;
-        if (tk8 != nullptr) {
-          LAUNCH_FN(c, "unet.dec0a", launch_dec0a_up_pp(EK, g8, c->stream, skip[0], x, PW + la.w_off, P + la.b_off, PW + lu.w_off, P + lu.b_off, y, h, w, nimg,
-                                                        (const u16*)c->bufs["unet16.zero"].p, tk8, tk_tab8, ntk8));
-          ConvFuse fz{};
-          fz.head_w = P + lh.w_off; fz.head_b = P + lh.b_off; fz.logits = logits;
-          return conv_layer16<EK>(c, ("unet." + nb).c_str(), L(nb), y, nullptr, ch, 0, x, h, w, nimg, 1, UF_HEAD, fz);
-        }
+      {
+        const int total = nimg * (w / 32) * (h / 8);
+        const unsigned grid = (unsigned)std::min(total, persistent_grid(c));
+        unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
+        if ((rc = unet_tickets(c, total, (int)grid, 1, &tk, &tk_tab, &ntk)) != SH_OK) return rc;
+        LAUNCH_FN(c, "unet.dec0a", launch_dec0a_up_pp(EK, grid, c->stream, skip[0], x, PW + la.w_off, P + la.b_off, PW + lu.w_off, P + lu.b_off, y, h, w, nimg,
+                                                      zp, tk, tk_tab, ntk));
       }
-      const int total = nimg * (w / 32) * (h / 16);
-      const bool tickets_on = !(getenv("SHOULDER_DMA_TICKETS") && getenv("SHOULDER_DMA_TICKETS")[0] == '0');
-      const YieldArg yl = (tickets_on && total >= c->num_cus) ? yield_arg(c) : YieldArg{nullptr, 0, 0};
-      const dim3 g((unsigned)std::min(total, ticket_grid(c, yl)));
-      unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
-      if ((rc = dma_tickets(c, total, (int)g.x, 1, &tk, &tk_tab, &ntk)) != SH_OK) return rc;
-      LAUNCH(c, "unet.dec0a", (k_dec0a_up16<EK>), g, dim3(UD_THREADS), skip[0], x, PW + la.w_off, P + la.b_off, PW + lu.w_off, P + lu.b_off, y, h, w, nimg,
-             (const u16*)c->bufs["unet16.zero"].p, tk, tk_tab, ntk, yl);
-      const sh_ctx::ULayer& l = L("head");
-      ConvFuse fz{};
-      fz.head_w = P + l.w_off; fz.head_b = P + l.b_off; fz.logits = logits;
-      if ((rc = conv_layer16<EK>(c, ("unet." + nb).c_str(), L(nb), y, nullptr, ch, 0, x, h, w, nimg, 1, UF_HEAD, fz)) != SH_OK) return rc;
+      {
+        const int total = nimg * (w / 32) * (h / 16);
+        const unsigned grid = (unsigned)std::min(total, persistent_grid(c));
+        unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
+        if ((rc = unet_tickets(c, total, (int)grid, 1, &tk, &tk_tab, &ntk)) != SH_OK) return rc;
+        LAUNCH_FN(c, "unet.dec0b", launch_dec0b_head_pp(EK, grid, c->stream, y, PW + lb.w_off, P + lb.b_off, P + lh.w_off, P + lh.b_off, logits, h, w, nimg,
+                                                        zp, tk, tk_tab, ntk));
+      }
       return SH_OK;
     }
     if ((rc = conv_layer16<EK>(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
     h *= 2; w *= 2; ch /= 2;
     if ((rc = conv_layer16<EK>(c, ("unet." + na).c_str(), L(na), skip[i], y, ch, ch, x, h, w, nimg, 1)) != SH_OK) return rc;
-    if (fused && i == 0) {
-      const sh_ctx::ULayer& l = L("head");
-      ConvFuse fz{};
-      fz.head_w = P + l.w_off; fz.head_b = P + l.b_off; fz.logits = logits;
-      if ((rc = conv_layer16<EK>(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1, UF_HEAD, fz)) != SH_OK) return rc;
-      return SH_OK;
-    }
     if ((rc = conv_layer16<EK>(c, ("unet." + nb).c_str(), L(nb), x, nullptr, ch, 0, y, h, w, nimg, 1)) != SH_OK) return rc;
     std::swap(x, y);
   }
@@ -2067,7 +1933,7 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
     slot = c->hslot; c->hslot ^= 1;
     int bad = -1; double ms = 0; std::string et;
     int hrc = hull_host_phase(c, c->hull_in, slot, b0, B, &bad, &ms, &et);
-    if (getenv("SH_DEBUG")) fprintf(stderr, "[sh] run_obb: foreground hull phase %.2f ms\n", ms);
+    if (c->sw.debug) fprintf(stderr, "[sh] run_obb: foreground hull phase %.2f ms\n", ms);
     if (c->timing) { KTimer& h = c->timers["host.hull"]; h.ms += ms; h.n += 1; }
     if (hrc == SH_ERR_HIP) { c->err = et; return hrc; }
     if (hrc != SH_OK) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", bad, hrc); return fail(c, hrc, m); }
@@ -2099,7 +1965,7 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
     const int TT = big ? 8 : SH_OBB_TILE;
     const int ntiles = (nfmax + TT - 1) / TT;
     // SHOULDER_OBB_PRUNE=0: every direction is evaluated (the A/B of the pruning bound: same frames, tests/test_gpu_hull.py)
-    const bool prune = !(getenv("SHOULDER_OBB_PRUNE") && getenv("SHOULDER_OBB_PRUNE")[0] == '0');
+    const bool prune = c->sw.obb_prune;
     for (int pass = 0; pass < 2; ++pass) {      // seed tile, then the directions its best volume cannot exclude
       LAUNCH(c, "k_obb_select", k_obb_select, dim3(B), dim3(256), buf<double>(c, "obb.lb"), cnt_nf, buf<unsigned long long>(c, "obb.lbmin_enc"),
              buf<unsigned long long>(c, "obb.best_enc"), (prune || pass == 0) ? pass : 2, buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"), buf<unsigned char>(c, "obb.seeded"));
@@ -2189,7 +2055,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   // Slice sets that hang on the same inputs share their launches (run_slice_sets): full + distal behind the box frame, neck contour +
   // proximal behind neck_z -- 8 launches and two passes over the mesh less per step; same sections (SHOULDER_SLICE_MERGE=0: one
   // set per launch group, the A/B of tests/test_gpu_slices.py)
-  const bool merge_env = !(getenv("SHOULDER_SLICE_MERGE") && getenv("SHOULDER_SLICE_MERGE")[0] == '0');      // (read per run: the tests switch it in-process)
+  const bool merge_env = c->sw.slice_merge;
   // The distal set and the first part of the trans-epicondylar stage (the rectangles of its rows, the ends of the widest one) need
   // nothing but the box frame.  Small batches (up to 16 humeri: one humerus gains 4 %, 6.01 -> 5.78 ms per run; at B = 64 two streams'
   // kernels just share the CUs and one lane LOSES 8 %): the whole branch runs on the side stream beside the full -> neck -> canal ->
@@ -2200,8 +2066,8 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
   // leaves free while the lane's own chain wants them -- so the fork is off by default (same records bit for bit either way) ...
   // Either fork only when the overflow tier is known to be idle for this batch (its pool counters are per set) and no per-launch
   // timing is on.
-  static const bool side_env = !(getenv("SHOULDER_SIDE_STREAM") && getenv("SHOULDER_SIDE_STREAM")[0] == '0');
-  const bool te_early_env = getenv("SHOULDER_TE_EARLY") && getenv("SHOULDER_TE_EARLY")[0] == '1';      // (read per run: the tests switch it in-process)
+  const bool side_env = c->sw.side_stream;
+  const bool te_early_env = c->sw.te_early == 1;
   const bool can_fork = side_env && (mask & SH_STAGE_DISTAL) && c->ovf_none_gen == c->batch_gen && c->timing != 1 && !c->redo_records;
   const bool side = can_fork && B <= 16;
   const bool te_early = can_fork && !side && te_early_env && (mask & SH_STAGE_TE) && (mask & SH_STAGE_ANP);
@@ -2232,7 +2098,7 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     // ... and by default it simply runs HERE, in the chain in front of the UNet pass instead of behind it: the same kernels on the same
     // stream, but the part of the step that follows the UNet -- what stands between the pass and the lane's next step -- is 0.3 ms
     // (0.6 ms beside the other lane's UNet) shorter: 8.00 -> 7.74 ms per step sustained, 8.48 -> 8.35 at 20 steps.  SHOULDER_TE_EARLY=0: behind the UNet.
-    const bool te_inline = !side && !te_early && !(getenv("SHOULDER_TE_EARLY") && getenv("SHOULDER_TE_EARLY")[0] == '0') && (mask & SH_STAGE_ANP);
+    const bool te_inline = !side && !te_early && c->sw.te_early != 0 && (mask & SH_STAGE_ANP);
     if (rc == SH_OK && (side || te_early || te_inline) && (mask & SH_STAGE_TE)) { rc = run_te_rows(c); te_rows_done = rc == SH_OK; }
     if (side || te_early) {
       const bool forked = c->stream == c->side_stream;
@@ -2304,13 +2170,11 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
     const bool scale_in_net = (c->params.unet_dtype == SH_UNET_BF16 || c->params.unet_dtype == SH_UNET_F16) && unet16_starts_fused(c, SH_ANP_ROWS, SH_MPROX);
     if (!scale_in_net || c->keep_products)
       LAUNCH(c, "k_anp_scale", k_anp_scale, dim3(64, B), dim3(256), buf<double>(c, "anp.raw"), buf<unsigned long long>(c, "anp.mm_enc"), buf<float>(c, "anp.image"));
-    lane_busy(c, 0);      // (this lane's chain rests until its pass is through: the other lane's pass may have the reserve)
     if ((rc = unet_turn_enter(c)) != SH_OK) return rc;
     if (scale_in_net) { c->unet_raw = buf<double>(c, "anp.raw"); c->unet_mm = buf<unsigned long long>(c, "anp.mm_enc"); }
     rc = unet_dispatch(c, buf<float>(c, "anp.image"), buf<float>(c, "anp.logits"), B, SH_ANP_ROWS, SH_MPROX);
     c->unet_raw = nullptr; c->unet_mm = nullptr;
     (void)unet_turn_leave(c);      // also after a failed pass: whatever was enqueued is what the next context waits for
-    lane_busy(c, 1);
     if (rc != SH_OK) return rc;
     LAUNCH(c, "k_anp_edge_count", k_anp_edge_count, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<float>(c, "anp.logits"), buf<int>(c, "anp.rowcnt"), buf<unsigned long long>(c, "anp.maskbits"));
     LAUNCH(c, "k_anp_edges", k_anp_edges, dim3(SH_ANP_ROWS / 8, B), dim3(512), buf<unsigned long long>(c, "anp.maskbits"), buf<double>(c, "anp.raw"),
@@ -2404,8 +2268,7 @@ int sh_set_overlap(sh_ctx* c, int on) {
 int sh_set_unet_turns(sh_ctx* c, int on) {
   if (!c) return SH_ERR_ARG;
   c->unet_turn = on != 0;
-  if (c->unet_turn) { (void)hipSetDevice(c->device); yield_join(c); }
-  else { unet_turn_forget(c); yield_leave(c); }
+  if (!c->unet_turn) unet_turn_forget(c);
   return SH_OK;
 }
 
@@ -2585,7 +2448,7 @@ static void start_prepare_staged(sh_ctx* c, bool hulls, const StlPhase stl, std:
       S.cv.notify_all();
     };
     if (hipSetDevice(c->device) != hipSuccess) { q.rc = SH_ERR_HIP; meta(SH_ERR_HIP, "hipSetDevice"); return; }
-    const bool dbg = getenv("SH_DEBUG") != nullptr;
+    const bool dbg = c->sw.debug;
     const auto tt0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count(); };
     double t_p0 = 0, t_meta = 0, t_pts = 0;
@@ -2989,7 +2852,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   // Windows: with the host hull in play the batch can be walked in windows of SHOULDER_WINDOW humeri; all device work of
   // a window is only enqueued, so the hulls of the next window are computed while it runs (off by default).
   int wsize = SH_WINDOW;
-  if (const char* e = getenv("SHOULDER_WINDOW")) { int v = atoi(e); if (v > 0) wsize = v; }     // tests exercise small windows
+  if (c->sw.window > 0) wsize = c->sw.window;     // tests exercise small windows
   const bool dev_hull = (mask & SH_STAGE_OBB) && device_hull_now(c);
   const int win = ((mask & SH_STAGE_OBB) && B > wsize && !dev_hull) ? wsize : B;      // (windows exist to overlap HOST hulls with device work)
   // hulls prepared by the background thread during the previous run (sh_set_overlap)?
@@ -3006,16 +2869,14 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     // the host hull needs its points (a device-generated batch: every run, a new batch is new data)
     auto t0 = std::chrono::steady_clock::now();
     HIPCHK(c, fetch_hull_points(c, hullpre_ptrs(c), c->stream));
-    if (getenv("SH_DEBUG")) fprintf(stderr, "[sh] submit: hull points fetched after %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (c->sw.debug) fprintf(stderr, "[sh] submit: hull points fetched after %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (c->timing && !c->h_verts_valid) { KTimer& a = c->timers["host.verts_d2h"]; a.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); a.n += 1; }
   }
   int rc = SH_OK, widx = 0;
-  lane_busy(c, 1);      // this lane's chain is in flight from here (k_unet_bf16_dma.h, YieldArg) ...
   for (int b0 = 0; b0 < B && rc == SH_OK; b0 += win, ++widx) {
     c->b0 = b0; c->Bwin = std::min(win, B - b0);
     rc = run_window(c, mask, widx == 0 ? prepared : -1);
   }
-  if (rc != SH_OK) lane_busy(c, 0);
   // everything of this run is enqueued: the host is free until the device is done -> hulls of the next run
   if (rc == SH_OK && c->overlap && (mask & SH_STAGE_OBB) && win == B && !dev_hull && !c->stg.active) start_prepare(c);
   c->b0 = 0; c->Bwin = B;
@@ -3046,7 +2907,6 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   // hold) and which humeri the device hull gave up (its own word per humerus: the status word can be overwritten by a later stage)
   LAUNCH(c, "k_stage_status", k_stage_status, dim3((unsigned)((std::max(B, 8) + 255) / 256)), dim3(256), (const int*)buf<int>(c, "err"), (const unsigned long long*)c->bufs["ovf.ctr"].p,
          dev_hull ? (const int*)buf<int>(c, "hulld.fail") : (const int*)nullptr, (char*)err_stage, B, status_ovf_off(B));
-  lane_busy(c, 0);      // ... to here
   HIPCHK(c, hipEventRecord(tk.ev, c->stream));
   tk.B = B; tk.pending = true; tk.mask = mask; tk.out_arg = out; tk.dev_hull = dev_hull; tk.gen = c->batch_gen;
   c->t_head ^= 1; ++c->n_pending;
@@ -3086,7 +2946,7 @@ int sh_collect(sh_ctx* c) {
       if (rc2 != SH_OK) return rc2;
       return sh_collect(c);
     }
-    if (getenv("SH_DEBUG")) fprintf(stderr, "[sh] collect: ovf need %llu %llu %llu cap %llu %llu %llu err0 %d\n", need_s, need_r, need_w, c->ovf_seg_cap, c->ovf_ring_cap, c->ovf_work_cap, tk.h_err[0]);
+    if (c->sw.debug) fprintf(stderr, "[sh] collect: ovf need %llu %llu %llu cap %llu %llu %llu err0 %d\n", need_s, need_r, need_w, c->ovf_seg_cap, c->ovf_ring_cap, c->ovf_work_cap, tk.h_err[0]);
     const unsigned long long need_e = tk.h_ovf[7];
     if (need_s > c->ovf_seg_cap || need_r > c->ovf_ring_cap || need_w > c->ovf_work_cap || need_e > (unsigned long long)c->end_cap) {
       // The batch has more overflow planes than the pools hold (a first dense mesh): grow them to what the run asked for,

@@ -34,6 +34,33 @@ def _ensure_chain_lib():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def engine_with_env(**env):
+    """An engine of its own, created while the given environment switches are set (the library reads its switches ONCE, when a context is
+    created -- include/shoulder_hip.h): the A/B arm of a test.  Forest and teacher network loaded."""
+    from shoulder_amd.engine import Engine
+    from shoulder_amd import unet_spec
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        e = Engine(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        e.load_rfc()
+        e.load_unet(_teacher_weights(), unet_spec.BASE, unet_spec.DEPTH)
+        yield e
+    finally:
+        e.close()
+
+
 @pytest.fixture(scope="session")
 def unet_weights():
     return _teacher_weights()

@@ -87,14 +87,11 @@ def test_windowed_run_matches_single_window(engine, oracle_bones):
     window k): a mesh must get the same landmarks whichever window it falls in."""
     h = oracle_bones("humerus_left")
     T = synth.similarity_transforms(20, h.verts)
-    engine.upload([(h.verts, h.faces)])
-    engine.synth_batch(T)
-    import os
-    os.environ["SHOULDER_WINDOW"] = "8"         # 20 meshes -> windows of 8 + 8 + 4 (default window: 64)
-    try:
-        big = engine.run(_lib.STAGE_ALL).copy()
-    finally:
-        del os.environ["SHOULDER_WINDOW"]
+    from conftest import engine_with_env
+    with engine_with_env(SHOULDER_WINDOW=8) as ew:      # 20 meshes -> windows of 8 + 8 + 4 (default window: 64)
+        ew.upload([(h.verts, h.faces)])
+        ew.synth_batch(T)
+        big = ew.run(_lib.STAGE_ALL).copy()
     assert (big["status"] == 0).all()
     engine.upload([(h.verts, h.faces)])
     engine.synth_batch(T[12:20])                # the same last 8 meshes in one window
@@ -212,30 +209,33 @@ def test_synthetic_batch_equivariance(engine, oracle_bones):
         np.testing.assert_array_equal(v[b], synth.apply_similarity(T[b], h.verts))
 
 
-def test_forked_trans_epicondylar_part_gives_the_same_records(engine, oracle_bones, monkeypatch):
+def test_forked_trans_epicondylar_part_gives_the_same_records(engine, oracle_bones):
     """The rectangles of the distal rows and the ends of the widest one (k_te_rows, k_te_ends: they need the distal set only) run in
     front of the UNet pass by default, on the side stream beside the proximal set, the groove and the UNet pass with SHOULDER_TE_EARLY=1,
-    behind the UNet with =0; k_te_orient (medial end first: needs the head's central axis) follows in front of the record.  Same kernels on the same inputs: the records are the sequential run's bit for bit,
-    run after run (the second run of a batch is the first that forks: the overflow tier is known to be idle by then)."""
+    behind the UNet with =0 (switches of a context, read when it is created); k_te_orient (medial end first: needs the head's central
+    axis) follows in front of the record.  Same kernels on the same inputs: the records are the sequential run's bit for bit, run after
+    run (the second run of a batch is the first that forks: the overflow tier is known to be idle by then)."""
+    from conftest import engine_with_env
     h = oracle_bones("humerus_left")
     B = 24
+    T = synth.similarity_transforms(B, h.verts, seed=5)
+    with engine_with_env(SHOULDER_TE_EARLY=0) as e0:      # behind the UNet (the order of the reference's accessors)
+        e0.upload([(h.verts, h.faces)])
+        e0.synth_batch(T)
+        e0.run(_lib.STAGE_ALL)
+        a = e0.run(_lib.STAGE_ALL).copy()
     engine.reset_params()
     engine.upload([(h.verts, h.faces)])
-    engine.synth_batch(synth.similarity_transforms(B, h.verts, seed=5))
-    try:
-        monkeypatch.setenv("SHOULDER_TE_EARLY", "0")      # behind the UNet (the order of the reference's accessors)
-        engine.run(_lib.STAGE_ALL)
-        a = engine.run(_lib.STAGE_ALL).copy()
-        for mode in ("1", None):      # forked beside the UNet; in the chain in front of it (the default)
-            if mode is None:
-                monkeypatch.delenv("SHOULDER_TE_EARLY", raising=False)
-            else:
-                monkeypatch.setenv("SHOULDER_TE_EARLY", mode)
-            for _ in range(3):
-                b = engine.run(_lib.STAGE_ALL)
-                assert (b["status"] == 0).all() and b.tobytes() == a.tobytes()
-    finally:
-        monkeypatch.delenv("SHOULDER_TE_EARLY", raising=False)
+    engine.synth_batch(T)
+    for _ in range(3):      # in the chain in front of the UNet (the default)
+        b = engine.run(_lib.STAGE_ALL)
+        assert (b["status"] == 0).all() and b.tobytes() == a.tobytes()
+    with engine_with_env(SHOULDER_TE_EARLY=1) as e1:      # forked beside the UNet
+        e1.upload([(h.verts, h.faces)])
+        e1.synth_batch(T)
+        for _ in range(3):
+            b = e1.run(_lib.STAGE_ALL)
+            assert (b["status"] == 0).all() and b.tobytes() == a.tobytes()
 
 
 def test_overlapped_hulls_identical_and_invalidated(engine, oracle_bones):
@@ -428,15 +428,3 @@ def test_packed_records_carry_the_full_records_fields(engine, oracle_bones):
     finally:
         engine.set_record_rows(0)
 
-
-def test_lanes_that_yield_their_reserve():
-    """SHOULDER_CU_YIELD=1 (off by default, measured neutral: DESIGN.md section 9): the ticketed UNet launches of a lane cover the whole
-    chip and their last workgroups take no ticket while the other lane's busy word is up.  Who computes an item changes, the
-    records do not; no launch is left without workgroups (tests/_yield_worker.py, a process of its own: the switch is read once)."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, SHOULDER_CU_YIELD="1")
-    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_yield_worker.py")], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert "YIELD_OK" in out.stdout, out.stdout[-500:] + out.stderr[-1500:]

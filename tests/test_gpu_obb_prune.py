@@ -22,30 +22,23 @@ def _obb(engine, B):
     return nf, vol, edge, lb, T
 
 
-@pytest.fixture()
-def prune_env():
-    old = os.environ.get("SHOULDER_OBB_PRUNE")
-    yield
-    if old is None:
-        os.environ.pop("SHOULDER_OBB_PRUNE", None)
-    else:
-        os.environ["SHOULDER_OBB_PRUNE"] = old
-
-
 @pytest.mark.parametrize("case", ["fixtures", "batch64"])
-def test_pruned_candidates_give_the_same_box(engine, oracle_bones, prune_env, case):
-    if case == "fixtures":
-        bones = [oracle_bones(n) for n in ("humerus_left", "humerus_left_flipped", "humerus_left_trab", "humerus_right")]
-        engine.upload([(b.verts, b.faces) for b in bones])
-        B = len(bones)
-    else:
+def test_pruned_candidates_give_the_same_box(engine, oracle_bones, case):
+    from conftest import engine_with_env
+
+    def load(e):
+        if case == "fixtures":
+            bones = [oracle_bones(n) for n in ("humerus_left", "humerus_left_flipped", "humerus_left_trab", "humerus_right")]
+            e.upload([(b.verts, b.faces) for b in bones])
+            return len(bones)
         h = oracle_bones("humerus_left")
-        B = 64
-        engine.upload([(h.verts, h.faces)])
-        engine.synth_batch(synth.similarity_transforms(B, h.verts, seed=1234))
-    os.environ["SHOULDER_OBB_PRUNE"] = "0"
-    nf, vol_all, edge_all, lb, T_all = _obb(engine, B)
-    os.environ["SHOULDER_OBB_PRUNE"] = "1"
+        e.upload([(h.verts, h.faces)])
+        e.synth_batch(synth.similarity_transforms(64, h.verts, seed=1234))
+        return 64
+    with engine_with_env(SHOULDER_OBB_PRUNE=0) as e_all:      # (a switch of the context, read when it is created)
+        B = load(e_all)
+        nf, vol_all, edge_all, lb, T_all = _obb(e_all, B)
+    B = load(engine)
     nf2, vol, edge, lb2, T = _obb(engine, B)
     np.testing.assert_array_equal(nf, nf2)
     np.testing.assert_array_equal(T, T_all)

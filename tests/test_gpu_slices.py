@@ -89,23 +89,27 @@ def test_neck_and_canal(engine, ran):
         np.testing.assert_allclose(ax[b], h.canal["axis_ct"], rtol=0, atol=1e-8)
 
 
-def test_merged_slice_sets_equal_separate_launches(engine, oracle_bones, monkeypatch):
+def test_merged_slice_sets_equal_separate_launches(engine, oracle_bones):
     """Round 4: full + distal and neck contour + proximal go through the set launches together (one plane-height launch, one pass
     over the mesh, one join grid per pair).  Against one launch group per set (SHOULDER_SLICE_MERGE=0): the same records and the
     same slice-layer buffers byte for byte, for a batch and for a single humerus (which keeps the distal set on its side stream)."""
+    from conftest import engine_with_env
     names = ["humerus_left", "humerus_left_flipped", "humerus_left_trab", "humerus_right"]
     hs = [oracle_bones(n) for n in names]
     engine.reset_params()
     engine.set_params(unet_dtype=_lib.UNET_BF16)
-    try:
+    with engine_with_env(SHOULDER_SLICE_MERGE=0) as e_sep:      # (a switch of the context, read when it is created)
+      e_sep.set_params(unet_dtype=_lib.UNET_BF16)
+      try:
         for meshes in ([(h.verts, h.faces) for h in hs] * 5, [(hs[2].verts, hs[2].faces)]):      # 20 humeri (> 16: merged), one humerus
             B = len(meshes)
             engine.upload(meshes)
+            e_sep.upload(meshes)
             out = {}
             for mode in ("1", "0", "1"):
-                monkeypatch.setenv("SHOULDER_SLICE_MERGE", mode)
-                lm = engine.run(_lib.STAGE_ALL).copy()
-                bufs = {k: engine.fetch(k, dt, shp).copy() for k, dt, shp in (
+                eng_ = engine if mode == "1" else e_sep
+                lm = eng_.run(_lib.STAGE_ALL).copy()
+                bufs = {k: eng_.fetch(k, dt, shp).copy() for k, dt, shp in (
                     ("full.areas", np.float64, (B, 200)), ("full.centroids", np.float64, (B, 200, 2)), ("distal.ring_n", np.int32, (B, 200)),
                     ("distal.ring", np.float64, (B, 200, 1025, 2)), ("prox.seg_count", np.int32, (B, 600)), ("prox.itr_start", np.float64, (B, 600, 2, 512)),
                     ("neckc.ring_n", np.int32, (B, 1)), ("neckc.centroids", np.float64, (B, 1, 2)))}
@@ -125,8 +129,7 @@ def test_merged_slice_sets_equal_separate_launches(engine, oracle_bones, monkeyp
                         for p in range(0, 200, 9):
                             n = int(rn[b, p]) + 1
                             np.testing.assert_array_equal(out["1"][1][k][b, p, :n], out["0"][1][k][b, p, :n])
-    finally:
-        monkeypatch.delenv("SHOULDER_SLICE_MERGE", raising=False)
+      finally:
         engine.set_params(unet_dtype=_lib.UNET_F32)
 
 

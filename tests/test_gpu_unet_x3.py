@@ -70,22 +70,23 @@ def test_bench_batch_same_edge_pixels_as_f32(engine):
     assert lmx.tobytes() == lm32.tobytes()
 
 
-def test_register_resident_upconv_bit_identical_f32x(engine, monkeypatch):
-    """k_upconv_x3r (k_unet_x3.h: a wave keeps the high / low f16 fragments of its source pixels, the split weights stream through LDS
-    one (group, phase) slice at a time; up0..up3) against k_conv_mfma_x3<1, NT> (tile staged and split per chunk and workgroup): per
-    accumulator the same MFMAs in the same order -> the logits are bit-identical, at both image sizes and an odd batch."""
+def test_f32x_network_is_deterministic_and_close_to_f32(engine):
+    """SH_UNET_F32X (k_unet_x3.h: three f16 MFMAs per product on split operands; up-convolutions with the high / low fragments of a
+    wave's source pixels resident in registers): the same logits bit for bit, run after run, an image alone or inside a batch, at both
+    image sizes and an odd batch -- and within 1e-5 of the exact f32 path's."""
     rng = np.random.default_rng(37)
-    engine.set_params(unet_dtype=_lib.UNET_F32X)
     try:
         for H, W, n in ((256, 512, 3), (512, 512, 2)):
             img = rng.random((n, H, W), dtype=np.float32)
-            monkeypatch.setenv("SHOULDER_X3_UPREG", "0")
+            engine.set_params(unet_dtype=_lib.UNET_F32)
+            exact = engine.unet_infer(img)
+            engine.set_params(unet_dtype=_lib.UNET_F32X)
             a = engine.unet_infer(img)
-            monkeypatch.setenv("SHOULDER_X3_UPREG", "1")
             for _ in range(2):
                 assert np.array_equal(a, engine.unet_infer(img))
+            assert np.array_equal(a[:1], engine.unet_infer(img[:1]))
+            assert float(np.abs(a - exact).max()) < 1e-5
     finally:
-        monkeypatch.delenv("SHOULDER_X3_UPREG", raising=False)
         engine.set_params(unet_dtype=_lib.UNET_F32)
 
 
