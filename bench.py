@@ -237,6 +237,12 @@ def hull_threads(world_local):
     return max(1, min(32, len(os.sched_getaffinity(0)) // max(1, world_local)))      # (pool size: affinity mask; the hull-mode decision counts a CPU quota too)
 
 
+def default_lanes(hull_mode, pipelined=True):
+    """Engine contexts per GPU: two with the hull on the host, three with the hull on the device (its lanes are serial chains with a
+    5.6 ms hull kernel on 64 CUs at their head) -- what eight ranks on one host get (sh_auto_hull_mode: 48 usable threads per rank needed)."""
+    return (3 if hull_mode == "device" else 2) if pipelined else 1
+
+
 def launch_ranks(n, argv, worker=None, timeout=None):
     """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N rank processes of one node
     ourselves -- fresh children, one per GPU, with the environment torch.distributed.run would give them (RANK, LOCAL_RANK,
@@ -353,7 +359,7 @@ def main():
     eng = Engine(local)
     if args.hull != "auto":      # (auto: what the engine chose at creation -- SHOULDER_HULL, else by the host's threads per rank)
         eng.set_hull_mode(args.hull)
-    lanes = (args.lanes if args.lanes > 0 else (3 if eng.hull_mode == "device" else 2)) if not args.no_pipeline else 1
+    lanes = args.lanes if (args.lanes > 0 and not args.no_pipeline) else default_lanes(eng.hull_mode, not args.no_pipeline)
     engs = [eng] + [Engine(local) for _ in range(lanes - 1)]
     REC = _lib.record_dtype(args.record_rows)
     for e in engs:
@@ -1022,6 +1028,10 @@ def cpu_baseline(verts, faces, T, weights, n_meshes, pool):
                        "per_worker_s": [round(x, 2) for x in per],
                        "host_cores": os.cpu_count(),
                        "sample": f"{pool} humeri, one per worker process (spawn) on {pool} of the host's {os.cpu_count()} hardware threads, wall {elp:.1f} s incl. start-up and imports; slowest worker's oracle time {max(per):.1f} s"}
+        # (the same leg as flat keys: a reader that keeps only scalars still sees that the pool ran)
+        out.update(pool_value=out["pool"]["value"], pool_cores=pool, pool_value_compute_only=out["pool"]["value_compute_only"], pool_wall_s=round(elp, 1))
+    else:
+        out["pool_skipped"] = f"pool of {pool} workers requested (--cpu-pool {pool})"
     return out
 
 

@@ -219,7 +219,10 @@ int  sh_landmarks_device(sh_ctx*, void** dev_ptr, size_t* nbytes);
  *                        and a forest of the same shape before (any values); receivers validate the block like sh_param_block_commit.
  *   sh_gather_landmarks  the records of every context's last run, rank order, to host memory at ctxs[0]: sum of the batch sizes
  *                        records of sh_record_bytes(rows) bytes each, `rows` = the record format all contexts are set to
- *                        (sh_set_record_rows; 0 = full sh_landmarks). */
+ *                        (sh_set_record_rows; 0 = full sh_landmarks).
+ * STATUS: EXPERIMENTAL for n > 1.  The build pool has one GPU per box: these calls have run on hardware as a group of ONE only
+ * (tests/test_gpu_comm.py prints the world size it ran with); the n > 1 legs -- the multi-rank ncclBroadcast, the grouped
+ * ncclSend / ncclRecv of the gather, destroying one rank's communicator while its siblings live -- are untested on hardware. */
 int  sh_comm_init_all(sh_ctx** ctxs, int n);
 int  sh_bcast_weights(sh_ctx** ctxs, int n, int root);
 int  sh_gather_landmarks(sh_ctx** ctxs, int n, sh_landmarks* out_root /* host */);
@@ -302,6 +305,10 @@ int  sh_enable_timing(sh_ctx*, int level);
  * same triangles and the same record bits, hence bit-identical frames.  sh_get_hull_mode: 0 host, 1 device. */
 int  sh_set_hull_mode(sh_ctx*, const char* mode);
 int  sh_get_hull_mode(const sh_ctx*);
+/* What "auto" resolves to for a context created by THIS process now (0 host, 1 device): usable hardware threads (affinity mask, cgroup
+ * CPU quota) divided by LOCAL_WORLD_SIZE against 16 (a rank alone on its host) / 48 (several ranks).  Needs no device: a launcher can
+ * size its lanes before it creates a context (bench.py: three lanes with the device hull, two with the host hull). */
+int  sh_auto_hull_mode(void);
 int  sh_set_overlap(sh_ctx*, int on);
 int  sh_discard_prepared(sh_ctx*);
 

@@ -79,7 +79,7 @@ EXPORTS = ["sh_ctx_create", "sh_ctx_destroy", "sh_last_error", "sh_default_param
            "sh_kernel_time_ms", "sh_enable_timing", "sh_set_overlap", "sh_discard_prepared", "sh_unet_infer", "sh_host_alloc", "sh_host_free", "sh_upload_stl", "sh_submit", "sh_collect",
            "sh_stage_meshes", "sh_stage_stl", "sh_commit_staged", "sh_staged", "sh_set_record_rows", "sh_record_bytes", "sh_anp_points",
            "sh_comm_init_all", "sh_bcast_weights", "sh_gather_landmarks", "sh_set_keep_products",
-           "sh_slice_mesh_planes", "sh_set_unet_turns", "sh_get_params", "sh_buffer_device", "sh_param_block_commit", "sh_set_hull_mode", "sh_get_hull_mode", "sh_ring"]
+           "sh_slice_mesh_planes", "sh_set_unet_turns", "sh_get_params", "sh_buffer_device", "sh_param_block_commit", "sh_set_hull_mode", "sh_get_hull_mode", "sh_auto_hull_mode", "sh_ring"]
 
 _lib = None
 
@@ -121,6 +121,7 @@ def load(build_if_missing=True):
     L.sh_param_block_commit.argtypes = [vp]
     L.sh_set_hull_mode.argtypes = [vp, cp]
     L.sh_get_hull_mode.argtypes = [vp]
+    L.sh_auto_hull_mode.argtypes = []
     L.sh_load_rfc.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_int]
     L.sh_load_unet.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t]
     L.sh_param_block.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]

@@ -385,6 +385,7 @@ int sh_set_hull_mode(sh_ctx* c, const char* mode) {
 }
 
 int sh_get_hull_mode(const sh_ctx* c) { return c ? c->hull_mode : SH_ERR_ARG; }
+int sh_auto_hull_mode(void) { return hull_mode_from(nullptr); }
 
 int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
   if (!out) return SH_ERR_ARG;

@@ -55,6 +55,7 @@ class LocalGroup:
     """Several GPUs driven from THIS process: one Engine per device, the library's own RCCL entry points (sh_comm_init_all /
     sh_bcast_weights / sh_gather_landmarks, include/shoulder_hip.h) instead of torch.distributed.  What a host without a
     process launcher (C, C++, an FFI binding) would do, spelled in Python; INTEGRATION.md section 4.3.
+    EXPERIMENTAL with more than one engine: run on hardware as a group of one only (include/shoulder_hip.h).
 
         g = LocalGroup([Engine(0), Engine(1)])       # rank i = engines[i]
         g.bcast_weights(root=0)                      # every engine has loaded parameters of the same shape before

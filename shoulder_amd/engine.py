@@ -200,7 +200,10 @@ class Engine:
         try:
             self._chk(self.L.sh_commit_staged(self.h, None, None))
         finally:
-            self._staged_keep = None
+            # the arrays / file images stay referenced while the batch is STILL staged (a refused commit -- runs in flight -- leaves it
+            # staged, and the library's background thread may still be copying from them)
+            if not self.staged:
+                self._staged_keep = None
         B = self.L.sh_batch_size(self.h)
         if getattr(self, "_staged_off", None) is not None:
             self.voff, self.foff = self._staged_off

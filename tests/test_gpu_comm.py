@@ -39,6 +39,7 @@ def lane(device, weights):
 @pytest.mark.parametrize("rows", [0, 512])
 def test_group_broadcasts_the_parameters_and_gathers_the_records(unet_weights, rows):
     world = 2 if n_devices() >= 2 else 1
+    print("sh_comm_* ran as a group of %d device(s)%s" % (world, "" if world > 1 else " -- the n > 1 legs (grouped send / recv, multi-rank broadcast) were NOT exercised"))
     meshes = cohort(6)
     # the records one context computes alone, with the real parameters
     ref = lane(0, unet_weights)
