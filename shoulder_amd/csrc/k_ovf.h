@@ -70,8 +70,8 @@ k_slice_emit_ovf(const double* __restrict__ vobb, const int* __restrict__ faces,
   for (long long fi = blockIdx.x * (long long)blockDim.x + threadIdx.x; fi < nf; fi += (long long)gridDim.x * blockDim.x) {
     const int* f = faces + 3 * (f0 + fi);
     const int id[3] = {f[0], f[1], f[2]};
-    double X[3], Y[3], Z[3];
-    for (int k = 0; k < 3; ++k) { X[k] = vb[3 * (size_t)id[k]]; Y[k] = vb[3 * (size_t)id[k] + 1]; Z[k] = vb[3 * (size_t)id[k] + 2]; }
+    double Z[3];
+    for (int k = 0; k < 3; ++k) Z[k] = vb[3 * (size_t)id[k] + 2];
     const double fzmin = fmin(Z[0], fmin(Z[1], Z[2])), fzmax = fmax(Z[0], fmax(Z[1], Z[2]));
     const double ka = (fzmin - z_first) * inv_step, kb = (fzmax - z_first) * inv_step;
     const double klo = fmin(ka, kb), khi = fmax(ka, kb);
@@ -99,10 +99,7 @@ k_slice_emit_ovf(const double* __restrict__ vobb, const int* __restrict__ faces,
       {  // start = crossing on the edge walked downwards (+ -> -)
         const int a = dn, c = (dn + 1) % 3;
         const int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
-        const double t = d[l] / (d[l] - d[h]);
-        sg.s_lo = (uint32_t)id[l]; sg.s_hi = (uint32_t)id[h];
-        sg.px = X[l] + t * (X[h] - X[l]);
-        sg.py = Y[l] + t * (Y[h] - Y[l]);
+        sg.s_lo = (uint32_t)id[l]; sg.s_hi = (uint32_t)id[h];      // (its point: seg_start_point, in the join)
       }
       {
         const int a = up, c = (up + 1) % 3;
@@ -147,7 +144,8 @@ k_ovf_plan_loops(int N, const int* __restrict__ seg_count, const Seg* __restrict
 #define SH_MAXLOOPS_G 1024      // loops per plane in the overflow tier's join (the LDS tiers: SH_MAXLOOPS = 32, more go here)
 
 // slice_link_plane (k_slices.h) with its arrays in the plane's workspace; every step in the same order with the same arithmetic
-__device__ inline void slice_link_plane_g(const int pl, int N, const int* __restrict__ seg_count, const Seg* __restrict__ sp, unsigned char* __restrict__ wk,
+__device__ inline void slice_link_plane_g(const int pl, int N, const int* __restrict__ seg_count, const Seg* __restrict__ sp, const double* __restrict__ vb /*verts_obb of the plane's mesh*/,
+             const double zpl /*the plane's height*/, unsigned char* __restrict__ wk,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops, int* __restrict__ ring_n, double* __restrict__ ring_out /*nullable*/,
              int select, int* __restrict__ err, double* __restrict__ areas_total) {
   constexpr int T = SH_HUGE_THREADS;
@@ -248,7 +246,7 @@ __device__ inline void slice_link_plane_g(const int pl, int N, const int* __rest
   __syncthreads();
   // (rx / ry do not alias the label buffers here, so no barrier is needed between reading labA and writing them)
   for (int i = tid; i < n; i += T)
-    if (posv[i] >= 0 && posv[i] < n) { rx[posv[i]] = sp[i].px; ry[posv[i]] = sp[i].py; }
+    if (posv[i] >= 0 && posv[i] < n) { const Seg sg = sp[i]; seg_start_point(vb, sg.s_lo, sg.s_hi, zpl, &rx[posv[i]], &ry[posv[i]]); }
   __syncthreads();
   // AABB over every loop vertex by all waves (min / max: order free), the per-loop sums by one wave per loop as in the LDS tiers
   const int lane = tid & 63, wave = tid >> 6;
@@ -317,11 +315,12 @@ __device__ inline void slice_link_plane_g(const int pl, int N, const int* __rest
 
 __global__ void __launch_bounds__(SH_HUGE_THREADS)
 k_slice_link_huge(int N, const int* __restrict__ seg_count, OvfPools P, OvfSet S, double* __restrict__ centroids, double* __restrict__ areas,
-                  int* __restrict__ nloops, int* __restrict__ ring_n, int want_ring, int select, int* __restrict__ err, double* __restrict__ areas_total) {
+                  int* __restrict__ nloops, int* __restrict__ ring_n, int want_ring, int select, int* __restrict__ err, double* __restrict__ areas_total,
+                  const double* __restrict__ vobb, const long long* __restrict__ voff, const double* __restrict__ zeff) {
   const int nl = *S.nlist;
   for (int i = blockIdx.x; i < nl; i += gridDim.x) {
     const int pl = S.list[i];
-    slice_link_plane_g(pl, N, seg_count, P.segs + S.soff[pl], P.work + S.woff[pl], centroids, areas, nloops, ring_n,
+    slice_link_plane_g(pl, N, seg_count, P.segs + S.soff[pl], vobb + 3 * voff[pl / N], zeff[pl], P.work + S.woff[pl], centroids, areas, nloops, ring_n,
                        want_ring ? P.ring + 2 * S.roff[pl] : (double*)nullptr, select, err, areas_total);
   }
 }

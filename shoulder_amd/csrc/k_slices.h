@@ -5,7 +5,7 @@
 //   verts_obb  float64 [sumV][3]        T_obb * v   (mesh.py:82,117: the mutated `obb.mesh`)
 //   zs, zeff   float64 [B][N]           linspace z of each plane, and z_orig + (zs - z_orig)
 //   seg_count  int32   [B][N]
-//   segs       Seg     [B][N][SH_MAXSEG] crossing segments, slot order = atomic arrival order
+//   segs       Seg     [B][N][SH_MAXSEG] crossing segments (16 B: the two edge keys), slot order = atomic arrival order
 //   centroids  float64 [B][N][2], areas float64 [B][N], nloops int32 [B][N]
 //   ring_n     int32   [B][N]           vertices of the largest loop (open count)
 //   ring       float64 [B][N][SH_MAXSEG+1][2]  largest loop, CCW, canonical start, closed
@@ -16,11 +16,23 @@
 
 namespace sh {
 
+// A crossing segment is the two mesh edges it runs between.  The start point is NOT stored (it was, as two doubles: half of the
+// slice layer's 1.34 GB per step): the join computes it from the edge's two vertices and the plane height with the expression the
+// section uses (seg_start_point), once per segment, with the planes of a humerus joined on ONE XCD so that its verts_obb (389 KB)
+// is served by that XCD's L2.
 struct __attribute__((aligned(16))) Seg {
   uint32_t s_lo, s_hi, e_lo, e_hi;  // mesh-edge keys (min vid, max vid) of the start / end crossing
-  double px, py;                    // start crossing point (OBB xy)
 };
-static_assert(sizeof(Seg) == 32, "Seg must be 32 bytes");
+static_assert(sizeof(Seg) == 16, "Seg must be 16 bytes");
+// crossing of mesh edge (lo, hi) with the plane at height z: oracle/section.py's formula, operation for operation
+__device__ inline void seg_start_point(const double* __restrict__ vb /*verts_obb of the mesh*/, uint32_t lo, uint32_t hi, double z, double* x, double* y) {
+  const double* pl = vb + 3 * (size_t)lo;
+  const double* ph = vb + 3 * (size_t)hi;
+  const double dl = pl[2] - z, dh = ph[2] - z;
+  const double t = dl / (dl - dh);
+  *x = pl[0] + t * (ph[0] - pl[0]);
+  *y = pl[1] + t * (ph[1] - pl[1]);
+}
 
 // order-preserving double <-> uint64 for atomic min/max
 __device__ inline unsigned long long enc_f64(double v) {
@@ -111,7 +123,7 @@ struct SliceSetDev {
   int* nlarge; ManyLoops many; unsigned long long* ovf_missed;
   PlaneAux aux;
 };
-struct SliceSets { SliceSetDev s[2]; int n; };
+struct SliceSets { SliceSetDev s[2]; int n; const double* vobb; const long long* voff; };      // (vobb / voff: the join recomputes the crossing points)
 
 __global__ void k_make_planes(SliceSets sets, const double* __restrict__ neck_z, int B) {
   const SliceSetDev& S = sets.s[blockIdx.y];
@@ -174,8 +186,8 @@ k_slice_emit(const double* __restrict__ vobb, const int* __restrict__ faces,
     const bool live = fi < nf;
     const int* f = faces + 3 * (f0 + (live ? fi : 0));
     int id[3] = {f[0], f[1], f[2]};
-    double X[3], Y[3], Z[3];
-    for (int k = 0; k < 3; ++k) { X[k] = vb[3 * (size_t)id[k]]; Y[k] = vb[3 * (size_t)id[k] + 1]; Z[k] = vb[3 * (size_t)id[k] + 2]; }
+    double Z[3];
+    for (int k = 0; k < 3; ++k) Z[k] = vb[3 * (size_t)id[k] + 2];
     double fzmin = fmin(Z[0], fmin(Z[1], Z[2])), fzmax = fmax(Z[0], fmax(Z[1], Z[2]));
     int lo_[2] = {1, 1}, hi_[2] = {0, 0};      // empty range: a lane without a triangle or without planes
     for (int si = 0; si < nsets; ++si) {
@@ -236,10 +248,7 @@ k_slice_emit(const double* __restrict__ vobb, const int* __restrict__ faces,
         {  // start = crossing on the edge walked downwards (+ -> -)
           int a = dn, c = (dn + 1) % 3;
           int l = id[a] < id[c] ? a : c, h = id[a] < id[c] ? c : a;
-          double t = d[l] / (d[l] - d[h]);
-          sg.s_lo = (uint32_t)id[l]; sg.s_hi = (uint32_t)id[h];
-          sg.px = X[l] + t * (X[h] - X[l]);
-          sg.py = Y[l] + t * (Y[h] - Y[l]);
+          sg.s_lo = (uint32_t)id[l]; sg.s_hi = (uint32_t)id[h];      // (its point: seg_start_point, in the join)
         }
         {
           int a = up, c = (up + 1) % 3;
@@ -278,6 +287,7 @@ __device__ inline uint32_t hash_key64(unsigned long long k) {
 
 template <int CAP>
 __device__ inline void slice_link_plane(const int pl, int N, const int* __restrict__ seg_count, const Seg* __restrict__ segs,
+             const double* __restrict__ vobb, const long long* __restrict__ voff, const double* __restrict__ zeff,
              double* __restrict__ centroids, double* __restrict__ areas, int* __restrict__ nloops,
              int* __restrict__ ring_n, double* __restrict__ ring /*nullable*/, int select, int* __restrict__ err,
              double* __restrict__ areas_total /*nullable: |sum of the signed loop areas| = Path2D.area*/, ManyLoops many, int* __restrict__ nlarge = nullptr) {
@@ -308,6 +318,8 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
   if (tid == 0) { n_loops = 0; bad = 0; }
   for (int i = tid; i < HASH; i += SH_LINK_THREADS) table[i] = -1;
   const Seg* sp = segs + (size_t)pl * SH_MAXSEG;
+  const double* vb = vobb + 3 * voff[b];
+  const double zpl = zeff[pl];
   for (int i = tid; i < n; i += SH_LINK_THREADS) {
     Seg s = sp[i];
     skey[i] = ((unsigned long long)s.s_lo << 32) | s.s_hi;
@@ -427,7 +439,7 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
   {
     int c = 0;
     for (int i = tid; i < n; i += SH_LINK_THREADS, ++c)
-      if (my_pos[c] >= 0 && my_pos[c] < n) { rx[my_pos[c]] = sp[i].px; ry[my_pos[c]] = sp[i].py; }
+      if (my_pos[c] >= 0 && my_pos[c] < n) { const Seg sg = sp[i]; seg_start_point(vb, sg.s_lo, sg.s_hi, zpl, &rx[my_pos[c]], &ry[my_pos[c]]); }
   }
   __syncthreads();
 #if defined(SH_ABL_LINK) && SH_ABL_LINK == 4
@@ -516,11 +528,17 @@ __device__ inline void slice_link_plane(const int pl, int N, const int* __restri
 // with more than SH_SMALLSEG segments -- a workgroup per plane would pay its 70 KB LDS allocation 40 000 times for nothing.
 __global__ void __launch_bounds__(SH_LINK_THREADS)
 k_slice_link(SliceSets sets, int B, int* __restrict__ err) {
-  const int n0 = B * sets.s[0].N;
-  const int si = (int)blockIdx.x >= n0 ? 1 : 0;      // grid: the planes of set 0, then those of set 1
+  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names a group of workgroups that share an L2): with the batch a
+  // multiple of 8, workgroup id joins a plane of humerus (id % 8) + 8 j, so the vertices of 1/8 of the batch -- what the crossing
+  // points are computed from -- stay in one XCD's L2 (3 MB at B = 64).  Placement changes speed only.
+  const int ntot = sets.s[0].N + (sets.n > 1 ? sets.s[1].N : 0);
+  int id = (int)blockIdx.x;
+  if (B % 8 == 0) { const int x = id & 7, j = id >> 3; id = (x + 8 * (j / ntot)) * ntot + j % ntot; }      // -> humerus-major plane id over both sets
+  const int b = id / ntot, kk = id - b * ntot;
+  const int si = kk >= sets.s[0].N ? 1 : 0;
   const SliceSetDev& S = sets.s[si];
-  slice_link_plane<SH_SMALLSEG>((int)blockIdx.x - (si ? n0 : 0), S.N, S.seg_count, S.segs, S.centroids, S.areas, S.nloops, S.ring_n, S.ring, S.select, err, S.areas_total,
-                                S.many, S.nlarge);
+  slice_link_plane<SH_SMALLSEG>(b * S.N + (kk - (si ? sets.s[0].N : 0)), S.N, S.seg_count, S.segs, sets.vobb, sets.voff, S.zeff, S.centroids, S.areas, S.nloops, S.ring_n,
+                                S.ring, S.select, err, S.areas_total, S.many, S.nlarge);
 }
 __global__ void __launch_bounds__(SH_LINK_THREADS)
 k_slice_link_large(SliceSets sets, int B, int* __restrict__ err) {
@@ -535,7 +553,7 @@ k_slice_link_large(SliceSets sets, int B, int* __restrict__ err) {
       const int cnt = S.seg_count[pl];
       if (cnt > SH_MAXSEG && S.ovf_missed && threadIdx.x == 0) atomicExch(S.ovf_missed, 1ull);
       if (cnt <= SH_SMALLSEG || cnt > SH_MAXSEG) continue;
-      slice_link_plane<SH_MAXSEG>(pl, S.N, S.seg_count, S.segs, S.centroids, S.areas, S.nloops, S.ring_n, S.ring, S.select, err, S.areas_total, S.many);
+      slice_link_plane<SH_MAXSEG>(pl, S.N, S.seg_count, S.segs, sets.vobb, sets.voff, S.zeff, S.centroids, S.areas, S.nloops, S.ring_n, S.ring, S.select, err, S.areas_total, S.many);
       __syncthreads();
     }
   }

@@ -1594,6 +1594,7 @@ static int run_slice_sets(sh_ctx* c, const SliceSpec* specs, int nspec) {
   const bool ovf_on = c->ovf_none_gen != c->batch_gen;      // (known from an earlier run of this batch: no plane overflows)
   SliceSets sets{};
   sets.n = nspec;
+  sets.vobb = buf<double>(c, "verts_obb"); sets.voff = buf<long long>(c, "voff");
   for (int i = 0; i < nspec; ++i) {
     const SliceSpec& sp = specs[i];
     const std::string p = sp.pfx;
@@ -1636,7 +1637,7 @@ static int run_slice_sets(sh_ctx* c, const SliceSpec* specs, int nspec) {
     if (ovf_on) {
       LAUNCH(c, "k_ovf_plan_loops", k_ovf_plan_loops, dim3(16), dim3(256), S.N, (const int*)S.seg_count, (const Seg*)S.segs, OP, OS[i], buf<int>(c, "err"));
       LAUNCH(c, "k_slice_link_huge", k_slice_link_huge, dim3(64), dim3(SH_HUGE_THREADS), S.N, (const int*)S.seg_count, OP, OS[i], S.centroids, S.areas, S.nloops, S.ring_n,
-             sp.ring ? 1 : 0, S.select, buf<int>(c, "err"), S.areas_total);
+             sp.ring ? 1 : 0, S.select, buf<int>(c, "err"), S.areas_total, (const double*)buf<double>(c, "verts_obb"), (const long long*)buf<long long>(c, "voff"), (const double*)S.zeff);
     }
     if (sp.resample) {
       RsWant want{c->keep_products ? 1 : 0, SH_ANP_ROW0, 0, 0};

@@ -1,6 +1,14 @@
-# A/B of two builds on one GPU box: SHOULDER_LIB=<alt .so> against the tree's library, interleaved 100-step regions of the headline leg
-ALT=${1:-shoulder_amd/lib/alt_prev.so}
-for k in 1 2 3 4; do for v in alt tree; do
-if [ $v = alt ]; then export SHOULDER_LIB=$PWD/$ALT; else unset SHOULDER_LIB; fi
-python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-extra-legs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'])"
-done; done
+#!/bin/bash
+# interleaved A/B of library builds on the headline (bench.py, steady state of STEPS steps): tools/probes/lib_ab.sh <rounds> <arm> ...
+#   arm = "base" (the in-tree library) or a library path; STEPS (default 100) steps per timed region
+R=$1; shift
+mkdir -p gpurun_out/ab
+for r in $(seq 1 $R); do
+  for arm in "$@"; do
+    tag=$(basename $arm .so)
+    unset SHOULDER_LIB
+    case $arm in base) ;; *) export SHOULDER_LIB=$PWD/$arm ;; esac
+    timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-extra-legs --steps ${STEPS:-100} --warmup 4 > gpurun_out/ab/lib_${tag}_r$r.log 2>&1 || { echo "FAILED $arm"; tail -5 gpurun_out/ab/lib_${tag}_r$r.log; exit 1; }
+    echo "$tag r$r $(tail -1 gpurun_out/ab/lib_${tag}_r$r.log | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')"
+  done
+done
