@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 PEAK_MFMA_F32_TF = 157.3       # dense f32 MFMA (= vector rate)
 PEAK_MFMA_BF16_TF = 2500.0
-ROUNDS = ("r04", "r03", "r02", "r01")      # committed profile sets, newest first
+ROUNDS = ("r05", "r04", "r03", "r02", "r01")      # committed profile sets, newest first
 
 
 def mfma_peak_tf(unet):

@@ -94,9 +94,8 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ud_lptr)smem);
   const int r0 = (ltid >> 2) & 63;
   const int q8 = ((ltid & 3) ^ ((r0 >> 1) & 2)) * 8;
-  int hpy[NHALO], hpx[NHALO];                                       // halo pixel of piece k (px >= 34: padding column)
-#pragma unroll
-  for (int k = 0; k < NHALO; ++k) { const int r = r0 + 64 * k; hpy[k] = r / UD_PW; hpx[k] = r - hpy[k] * UD_PW; }
+  // (halo pixel of piece k: row r0 + 64 k = py * 36 + px, px >= 34: padding column -- recomputed per item: two registers per piece
+  //  kept for the whole launch pushed the pooled instantiation into scratch)
   // weight rows: lanes r0 >= 8 hold row j = r0 - 8 of tap k - 10 in piece k, lanes r0 < 8 row j = r0 + 56 of tap k - 11
   const bool wlow = r0 < 8;                                          // (these lanes carry the last 8 halo rows in piece 10)
   const int wj = wlow ? r0 + 56 : r0 - 8;
@@ -111,13 +110,24 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     i_ty = w % tiles_y; i_img = w / tiles_y;
   };
   decode(w_begin);
-  int pixoff[NHALO];
+  i_g = __builtin_amdgcn_readfirstlane(i_g); i_tx = __builtin_amdgcn_readfirstlane(i_tx);
+  i_ty = __builtin_amdgcn_readfirstlane(i_ty); i_img = __builtin_amdgcn_readfirstlane(i_img);
+  // The pixel a halo piece fetches: eleven offsets per lane, set up once per item (pixoff).  In the instantiation with the fused pool
+  // and streamed weights (LAZY) they are recomputed where the piece is issued instead: there the eleven registers -- and what hipcc
+  // hoists around them -- pushed the kernel into scratch, with a vmcnt(0) behind every reload between two LDS-DMA pieces (enc2b 0.26 ->
+  // 0.48 ms).  Everywhere else the recomputation costs more than it frees (66 vector instructions per step beside the compute wave
+  // of the SIMD: the 3x3 layers 5-12 % slower).
+  constexpr bool LAZY = (FUSE & UF_POOL) != 0 && WRES == 0;
+  auto halo_pixel = [&](int r0v, int k) -> int {      // image pixel index of halo row r0 + 64 k of the item being staged, -1: zero padding
+    const int r = r0v + 64 * k, hpy = r / UD_PW, hpx = r - hpy * UD_PW;
+    const int gx = i_tx * 32 + hpx - 1, gy = i_ty * 16 + hpy - 1;
+    return (hpx < 34 && gx >= 0 && gx < W && gy >= 0 && gy < H) ? gy * W + gx : -1;
+  };
+  int pixoff[LAZY ? 1 : NHALO];
   auto item_lane_setup = [&]() {
+    if constexpr (!LAZY) {
 #pragma unroll
-    for (int k = 0; k < NHALO; ++k) {
-      const int gx = i_tx * 32 + hpx[k] - 1, gy = i_ty * 16 + hpy[k] - 1;
-      const bool ok = hpx[k] < 34 && gx >= 0 && gx < W && gy >= 0 && gy < H;
-      pixoff[k] = ok ? gy * W + gx : -1;
+      for (int k = 0; k < NHALO; ++k) pixoff[k] = halo_pixel(r0, k);
     }
   };
   auto stage = [&](int cc, int buf) {      // all pieces of step (current item, chunk cc) -> buffer buf; loader waves only
@@ -128,13 +138,17 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     const ET* simg = (first ? src0 : src1) + (size_t)i_img * H * W * Cs;
     const ET* wbase = wgt + ((size_t)cc * Cout + i_g * WR) * 32;
     const unsigned lbase = lds0 + (unsigned)(buf * BUFB + lw * 1024);      // (LDS byte address: the pieces are inline assembly, k_unet16_base.h)
+    int r0v = r0;
+    if constexpr (LAZY) asm volatile("" : "+v"(r0v));      // (opaque per call: nothing of the recomputation is hoisted out of the loop)
 #pragma unroll
     for (int k = 0; k < NPIECE; ++k) {
       if (k < NHALO - 1) {
-        const ET* p = pixoff[k] >= 0 ? simg + (unsigned)((cb + pixoff[k]) * 32 + q8) : zero_page;
+        const int po = LAZY ? halo_pixel(r0v, k) : pixoff[LAZY ? 0 : k];
+        const ET* p = po >= 0 ? simg + (unsigned)((cb + po) * 32 + q8) : zero_page;
         ud_dma16(lbase + k * 4096, p);
       } else if (k == NHALO - 1) {      // rows 640..703: 8 halo rows, then the first 56 weight rows
-        const ET* pi = pixoff[k] >= 0 ? simg + (unsigned)((cb + pixoff[k]) * 32 + q8) : zero_page;
+        const int po = LAZY ? halo_pixel(r0v, k) : pixoff[LAZY ? 0 : k];
+        const ET* pi = po >= 0 ? simg + (unsigned)((cb + po) * 32 + q8) : zero_page;
         if constexpr (WRES != 0) {
           if (wlow) ud_dma16(lbase + k * 4096, pi);
         } else {
@@ -200,6 +214,12 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
           n_cc = 0; new_item = true;
         } else { has_next = false; more = false; }
       }
+      // (the walk is the same in every lane: say so, or hipcc keeps it -- and the 64-bit source addresses it feeds -- in vector registers,
+      //  which pushed the pooled instantiation into scratch, with a vmcnt(0) behind every reload between two LDS-DMA pieces)
+      i_g = __builtin_amdgcn_readfirstlane(i_g); i_tx = __builtin_amdgcn_readfirstlane(i_tx);
+      i_ty = __builtin_amdgcn_readfirstlane(i_ty); i_img = __builtin_amdgcn_readfirstlane(i_img);
+      w = __builtin_amdgcn_readfirstlane(w); w_end = __builtin_amdgcn_readfirstlane(w_end);
+      n_cc = __builtin_amdgcn_readfirstlane(n_cc);
       if (loader) {
         if (has_next) {
           if (new_item) item_lane_setup();
@@ -268,21 +288,12 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
           *(v8*)(ob + (lo + (unsigned)((2 * mp) * W * 32 + 8 * h))) = oa;
           *(v8*)(ob + (lo + (unsigned)((2 * mp + 1) * W * 32 + 8 * h))) = ob8;
           if (FUSE & UF_POOL) {
-            v8 op;
-            if (relu) {      // 2x2 max on the rounded non-negative values (they order like int16): rows inside the lane, columns with lane ^ 1
-              unsigned pv[4];
+            // 2x2 max on the rounded, ReLU'd values (non-negative: they order like int16; the host fuses the pool behind a ReLU only):
+            // rows inside the lane, columns with lane ^ 1
+            u32x4 pv;
 #pragma unroll
-              for (int i = 0; i < 4; ++i) pv[i] = pp_pkmax(ua[i], ub[i]);
-              pp_pkmax_lane1_n(pv);
-              op = __builtin_bit_cast(v8, u32x4{pv[0], pv[1], pv[2], pv[3]});
-            } else {
-#pragma unroll
-              for (int r = 0; r < 8; ++r) {      // (rounding to ET is monotonic: the same value as pooling first)
-                float vp = fmaxf(acc[2 * mp][2 * h + (r >> 2)][r & 3], acc[2 * mp + 1][2 * h + (r >> 2)][r & 3]);
-                vp = fmaxf(vp, __shfl_xor(vp, 1));
-                op[r] = (ET)vp;
-              }
-            }
+            for (int i = 0; i < 4; ++i) pv[i] = pp_pkmax_lane1(pp_pkmax(ua[i], ub[i]));      // (one dword at a time: the batched form's temporaries spilled here)
+            const v8 op = __builtin_bit_cast(v8, pv);
             if (!(li & 1)) *(v8*)(pb + (plo + (unsigned)(mp * (W >> 1) * 32 + 8 * h))) = op;
           }
         }

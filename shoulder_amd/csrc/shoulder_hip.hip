@@ -1346,7 +1346,7 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
   const int tiles = (H / UN_TH) * (W / UN_TW);
   const dim3 blk(UN_THREADS);
   const bool ldr = !c->unet_reference && L.taps == 9 && L.cout % 64 == 0 && L.cout <= 512 && W % 32 == 0 && H % 16 == 0 && C0 % 32 == 0 && C1 % 32 == 0 &&
-                   (fuse == 0 || fuse == UF_POOL);
+                   (fuse == 0 || (fuse == UF_POOL && relu));      // (its fused pool works on ReLU'd values)
   if (ldr) {
     int rc0;
     if ((rc0 = ensure(c, "unet16.zero", 256, 2)) != SH_OK) return rc0;

@@ -5,7 +5,7 @@
 # Counters are collected in their own runs (no trace domains beside --pmc), the program directly after `--`.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-RND=${RND:-r04}
+RND=${RND:-r05}
 O=gpurun_out/prof_$RND
 UNET=${1:-bf16}
 mkdir -p $O

@@ -1,7 +1,7 @@
 #!/bin/bash
 # After tools/collect_profiles.sh (its outputs merged back under gpurun_out/prof_$RND/): write the summaries the judge reads into profiles/.
 set -e
-RND=${RND:-r04}
+RND=${RND:-r05}
 P=gpurun_out/prof_$RND
 cp $P/stats_bf16/stats_kernel_stats.csv profiles/${RND}_kernel_stats_b64_bf16.csv
 cp $P/stats1_bf16/stats_kernel_stats.csv profiles/${RND}_kernel_stats_b64_bf16_one_lane.csv
