@@ -747,6 +747,9 @@ k_enc0_pp(const float* __restrict__ image, const float* __restrict__ w0 /*[9][32
 #define DA_SMEM (DA_W + 2 * 9 * 32 * 64)     // 156 672
 #define DA_NSP 6                             // LDS-DMA pieces per staging wave: skip halo (1 440 slots of 16 B) ...
 #define DA_NLP 4                             // ... and low tile (864 slots)
+#ifndef DA_ONPRIO
+#define DA_ONPRIO 0                          // s_setprio of a wave while it multiplies
+#endif
 
 template <int EK>
 __global__ void __launch_bounds__(PP_THREADS)
@@ -980,6 +983,7 @@ k_dec0a_up_pp(const u16* __restrict__ skip_ /*[img][H W][32]*/, const u16* __res
         // Six groups (chunk, dx) of three taps.  The pixel rows of the next group and the (up chunk's) weight fragments of the next tap
         // are requested before the MFMAs of this tap: hipcc otherwise reads a fragment right in front of its first use, one exposed
         // LDS latency per four MFMAs (measured: 4 000 - 4 800 cycles for the 144 MFMAs of a phase).
+        if (DA_ONPRIO) __builtin_amdgcn_s_setprio(DA_ONPRIO);
         const unsigned char* sb0 = smem + bf * DA_HB;
         const unsigned char* sb1 = smem + DA_UP + bf * DA_HB;
         const unsigned char* wbp = smem + DA_W + woff;
@@ -1010,6 +1014,7 @@ k_dec0a_up_pp(const u16* __restrict__ skip_ /*[img][H W][32]*/, const u16* __res
             for (int n = 0; n < 2; ++n) acc[m][n] = E16<ET>::mfma(wf[t % 3][n], xq[g & 1][m + dy], acc[m][n]);
           __builtin_amdgcn_sched_barrier(0);
         }
+        if (DA_ONPRIO) __builtin_amdgcn_s_setprio(0);
       }
 #ifdef PP_STAMP
       asm volatile("" :: "v"(acc[3][1]), "v"(acc[0][0]));
