@@ -59,22 +59,8 @@ def hull(verts: np.ndarray):
     return h.vertices, tri[ok], n[ok] / ln[ok][:, None]
 
 
-def oriented_bounds(verts: np.ndarray):
-    """-> (T 4x4 CT->OBB, extents (3,) ascending, min volume)."""
-    verts = np.asarray(verts, dtype=np.float64)
-    hv_ids, _, normals = hull(verts)
-    hv = verts[hv_ids]
-    best = (np.inf, None)
-    for n in normals:
-        u, v = _basis(n)
-        h = hv @ n
-        height = h.max() - h.min()
-        area, e2, ea, eb = min_area_rect_2d(np.c_[hv @ u, hv @ v])
-        vol = area * height
-        if vol < best[0]:
-            e = e2[0] * u + e2[1] * v
-            best = (vol, (n, e, np.cross(n, e), np.array([height, ea, eb])))
-    vol, (a0, a1, a2, ext) = best
+def _frame_of(verts, a0, a1, a2, ext, vol):
+    """the chosen box -> (T 4x4 CT->OBB, extents ascending, volume): axes by ascending extent, signs fixed by vertex 0, centred"""
     order = np.argsort(ext, kind="stable")
     A = np.stack([a0, a1, a2])[order]
     R = A.copy()
@@ -91,6 +77,74 @@ def oriented_bounds(verts: np.ndarray):
     T[:3, :3] = R
     T[:3, 3] = -c
     return T, ext[order], vol
+
+
+def oriented_bounds(verts: np.ndarray):
+    """-> (T 4x4 CT->OBB, extents (3,) ascending, min volume)."""
+    verts = np.asarray(verts, dtype=np.float64)
+    hv_ids, _, normals = hull(verts)
+    hv = verts[hv_ids]
+    best = (np.inf, None)
+    for n in normals:
+        u, v = _basis(n)
+        h = hv @ n
+        height = h.max() - h.min()
+        area, e2, ea, eb = min_area_rect_2d(np.c_[hv @ u, hv @ v])
+        vol = area * height
+        if vol < best[0]:
+            e = e2[0] * u + e2[1] * v
+            best = (vol, (n, e, np.cross(n, e), np.array([height, ea, eb])))
+    vol, (a0, a1, a2, ext) = best
+    return _frame_of(verts, a0, a1, a2, ext, vol)
+
+
+def oriented_bounds_large(verts: np.ndarray, chunk: int = 128):
+    """oriented_bounds for hulls with tens of thousands of faces, where one qhull call per face normal (the loop above) takes a
+    quarter of an hour: the 2-D hull of the projection along a face normal is read off the 3-D hull instead -- its edges are the
+    hull edges whose two faces see the direction from opposite sides -- and the rectangle of every such edge is taken over the
+    silhouette's vertices, a chunk of directions per matrix product.  Same candidate set, same minimum; pinned against
+    oriented_bounds on the fixtures (tests/test_oracle_obb_large.py).  Test infrastructure like everything in oracle/."""
+    verts = np.asarray(verts, dtype=np.float64)
+    hv_ids, tri, normals = hull(verts)
+    hv = verts[hv_ids]
+    # undirected hull edges with their two faces
+    e = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]])
+    fid = np.tile(np.arange(len(tri)), 3)
+    key = np.sort(e, axis=1)
+    order = np.lexsort((key[:, 1], key[:, 0]))
+    key, fid = key[order], fid[order]
+    assert len(key) % 2 == 0 and (key[0::2] == key[1::2]).all(), "hull is not a closed 2-manifold"
+    ev, ef, eg = key[0::2], fid[0::2], fid[1::2]
+    # (qhull's simplices are not wound consistently: the side test needs outward normals, the candidates keep hull()'s)
+    out = normals * np.where(np.einsum("ij,ij->i", normals, verts[tri[:, 0]] - hv.mean(axis=0)) < 0, -1.0, 1.0)[:, None]
+    best = (np.inf, None)
+    for c0 in range(0, len(normals), chunk):
+        N = normals[c0:c0 + chunk]
+        H = hv @ N.T
+        height = H.max(axis=0) - H.min(axis=0)
+        front = (out @ N.T) > 0.0
+        sil = front[ef] != front[eg]
+        for j in range(len(N)):
+            n = N[j]
+            u, v = _basis(n)
+            se = ev[sil[:, j]]
+            ids = np.unique(se)
+            p2 = np.c_[verts[ids] @ u, verts[ids] @ v]
+            d = np.c_[verts[se[:, 1]] @ u, verts[se[:, 1]] @ v] - np.c_[verts[se[:, 0]] @ u, verts[se[:, 0]] @ v]
+            ln = np.linalg.norm(d, axis=1)
+            d = d[ln > 0] / ln[ln > 0][:, None]
+            a = p2 @ d.T
+            b = p2 @ np.c_[-d[:, 1], d[:, 0]].T
+            ea = a.max(axis=0) - a.min(axis=0)
+            eb = b.max(axis=0) - b.min(axis=0)
+            area = ea * eb
+            i = int(np.argmin(area))
+            vol = float(area[i]) * float(height[j])
+            if vol < best[0]:
+                e3 = d[i, 0] * u + d[i, 1] * v
+                best = (vol, (n, e3, np.cross(n, e3), np.array([float(height[j]), float(ea[i]), float(eb[i])])))
+    vol, (a0, a1, a2, ext) = best
+    return _frame_of(verts, a0, a1, a2, ext, vol)
 
 
 def least_squares_circle(xy: np.ndarray):
@@ -121,9 +175,10 @@ def head_end_flip(z_bounds, residus):
     return bool(humeral_end < 0)                                 # mesh.py:112
 
 
-def full_obb(verts: np.ndarray, faces: np.ndarray):
-    """mesh.py:63-125 -> dict(transform, z_bounds, z_length, verts_obb, flipped, residus)."""
-    T_obb, ext, vol = oriented_bounds(verts)
+def full_obb(verts: np.ndarray, faces: np.ndarray, bounds=None):
+    """mesh.py:63-125 -> dict(transform, z_bounds, z_length, verts_obb, flipped, residus).  `bounds`: oriented_bounds (default) or
+    oriented_bounds_large for a hull of tens of thousands of faces."""
+    T_obb, ext, vol = (bounds or oriented_bounds)(verts)
     v = transform_pts(verts, T_obb)
     z_bounds = (float(v[:, 2].min()), float(v[:, 2].max()))      # mesh.py:85
     z_length = abs(z_bounds[0]) + abs(z_bounds[1])               # mesh.py:86

@@ -12,8 +12,8 @@
 
 namespace sh {
 
-#define SH_ANP_CAP 65536
 #define SH_IMG (SH_ANP_ROWS * SH_MPROX)
+#define SH_ANP_CAP SH_IMG      // edge pixels kept per humerus: a mask has no more edge pixels than pixels (was 65 536 + SH_ERR_CAPACITY)
 
 __global__ void k_anp_rows(const double* __restrict__ itr_start /*[B][600][2][512]*/, const double* __restrict__ bg_theta,
                            double* __restrict__ raw, double* __restrict__ t01 /*[B][rows][2]: the ends of the row's sampling grid.  The shifted

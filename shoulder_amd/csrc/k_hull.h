@@ -25,6 +25,7 @@
 // host quickhull writes its normals the same way, so both paths hand k_obb_candidates the same bits), edges (va, vb, f, g).
 #pragma once
 #include "k_hullpre.h"
+#include "k_obb.h"      // HullCap: the per-humerus strides of the hull record
 
 namespace sh {
 
@@ -147,7 +148,8 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
               double* __restrict__ hv, double* __restrict__ normals, int* __restrict__ edges,
               int* __restrict__ nv_out, int* __restrict__ nf_out, int* __restrict__ ne_out,
               int* __restrict__ fail_out /*[B]: 0 or a positive reason*/, int* __restrict__ rounds_out /*[B] (nullable)*/,
-              const int* __restrict__ skip /*[B] (nullable): 1 = this humerus' record is already in place (host quickhull), leave it*/) {
+              const int* __restrict__ skip /*[B] (nullable): 1 = this humerus' record is already in place (host quickhull), leave it*/,
+              const HullCap hc) {
   __shared__ HdPlane s_pl[HD_SLOTS];                       // 98 304 B
   __shared__ unsigned long long s_key[HD_SLOTS];           // 24 576 B  apex keys; face ids at the end
   __shared__ short s_conf[HD_NMAX];                        // 16 384 B  conflict face of a point (-1 inside, -2 inserted); vertex ids at the end
@@ -177,9 +179,9 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
   int* freestack = sc.freestack + (size_t)b * HD_SLOTS;
   unsigned long long* tkeys = sc.tkeys + (size_t)b * HD_TBL;
   unsigned* tvals = sc.tvals + (size_t)b * HD_TBL;
-  double* HV = hv + (size_t)b * SH_HV * 3;
-  double* NR = normals + (size_t)b * SH_HF * 3;
-  int* ED = edges + (size_t)b * SH_HE * 4;
+  double* HV = hv + (size_t)b * hc.v * 3;
+  double* NR = normals + (size_t)b * hc.f * 3;
+  int* ED = edges + (size_t)b * hc.e * 4;
   // failure: the reason for the host (which then runs its own quickhull for this batch) and a small WELL-FORMED record -- the unit
   // tetrahedron -- so that the kernels already queued behind this one (candidate boxes, frame, slices ...) work on finite, in-range
   // data for this humerus; its status word says that its landmarks are void
@@ -609,11 +611,11 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
     const int pos = nvh + hd_block_scan(flag, s_w, &t2);
     if (flag) {
       s_conf[q] = (short)pos;
-      if (pos < SH_HV) { HV[3 * pos] = (double)P[3 * q]; HV[3 * pos + 1] = (double)P[3 * q + 1]; HV[3 * pos + 2] = (double)P[3 * q + 2]; }
+      if (pos < hc.v) { HV[3 * pos] = (double)P[3 * q]; HV[3 * pos + 1] = (double)P[3 * q + 1]; HV[3 * pos + 2] = (double)P[3 * q + 2]; }
     }
     nvh += t2;
   }
-  if (nvh > SH_HV || nf > SH_HF) HD_FAIL(41);
+  if (nvh > hc.v || nf > hc.f) HD_FAIL(41);
   // normals: triangle rotated to its smallest vertex first, centred coordinates (sh_hull.h writes the same)
   for (int f = tid; f < nslots; f += HD_THREADS) {
     if (s_alive[f] != 1) continue;
@@ -650,7 +652,7 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
       const unsigned long long key = (1ull << 40) | ((unsigned long long)bq << 13) | (unsigned long long)a;
       int sl;
       if (!hd_tbl_slot(tkeys, key, false, &sl)) atomicMax(&s_fail, 31);
-      else if (pos < SH_HE) {
+      else if (pos < hc.e) {
         const int g = (int)__hip_atomic_load(&tvals[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ED[4 * pos] = s_conf[a]; ED[4 * pos + 1] = s_conf[bq]; ED[4 * pos + 2] = (int)s_key[f]; ED[4 * pos + 3] = (int)s_key[g];
       }
@@ -659,7 +661,7 @@ k_hull_rounds(const float* __restrict__ kept, const long long* __restrict__ koff
   }
   __syncthreads();
   if (s_fail) HD_FAIL(s_fail);
-  if (neh > SH_HE || nvh - neh + nf != 2 || 2 * neh != 3 * nf) HD_FAIL(32);
+  if (neh > hc.e || nvh - neh + nf != 2 || 2 * neh != 3 * nf) HD_FAIL(32);
   if (tid == 0) { nv_out[b] = nvh; nf_out[b] = nf; ne_out[b] = neh; fail_out[b] = 0; if (rounds_out) rounds_out[b] = rounds; }
 #undef HD_FAIL
 }

@@ -21,9 +21,12 @@ namespace sh {
 
 // hull record capacities (HBM): vertices / faces / edges per humerus.  The fixtures' hulls have 1 368 / 2 732 / 4 098; the hull of
 // a 519 k-triangle humerus 4 209 / 8 414 / 12 621; a convex region sampled more densely keeps more of its vertices on the hull.
+// These are the capacities a context STARTS with; a batch with a larger hull grows the record (sh_ctx::hcap) and every kernel
+// takes the per-humerus strides as an argument.
 #define SH_HV 16384
 #define SH_HF 32768
 #define SH_HE 49152
+struct HullCap { int v, f, e; };      // per-humerus strides of hull.hv / hull.normals (+ the per-face obb.* arrays) / hull.edges
 #define SH_ENDCAP 8192      // crossing points of an end section (mesh.py:91-107) a context starts with; ~330 at the fixture resolution, ~1 300 on a 519 k-triangle mesh.
                             // A run that meets more records how many (overflow counter word 7) and sh_collect grows the buffer and runs the batch again
 
@@ -43,17 +46,17 @@ __device__ inline void obb_basis(const double* n, double* u, double* v) { plane_
 // 2 x area of every hull face from the edge records: the directed edges (a -> b) of face f sum a x b to 2 A_f n_f
 __global__ void __launch_bounds__(256)
 k_obb_face_area2(const double* __restrict__ hv, const double* __restrict__ normals, const int* __restrict__ edges, const int* __restrict__ ne_,
-                 double* __restrict__ area2 /*[B][SH_HF], zero*/) {
+                 double* __restrict__ area2 /*[B][hc.f], zero*/, const HullCap hc) {
   const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
   if (e >= ne_[b]) return;
-  const double* P = hv + (size_t)b * SH_HV * 3;
-  const double* NN = normals + (size_t)b * SH_HF * 3;
-  const int4 ed = *(const int4*)(edges + ((size_t)b * SH_HE + e) * 4);
+  const double* P = hv + (size_t)b * hc.v * 3;
+  const double* NN = normals + (size_t)b * hc.f * 3;
+  const int4 ed = *(const int4*)(edges + ((size_t)b * hc.e + e) * 4);
   const double a[3] = {P[3 * ed.x] - P[0], P[3 * ed.x + 1] - P[1], P[3 * ed.x + 2] - P[2]};
   const double q[3] = {P[3 * ed.y] - P[0], P[3 * ed.y + 1] - P[1], P[3 * ed.y + 2] - P[2]};
   const double cr[3] = {a[1] * q[2] - a[2] * q[1], a[2] * q[0] - a[0] * q[2], a[0] * q[1] - a[1] * q[0]};
-  atomicAdd(&area2[(size_t)b * SH_HF + ed.z], dot3(cr, NN + 3 * (size_t)ed.z));
-  atomicAdd(&area2[(size_t)b * SH_HF + ed.w], -dot3(cr, NN + 3 * (size_t)ed.w));
+  atomicAdd(&area2[(size_t)b * hc.f + ed.z], dot3(cr, NN + 3 * (size_t)ed.z));
+  atomicAdd(&area2[(size_t)b * hc.f + ed.w], -dot3(cr, NN + 3 * (size_t)ed.w));
 }
 
 // 128 directions per workgroup, two per lane (a record read serves both); the SH_OBB_BND_SPLIT waves share the vertices and
@@ -65,8 +68,8 @@ k_obb_face_area2(const double* __restrict__ hv, const double* __restrict__ norma
 #define SH_OBB_BND_THREADS (64 * SH_OBB_BND_SPLIT)
 __global__ void __launch_bounds__(SH_OBB_BND_THREADS)
 k_obb_bounds(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
-             const double* __restrict__ area2, double* __restrict__ lb_out /*[B][SH_HF]*/, unsigned long long* __restrict__ lbmin_enc /*[B], ~0*/,
-             double* __restrict__ cand_vol, int* __restrict__ cand_edge, int ntiles, int B) {
+             const double* __restrict__ area2, double* __restrict__ lb_out /*[B][hc.f]*/, unsigned long long* __restrict__ lbmin_enc /*[B], ~0*/,
+             double* __restrict__ cand_vol, int* __restrict__ cand_edge, int ntiles, int B, const HullCap hc) {
   constexpr int S = SH_OBB_BND_SPLIT;
   __shared__ double s_mn[S][2][64], s_mx[S][2][64], s_s[S][2][64];
   // XCD-aware order as in k_obb_candidates: linear id L -> humerus 8 * chunk + L % 8, so all tiles of a humerus read its hull
@@ -77,9 +80,9 @@ k_obb_bounds(const double* __restrict__ hv, const int* __restrict__ nv_, const d
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nv = nv_[b], nf = nf_[b];
   if (tile * SH_OBB_BND_DIRS >= nf) return;
-  const double* P = hv + (size_t)b * SH_HV * 3;
-  const double* NN = normals + (size_t)b * SH_HF * 3;
-  const double* A2 = area2 + (size_t)b * SH_HF;
+  const double* P = hv + (size_t)b * hc.v * 3;
+  const double* NN = normals + (size_t)b * hc.f * 3;
+  const double* A2 = area2 + (size_t)b * hc.f;
   int jd[2];
   double n[2][3];
 #pragma unroll
@@ -135,9 +138,9 @@ k_obb_bounds(const double* __restrict__ hv, const int* __restrict__ nv_, const d
   const double lb = 0.25 * fs * (fmx - fmn);
   unsigned long long enc = ~0ull;
   if (j < nf) {
-    lb_out[(size_t)b * SH_HF + j] = lb;
-    cand_vol[(size_t)b * SH_HF + j] = 1e300;
-    cand_edge[(size_t)b * SH_HF + j] = 0x7fffffff;
+    lb_out[(size_t)b * hc.f + j] = lb;
+    cand_vol[(size_t)b * hc.f + j] = 1e300;
+    cand_edge[(size_t)b * hc.f + j] = 0x7fffffff;
     if (lb >= 0.0) enc = (unsigned long long)__double_as_longlong(lb);      // (a NaN bound takes no part; its direction survives below)
   }
   for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(enc, off); enc = o < enc ? o : enc; }
@@ -153,14 +156,14 @@ k_obb_bounds(const double* __restrict__ hv, const int* __restrict__ nv_, const d
 __global__ void __launch_bounds__(256)
 k_obb_select(const double* __restrict__ lb_, const int* __restrict__ nf_, const unsigned long long* __restrict__ lbmin_enc,
              const unsigned long long* __restrict__ best_enc, int pass, int* __restrict__ dir_list, int* __restrict__ dir_count,
-             unsigned char* __restrict__ seeded /*[B][SH_HF]*/) {
+             unsigned char* __restrict__ seeded /*[B][hc.f]*/, const HullCap hc) {
   __shared__ int s_w[4];
   __shared__ int s_base;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nf = nf_[b];
-  const double* lb = lb_ + (size_t)b * SH_HF;
-  int* out = dir_list + (size_t)b * SH_HF;
-  unsigned char* sd = seeded + (size_t)b * SH_HF;
+  const double* lb = lb_ + (size_t)b * hc.f;
+  int* out = dir_list + (size_t)b * hc.f;
+  unsigned char* sd = seeded + (size_t)b * hc.f;
   double thr;
   if (pass == 0) {
     const unsigned long long m = lbmin_enc[b];
@@ -204,27 +207,44 @@ k_obb_select(const double* __restrict__ lb_, const int* __restrict__ nf_, const 
 //   edges     mask[f] ^ mask[g] = directions for which the edge is on the silhouette -> per-direction lists
 //   scans     four directions at a time: project the silhouette start vertices (LDS), then every silhouette
 //             edge takes the extents of all of them (ns x ns, fp64) -> min-area rectangle
-// Two capacity tiers (the hull record in HBM is sized for the large one, SH_HV / SH_HF / SH_HE; only this kernel keeps per-face
+// Two capacity tiers (the hull record in HBM is sized for the large one, hc.v / hc.f / hc.e; only this kernel keeps per-face
 // and per-silhouette state in LDS):  <16, 4, 512, 8192, unsigned short>  hulls of up to 8 192 faces -- every fixture (2 732) and
 // everything the device hull produces (3 072 slots) -- two workgroups per CU;  <8, 1, 2048, 32768, unsigned> the hull of a dense
 // mesh (a 519 k-triangle humerus: 8 414 faces), one workgroup per CU, chosen by the host when a hull of the launch needs it.
-template <int T, int G, int SIL, int HFCAP, typename LT>
-__global__ void __launch_bounds__(SH_OBB_THREADS)
-k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
+// A third tier without limits, <8, 1, 0, 0, unsigned, true>: face masks, silhouette lists and projected start points in a workspace
+// in global memory (ObbWs: one slice per workgroup; a grid of ws.nwg workgroups walks the tiles), for hulls above 32 768 faces and
+// for directions whose silhouette has more edges than the LDS tiers hold (a run that meets one records the count in ws.need and
+// sh_collect runs the batch again on the tier that holds it).  Same arithmetic, same (area, edge) order: same candidate records.
+struct ObbWs {
+  unsigned char* fmask;            // [nwg][hc.f]
+  unsigned* lists;                 // [nwg][8][silcap]
+  double2* sxy;                    // [nwg][silcap]
+  double* area;                    // [nwg][silcap]
+  int silcap, nwg;
+  unsigned long long* need;        // [2]: the largest silhouette a direction had, in edges; 1 when a hull had more faces than the tier's masks
+};
+template <int T, int G, int SIL, int HFCAP, typename LT, bool GLOB>
+__device__ __forceinline__ void
+obb_candidates_tile(const int Lid, const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
                  const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge,
                  int* __restrict__ err, unsigned long long* __restrict__ best_enc /*[B]: bits of the smallest candidate volume so far, ~0 = none*/,
-                 const int* __restrict__ dir_list /*[B][SH_HF]: the directions (hull faces) to evaluate*/, const int* __restrict__ dir_count /*[B]*/,
-                 int ntiles, int B, int skip_on /*0: no in-kernel skip either (A/B of the pruning)*/) {
+                 const int* __restrict__ dir_list /*[B][hc.f]: the directions (hull faces) to evaluate*/, const int* __restrict__ dir_count /*[B]*/,
+                 int ntiles, int B, int skip_on /*0: no in-kernel skip either (A/B of the pruning)*/, const HullCap hc, const ObbWs ws) {
   constexpr int NW = SH_OBB_THREADS / 64;
   constexpr int FB = (int)sizeof(LT) * 8 - 1;      // flag bit of a list entry: the edge's first face is the front face
   typedef typename std::conditional<(T > 8), unsigned short, unsigned char>::type MT;
   __shared__ double tn[T][3], tu[T][3], tv[T][3];
   __shared__ double red[NW][2 * T];
   __shared__ double hlo[T], hhi[T];
-  __shared__ MT fmask[HFCAP];
-  __shared__ LT lists[T][SIL];      // edge id | (first face is the front face) << FB
+  __shared__ MT fmask_s[GLOB ? 1 : HFCAP];
+  __shared__ LT lists_s[GLOB ? 1 : T * SIL];      // [T][silcap]: edge id | (first face is the front face) << FB
   __shared__ int cnt[T];
-  __shared__ double2 sxy[G][SIL];
+  __shared__ double2 sxy_s[GLOB ? 1 : G * SIL];   // [G][silcap]
+  MT* const fmask = GLOB ? (MT*)(ws.fmask + (size_t)blockIdx.x * hc.f) : fmask_s;
+  LT* const lists = GLOB ? (LT*)(ws.lists + (size_t)blockIdx.x * T * ws.silcap) : lists_s;
+  double2* const sxy = GLOB ? ws.sxy + (size_t)blockIdx.x * G * ws.silcap : sxy_s;
+  const int silcap = GLOB ? ws.silcap : SIL;
+#define LIX(row, col) (GLOB ? (size_t)(row) * (size_t)silcap + (size_t)(col) : (size_t)((row) * SIL + (col)))
   __shared__ unsigned long long g_area[G];
   __shared__ int g_edge[G];
   __shared__ double g_hull2[NW][G];  // per wave: twice the signed area of the projected hull (shoelace over the directed silhouette edges)
@@ -233,20 +253,20 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
   // XCD-aware order: consecutive workgroups go to the 8 XCDs in turn, each with its own L2.  Linear id L -> humerus
   // 8 * chunk + L % 8, so every tile of a humerus runs on one XCD and its hull record (160 KB, re-read by all 171 tiles)
   // stays in that XCD's L2: 8 records at a time per XCD instead of all B of them.
-  const int Lid = blockIdx.x, chunk = Lid / (8 * ntiles), rr = Lid - chunk * 8 * ntiles;
+  const int chunk = Lid / (8 * ntiles), rr = Lid - chunk * 8 * ntiles;
   const int b = chunk * 8 + (rr & 7);
   if (b >= B) return;
   const int f0 = (rr >> 3) * T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = nv_[b], nf = nf_[b], ne = ne_[b];
-  if (nf > HFCAP) { if (tid == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); return; }
+  if (!GLOB && nf > HFCAP) { if (tid == 0) { atomicExch(&err[b], SH_ERR_CAPACITY_DEV); atomicMax(ws.need + 1, 1ull); } return; }
   const int ndir = dir_count[b];
   if (f0 >= ndir) return;
   const int nt = min(T, ndir - f0);                    // directions in this tile: entries f0 .. f0 + nt - 1 of the humerus's list
-  const double* P = hv + (size_t)b * SH_HV * 3;
-  const double* NN = normals + (size_t)b * SH_HF * 3;
-  const int* E = edges + (size_t)b * SH_HE * 4;
+  const double* P = hv + (size_t)b * hc.v * 3;
+  const double* NN = normals + (size_t)b * hc.f * 3;
+  const int* E = edges + (size_t)b * hc.e * 4;
   if (tid < T) {
-    const int dir = dir_list[(size_t)b * SH_HF + f0 + (tid < nt ? tid : 0)];
+    const int dir = dir_list[(size_t)b * hc.f + f0 + (tid < nt ? tid : 0)];
     s_dir[tid] = dir;
     const double* N = NN + 3 * (size_t)dir;
     double n[3] = {N[0], N[1], N[2]}, u[3], v[3];
@@ -294,7 +314,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
       unsigned m = 0;
 #pragma unroll
       for (int j = 0; j < T; ++j) m |= (dot3(q[u], tn[j]) > 0 ? 1u : 0u) << j;
-      if (f2 < nf && f2 < HFCAP) fmask[f2] = (MT)m;
+      if (f2 < nf && (GLOB || f2 < HFCAP)) fmask[f2] = (MT)m;
     }
   }
   __syncthreads();
@@ -319,7 +339,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
         const int j = __ffs(x) - 1;
         x &= x - 1;
         const int s = atomicAdd(&cnt[j], 1);
-        if (s < SIL) lists[j][s] = (LT)((unsigned)e | (((m1 >> j) & 1u) << FB));
+        if (s < silcap) lists[LIX(j, s)] = (LT)((unsigned)e | (((m1 >> j) & 1u) << FB));
       }
     }
   }
@@ -332,7 +352,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     for (int jj = 0; jj < G; ++jj) {
       const int j = g0 + jj;
       int c = j < nt ? cnt[j] : 0;
-      if (c > SIL) { if (tid == 0) atomicExch(&err[b], SH_ERR_CAPACITY_DEV); c = SIL; }
+      if (c > silcap) { if (tid == 0) { atomicExch(&err[b], SH_ERR_CAPACITY_DEV); atomicMax(ws.need, (unsigned long long)c); } c = silcap; }
       ns[jj] = c; pre[jj + 1] = pre[jj] + c;
     }
     if (tid < G) { g_area[tid] = (unsigned long long)__double_as_longlong(1e300); g_edge[tid] = 0x7fffffff; g_skip[tid] = 0; }
@@ -347,13 +367,13 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
 #pragma unroll
       for (int k = 1; k < G; ++k) jj += it >= pre[k] ? 1 : 0;
       const int s = it - pre[jj], j = g0 + jj;
-      const unsigned rec = lists[j][s];
+      const unsigned rec = lists[LIX(j, s)];
       const int e = (int)(rec & ((1u << FB) - 1u));
       const bool fwd = (rec >> FB) != 0;
       const double* p = P + 3 * (size_t)(fwd ? E[4 * e] : E[4 * e + 1]);
       const double* q = P + 3 * (size_t)(fwd ? E[4 * e + 1] : E[4 * e]);
       const double2 a = make_double2(dot3(p, tu[j]), dot3(p, tv[j]));
-      sxy[jj][s] = a;
+      sxy[LIX(jj, s)] = a;
       const double cr = a.x * dot3(q, tv[j]) - dot3(q, tu[j]) * a.y;      // start x end of the directed edge
 #pragma unroll
       for (int k = 0; k < G; ++k) h2[k] += jj == k ? cr : 0.0;
@@ -382,6 +402,49 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
 #endif
     }
     __syncthreads();
+    if constexpr (GLOB) {
+      // (any silhouette length: the areas of a direction's edges go to the workspace, the (area, edge) minimum is resolved in a second sweep)
+      double* const ar = ws.area + (size_t)blockIdx.x * G * silcap;
+      const int nit = pre[G];
+      for (int it = tid; it < nit; it += SH_OBB_THREADS) {
+        int jj = 0;
+#pragma unroll
+        for (int k = 1; k < G; ++k) jj += it >= pre[k] ? 1 : 0;
+        const int s = it - pre[jj], j = g0 + jj, n2 = g_skip[jj] ? 0 : ns[jj];
+        const int e = (int)((unsigned)lists[LIX(j, s)] & ((1u << FB) - 1u));
+        double ex = 0.0, ey = 0.0, l = 0.0, area = 1e300;
+        if (n2 > 0) {
+          const double* pa3 = P + 3 * (size_t)E[4 * e]; const double* pc3 = P + 3 * (size_t)E[4 * e + 1];
+          ex = dot3(pc3, tu[j]) - dot3(pa3, tu[j]); ey = dot3(pc3, tv[j]) - dot3(pa3, tv[j]);
+          l = sqrt(ex * ex + ey * ey);
+        }
+        if (l != 0.0) {
+          ex /= l; ey /= l;
+          double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
+          const double2* sq = sxy + LIX(jj, 0);
+#pragma unroll 4
+          for (int s2 = 0; s2 < n2; ++s2) {
+            const double2 q = sq[s2];
+            const double pa = q.x * ex + q.y * ey, pb = q.y * ex - q.x * ey;
+            amin = fmin(amin, pa); amax = fmax(amax, pa); bmin = fmin(bmin, pb); bmax = fmax(bmax, pb);
+          }
+          area = (amax - amin) * (bmax - bmin);
+          atomicMin(&g_area[jj], (unsigned long long)__double_as_longlong(area));
+        }
+        ar[LIX(jj, s)] = area;
+      }
+      __syncthreads();
+      for (int it = tid; it < nit; it += SH_OBB_THREADS) {
+        int jj = 0;
+#pragma unroll
+        for (int k = 1; k < G; ++k) jj += it >= pre[k] ? 1 : 0;
+        const int s = it - pre[jj], j = g0 + jj;
+        const double area = ar[LIX(jj, s)];
+        if (area < 1e299 && (unsigned long long)__double_as_longlong(area) == g_area[jj])
+          atomicMin(&g_edge[jj], (int)((unsigned)lists[LIX(j, s)] & ((1u << FB) - 1u)));
+      }
+      __syncthreads();
+    } else {
     // every lane takes item tid of each pass of 256 (edge s of direction jj) and remembers (area, edge, direction);
     // lexicographic (area, edge) minimum per direction in two steps: areas are non-negative doubles, so their bit
     // patterns order like the values
@@ -397,7 +460,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
 #pragma unroll
         for (int k = 1; k < G; ++k) jj += it >= pre[k] ? 1 : 0;
         const int s = it - pre[jj], j = g0 + jj, n2 = g_skip[jj] ? 0 : ns[jj];
-        const int e = (int)((unsigned)lists[j][s] & ((1u << FB) - 1u));
+        const int e = (int)((unsigned)lists[LIX(j, s)] & ((1u << FB) - 1u));
         double ex = 0.0, ey = 0.0, l = 0.0;
         if (n2 > 0) {      // (a skipped direction costs no gathers here)
           const double* pa3 = P + 3 * (size_t)E[4 * e]; const double* pc3 = P + 3 * (size_t)E[4 * e + 1];
@@ -407,7 +470,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
         if (l != 0.0) {
           ex /= l; ey /= l;
           double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
-          const double2* sq = sxy[jj];
+          const double2* sq = sxy + LIX(jj, 0);
 #pragma unroll 4
           for (int s2 = 0; s2 < n2; ++s2) {
             const double2 q = sq[s2];
@@ -424,14 +487,33 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
     for (int p = 0; p < NP; ++p)
       if (j_[p] >= 0 && (unsigned long long)__double_as_longlong(a_[p]) == g_area[j_[p]]) atomicMin(&g_edge[j_[p]], e_[p]);
     __syncthreads();
+    }
     if (tid < G && g0 + tid < nt) {
       const int j = g0 + tid;
       const double vol = g_skip[tid] ? 1e300 : __longlong_as_double((long long)g_area[tid]) * (hhi[j] - hlo[j]);
-      cand_vol[(size_t)b * SH_HF + s_dir[j]] = vol;
-      cand_edge[(size_t)b * SH_HF + s_dir[j]] = g_edge[tid];
+      cand_vol[(size_t)b * hc.f + s_dir[j]] = vol;
+      cand_edge[(size_t)b * hc.f + s_dir[j]] = g_edge[tid];
       if (vol < 1e299) atomicMin(&best_enc[b], (unsigned long long)__double_as_longlong(vol));
     }
     __syncthreads();
+  }
+#undef LIX
+}
+
+template <int T, int G, int SIL, int HFCAP, typename LT, bool GLOB = false>
+__global__ void __launch_bounds__(SH_OBB_THREADS)
+k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, const double* __restrict__ normals, const int* __restrict__ nf_,
+                 const int* __restrict__ edges, const int* __restrict__ ne_, double* __restrict__ cand_vol, int* __restrict__ cand_edge,
+                 int* __restrict__ err, unsigned long long* __restrict__ best_enc, const int* __restrict__ dir_list, const int* __restrict__ dir_count,
+                 int ntiles, int B, int skip_on, const HullCap hc, const ObbWs ws) {
+  if constexpr (GLOB) {      // a grid of ws.nwg workgroups walks the tiles, every workgroup with its slice of the workspace
+    const int ntot = ntiles * ((B + 7) / 8) * 8;
+    for (int Lid = blockIdx.x; Lid < ntot; Lid += gridDim.x) {
+      obb_candidates_tile<T, G, SIL, HFCAP, LT, GLOB>(Lid, hv, nv_, normals, nf_, edges, ne_, cand_vol, cand_edge, err, best_enc, dir_list, dir_count, ntiles, B, skip_on, hc, ws);
+      __syncthreads();      // (the tile's shared state is done with)
+    }
+  } else {
+    obb_candidates_tile<T, G, SIL, HFCAP, LT, GLOB>(blockIdx.x, hv, nv_, normals, nf_, edges, ne_, cand_vol, cand_edge, err, best_enc, dir_list, dir_count, ntiles, B, skip_on, hc, ws);
   }
 }
 
@@ -439,7 +521,7 @@ k_obb_candidates(const double* __restrict__ hv, const int* __restrict__ nv_, con
 __global__ void __launch_bounds__(256)
 k_obb_pick(const double* __restrict__ hv, const double* __restrict__ normals, const int* __restrict__ nf_, const int* __restrict__ edges,
            const double* __restrict__ cand_vol, const int* __restrict__ cand_edge, const float* __restrict__ verts,
-           const long long* __restrict__ voff, double* __restrict__ T_pre, double* __restrict__ zb_pre, int* __restrict__ err) {
+           const long long* __restrict__ voff, double* __restrict__ T_pre, double* __restrict__ zb_pre, int* __restrict__ err, const HullCap hc) {
   __shared__ double wv[4];
   __shared__ int wi[4];
   __shared__ double R[9];
@@ -449,7 +531,7 @@ k_obb_pick(const double* __restrict__ hv, const double* __restrict__ normals, co
   double best = 1e300;
   int bf = 0x7fffffff;
   for (int f = tid; f < nf; f += 256) {
-    double v = cand_vol[(size_t)b * SH_HF + f];
+    double v = cand_vol[(size_t)b * hc.f + f];
     if (v < best || (v == best && f < bf)) { best = v; bf = f; }
   }
   for (int off = 32; off > 0; off >>= 1) {
@@ -462,13 +544,13 @@ k_obb_pick(const double* __restrict__ hv, const double* __restrict__ normals, co
   if (tid == 0) {
     for (int w = 1; w < 4; ++w) if (wv[w] < best || (wv[w] == best && wi[w] < bf)) { best = wv[w]; bf = wi[w]; }
     if (bf == 0x7fffffff || !(best < 1e299)) { atomicCAS(&err[b], 0, SH_ERR_GEOMETRY_DEV); bf = 0; }
-    const double* N = normals + ((size_t)b * SH_HF + bf) * 3;
+    const double* N = normals + ((size_t)b * hc.f + bf) * 3;
     double n[3] = {N[0], N[1], N[2]}, u[3], v[3];
     obb_basis(n, u, v);
-    int e = cand_edge[(size_t)b * SH_HF + bf];
-    const int* E = edges + ((size_t)b * SH_HE + (e < 0 || e >= SH_HE ? 0 : e)) * 4;
-    const double* pa = hv + ((size_t)b * SH_HV + min(max(E[0], 0), SH_HV - 1)) * 3;      // (clamped: a void record must not turn into a wild read)
-    const double* pc = hv + ((size_t)b * SH_HV + min(max(E[1], 0), SH_HV - 1)) * 3;
+    int e = cand_edge[(size_t)b * hc.f + bf];
+    const int* E = edges + ((size_t)b * hc.e + (e < 0 || e >= hc.e ? 0 : e)) * 4;
+    const double* pa = hv + ((size_t)b * hc.v + min(max(E[0], 0), hc.v - 1)) * 3;      // (clamped: a void record must not turn into a wild read)
+    const double* pc = hv + ((size_t)b * hc.v + min(max(E[1], 0), hc.v - 1)) * 3;
     double d[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
     double ex = dot3(d, u), ey = dot3(d, v);
     double l = sqrt(ex * ex + ey * ey);

@@ -103,6 +103,13 @@ struct sh_ctx {
   // and parameters skip the overflow tier's launches (they would all return at once: ~17 launches, ~60 us per step)
   unsigned long long ovf_none_gen = ~0ull;
   int end_cap = SH_ENDCAP;                   // points per end section "obb.endpts" holds (grown by sh_collect like the pools)
+  unsigned long long obb_gen = ~0ull;        // the batch generation the three fields below belong to
+  HullCap hcap = {SH_HV, SH_HF, SH_HE};      // per-humerus capacity (= stride) of the hull record and the per-face obb.* arrays; a batch with a larger
+                                             // hull grows it (grow_hull_records) -- every kernel takes the strides as an argument
+  int obb_sil_need = 0;                      // the longest silhouette (edges) a direction of the resident batch had when it overflowed a tier of
+                                             // k_obb_candidates: later runs take the tier that holds it (reset with the batch)
+  bool obb_nf_over = false;                  // a device-hull run met a hull with more faces than its candidates tier masks: the next run takes the workspace tier
+  bool hull_force_host = false;              // the resident batch has a hull above the device hull's record: its hulls come from the host (reset with the batch)
   bool redo_records = false;               // run_obb: the hull records of the window are in place already (redo_given_up)
   int redo_nf = 0;
   std::vector<float> h_verts;                // host copy of the vertices (hull stage)
@@ -572,9 +579,9 @@ static int alloc_batch(sh_ctx* c) {
   ENS("flipped", (size_t)B * 4, 4);
   HIPCHK(c, hipMemsetAsync(buf<int>(c, "flipped"), 0, (size_t)B * 4, c->stream));
   // oriented bounding box
-  ENS("hull.hv", (size_t)B * SH_HV * 3 * 8, 8);
-  ENS("hull.normals", (size_t)B * SH_HF * 3 * 8, 8);
-  ENS("hull.edges", (size_t)B * SH_HE * 4 * 4, 4);
+  ENS("hull.hv", (size_t)B * c->hcap.v * 3 * 8, 8);
+  ENS("hull.normals", (size_t)B * c->hcap.f * 3 * 8, 8);
+  ENS("hull.edges", (size_t)B * c->hcap.e * 4 * 4, 4);
   ENS("hull.nv", (size_t)B * 4, 4);
   ENS("hull.nf", (size_t)B * 4, 4);
   ENS("hull.ne", (size_t)B * 4, 4);
@@ -602,15 +609,15 @@ static int alloc_batch(sh_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&c->h_koff, (size_t)(B + 1) * 8));
     c->h_nkept_cap = B;
   }
-  ENS("obb.cand_vol", (size_t)B * SH_HF * 8, 8);
-  ENS("obb.cand_edge", (size_t)B * SH_HF * 4, 4);
+  ENS("obb.cand_vol", (size_t)B * c->hcap.f * 8, 8);
+  ENS("obb.cand_edge", (size_t)B * c->hcap.f * 4, 4);
   ENS("obb.best_enc", (size_t)B * 8, 8);
   ENS("obb.lbmin_enc", (size_t)B * 8, 8);
-  ENS("obb.area2", (size_t)B * SH_HF * 8, 8);
-  ENS("obb.lb", (size_t)B * SH_HF * 8, 8);
-  ENS("obb.dir_list", (size_t)B * SH_HF * 4, 4);
+  ENS("obb.area2", (size_t)B * c->hcap.f * 8, 8);
+  ENS("obb.lb", (size_t)B * c->hcap.f * 8, 8);
+  ENS("obb.dir_list", (size_t)B * c->hcap.f * 4, 4);
   ENS("obb.dir_count", (size_t)B * 4, 4);
-  ENS("obb.seeded", (size_t)B * SH_HF, 1);
+  ENS("obb.seeded", (size_t)B * c->hcap.f, 1);
   ENS("obb.T_pre", (size_t)B * 16 * 8, 8);
   ENS("obb.zb_pre", (size_t)B * 2 * 8, 8);
   ENS("obb.endpts", (size_t)B * 2 * c->end_cap * 2 * 8, 8);
@@ -1553,7 +1560,7 @@ static int ovf_pools(sh_ctx* c, OvfPools* P) {
   if ((rc = ensure(c, "ovf.segs", c->ovf_seg_cap * sizeof(Seg), 1)) != SH_OK) return rc;
   if ((rc = ensure(c, "ovf.ring", c->ovf_ring_cap * 16, 8)) != SH_OK) return rc;
   if ((rc = ensure(c, "ovf.work", c->ovf_work_cap, 1)) != SH_OK) return rc;
-  if ((rc = ensure(c, "ovf.ctr", 64, 8)) != SH_OK) return rc;
+  if ((rc = ensure(c, "ovf.ctr", 128, 8)) != SH_OK) return rc;      // words 0..7: the slice layer's pools (k_ovf.h) and the end sections; 8, 9: k_obb_candidates (ObbWs::need)
   for (const char* n : {"ovf.segs", "ovf.ring", "ovf.work", "ovf.ctr"}) c->bufs[n].per_mesh = 0;
   P->segs = (Seg*)c->bufs["ovf.segs"].p; P->ring = (double*)c->bufs["ovf.ring"].p; P->work = (unsigned char*)c->bufs["ovf.work"].p;
   P->seg_cap = c->ovf_seg_cap; P->ring_cap = c->ovf_ring_cap; P->work_cap = c->ovf_work_cap;
@@ -1840,6 +1847,7 @@ again:
 #undef HULLCHK
   double* hv = hs.hv; double* nr = hs.nr; int* ed = hs.ed; int* counts = hs.cnt;
   std::vector<int> status(B, 0);
+  std::vector<int> demand(3 * (size_t)B, 0);      // of the humeri whose hull does not fit the staging pitch
   static const bool gate_on = !(getenv("SHOULDER_HULL_GATE") && getenv("SHOULDER_HULL_GATE")[0] == '0');
   std::atomic<int> next(0);
   auto work = [&]() {
@@ -1856,8 +1864,7 @@ again:
       for (long long i = 0; i < 3 * nv; ++i) P[i] = (double)src[i];
       if (!shhull::convex_hull(P.data(), (int)nv, H)) { status[b] = SH_ERR_GEOMETRY; continue; }
       int hn = (int)H.vert_ids.size(), fn = (int)H.tris.size() / 3, en = (int)H.edges.size() / 4;
-      if (hn > SH_HV || fn > SH_HF || en > SH_HE) { status[b] = SH_ERR_CAPACITY; continue; }
-      if (hn > hs.pv || fn > hs.pf || en > hs.pe) { status[b] = 1; continue; }      // does not fit the small staging pitch: see below
+      if (hn > hs.pv || fn > hs.pf || en > hs.pe) { status[b] = 1; demand[3 * (size_t)b] = hn; demand[3 * (size_t)b + 1] = fn; demand[3 * (size_t)b + 2] = en; continue; }      // does not fit the staging pitch: see below
       for (int i = 0; i < hn; ++i)
         for (int k = 0; k < 3; ++k) hv[((size_t)b * hs.pv + i) * 3 + k] = P[3 * (size_t)H.vert_ids[i] + k];
       std::copy(H.normals.begin(), H.normals.end(), nr + (size_t)b * hs.pf * 3);
@@ -1875,8 +1882,12 @@ again:
     if (gate_on) HullPhaseGate::instance().leave();
   } while (next.load() < B);      // (a background phase that handed the pool over: the remaining humeri)
   if (!grown && std::find(status.begin(), status.end(), 1) != status.end()) {
-    // a hull larger than the staging pitch (a dense mesh): this slot gets the full record capacity and the phase runs again
-    hs.pv = SH_HV; hs.pf = SH_HF; hs.pe = SH_HE;
+    // a hull larger than the staging pitch (a dense mesh): this slot gets the record capacity -- or, above it, what the largest hull
+    // of the batch needs (the device record grows at the upload: grow_hull_records) -- and the phase runs again
+    int dv = SH_HV, df = SH_HF, de = SH_HE;
+    for (int b = 0; b < B; ++b) { dv = std::max(dv, demand[3 * (size_t)b]); df = std::max(df, demand[3 * (size_t)b + 1]); de = std::max(de, demand[3 * (size_t)b + 2]); }
+    auto up = [](int x) { return (x + 1023) / 1024 * 1024; };
+    hs.pv = up(dv); hs.pf = up(df); hs.pe = up(de);
     grown = true;
     std::fill(status.begin(), status.end(), 0);
     next = 0;
@@ -1890,15 +1901,45 @@ again:
 
 // Hull records of pinned slot `slot` -> device buffers on stream `st`: only the used head of every fixed-capacity record
 // crosses PCIe (one strided copy per array).  `dst` = {hull.hv, hull.normals, hull.edges, hull.nv, hull.nf, hull.ne}.
+// do the hulls of pinned slot `slot` fit the device record?  (the background threads upload only when they do: growing re-allocates)
+static bool hull_fits(const sh_ctx* c, int slot, int B, int* need /*[3] or null*/) {
+  const int* counts = c->hstage[slot].cnt;
+  int nvmax = 1, nfmax = 1, nemax = 1;
+  for (int b = 0; b < B; ++b) { nvmax = std::max(nvmax, counts[b]); nfmax = std::max(nfmax, counts[B + b]); nemax = std::max(nemax, counts[2 * B + b]); }
+  if (need) { need[0] = nvmax; need[1] = nfmax; need[2] = nemax; }
+  return nvmax <= c->hcap.v && nfmax <= c->hcap.f && nemax <= c->hcap.e;
+}
+// A hull above the record's capacity (a strictly convex surface keeps every vertex: 16 384 is not a bound of the reference's
+// `convex_hull`, mesh.py:82): the hull record and the per-face arrays of the OBB stage are re-allocated at strides that hold it.
+// Foreground only, nothing of this context in flight reads them afterwards (hipFree waits for the device).
+static int grow_hull_records(sh_ctx* c, int nv, int nf, int ne) {
+  auto up = [](int x) { return (x + x / 8 + 1023) / 1024 * 1024; };
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (nv > c->hcap.v) c->hcap.v = up(nv);
+  if (nf > c->hcap.f) c->hcap.f = up(nf);
+  if (ne > c->hcap.e) c->hcap.e = up(ne);
+  const size_t B = (size_t)c->B;
+  const struct { const char* n; size_t per; int elem; } arr[] = {
+      {"hull.hv", (size_t)c->hcap.v * 24, 8}, {"hull.normals", (size_t)c->hcap.f * 24, 8}, {"hull.edges", (size_t)c->hcap.e * 16, 4},
+      {"obb.cand_vol", (size_t)c->hcap.f * 8, 8}, {"obb.cand_edge", (size_t)c->hcap.f * 4, 4}, {"obb.area2", (size_t)c->hcap.f * 8, 8},
+      {"obb.lb", (size_t)c->hcap.f * 8, 8}, {"obb.dir_list", (size_t)c->hcap.f * 4, 4}, {"obb.seeded", (size_t)c->hcap.f, 1}};
+  for (const auto& a : arr) {
+    if (int e = ensure(c, a.n, B * a.per, a.elem)) return e;
+    c->bufs[a.n].per_mesh = a.per;
+  }
+  if (c->sw.debug) fprintf(stderr, "[sh] hull record grown to %d vertices / %d faces / %d edges per humerus\n", c->hcap.v, c->hcap.f, c->hcap.e);
+  return SH_OK;
+}
 static hipError_t hull_upload(sh_ctx* c, int slot, int B, void* const dst[6], hipStream_t st) {
   sh_ctx::HullStage& hs = c->hstage[slot];
   const int* counts = hs.cnt;
   int nvmax = 1, nfmax = 1, nemax = 1;
   for (int b = 0; b < B; ++b) { nvmax = std::max(nvmax, counts[b]); nfmax = std::max(nfmax, counts[B + b]); nemax = std::max(nemax, counts[2 * B + b]); }
+  if (nvmax > c->hcap.v || nfmax > c->hcap.f || nemax > c->hcap.e) return hipErrorInvalidValue;      // (callers check hull_fits / grow first)
   hipError_t e;
-  if ((e = hipMemcpy2DAsync(dst[0], (size_t)SH_HV * 24, hs.hv, (size_t)hs.pv * 24, (size_t)nvmax * 24, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  if ((e = hipMemcpy2DAsync(dst[1], (size_t)SH_HF * 24, hs.nr, (size_t)hs.pf * 24, (size_t)nfmax * 24, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  if ((e = hipMemcpy2DAsync(dst[2], (size_t)SH_HE * 16, hs.ed, (size_t)hs.pe * 16, (size_t)nemax * 16, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpy2DAsync(dst[0], (size_t)c->hcap.v * 24, hs.hv, (size_t)hs.pv * 24, (size_t)nvmax * 24, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpy2DAsync(dst[1], (size_t)c->hcap.f * 24, hs.nr, (size_t)hs.pf * 24, (size_t)nfmax * 24, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemcpy2DAsync(dst[2], (size_t)c->hcap.e * 16, hs.ed, (size_t)hs.pe * 16, (size_t)nemax * 16, B, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(dst[3], counts, (size_t)B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(dst[4], counts + B, (size_t)B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
   if ((e = hipMemcpyAsync(dst[5], counts + 2 * B, (size_t)B * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
@@ -1909,11 +1950,12 @@ static hipError_t hull_upload(sh_ctx* c, int slot, int B, void* const dst[6], hi
 
 // mesh.py:63-125.  Host: convex hulls (hull_host_phase; already done by the background thread when `prepared_slot`
 // >= 0).  Device: candidate boxes for every hull face, pick + frame, end sections, circle fits, flip (k_obb.h).
-static bool device_hull_now(const sh_ctx* c) { return c->hull_mode == 1; }
+static bool device_hull_now(const sh_ctx* c) { return c->hull_mode == 1 && !(c->hull_force_host && c->obb_gen == c->batch_gen); }
 
 static int run_obb(sh_ctx* c, int prepared_slot) {
   const int B = c->Bwin, b0 = c->b0;
   int nfmax = 1;
+  if (c->obb_gen != c->batch_gen) { c->obb_gen = c->batch_gen; c->obb_sil_need = 0; c->obb_nf_over = false; c->hull_force_host = false; }
   if (c->redo_records) {
     nfmax = std::max(1, c->redo_nf);      // (redo_given_up put the host quickhull's records of this window into hull.*)
   } else if (device_hull_now(c)) {
@@ -1925,7 +1967,7 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
                    buf<int>(c, "hulld.freestack"), buf<unsigned long long>(c, "hulld.tkeys"), buf<unsigned>(c, "hulld.tvals")};
     LAUNCH(c, "k_hull_rounds", k_hull_rounds, dim3(B), dim3(HD_THREADS), (const float*)c->bufs["hullpre.kept"].p, (const long long*)c->bufs["hullpre.koff"].p, hs,
            buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), buf<int>(c, "hull.nv"), buf<int>(c, "hull.nf"), buf<int>(c, "hull.ne"),
-           buf<int>(c, "hulld.fail"), buf<int>(c, "hulld.rounds"), (const int*)buf<int>(c, "hulld.skip"));
+           buf<int>(c, "hulld.fail"), buf<int>(c, "hulld.rounds"), (const int*)buf<int>(c, "hulld.skip"), c->hcap);
     LAUNCH(c, "k_hull_flag", k_hull_flag, dim3((B + 63) / 64), dim3(64), buf<int>(c, "hulld.fail"), buf<int>(c, "err"), B);
     nfmax = std::max((int)HD_SLOTS, c->skip_nfmax);      // (the face counts stay on the device: the candidate kernel's tiles beyond a hull's faces return at once;
                                                          //  a humerus kept on the host hull may have more faces than the device hull has slots)
@@ -1942,6 +1984,13 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   }
   const int* counts = c->hstage[slot].cnt;
   for (int b = 0; b < B; ++b) nfmax = std::max(nfmax, counts[B + b]);
+  {
+    int need[3];
+    if (!hull_fits(c, slot, B, need)) {      // (never with an early upload: the background threads upload only what fits)
+      int grc = grow_hull_records(c, need[0], need[1], need[2]);
+      if (grc != SH_OK) return grc;
+    }
+  }
   if (!(prepared_slot >= 0 && c->prep.uploaded)) {
     void* const dst[6] = {buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), buf<int>(c, "hull.nv"), buf<int>(c, "hull.nf"), buf<int>(c, "hull.ne")};
     HIPCHK(c, hull_upload(c, slot, B, dst, c->stream));
@@ -1952,43 +2001,63 @@ static int run_obb(sh_ctx* c, int prepared_slot) {
   const int* cnt_ne = buf<int>(c, "hull.ne");
   {
     FILL(c, {buf<unsigned long long>(c, "obb.best_enc"), (size_t)B * 8, 0xFF} /*"no candidate volume yet"*/, {buf<unsigned long long>(c, "obb.lbmin_enc"), (size_t)B * 8, 0xFF},
-         {buf<double>(c, "obb.area2"), (size_t)B * SH_HF * 8, 0}, {buf<int>(c, "obb.endcnt"), (size_t)B * 2 * 4, 0},
+         {buf<double>(c, "obb.area2"), (size_t)B * c->hcap.f * 8, 0}, {buf<int>(c, "obb.endcnt"), (size_t)B * 2 * 4, 0},
          {buf<unsigned long long>(c, "zb_enc"), (size_t)B * 16, 0xFF} /*z bounds: "nothing seen yet"*/, {buf<unsigned long long>(c, "anp.mm_enc"), (size_t)B * 16, 0xFF});
     c->bounds_cleared = true;
     const int nemax = 3 * nfmax / 2 + 3;      // (a closed triangulated surface: 2 E = 3 F)
-    LAUNCH(c, "k_obb_face_area2", k_obb_face_area2, dim3((unsigned)((std::min(nemax, SH_HE) + 255) / 256), (unsigned)B), dim3(256), buf<double>(c, "hull.hv"),
-           buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.area2"));
+    const HullCap hc = c->hcap;
+    LAUNCH(c, "k_obb_face_area2", k_obb_face_area2, dim3((unsigned)((std::min(nemax, hc.e) + 255) / 256), (unsigned)B), dim3(256), buf<double>(c, "hull.hv"),
+           buf<double>(c, "hull.normals"), buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.area2"), hc);
     const int bnd_tiles = (nfmax + SH_OBB_BND_DIRS - 1) / SH_OBB_BND_DIRS;
     LAUNCH(c, "k_obb_bounds", k_obb_bounds, dim3((unsigned)(bnd_tiles * ((B + 7) / 8) * 8)), dim3(SH_OBB_BND_THREADS),
            buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<double>(c, "obb.area2"), buf<double>(c, "obb.lb"),
-           buf<unsigned long long>(c, "obb.lbmin_enc"), buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), bnd_tiles, B);
-    // capacity tier of k_obb_candidates (k_obb.h): the small one unless a hull of this launch has more than 8 192 faces
-    const bool big = nfmax > 8192;
-    const int TT = big ? 8 : SH_OBB_TILE;
+           buf<unsigned long long>(c, "obb.lbmin_enc"), buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), bnd_tiles, B, hc);
+    // capacity tier of k_obb_candidates (k_obb.h): the small one unless a hull of this launch has more than 8 192 faces or a direction
+    // of an earlier run of this batch had more than 512 silhouette edges; the workspace tier above 32 768 faces / 2 048 edges
+    const bool huge = nfmax > 32768 || c->obb_sil_need > 2048 || c->obb_nf_over;
+    const bool big = !huge && (nfmax > 8192 || c->obb_sil_need > 512);
+    const int TT = (big || huge) ? 8 : SH_OBB_TILE;
     const int ntiles = (nfmax + TT - 1) / TT;
+    ObbWs ws{};
+    ws.need = (unsigned long long*)c->bufs["ovf.ctr"].p + 8;
+    if (huge) {
+      ws.nwg = 256;
+      ws.silcap = std::max(hc.v + 64, c->obb_sil_need + c->obb_sil_need / 8);      // (a silhouette is a cycle of the hull's graph; more only on degenerate input: then the demand is recorded)
+      int wrc;
+      if ((wrc = ensure(c, "obb.ws_fmask", (size_t)ws.nwg * hc.f, 1)) != SH_OK || (wrc = ensure(c, "obb.ws_lists", (size_t)ws.nwg * 8 * ws.silcap * 4, 4)) != SH_OK ||
+          (wrc = ensure(c, "obb.ws_sxy", (size_t)ws.nwg * ws.silcap * 16, 8)) != SH_OK || (wrc = ensure(c, "obb.ws_area", (size_t)ws.nwg * ws.silcap * 8, 8)) != SH_OK) return wrc;
+      for (const char* n : {"obb.ws_fmask", "obb.ws_lists", "obb.ws_sxy", "obb.ws_area"}) c->bufs[n].per_mesh = 0;
+      ws.fmask = (unsigned char*)c->bufs["obb.ws_fmask"].p; ws.lists = (unsigned*)c->bufs["obb.ws_lists"].p;
+      ws.sxy = (double2*)c->bufs["obb.ws_sxy"].p; ws.area = (double*)c->bufs["obb.ws_area"].p;
+    }
     // SHOULDER_OBB_PRUNE=0: every direction is evaluated (the A/B of the pruning bound: same frames, tests/test_gpu_hull.py)
     const bool prune = c->sw.obb_prune;
     for (int pass = 0; pass < 2; ++pass) {      // seed tile, then the directions its best volume cannot exclude
       LAUNCH(c, "k_obb_select", k_obb_select, dim3(B), dim3(256), buf<double>(c, "obb.lb"), cnt_nf, buf<unsigned long long>(c, "obb.lbmin_enc"),
-             buf<unsigned long long>(c, "obb.best_enc"), (prune || pass == 0) ? pass : 2, buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"), buf<unsigned char>(c, "obb.seeded"));
+             buf<unsigned long long>(c, "obb.best_enc"), (prune || pass == 0) ? pass : 2, buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"), buf<unsigned char>(c, "obb.seeded"), hc);
       const int nt_pass = pass == 0 ? SH_OBB_TILE / TT : ntiles;      // (the seed pass: up to SH_OBB_TILE directions)
       const dim3 cg((unsigned)(nt_pass * ((B + 7) / 8) * 8));
-      if (big) {
+      if (huge) {
+        LAUNCH(c, pass == 0 ? "k_obb_seed" : "k_obb_candidates", (k_obb_candidates<8, 1, 0, 0, unsigned, true>), dim3((unsigned)std::min<unsigned>(cg.x, (unsigned)ws.nwg)), dim3(SH_OBB_THREADS),
+               buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"),
+               buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"), buf<unsigned long long>(c, "obb.best_enc"), buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"),
+               nt_pass, B, prune ? 1 : 0, hc, ws);
+      } else if (big) {
         LAUNCH(c, pass == 0 ? "k_obb_seed" : "k_obb_candidates", (k_obb_candidates<8, 1, 2048, 32768, unsigned>), cg, dim3(SH_OBB_THREADS),
                buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"),
                buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"), buf<unsigned long long>(c, "obb.best_enc"), buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"),
-               nt_pass, B, prune ? 1 : 0);
+               nt_pass, B, prune ? 1 : 0, hc, ws);
       } else {
         LAUNCH(c, pass == 0 ? "k_obb_seed" : "k_obb_candidates", (k_obb_candidates<SH_OBB_TILE, SH_OBB_GROUP, 512, 8192, unsigned short>), cg, dim3(SH_OBB_THREADS),
                buf<double>(c, "hull.hv"), cnt_nv, buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"), cnt_ne, buf<double>(c, "obb.cand_vol"),
                buf<int>(c, "obb.cand_edge"), buf<int>(c, "err"), buf<unsigned long long>(c, "obb.best_enc"), buf<int>(c, "obb.dir_list"), buf<int>(c, "obb.dir_count"),
-               nt_pass, B, prune ? 1 : 0);
+               nt_pass, B, prune ? 1 : 0, hc, ws);
       }
     }
   }
   LAUNCH(c, "k_obb_pick", k_obb_pick, dim3(B), dim3(256), buf<double>(c, "hull.hv"), buf<double>(c, "hull.normals"), cnt_nf, buf<int>(c, "hull.edges"),
          buf<double>(c, "obb.cand_vol"), buf<int>(c, "obb.cand_edge"), buf<float>(c, "verts"), buf<long long>(c, "voff"), buf<double>(c, "obb.T_pre"),
-         buf<double>(c, "obb.zb_pre"), buf<int>(c, "err"));
+         buf<double>(c, "obb.zb_pre"), buf<int>(c, "err"), c->hcap);
   if (!c->obb_done_ev) HIPCHK(c, hipEventCreateWithFlags(&c->obb_done_ev, hipEventDisableTiming));
   HIPCHK(c, hipEventRecord(c->obb_done_ev, c->stream));      // hull.* device buffers are free for the next run's records from here
   if (c->params.bone_kind == SH_BONE_PROXIMAL) {
@@ -2439,8 +2508,8 @@ static void start_prepare_staged(sh_ctx* c, bool hulls, const StlPhase stl, std:
   struct Dst { void* p[6]; } dst = {{c->bufs["hull.hv"].p, c->bufs["hull.normals"].p, c->bufs["hull.edges"].p, c->bufs["hull.nv"].p, c->bufs["hull.nf"].p, c->bufs["hull.ne"].p}};
   // early upload only into buffers that will not be re-allocated by the commit (alloc_batch grows them for a larger batch)
   const size_t nB = (size_t)S.B;
-  const bool can_upload = c->obb_done_ev != nullptr && dst.p[0] && c->bufs["hull.hv"].bytes >= nB * SH_HV * 24 && c->bufs["hull.normals"].bytes >= nB * SH_HF * 24 &&
-                          c->bufs["hull.edges"].bytes >= nB * SH_HE * 16 && c->bufs["hull.nv"].bytes >= nB * 4 && c->bufs["hull.nf"].bytes >= nB * 4 && c->bufs["hull.ne"].bytes >= nB * 4;
+  const bool can_upload = c->obb_done_ev != nullptr && dst.p[0] && c->bufs["hull.hv"].bytes >= nB * c->hcap.v * 24 && c->bufs["hull.normals"].bytes >= nB * c->hcap.f * 24 &&
+                          c->bufs["hull.edges"].bytes >= nB * c->hcap.e * 16 && c->bufs["hull.nv"].bytes >= nB * 4 && c->bufs["hull.nf"].bytes >= nB * 4 && c->bufs["hull.ne"].bytes >= nB * 4;
   const int B = S.B;
   p.th = std::thread([c, hp, dst, can_upload, hulls, stl, B, phase0]() {
     sh_ctx::Prepared& q = c->prep;
@@ -2740,7 +2809,13 @@ static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot
     if (!shhull::convex_hull(P.data(), (int)nv, H)) status = SH_ERR_GEOMETRY;
     else {
       hn = (int)H.vert_ids.size(); fn = (int)H.tris.size() / 3; en = (int)H.edges.size() / 4;
-      if (hn > SH_HV || fn > SH_HF || en > SH_HE) status = SH_ERR_CAPACITY;
+      if (hn > c->hcap.v || fn > c->hcap.f || en > c->hcap.e) {
+        // above the record: growing it here would drop the other humeri's records -- the batch runs again with its hulls from the
+        // host (hull_host_phase sizes the staging, run_obb grows the record), and stays there while it is resident
+        c->hull_force_host = true;
+        if (need) need[3] = 1;
+        return SH_OK;
+      }
     }
     if (status != 0) { char m[96]; snprintf(m, sizeof m, "mesh %d: convex hull failed (%d)", b, status); return fail(c, status, m); }
     std::vector<double> hvd(3 * (size_t)hn);
@@ -2749,9 +2824,9 @@ static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot
     c->b0 = 0; c->Bwin = B;
     const int counts[3] = {hn, fn, en}, one = 1;
     // (pageable sources: hipMemcpyAsync stages them before it returns)
-    HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.hv") + (size_t)b * SH_HV * 3, hvd.data(), hvd.size() * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.normals") + (size_t)b * SH_HF * 3, H.normals.data(), (size_t)fn * 24, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.edges") + (size_t)b * SH_HE * 4, H.edges.data(), (size_t)en * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.hv") + (size_t)b * c->hcap.v * 3, hvd.data(), hvd.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf<double>(c, "hull.normals") + (size_t)b * c->hcap.f * 3, H.normals.data(), (size_t)fn * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.edges") + (size_t)b * c->hcap.e * 4, H.edges.data(), (size_t)en * 16, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.nv") + b, &counts[0], 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.nf") + b, &counts[1], 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(buf<int>(c, "hull.ne") + b, &counts[2], 4, hipMemcpyHostToDevice, c->stream));
@@ -2793,13 +2868,14 @@ static int redo_given_up(sh_ctx* c, sh_ctx::Ticket& tk, const std::string& tslot
 }
 
 static inline size_t status_ovf_off(int B) { return ((size_t)B * 4 + 7) & ~(size_t)7; }
-static inline size_t status_bytes(int B) { return status_ovf_off(B) + 64 + (size_t)B * 4; }
+#define SH_NCTR 16
+static inline size_t status_bytes(int B) { return status_ovf_off(B) + SH_NCTR * 8 + (size_t)B * 4; }
 // the status block of a run (layout: sh_submit) from the live words, one launch
 __global__ void k_stage_status(const int* __restrict__ err, const unsigned long long* __restrict__ ovf_ctr, const int* __restrict__ hull_fail /*or null*/,
                                char* __restrict__ dst, int B, size_t ovf_off) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) { ((int*)dst)[i] = err[i]; ((int*)(dst + ovf_off + 64))[i] = hull_fail ? hull_fail[i] : 0; }
-  if (i < 8) ((unsigned long long*)(dst + ovf_off))[i] = ovf_ctr[i];
+  if (i < B) { ((int*)dst)[i] = err[i]; ((int*)(dst + ovf_off + SH_NCTR * 8))[i] = hull_fail ? hull_fail[i] : 0; }
+  if (i < SH_NCTR) ((unsigned long long*)(dst + ovf_off))[i] = ovf_ctr[i];
 }
 
 int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
@@ -2819,7 +2895,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     tk.cap = B;
   }
   tk.h_ovf = (unsigned long long*)((char*)tk.h_err + status_ovf_off(B));      // (the layout follows THIS run's batch size)
-  tk.h_fail = (int*)((char*)tk.h_err + status_ovf_off(B) + 64);
+  tk.h_fail = (int*)((char*)tk.h_err + status_ovf_off(B) + SH_NCTR * 8);
   if (!tk.ev) HIPCHK(c, hipEventCreateWithFlags(&tk.ev, hipEventDisableTiming));
   {      // the other ticket's pinned block, event and device staging with the first one (else the context's SECOND run pays for them)
     sh_ctx::Ticket& to = c->tickets[c->t_head ^ 1];
@@ -2844,7 +2920,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     int prc = alloc_prox(c);
     if (prc != SH_OK) return prc;
   }
-  { OvfPools OP; int orc = ovf_pools(c, &OP); if (orc != SH_OK) return orc; FILL(c, {buf<int>(c, "err"), (size_t)B * 4, 0}, {OP.ctr, 64, 0}); }      // overflow pools: empty, no demand recorded
+  { OvfPools OP; int orc = ovf_pools(c, &OP); if (orc != SH_OK) return orc; FILL(c, {buf<int>(c, "err"), (size_t)B * 4, 0}, {OP.ctr, 128, 0}); }      // overflow pools: empty, no demand recorded
   if ((mask & SH_STAGE_APPLY) && !(mask & SH_STAGE_CSYS)) return fail(c, SH_ERR_ARG, "sh_run: SH_STAGE_APPLY needs SH_STAGE_CSYS in the same run");
   // a proximal humerus' frame is canal / articular (bone.py:53-62): k_pack builds it from the anatomic-neck axes of THIS run
   if (c->params.bone_kind == SH_BONE_PROXIMAL && (mask & SH_STAGE_CSYS) && !(mask & SH_STAGE_ANP))
@@ -2907,7 +2983,7 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
   }
   // status words, what the run asked of the overflow pools (k_ovf.h: sh_collect grows them and runs again if it was more than they
   // hold) and which humeri the device hull gave up (its own word per humerus: the status word can be overwritten by a later stage)
-  LAUNCH(c, "k_stage_status", k_stage_status, dim3((unsigned)((std::max(B, 8) + 255) / 256)), dim3(256), (const int*)buf<int>(c, "err"), (const unsigned long long*)c->bufs["ovf.ctr"].p,
+  LAUNCH(c, "k_stage_status", k_stage_status, dim3((unsigned)((std::max(B, SH_NCTR) + 255) / 256)), dim3(256), (const int*)buf<int>(c, "err"), (const unsigned long long*)c->bufs["ovf.ctr"].p,
          dev_hull ? (const int*)buf<int>(c, "hulld.fail") : (const int*)nullptr, (char*)err_stage, B, status_ovf_off(B));
   HIPCHK(c, hipEventRecord(tk.ev, c->stream));
   tk.B = B; tk.pending = true; tk.mask = mask; tk.out_arg = out; tk.dev_hull = dev_hull; tk.gen = c->batch_gen;
@@ -2949,6 +3025,21 @@ int sh_collect(sh_ctx* c) {
       return sh_collect(c);
     }
     if (c->sw.debug) fprintf(stderr, "[sh] collect: ovf need %llu %llu %llu cap %llu %llu %llu err0 %d\n", need_s, need_r, need_w, c->ovf_seg_cap, c->ovf_ring_cap, c->ovf_work_cap, tk.h_err[0]);
+    if ((tk.h_ovf[8] != 0 || tk.h_ovf[9] != 0) && (tk.mask & SH_STAGE_OBB) && tk.gen == c->batch_gen) {
+      // k_obb_candidates met a direction with more silhouette edges than its tier's lists hold (or, behind a device hull, a record with
+      // more faces than its masks): the records of this run are void -- the batch again, on the tier that holds it (run_obb)
+      if (c->n_pending != 0)
+        return fail(c, SH_ERR_CAPACITY, "the OBB stage needs a larger tier while another run is in flight: collect it, then run the batch again (the tier is chosen by then)");
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if ((int)tk.h_ovf[8] <= c->obb_sil_need && !(tk.h_ovf[9] != 0 && !c->obb_nf_over))
+        return fail(c, SH_ERR_CAPACITY, "k_obb_candidates: silhouette demand did not shrink on the workspace tier");      // (cannot happen: its lists hold what the last run asked for)
+      c->obb_sil_need = std::max(c->obb_sil_need, (int)std::min<unsigned long long>(tk.h_ovf[8], 1ull << 30));
+      if (tk.h_ovf[9] != 0) c->obb_nf_over = true;
+      const uint32_t mask = tk.mask; sh_landmarks* out = tk.out_arg;
+      int rc2 = sh_submit(c, mask, out);
+      if (rc2 != SH_OK) return rc2;
+      return sh_collect(c);
+    }
     const unsigned long long need_e = tk.h_ovf[7];
     if (need_s > c->ovf_seg_cap || need_r > c->ovf_ring_cap || need_w > c->ovf_work_cap || need_e > (unsigned long long)c->end_cap) {
       // The batch has more overflow planes than the pools hold (a first dense mesh): grow them to what the run asked for,

@@ -313,3 +313,75 @@ def test_two_million_triangles_match_the_oracle(engine, rfc_tables, unet_weights
     for k in ("canal_axis", "te_axis", "groove_axis", "anp_plane_point", "anp_axis_normal", "anp_axis_central", "csys"):
         np.testing.assert_allclose(np.asarray(r[k]).reshape(np.shape(L[k])), L[k], rtol=0, atol=1e-6, err_msg=k)
     engine.upload([(v, f)])                                            # (the session's engine goes back to a small batch)
+
+
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_a_strictly_convex_surface_with_17k_hull_vertices(mode, unet_weights):
+    """the hull record held 16 384 vertices and k_obb_candidates 32 768 face masks -- `convex_hull` of the reference
+    (mesh.py:82) has no such bound.  Every one of this surface's 17 000 vertices is on its hull (33 996 faces): the record grows
+    (sh_ctx::hcap, strides as kernel arguments), the candidates run on the workspace tier (ObbWs), and the frame equals the oracle's
+    (oracle/obb.py: oriented_bounds_large, pinned against oriented_bounds in tests/test_oracle_obb_large.py).  Device mode: all
+    17 000 points survive the prefilter, k_hull_rounds gives the humerus up, its host hull is above the record -> the batch runs again
+    with host hulls.  A fixture rides along: its frame must not change beside the large record."""
+    from conftest import convex_surface
+    from oracle import obb
+    from shoulder_amd import unet_spec
+    from shoulder_amd.engine import Engine
+    v, f = convex_surface(17000, seed=5)
+    small_v, small_f = load_stl(os.path.join(BONES, "humerus_right.stl"))
+    O = obb.full_obb(v.astype(np.float64), f, bounds=obb.oriented_bounds_large)
+    e = Engine(0)
+    try:
+        e.set_hull_mode(mode)
+        e.upload([(small_v, small_f)])
+        ref = e.run(_lib.STAGE_OBB).copy()
+        e.upload([(v, f), (small_v, small_f)])
+        lm = e.run(_lib.STAGE_OBB).copy()
+        assert (lm["status"] == 0).all()
+        nv = e.fetch("hull.nv", np.int32, (2,))
+        assert nv[0] == 17000
+        np.testing.assert_allclose(lm[0]["obb_transform"].reshape(4, 4), O["transform"], rtol=0, atol=1e-6)
+        assert bool(lm[0]["flipped"]) == O["flipped"]
+        np.testing.assert_array_equal(lm[1]["obb_transform"], ref[0]["obb_transform"])
+        again = e.run(_lib.STAGE_OBB).copy()                                # the resident batch: right the first time now
+        assert again.tobytes() == lm.tobytes()
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("nrim,size,tier", [(700, 1.0, "large"), (2200, 4.0, "workspace")])
+def test_a_silhouette_longer_than_the_tier_lists(nrim, size, tier):
+    """A lens with `nrim` vertices on its equator has a hull of a few thousand faces -- the small tier of k_obb_candidates -- but seen
+    along its short axis the silhouette IS the equator: more edges than the tier lists (512; 2 048 in the large tier).  Such a run
+    ended in SH_ERR_CAPACITY for the humerus; now it records the demand and sh_collect runs the batch again on the tier that holds it
+    (the workspace tier above 2 048).  Box frames against the oracle."""
+    from conftest import lens_surface
+    from oracle import obb
+    from shoulder_amd.engine import Engine
+    v, f = lens_surface(nrim, 600, seed=2, size=size)
+    assert len(f) <= 8192
+    T_box, ext, vol = obb.oriented_bounds_large(v.astype(np.float64))
+    small_v, small_f = load_stl(os.path.join(BONES, "humerus_left.stl"))
+    e = Engine(0)
+    try:
+        e.set_hull_mode("host")
+        e.upload([(small_v, small_f), (v, f)])
+        lm = e.run(_lib.STAGE_OBB).copy()
+        assert (lm["status"] == 0).all()
+        # the box frame (mesh.py:82).  Not the head-end flip behind it: the end sections of a lens are flat arcs, their circle fits
+        # (mesh.py:102) are ill-conditioned and the two restatements of the optimiser stop at different radii.
+        np.testing.assert_allclose(e.fetch("obb.T_pre", np.float64, (2, 4, 4))[1], T_box, rtol=0, atol=1e-6)
+        has_ws = True
+        try:
+            e.fetch("obb.ws_fmask", np.uint8, (16,))
+        except Exception:
+            has_ws = False
+        assert has_ws == (tier == "workspace")
+        again = e.run(_lib.STAGE_OBB).copy()                                  # the resident batch: on the right tier the first time now
+        assert again[0].tobytes() == lm[0].tobytes()
+        np.testing.assert_allclose(e.fetch("obb.T_pre", np.float64, (2, 4, 4))[1], T_box, rtol=0, atol=1e-6)
+        e.upload([(small_v, small_f)])                                        # the next batch starts on the small tier again
+        alone = e.run(_lib.STAGE_OBB).copy()
+        np.testing.assert_array_equal(alone[0]["obb_transform"], lm[0]["obb_transform"])
+    finally:
+        e.close()
