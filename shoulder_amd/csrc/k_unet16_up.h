@@ -1,6 +1,7 @@
 // k_unet16_up.h -- 2x2 stride-2 transposed convolutions (the decoder's up-sampling) of the 16-bit UNet.
 #pragma once
 #include "k_unet_bf16.h"
+#include "k_unet16_base.h"
 
 namespace sh {
 
@@ -108,106 +109,132 @@ k_upconv16(const u16* __restrict__ src_, int Cin, const u16* __restrict__ wgt_ /
 // ---- the same layer with the source pixels held in REGISTERS ---------------------------------------------------------------
 // k_upconv16 stages a 16 x 16 source tile per 32-channel chunk and (row parity, 32-cout group): the tile is read 2 Cout / 32 times
 // from L2, and a chunk is 16 MFMAs per wave between two workgroup barriers (matrix pipe busy 0.19, 0.3-0.4 of the HBM roof).
-// Here a workgroup (8 waves) owns a 32 x 16 source tile for ALL 4 Cout outputs of its pixels: every wave loads its 4 rows x 16
-// pixels x Cin once, straight into the MFMA pixel fragments (4 NCH fragments = 64 / 128 VGPRs for Cin = 128 / 256), and keeps
-// them for the whole launch; only the weights -- one (32-cout group, phase) slice of NCH x 32 rows at a time, 8 / 16 KB -- go through
-// LDS, fetched into registers while the previous slice is multiplied (one barrier per slice of 4 x 2 x NCH MFMAs per wave).
-// Input bytes come from HBM exactly once, the two 64-byte halves of an output line (dx = 0, 1) leave the same wave in
-// consecutive slices.  Same accumulation (bias in the accumulator, chunks in order) and the same channel dealing as
-// k_upconv16: bit-identical results (tests/test_gpu_unet_bf16.py::test_register_resident_upconv_bit_identical).
-// Cin = 512 (up3): 2 rows per wave (MT = 2, 128 fragment registers), a 32 x 8 source tile per workgroup.
+// Here a workgroup (8 waves) owns a 32 x 4 MT source tile for ALL 4 Cout outputs of its pixels: every wave loads its MT rows x 16
+// pixels x Cin once, straight into the MFMA pixel fragments (MT x NCH fragments: 64 / 128 / 128 VGPRs for Cin = 128 / 256 / 512 with
+// MT = 4 / 4 / 2), and keeps them for the whole launch; only the weights go through LDS.  Round 3-4's form of it (k_upconv16r)
+// synchronised its eight waves after every (32-cout group, phase) slice -- 32 or 64 MFMAs per wave between two barriers, the next
+// slice's weights through registers, per-element conversions: matrix pipe busy 0.15-0.23, waves parked at the barrier a third of
+// the time.  Here the weights of PPB phases of a group (all four for Cin = 128 / 256; two for Cin = 512, whose 4 x 512 rows would
+// not fit twice) are one LDS-DMA transfer (inline assembly, the slot swizzle on the source address) that lands while the previous
+// group is multiplied; one barrier per PPB x MT x 2 x NCH MFMAs of a wave; the conversions in pairs; stores as assembly, so that the
+// counted wait in front of the barrier retires exactly the transfer (the PPB x MT stores behind it may still be in flight).
+// Input bytes come from HBM exactly once, the two 64-byte halves of an output line (dx = 0, 1) leave the same wave in consecutive
+// phases.  Same accumulation (bias in the accumulator, chunks in order) and the same channel dealing as k_upconv16: the same tensor
+// bit for bit.  Alone at B = 64: up3 0.115 -> 0.078 ms, up2 0.126 -> 0.111, up1 0.188 -> 0.186 (the 0.54 GB it writes).
 #define UPR_THREADS 512
+template <int N> __device__ inline void up_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int EK, int NCH, int MT = 4>      // MT: source rows (16-pixel MFMA tiles) per wave; a workgroup owns 4 MT rows x 32 pixels
+template <int EK, int NCH, int MT, int PPB>
 __global__ void __launch_bounds__(UPR_THREADS)
-k_upconv16r(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed [4][NCH][Cout][32]*/, const float* __restrict__ bias,
+k_upconv16g(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed [4][NCH][Cout][32]*/, const float* __restrict__ bias,
             u16* __restrict__ dst_, int H, int W, int Cout) {
   using ET = typename EKT<EK>::type;
   using v8 = typename E16<ET>::v8;
+  using v2 = typename E16<ET>::v2;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const ET* wgt = (const ET*)wgt_;
-  constexpr int WROWS = NCH * 32;                      // LDS rows of a weight slice: [chunk][16 n + i]
-  constexpr int WPASS = WROWS * 4 / UPR_THREADS;       // 16-byte pieces per thread and slice: 1 / 2
-  static_assert(WROWS * 4 % UPR_THREADS == 0, "whole passes");
-  __shared__ __attribute__((aligned(16))) ET s_w[2][WROWS * UB_PSTR];
+  constexpr int WROWS = NCH * 32;                              // LDS rows of one phase's slice: [chunk][16 n + i]
+  constexpr int NPC = PPB * WROWS * 4 / UPR_THREADS;           // 16-byte pieces per thread and transfer
+  static_assert(PPB * WROWS * 4 % UPR_THREADS == 0 && PPB * MT <= 32 && PPB % 2 == 0, "whole pieces; the counted wait; whole row parities");
+  constexpr int BUFB = PPB * WROWS * 64;                       // bytes of a weight buffer
+  __shared__ __attribute__((aligned(1024))) unsigned char s_w[2 * BUFB];
   __shared__ __attribute__((aligned(16))) float s_b[512];
   const int tiles_x = W / 32;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, img = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < Cout) s_b[tid] = bias[tid];
   const int li = lane & 15, lk = lane >> 4;
   const int xh = wave & 1, rg = wave >> 1;
   const int x0 = tx * 32 + xh * 16 + li, y0 = (ty * 4 + rg) * MT;
   const ET* in = (const ET*)src_ + (size_t)img * H * W * (NCH * 32);
-  const int groups = Cout >> 5, nslice = groups * 4;
-
-  // weight slice t = (group g = t >> 2, phase ph = t & 3): piece e -> LDS row r = e >> 2 = 32 cc + j, slot q
-  int wt_src[WPASS], wt_lds[WPASS];
+  const int groups = Cout >> 5;
+  constexpr int NT = 4 / PPB;                                  // transfers per group
+  const int ntr = groups * NT;
+  // transfer u = (group g = u / NT, phases PPB (u % NT) ..): piece e = tid + 512 k -> phase p = e / (4 WROWS), row r = 32 cc + j, LDS slot e & 3;
+  // the LDS position is linear in e (1 KB per wave and piece), the slot swizzle of UB_OFF is applied to the SOURCE slot
+  unsigned wsrc[NPC];
 #pragma unroll
-  for (int k = 0; k < WPASS; ++k) {
-    const int e = tid + k * UPR_THREADS, q = e & 3, r = e >> 2, cc = r >> 5, j = r & 31;
+  for (int k = 0; k < NPC; ++k) {
+    const int e = tid + k * UPR_THREADS, ph = e / (4 * WROWS), rem = e - ph * 4 * WROWS, r = rem >> 2, cc = r >> 5, j = r & 31;
     const int ch = 8 * ((j & 15) >> 2) + 4 * (j >> 4) + (j & 3);      // LDS row 16 n + i holds channel 8 (i >> 2) + 4 n + (i & 3) of the group
-    wt_src[k] = (cc * Cout + ch) * 32 + q * 8;
-    wt_lds[k] = UB_OFF(r, q);
+    wsrc[k] = (unsigned)(((ph * NCH + cc) * Cout + ch) * 32 + (((rem & 3) ^ ((r >> 1) & 2)) << 3));
   }
-  u32x4 rwt[WPASS];
-  auto load_slice = [&](int t) {
-    const ET* wsl = wgt + ((size_t)(t & 3) * NCH * Cout + (size_t)(t >> 2) * 32) * 32;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ud_lptr)s_w) + (unsigned)(wave * 1024);
+  auto fetch = [&](int u) __attribute__((always_inline)) {
+    const ET* wsl = wgt + ((size_t)((u % NT) * PPB) * NCH * Cout + (size_t)(u / NT) * 32) * 32;
+    const unsigned lb = lds0 + (unsigned)((u & 1) * BUFB);
 #pragma unroll
-    for (int k = 0; k < WPASS; ++k) rwt[k] = *(const u32x4*)(wsl + wt_src[k]);
+    for (int k = 0; k < NPC; ++k) ud_dma16(lb + k * 8192, wsl + wsrc[k]);
   };
-  auto put_slice = [&](int b) {
-#pragma unroll
-    for (int k = 0; k < WPASS; ++k) *(u32x4*)(s_w[b] + wt_lds[k]) = rwt[k];
-  };
-  load_slice(0);
+  fetch(0);
   // the wave's pixels: fragment (m, cc) = 8 channels 32 cc + 8 lk .. of pixel (y0 + m, x0)
   v8 xf[MT][NCH];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) xf[m][cc] = *(const v8*)(in + ((size_t)cc * H * W + (size_t)(y0 + m) * W + x0) * 32 + 8 * lk);
-  // the pixel fragments are USED here, so hipcc's waits for them stand in front of the slice loop: inside it they were counted waits
-  // that ended in s_waitcnt vmcnt(0) in the middle of every slice -- the slice's own weight prefetch and the previous slice's stores
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) { u32x4 t = __builtin_bit_cast(u32x4, xf[m][cc]); asm volatile("" : "+v"(t)); xf[m][cc] = __builtin_bit_cast(v8, t); }
-  put_slice(0);
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 
   const int OW = 2 * W, OH = 2 * H;
   ET* out0 = (ET*)dst_ + (size_t)img * OH * OW * Cout;
-  for (int t = 0; t < nslice; ++t) {
-    const int g = t >> 2, dy = (t >> 1) & 1, dx = t & 1;
-    if (t + 1 < nslice) load_slice(t + 1);      // in flight during the MFMAs below
-    f32x4 acc[MT][2];
+#pragma unroll 1
+  for (int u = 0; u < ntr; ++u) {
+    const int g = u / NT;
+    const bool more = u + 1 < ntr;
+    if (more) fetch(u + 1);      // lands during the MFMAs below; its last readers passed the barrier that ended transfer u - 1
+    const unsigned char* sw = s_w + (u & 1) * BUFB;
+    ET* out = out0 + (size_t)g * OH * OW * 32;      // this group's 32-channel plane
+    f32x4 bv[2];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const f32x4 bv = *(const f32x4*)(s_b + g * 32 + 8 * lk + 4 * n);
+    for (int n = 0; n < 2; ++n) bv[n] = *(const f32x4*)(s_b + g * 32 + 8 * lk + 4 * n);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m][n] = bv;
-    }
-    const ET* sw = s_w[t & 1];
+    for (int pq = 0; pq < PPB / 2; ++pq) {      // a row parity dy: both column phases together, so that the two 64-byte halves of an output line leave back to back
+      const int dy = (u % NT) * (PPB / 2) + pq;
+      f32x4 acc[2][MT][2];
 #pragma unroll
-    for (int cc = 0; cc < NCH; ++cc) {
-      v8 wf[2];
+      for (int dx = 0; dx < 2; ++dx)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) wf[n] = *(const v8*)(sw + UB_OFF(cc * 32 + n * 16 + li, lk));
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[dx][m][n] = bv[n];
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc) {
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          v8 wf[2];
+#pragma unroll
+          for (int n = 0; n < 2; ++n) wf[n] = *(const v8*)(sw + (size_t)((2 * pq + dx) * WROWS) * 64 + UB_OFF(cc * 32 + n * 16 + li, lk) * 2);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[dx][m][n] = E16<ET>::mfma(wf[n], xf[m][cc], acc[dx][m][n]);
+        }
+      }
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xf[m][cc], acc[m][n]);
-    }
-    ET* out = out0 + (size_t)g * OH * OW * 32;      // this group's 32-channel plane
+        for (int dx = 0; dx < 2; ++dx) {
+          u32x4 o;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      v8 o;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = (ET)acc[m][r >> 2][r & 3];
-      *(v8*)(out + ((size_t)(2 * (y0 + m) + dy) * OW + 2 * x0 + dx) * 32 + 8 * lk) = o;
+          for (int n = 0; n < 2; ++n) {
+            const f32x2 a01 = {acc[dx][m][n][0], acc[dx][m][n][1]}, a23 = {acc[dx][m][n][2], acc[dx][m][n][3]};
+            o[2 * n] = __builtin_bit_cast(unsigned, __builtin_convertvector(a01, v2));
+            o[2 * n + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(a23, v2));
+          }
+          ud_store16(out + ((size_t)(2 * (y0 + m) + dy) * OW + 2 * x0 + dx) * 32 + 8 * lk, o);
+        }
     }
-    if (t + 1 < nslice) put_slice((t + 1) & 1);      // its last readers passed the barrier that ended slice t - 1
-    __syncthreads();
+    // the next transfer has landed (it is older than this iteration's PPB x MT stores)
+    if (more) up_wait_vm<PPB * MT>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   }
 }
 

@@ -293,7 +293,7 @@ k_conv_mfma_x3(const float* __restrict__ src0, const float* __restrict__ src1, i
 // ---- 2x2 stride-2 transposed convolution of the F32X path with the source pixels held in registers ------------------------------
 // k_conv_mfma_x3<1, NT> runs one (16x16 source tile, 16 NT couts, phase) per workgroup: the f32 tile is read 4 Cout / (16 NT) times
 // and split again every time, a chunk is 12 NT MFMAs per wave between two barriers (up0..up3: 0.74 + 0.46 + 0.37 + 0.29 ms at
-// B = 64 for 1.9 + 1.0 + 0.5 + 0.3 GB of tensors).  As in k_upconv16r (k_unet16_l0.h) a workgroup of 8 waves owns a 32 x (4 MT)
+// B = 64 for 1.9 + 1.0 + 0.5 + 0.3 GB of tensors).  As in the 16-bit up-convolution (k_unet16_up.h) a workgroup of 8 waves owns a 32 x (4 MT)
 // source tile for all 4 Cout outputs: a wave loads its MT rows x 16 pixels x Cin once, splits them into the high / low f16
 // fragments (x_hi = f16(x), x_lo = f16(x - x_hi): the arithmetic of the staged form) and keeps both for the whole launch
 // (2 x 4 MT NCH registers); the split weights stream through LDS, one (32-cout group, phase) slice at a time, fetched into registers

@@ -1340,7 +1340,7 @@ static int unet_tickets(sh_ctx* c, int total, int nwg, int ngrp, unsigned** tk, 
 }
 
 // One layer of the 16-bit network.  3x3 convs with a multiple of 64 output channels on 32 x 16-tileable maps run on the persistent
-// LDS-DMA kernel (k_unet16_ldr.h; UF_POOL: the 2x2 max pool written beside the output); 2x2 transposed convs on k_upconv16r /
+// LDS-DMA kernel (k_unet16_ldr.h; UF_POOL: the 2x2 max pool written beside the output); 2x2 transposed convs on k_upconv16g /
 // k_upconv16; everything else on the generic two-barrier kernel k_conv_mfma16 (k_unet_bf16.h), which is also the whole of the
 // REFERENCE network (sh_ctx::unet_reference: layer by layer, nothing fused, no persistent kernel -- what the tests hold the
 // production kernels against).
@@ -1380,10 +1380,12 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 2, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
     else return fail(c, SH_ERR_ARG, "unet: unsupported fusion");
   } else if (!c->unet_reference && L.cout % 32 == 0 && C1 == 0 && C0 % 32 == 0) {
-    // 2x2 transposed conv (k_unet16_up.h): source pixels in registers for Cin = 128 / 256, the staged form otherwise
-    const bool upr = W % 32 == 0 && H % 16 == 0 && (C0 == 128 || C0 == 256) && L.cout <= 512;
-    if (upr && C0 == 128) { LAUNCH(c, lname, (k_upconv16r<EK, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
-    else if (upr) { LAUNCH(c, lname, (k_upconv16r<EK, 8>), dim3((W / 32) * (H / 16), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
+    // 2x2 transposed conv (k_unet16_up.h): source pixels in registers, the weights of a 32-cout group by LDS-DMA, one barrier per
+    // group (Cin = 512: per two phases); the staged form otherwise
+    const bool upg = W % 32 == 0 && H % 16 == 0 && (C0 == 128 || C0 == 256 || C0 == 512) && L.cout <= 512;
+    if (upg && C0 == 128) { LAUNCH(c, lname, (k_upconv16g<EK, 4, 4, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
+    else if (upg && C0 == 256) { LAUNCH(c, lname, (k_upconv16g<EK, 8, 4, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
+    else if (upg) { LAUNCH(c, lname, (k_upconv16g<EK, 16, 2, 2>), dim3((W / 32) * (H / 8), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
     else { LAUNCH(c, lname, (k_upconv16<EK>), dim3(tiles, L.cout / 32, nimg * 2), dim3(UPC_THREADS), src0, C0, w, b, dst, H, W, L.cout); }
   } else if (L.cout % 64 == 0) {
     LAUNCH(c, lname, (k_conv_mfma16<EK, 1, 4, 0>), dim3(tiles, L.cout / 64, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
