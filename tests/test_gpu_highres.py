@@ -385,3 +385,38 @@ def test_a_silhouette_longer_than_the_tier_lists(nrim, size, tier):
         np.testing.assert_array_equal(alone[0]["obb_transform"], lm[0]["obb_transform"])
     finally:
         e.close()
+
+
+def test_a_large_hull_arrives_in_a_staged_batch_and_through_prepared_hulls():
+    """The hull record's growth on the paths where a background thread computes the hulls: a batch staged beside a run in flight
+    (sh_stage_meshes: the thread may upload hulls early only when they fit the record -- these do not, the first run grows it and
+    uploads) and the prepared hulls of an overlapped resident batch (sh_set_overlap).  Same frames as the synchronous upload."""
+    from conftest import convex_surface
+    from shoulder_amd.engine import Engine
+    v, f = convex_surface(17000, seed=5)
+    small_v, small_f = load_stl(os.path.join(BONES, "humerus_right.stl"))
+    e = Engine(0)
+    try:
+        e.set_hull_mode("host")
+        e.upload([(v, f), (small_v, small_f)])
+        want = e.run(_lib.STAGE_OBB).copy()
+        assert (want["status"] == 0).all()
+    finally:
+        e.close()
+    e = Engine(0)
+    try:
+        e.set_hull_mode("host")
+        e.set_overlap(True)
+        e.upload([(small_v, small_f), (small_v, small_f)])
+        e.submit(_lib.STAGE_OBB)                                     # a run in flight on the ordinary record ...
+        e.stage([(v, f), (small_v, small_f)])                        # ... while the batch with the large hull is staged beside it
+        first = e.collect().copy()
+        assert (first["status"] == 0).all()
+        e.commit_staged()
+        got = e.run(_lib.STAGE_OBB).copy()                           # hulls from the staging thread; the record grows here
+        np.testing.assert_array_equal(got["obb_transform"], want["obb_transform"])
+        again = e.run(_lib.STAGE_OBB).copy()                         # hulls prepared beside the previous run, uploaded early (they fit now)
+        np.testing.assert_array_equal(again["obb_transform"], want["obb_transform"])
+        assert (got["status"] == 0).all() and (again["status"] == 0).all()
+    finally:
+        e.close()
