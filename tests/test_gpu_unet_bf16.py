@@ -216,7 +216,7 @@ def test_other_widths_and_depths(base, depth, H, W):
 
 @pytest.mark.parametrize("name", ["bf16", "f16"])
 def test_first_kernel_scales_the_raw_image_itself(engine, oracle_bones, name):
-    """In the 16-bit network k_enc0_fused16 reads the UNSCALED image ("anp.raw", f64) and applies the MinMaxScaler arithmetic of
+    """In the 16-bit network k_enc0_pp reads the UNSCALED image ("anp.raw", f64) and applies the MinMaxScaler arithmetic of
     k_anp_scale where it loads its patches (no "anp.image" pass): the logits are those of the same network fed the f32 image, bit
     for bit, and a run that also writes the image (sh_set_keep_products) gives the same record."""
     h = oracle_bones("humerus_left_flipped")

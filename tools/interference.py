@@ -11,14 +11,14 @@ def load(path):
     rows = list(csv.DictReader(open(path)))
     return sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void sh::", "").replace("sh::", "")[:44], r["Queue_Id"]) for r in rows)
 
-is_head = lambda n: "k_head16" in n or "k_dec0b_head3" in n or "k_conv3_dma16<0, 2, 2, 1, 2>" in n
+is_head = lambda n: "k_dec0b_head_pp" in n
 def passes(ev, skip):
     out = []
-    for q in sorted({e[3] for e in ev if "k_enc0_fused16" in e[2]}):
+    for q in sorted({e[3] for e in ev if "k_enc0_pp" in e[2]}):
         L = [e for e in ev if e[3] == q]
         i = n = 0
         while i < len(L):
-            if "k_enc0_fused16" not in L[i][2]:
+            if "k_enc0_pp" not in L[i][2]:
                 i += 1; continue
             j = i
             while j < len(L) and not is_head(L[j][2]): j += 1
@@ -34,7 +34,7 @@ base = collections.defaultdict(list)
 for P in passes(ev1, skip):
     for k, e in enumerate(P): base[k].append(e[1] - e[0])
 base = {k: statistics.median(v) for k, v in base.items()}
-unet_q = {e[3] for e in ev2 if "k_enc0_fused16" in e[2]}
+unet_q = {e[3] for e in ev2 if "k_enc0_pp" in e[2]}
 names = sorted({e[2] for e in ev2 if "conv" not in e[2] and "enc0" not in e[2] and "dec0" not in e[2] and "pack" not in e[2]})
 col = {n: i for i, n in enumerate(names)}
 others = [e for e in ev2 if e[2] in col]

@@ -8,14 +8,14 @@ skip = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]) for r in rows]
 t0 = min(e[0] for e in ev)
 ms = lambda t: (t - t0) / 1e6
-lanes = sorted({e[3] for e in ev if "k_enc0_fused16" in e[2]})
+lanes = sorted({e[3] for e in ev if "k_enc0_pp" in e[2]})
 passes = []
 for q in lanes:
     L = sorted(e for e in ev if e[3] == q)
     first = [e for e in L if "k_obb_face_area2" in e[2]]
-    scale = [e for e in L if "k_anp_scale" in e[2]]
-    enc = [e for e in L if "k_enc0_fused16" in e[2]]
-    head = [e for e in L if "k_head16" in e[2] or "k_dec0b_head3" in e[2] or "k_conv3_dma16<0, 2, 2, 1, 2>" in e[2]]
+    scale = [e for e in L if "k_anp_rows" in e[2]]      # the last kernel of the chain in front of the pass (the 16-bit network scales the image where it reads it)
+    enc = [e for e in L if "k_enc0_pp" in e[2]]
+    head = [e for e in L if "k_dec0b_head_pp" in e[2]]
     app = [e for e in L if "k_apply_csys" in e[2]]
     n = min(len(first), len(scale), len(enc), len(head), len(app))
     pre = [round(ms(scale[i][1]) - ms(first[i][0]), 2) for i in range(skip, n)]

@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
 """Gaps between consecutive kernels INSIDE the UNet passes of a bench run (rocprofv3 --kernel-trace CSV): per boundary (kernel -> next
-kernel of the same queue, from k_enc0_fused16 to the head kernel) the median idle time, and per pass the sum of kernel durations against
+kernel of the same queue, from k_enc0_pp to the head kernel) the median idle time, and per pass the sum of kernel durations against
 the span of the pass.  usage: tools/unet_gaps.py <kernel_trace.csv> [first_pass]"""
 import csv, sys, statistics
 rows = list(csv.DictReader(open(sys.argv[1])))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]) for r in rows)
 short = lambda n: n.split("(")[0].replace("void sh::", "").replace("sh::", "")[:40]
-is_head = lambda n: "k_head16" in n or "k_dec0b_head3" in n or "k_conv3_dma16<0, 2, 2, 1, 2>" in n or "k_conv3_dma16<1, 2, 2, 1, 2>" in n
+is_head = lambda n: "k_dec0b_head_pp" in n
 gaps, sums, spans, durs = {}, [], [], {}
-for q in sorted({e[3] for e in ev if "k_enc0_fused16" in e[2]}):
+for q in sorted({e[3] for e in ev if "k_enc0_pp" in e[2]}):
     L = [e for e in ev if e[3] == q]
     i, npass = 0, 0
     while i < len(L):
-        if "k_enc0_fused16" not in L[i][2]:
+        if "k_enc0_pp" not in L[i][2]:
             i += 1
             continue
         j = i
