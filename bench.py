@@ -189,7 +189,7 @@ def sym_key(name, unet, cout, fused_net=True, raw_image=True):
             return "k_dec0b_head_pp<%s>" % unet      # dec0b + head: only the logits leave the kernel
         if up:
             if cin in (128, 256, 512):      # source pixels resident in MFMA fragments, a group's weights by LDS-DMA (k_unet16_up.h)
-                return "k_upconv16g<%s,%d,%d,%d>" % (unet, cin // 32, 2 if cin == 512 else 4, 2 if cin == 512 else 4)
+                return "k_upconv16g<%s,%d,%d,%d,%s>" % (unet, cin // 32, 4 if cin == 128 else 2, 2 if cin == 512 else 4, "false" if cin == 512 else "true")
             return "k_upconv16<%s>" % unet                           # 2x2 transposed conv, both column phases per workgroup
         if cout % 64 == 0:      # persistent LDS-DMA conv with loader waves (k_unet16_ldr.h): <EK, FUSE (UF_POOL = 4), weights resident>
             fuse = 4 if name in ("unet.enc1b", "unet.enc2b", "unet.enc3b") else 0

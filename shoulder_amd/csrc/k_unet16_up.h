@@ -124,10 +124,10 @@ k_upconv16(const u16* __restrict__ src_, int Cin, const u16* __restrict__ wgt_ /
 #define UPR_THREADS 512
 template <int N> __device__ inline void up_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int EK, int NCH, int MT, int PPB>
+template <int EK, int NCH, int MT, int PPB, bool PERSIST /*false: one workgroup per item, item = blockIdx.x (no second set of pixel registers)*/>
 __global__ void __launch_bounds__(UPR_THREADS)
 k_upconv16g(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed [4][NCH][Cout][32]*/, const float* __restrict__ bias,
-            u16* __restrict__ dst_, int H, int W, int Cout) {
+            u16* __restrict__ dst_, int H, int W, int Cout, int nimg, unsigned* __restrict__ ticket, const int* __restrict__ tk_tab, int ntk) {
   using ET = typename EKT<EK>::type;
   using v8 = typename E16<ET>::v8;
   using v2 = typename E16<ET>::v2;
@@ -137,16 +137,21 @@ k_upconv16g(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed 
   constexpr int NPC = PPB * WROWS * 4 / UPR_THREADS;           // 16-byte pieces per thread and transfer
   static_assert(PPB * WROWS * 4 % UPR_THREADS == 0 && PPB * MT <= 32 && PPB % 2 == 0, "whole pieces; the counted wait; whole row parities");
   constexpr int BUFB = PPB * WROWS * 64;                       // bytes of a weight buffer
-  __shared__ __attribute__((aligned(1024))) unsigned char s_w[2 * BUFB];
+  // (at least 84 KB: ONE workgroup per CU, like the persistent convolutions -- two per CU spread over all 256 CUs and the reserve is gone)
+  __shared__ __attribute__((aligned(1024))) unsigned char s_w[2 * BUFB > 84 * 1024 ? 2 * BUFB : 84 * 1024];
   __shared__ __attribute__((aligned(16))) float s_b[512];
-  const int tiles_x = W / 32;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, img = blockIdx.y;
+  __shared__ int s_q[2];
+  // A workgroup walks items (image, 32 x 4 MT source tile) handed out by work tickets as in k_conv3_ldr16: launched on the grid of the
+  // persistent convolutions (the CUs a lane's UNet pass owns while another lane's geometry runs on the reserve), the kernel does not
+  // contend with that lane's workgroups for CUs -- as one workgroup per item it took 1.5-1.7 x its time alone inside the two-lane
+  // region, the persistent kernels 1.04-1.24 x.  The pixels of the next item are requested at the start of this one (a second set of
+  // fragment registers); the weight transfers run on across the items (the first group's weights of the next item land during the
+  // last group of this one); when a layer's weights fit the two buffers they are fetched once.
+  const int tiles_x = W / 32, tiles = tiles_x * (H / (4 * MT)), nitems = tiles * nimg;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < Cout) s_b[tid] = bias[tid];
   const int li = lane & 15, lk = lane >> 4;
   const int xh = wave & 1, rg = wave >> 1;
-  const int x0 = tx * 32 + xh * 16 + li, y0 = (ty * 4 + rg) * MT;
-  const ET* in = (const ET*)src_ + (size_t)img * H * W * (NCH * 32);
   const int groups = Cout >> 5;
   constexpr int NT = 4 / PPB;                                  // transfers per group
   const int ntr = groups * NT;
@@ -160,35 +165,77 @@ k_upconv16g(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed 
     wsrc[k] = (unsigned)(((ph * NCH + cc) * Cout + ch) * 32 + (((rem & 3) ^ ((r >> 1) & 2)) << 3));
   }
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ud_lptr)s_w) + (unsigned)(wave * 1024);
-  auto fetch = [&](int u) __attribute__((always_inline)) {
+  auto fetch_to = [&](int u, int bufi) __attribute__((always_inline)) {      // transfer u of an item -> weight buffer bufi
     const ET* wsl = wgt + ((size_t)((u % NT) * PPB) * NCH * Cout + (size_t)(u / NT) * 32) * 32;
-    const unsigned lb = lds0 + (unsigned)((u & 1) * BUFB);
+    const unsigned lb = lds0 + (unsigned)(bufi * BUFB);
 #pragma unroll
     for (int k = 0; k < NPC; ++k) ud_dma16(lb + k * 8192, wsl + wsrc[k]);
   };
+  auto fetch = [&](int u) __attribute__((always_inline)) { fetch_to(u, u & 1); };
+  const bool resident = ntr <= 2;      // the layer's weights fit the two buffers: fetched once
+  if (PERSIST && tid == 0) { s_q[0] = ud_take_ticket(ticket); s_q[1] = ud_take_ticket(ticket); }
   fetch(0);
-  // the wave's pixels: fragment (m, cc) = 8 channels 32 cc + 8 lk .. of pixel (y0 + m, x0)
-  v8 xf[MT][NCH];
+  if (resident && ntr == 2) fetch(1);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const int t0 = PERSIST ? __builtin_amdgcn_readfirstlane(s_q[0]) : 0;
+  if (PERSIST && t0 >= ntk) return;
+  if (!PERSIST && (int)blockIdx.x >= nitems) return;
+  int w = PERSIST ? tk_tab[t0] : (int)blockIdx.x, wend = PERSIST ? tk_tab[t0 + 1] : w + 1, qk = 1;      // the item in hand, the end of its ticket, the slot of the next ticket
+  int uu = 0;                                             // transfers consumed so far: buffer parity
+  const int OW = 2 * W, OH = 2 * H;
+  // the wave's pixels of an item: fragment (m, cc) = 8 channels 32 cc + 8 lk .. of pixel (y0 + m, x0)
+  auto pixels = [&](int item, v8 (&x)[MT][NCH]) __attribute__((always_inline)) {
+    const int img = item / tiles, tl = item - img * tiles;
+    const int x0 = (tl % tiles_x) * 32 + xh * 16 + li, y0 = ((tl / tiles_x) * 4 + rg) * MT;
+    const ET* in = (const ET*)src_ + (size_t)img * H * W * (NCH * 32);
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int cc = 0; cc < NCH; ++cc) xf[m][cc] = *(const v8*)(in + ((size_t)cc * H * W + (size_t)(y0 + m) * W + x0) * 32 + 8 * lk);
+      for (int cc = 0; cc < NCH; ++cc) x[m][cc] = *(const v8*)(in + ((size_t)cc * H * W + (size_t)(y0 + m) * W + x0) * 32 + 8 * lk);
+  };
+  v8 xf[MT][NCH], xn[PERSIST ? MT : 1][PERSIST ? NCH : 1];
+  pixels(w, xf);
+#pragma unroll 1
+  for (;;) {
+  const int item = w;
+  const int img = item / tiles, tl = item - img * tiles;
+  const int x0 = (tl % tiles_x) * 32 + xh * 16 + li, y0 = ((tl / tiles_x) * 4 + rg) * MT;
+  // the pixel fragments are USED here, so hipcc's wait for them stands here and not inside the transfer loop
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) { u32x4 t = __builtin_bit_cast(u32x4, xf[m][cc]); asm volatile("" : "+v"(t)); xf[m][cc] = __builtin_bit_cast(v8, t); }
+  // (everything of this wave is retired here: the pixels, the previous item's stores, a transfer issued during its last group)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  // the next item: the next one of this ticket, or the first one of the ticket taken an item ago (lane 0 then takes another)
+  bool nlive = PERSIST;
+  if constexpr (PERSIST) {
+    if (w + 1 < wend) ++w;
+    else {
+      const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);
+      if (nt < ntk) {
+        if (tid == 0) s_q[qk ^ 1] = ud_take_ticket(ticket);
+        qk ^= 1;
+        w = tk_tab[nt]; wend = tk_tab[nt + 1];
+      } else nlive = false;
+    }
+    if (nlive) pixels(w, xn);      // in flight during this item's groups
+  }
+  asm volatile("" ::: "memory");
 
-  const int OW = 2 * W, OH = 2 * H;
   ET* out0 = (ET*)dst_ + (size_t)img * OH * OW * Cout;
 #pragma unroll 1
-  for (int u = 0; u < ntr; ++u) {
+  for (int u = 0; u < ntr; ++u, ++uu) {
     const int g = u / NT;
-    const bool more = u + 1 < ntr;
-    if (more) fetch(u + 1);      // lands during the MFMAs below; its last readers passed the barrier that ended transfer u - 1
-    const unsigned char* sw = s_w + (u & 1) * BUFB;
+    // the next transfer (of this item, or the first one of the next item) lands during the MFMAs below; the last readers of its
+    // buffer passed the barrier that ended the previous transfer
+    const bool more = !resident && (u + 1 < ntr || nlive);
+    if (more) fetch_to(u + 1 < ntr ? u + 1 : 0, (uu + 1) & 1);
+    const unsigned char* sw = s_w + ((resident ? u : uu) & 1) * BUFB;
     ET* out = out0 + (size_t)g * OH * OW * 32;      // this group's 32-channel plane
     f32x4 bv[2];
 #pragma unroll
@@ -236,6 +283,14 @@ k_upconv16g(const u16* __restrict__ src_, const u16* __restrict__ wgt_ /*packed 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
+  if (!nlive) break;
+  if constexpr (PERSIST) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc) xf[m][cc] = xn[m][cc];
+  }
+  }      // items
 }
 
 }  // namespace sh

@@ -1383,9 +1383,17 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     // 2x2 transposed conv (k_unet16_up.h): source pixels in registers, the weights of a 32-cout group by LDS-DMA, one barrier per
     // group (Cin = 512: per two phases); the staged form otherwise
     const bool upg = W % 32 == 0 && H % 16 == 0 && (C0 == 128 || C0 == 256 || C0 == 512) && L.cout <= 512;
-    if (upg && C0 == 128) { LAUNCH(c, lname, (k_upconv16g<EK, 4, 4, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
-    else if (upg && C0 == 256) { LAUNCH(c, lname, (k_upconv16g<EK, 8, 4, 4>), dim3((W / 32) * (H / 16), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
-    else if (upg) { LAUNCH(c, lname, (k_upconv16g<EK, 16, 2, 2>), dim3((W / 32) * (H / 8), nimg), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout); }
+    if (upg) {
+      // items = (image, source tile of 32 x 4 MT pixels) on the grid of the persistent convolutions, handed out by work tickets; up3 has
+      // about one item per CU: one workgroup per item
+      const int mt = C0 == 128 ? 4 : 2, nitems = (W / 32) * (H / (4 * mt)) * nimg;
+      const int grid = C0 == 512 ? nitems : std::min(nitems, persistent_grid(c));
+      unsigned* tk = nullptr; const int* tk_tab = nullptr; int ntk = 0;
+      if (C0 != 512) { const int trc = unet_tickets(c, nitems, grid, 1, &tk, &tk_tab, &ntk); if (trc != SH_OK) return trc; }
+      if (C0 == 128) { LAUNCH(c, lname, (k_upconv16g<EK, 4, 4, 4, true>), dim3((unsigned)grid), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout, nimg, tk, tk_tab, ntk); }
+      else if (C0 == 256) { LAUNCH(c, lname, (k_upconv16g<EK, 8, 2, 4, true>), dim3((unsigned)grid), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout, nimg, tk, tk_tab, ntk); }
+      else { LAUNCH(c, lname, (k_upconv16g<EK, 16, 2, 2, false>), dim3((unsigned)grid), dim3(UPR_THREADS), src0, w, b, dst, H, W, L.cout, nimg, tk, tk_tab, ntk); }
+    }
     else { LAUNCH(c, lname, (k_upconv16<EK>), dim3(tiles, L.cout / 32, nimg * 2), dim3(UPC_THREADS), src0, C0, w, b, dst, H, W, L.cout); }
   } else if (L.cout % 64 == 0) {
     LAUNCH(c, lname, (k_conv_mfma16<EK, 1, 4, 0>), dim3(tiles, L.cout / 64, nimg * 4), blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, 0, fz);
