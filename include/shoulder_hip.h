@@ -31,7 +31,11 @@ typedef enum sh_status {
   SH_ERR_ARG = -1,      /* bad argument / shape */
   SH_ERR_HIP = -2,      /* HIP runtime error (text in sh_last_error) */
   SH_ERR_STATE = -3,    /* call order: meshes / parameters not loaded */
-  SH_ERR_CAPACITY = -4, /* a per-slice or per-mesh capacity was exceeded */
+  SH_ERR_CAPACITY = -4, /* a capacity was exceeded.  Since round 5 the stages grow what they need (crossings and loops per
+                           section, end-section points, hull vertices / faces, silhouette edges of a box candidate: the run
+                           is repeated inside sh_collect) -- what is left: a caller-sized output that is too small (the
+                           counts returned say how large), more than 1 024 closed loops in ONE section, and a growth
+                           that is needed while a second run is in flight (collect it, run again) */
   SH_ERR_GEOMETRY = -5, /* degenerate input: open contour, empty slice, ray miss, ... */
   SH_ERR_NOMEM = -6
 } sh_status;
