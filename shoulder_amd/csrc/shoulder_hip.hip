@@ -2966,8 +2966,8 @@ int sh_submit(sh_ctx* c, uint32_t mask, sh_landmarks* out) {
     rc = run_window(c, mask, widx == 0 ? prepared : -1);
   }
   // everything of this run is enqueued: the host is free until the device is done -> hulls of the next run
+  c->b0 = 0; c->Bwin = B;      // (in front of start_prepare: it looks the device buffers up through the window offset)
   if (rc == SH_OK && c->overlap && (mask & SH_STAGE_OBB) && win == B && !dev_hull && !c->stg.active) start_prepare(c);
-  c->b0 = 0; c->Bwin = B;
   if (mask & SH_STAGE_OBB) c->obb_injected = true;
   if (rc != SH_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
   // (`out` may also be device memory, e.g. the send buffer of a gather: hipMemcpyDefault)
