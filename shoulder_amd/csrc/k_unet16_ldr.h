@@ -35,14 +35,24 @@ namespace sh {
 #define UL_NCW 4                          // compute waves; waves UL_NCW .. 7 load
 #define UL_LTHREADS 256                   // lanes of the loader half
 
+// The second source as an UP-CONVOLUTION computed in place (UPL = chunks of the low-resolution input, 0 = off): the decoder's
+// conv reads concat(skip, up(low)); instead of fetching the "up" chunks of a halo tile from a tensor that a launch of its own wrote
+// (0.54 GB out, 0.54 GB back in at level 1), the four LOADER waves -- which hold the registers of a compute wave and use a fifth of
+// them -- compute them: wave lw owns output phase (dy, dx) = (lw >> 1, lw & 1), 9 x 17 of the 18 x 34 halo pixels, ten groups of 16;
+// pixel fragments (18 x 10 low-resolution pixels x UPL chunks) and weight fragments come straight from L2 into registers, 8 UPL MFMAs
+// per group on the matrix pipe the compute wave of the SIMD is using, the rounded result goes to the halo rows the DMA would have
+// filled (zeros outside the image).  Same arithmetic in the same order as k_upconv16g (bias in the accumulator, chunks in order), so
+// the conv sees the same 16-bit values.  For layers with ONE cout group only (level 1): every group of a tile would compute the chunk again.
+struct UpSrc { const u16* low; const u16* w /*packed [4][UPL][C1][32]*/; const float* b; };
+
 // FUSE: 0 or UF_POOL.  WRES: 0 = weights staged with every step; 1 = one cout group whose packed weights fit behind the two
 // input buffers (nchunk <= 2): loaded once per workgroup.
-template <int EK, int FUSE, int WRES>
+template <int EK, int FUSE, int WRES, int UPL = 0>
 __global__ void __launch_bounds__(UD_THREADS)
 k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int C0, int C1,
               const u16* __restrict__ wgt_, const float* __restrict__ bias, u16* __restrict__ dst_,
               int H, int W, int Cout, int relu, int nimg, const u16* __restrict__ zero_page_, u16* __restrict__ pooled_,
-              unsigned* __restrict__ ticket /*zero at launch*/, const int* __restrict__ tk_tab /*[ntk + 1] item bounds*/, int ntk) {
+              unsigned* __restrict__ ticket /*zero at launch*/, const int* __restrict__ tk_tab /*[ntk + 1] item bounds*/, int ntk, const UpSrc up) {
   using ET = typename EKT<EK>::type;
   const ET* src0 = (const ET*)src0_;
   const ET* src1 = (const ET*)src1_;
@@ -140,25 +150,87 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     const unsigned lbase = lds0 + (unsigned)(buf * BUFB + lw * 1024);      // (LDS byte address: the pieces are inline assembly, k_unet16_base.h)
     int r0v = r0;
     if constexpr (LAZY) asm volatile("" : "+v"(r0v));      // (opaque per call: nothing of the recomputation is hoisted out of the loop)
+    const bool upstep = UPL != 0 && !first;      // the halo rows of this step are computed (up_chunk below), only its weights are fetched
 #pragma unroll
     for (int k = 0; k < NPIECE; ++k) {
       if (k < NHALO - 1) {
-        const int po = LAZY ? halo_pixel(r0v, k) : pixoff[LAZY ? 0 : k];
-        const ET* p = po >= 0 ? simg + (unsigned)((cb + po) * 32 + q8) : zero_page;
-        ud_dma16(lbase + k * 4096, p);
+        if (!upstep) {
+          const int po = LAZY ? halo_pixel(r0v, k) : pixoff[LAZY ? 0 : k];
+          const ET* p = po >= 0 ? simg + (unsigned)((cb + po) * 32 + q8) : zero_page;
+          ud_dma16(lbase + k * 4096, p);
+        }
       } else if (k == NHALO - 1) {      // rows 640..703: 8 halo rows, then the first 56 weight rows
         const int po = LAZY ? halo_pixel(r0v, k) : pixoff[LAZY ? 0 : k];
         const ET* pi = po >= 0 ? simg + (unsigned)((cb + po) * 32 + q8) : zero_page;
         if constexpr (WRES != 0) {
-          if (wlow) ud_dma16(lbase + k * 4096, pi);
+          if (wlow && !upstep) ud_dma16(lbase + k * 4096, pi);
         } else {
           const ET* p = wlow ? pi : wbase + (wlane + k * wtap_stride);
-          ud_dma16(lbase + k * 4096, p);
+          if (!(wlow && upstep)) ud_dma16(lbase + k * 4096, p);
         }
       } else if (k < NPIECE - 1) {
         ud_dma16(lbase + k * 4096, (wbase + (wlane + k * wtap_stride)));
       } else {                          // the last piece: rows 1216..1223 only (tap 8, rows 56..63)
         if (wlow) ud_dma16(lbase + k * 4096, (wbase + (wlane + k * wtap_stride)));
+      }
+    }
+    if constexpr (UPL != 0) {
+      if (upstep) {
+        // ---- the halo rows of up chunk u = 32 channels of up(low): this wave's phase, ten groups of 16 pixels
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        using v2 = typename E16<ET>::v2;
+        const int u = (c0 - C0) >> 5;
+        const int H2 = H >> 1, W2 = W >> 1;
+        const int pdy = lw >> 1, pdx = lw & 1, oy = pdy == 0 ? 1 : 0, ox = pdx == 0 ? 1 : 0;
+        const ET* limg = (const ET*)up.low + (size_t)i_img * H2 * W2 * (UPL * 32);
+        const ET* uwp = (const ET*)up.w + ((size_t)(lw * UPL) * C1 + u * 32 + 8 * (li >> 2) + (li & 3)) * 32 + 8 * lk;
+        v8 uw[UPL][2];
+#pragma unroll
+        for (int kc = 0; kc < UPL; ++kc)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) uw[kc][n] = *(const v8*)(uwp + ((size_t)kc * C1 + 4 * n) * 32);
+        f32x4 ubv[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) ubv[n] = *(const f32x4*)(up.b + u * 32 + 8 * lk + 4 * n);
+        unsigned char* hb = smem + buf * BUFB;
+        const int ly0 = i_ty * 8 - 1 + oy, lx0 = i_tx * 16 - 1 + ox;
+        // a rolling window of five groups' pixel fragments: the loads of group g + 5 go out behind the MFMAs of group g, so a step
+        // pays one L2 latency, not one per batch (all ten at once do not fit the loader's registers)
+        constexpr int WIN = 5;
+        v8 xf[WIN][UPL];
+        bool inside[WIN];
+        auto request = [&](int g) __attribute__((always_inline)) {
+          const int t = 16 * g + li, a = t / 17, bc = t - a * 17;
+          const int ly = ly0 + a, lx = lx0 + bc;
+          inside[g % WIN] = ly >= 0 && ly < H2 && lx >= 0 && lx < W2;
+          const unsigned po = (unsigned)(min(max(ly, 0), H2 - 1) * W2 + min(max(lx, 0), W2 - 1));      // (unconditional, clamped: a load in a branch is waited for at its join)
+#pragma unroll
+          for (int kc = 0; kc < UPL; ++kc) xf[g % WIN][kc] = *(const v8*)(limg + ((size_t)kc * H2 * W2 + po) * 32 + 8 * lk);
+        };
+#pragma unroll
+        for (int g = 0; g < WIN; ++g) request(g);
+#pragma unroll
+        for (int g = 0; g < 10; ++g) {
+          f32x4 ua[2];
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            ua[n] = ubv[n];
+#pragma unroll
+            for (int kc = 0; kc < UPL; ++kc) ua[n] = E16<ET>::mfma(uw[kc][n], xf[g % WIN][kc], ua[n]);
+          }
+          const bool in_g = inside[g % WIN];
+          if (g + WIN < 10) request(g + WIN);
+          u32x4 o;
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const f32x2 a01 = {ua[n][0], ua[n][1]}, a23 = {ua[n][2], ua[n][3]};
+            o[2 * n] = __builtin_bit_cast(unsigned, __builtin_convertvector(a01, v2));
+            o[2 * n + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(a23, v2));
+          }
+          if (!in_g) o = u32x4{0u, 0u, 0u, 0u};      // outside the image: the conv's zero padding
+          const int t = 16 * g + li, a = t / 17, bc = t - a * 17;
+          if (t < 153) *(u32x4*)(hb + UB_OFF((2 * a + oy) * UD_PW + 2 * bc + ox, lk) * 2) = o;
+        }
       }
     }
   };
@@ -175,12 +247,159 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
     woff = UB_OFF(UD_INROWS + li, lk) * 2;
   }
 
+  // ---- the walk: the step after (this item, chunk cc).  Every wave keeps it (the compute waves need the item's coordinates for their
+  // epilogue); the same in every lane: say so, or hipcc keeps it -- and the 64-bit source addresses it feeds -- in vector registers,
+  // which pushed the pooled instantiation into scratch, with a vmcnt(0) behind every reload between two LDS-DMA pieces
+  int w = w_begin;
+  auto walk = [&](int cc, int& n_cc, bool& has_next, bool& new_item, bool& more) __attribute__((always_inline)) {
+    n_cc = cc + 1;
+    has_next = true; new_item = false;
+    if (n_cc < nchunk) {
+    } else if (w + 1 < w_end) {
+      ++w;
+      if (++i_g == ngroups) { i_g = 0; if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; ++i_img; } } }
+      n_cc = 0; new_item = true;
+    } else {      // next ticket: its id was written before this step's barrier; the slot it frees is refilled for the one after
+      const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);
+      if (nt < ntk) {
+        if (tid == UL_LTHREADS) s_q[qk ^ 1] = ud_take_ticket(ticket);
+        qk ^= 1;
+        w = tk_tab[nt]; w_end = tk_tab[nt + 1];
+        decode(w);
+        n_cc = 0; new_item = true;
+      } else { has_next = false; more = false; }
+    }
+    i_g = __builtin_amdgcn_readfirstlane(i_g); i_tx = __builtin_amdgcn_readfirstlane(i_tx);
+    i_ty = __builtin_amdgcn_readfirstlane(i_ty); i_img = __builtin_amdgcn_readfirstlane(i_img);
+    w = __builtin_amdgcn_readfirstlane(w); w_end = __builtin_amdgcn_readfirstlane(w_end);
+    n_cc = __builtin_amdgcn_readfirstlane(n_cc);
+  };
+  // ---- a compute wave's step: per column offset the 10 pixel rows, per tap the 4 weight fragments (compiler-scheduled)
+  auto multiply = [&](f32x4 (&acc)[8][4], int cc, int buf) __attribute__((always_inline)) {
+    const unsigned char* sb = smem + buf * BUFB;
+    const unsigned char* wbp = WRES ? smem + WRES_OFF + cc * 9 * WR * 64 + (woff - UD_INROWS * 64) : sb + woff;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      v8 xq[10];
+#pragma unroll
+      for (int s = 0; s < 10; ++s) xq[s] = *(const v8*)(sb + xoff[s & 1][dx] + (s & ~1) * UD_PW * 64);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int tap = dy * 3 + dx;
+        v8 wf[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) wf[n] = *(const v8*)(wbp + (tap * WR + n * 16) * 64);
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xq[m + dy], acc[m][n]);
+      }
+    }
+  };
+  // ---- a compute wave's epilogue of the item at (c_img, c_y0, c_x0), cout group c_n0
+  auto epilogue = [&](const f32x4 (&acc)[8][4], int c_x0, int c_y0, int c_img, int c_n0) __attribute__((always_inline)) {
+    // channel-blocked output: channel c_n0 + 16 lk + 8 h of pixel (gy, gx) is element ((c >> 5) HW + pix) 32 + (c & 31); one
+    // uniform 64-bit base per item and one 32-bit lane offset, the rest of every address is a constant
+    const unsigned HW = (unsigned)(H * W);
+    ET* ob = dst + ((size_t)c_img * Cout + c_n0) * HW;
+    const unsigned lo = (((unsigned)(lk >> 1) * HW + (unsigned)((c_y0 + rg8 * 8) * W + c_x0 + xh * 16 + li)) << 5) + 16u * (lk & 1);
+    ET* pb = pooled;
+    unsigned plo = 0;
+    if (FUSE & UF_POOL) {
+      pb = pooled + ((size_t)c_img * Cout + c_n0) * (HW >> 2);
+      plo = (((unsigned)(lk >> 1) * (HW >> 2) + (unsigned)(((c_y0 + rg8 * 8) >> 1) * (W >> 1) + ((c_x0 + xh * 16 + li) >> 1))) << 5) + 16u * (lk & 1);
+    }
+#pragma unroll
+    for (int mp = 0; mp < 4; ++mp)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // Rounded in pairs (one v_cvt_pk per two values), then ReLU on the rounded 16-bit values, two per instruction: a negative
+        // bf16 / f16 is a negative int16 (sign bit), so max(bits, 0) as packed int16 is max(x, +0.0) -- rounding is monotonic and keeps
+        // the sign, -0.0 becomes +0.0 either way: the same bits as fmaxf on the f32 accumulators followed by the conversion (NaN aside,
+        // which no layer produces from finite input).  Without ReLU the max is against the smallest int16: the identity.  (fmaxf is two
+        // v_max_f32 per value -- it quiets NaNs first -- and a `relu` flag tested per value a select: 380 instead of 128 instructions.)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        using v2 = typename E16<ET>::v2;
+        const unsigned zsel = relu ? 0u : 0x80008000u;
+        u32x4 ua, ub;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4& ra = acc[2 * mp][2 * h + (i >> 1)];
+          const f32x4& rb = acc[2 * mp + 1][2 * h + (i >> 1)];
+          const f32x2 pa = {ra[2 * (i & 1)], ra[2 * (i & 1) + 1]}, pb2 = {rb[2 * (i & 1)], rb[2 * (i & 1) + 1]};
+          ua[i] = pp_pkmax(__builtin_bit_cast(unsigned, __builtin_convertvector(pa, v2)), zsel);
+          ub[i] = pp_pkmax(__builtin_bit_cast(unsigned, __builtin_convertvector(pb2, v2)), zsel);
+        }
+        const v8 oa = __builtin_bit_cast(v8, ua), ob8 = __builtin_bit_cast(v8, ub);
+        *(v8*)(ob + (lo + (unsigned)((2 * mp) * W * 32 + 8 * h))) = oa;
+        *(v8*)(ob + (lo + (unsigned)((2 * mp + 1) * W * 32 + 8 * h))) = ob8;
+        if (FUSE & UF_POOL) {
+          // 2x2 max on the rounded, ReLU'd values (non-negative: they order like int16; the host fuses the pool behind a ReLU only):
+          // rows inside the lane, columns with lane ^ 1
+          u32x4 pv;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pv[i] = pp_pkmax_lane1(pp_pkmax(ua[i], ub[i]));      // (one dword at a time: the batched form's temporaries spilled here)
+          const v8 op = __builtin_bit_cast(v8, pv);
+          if (!(li & 1)) *(v8*)(pb + (plo + (unsigned)(mp * (W >> 1) * 32 + 8 * h))) = op;
+        }
+      }
+  };
+
+  if constexpr (UPL != 0) {
+    // The two jobs as two loops (the same walk, the same barriers): with one loop for both, the compute wave's 128 accumulators are
+    // live in the loader's branch as well, and the fragments of the up-convolution do not fit beside them.
+    if (loader) {
+      item_lane_setup();
+      stage(0, 0);
+      int buf = 0;
+      for (;;) {
+        bool more = true;
+        for (int cc = 0; cc < nchunk; ++cc) {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // this wave's pieces of the step have landed, what it computed of them is written
+          __builtin_amdgcn_s_barrier();
+          int n_cc; bool has_next, new_item;
+          walk(cc, n_cc, has_next, new_item, more);
+          if (has_next) {
+            if (new_item) item_lane_setup();
+            stage(n_cc, buf ^ 1);
+          }
+          buf ^= 1;
+        }
+        if (!more) break;
+      }
+    } else {
+      int buf = 0;
+      for (;;) {
+        bool more = true;
+        const int c_x0 = i_tx * 32, c_y0 = i_ty * 16, c_img = i_img, c_n0 = i_g * WR;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const f32x4 bv = *(const f32x4*)(s_bias + c_n0 + 16 * lk + 4 * n);
+#pragma unroll
+          for (int m = 0; m < 8; ++m) acc[m][n] = bv;
+        }
+        for (int cc = 0; cc < nchunk; ++cc) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          int n_cc; bool has_next, new_item;
+          walk(cc, n_cc, has_next, new_item, more);
+          multiply(acc, cc, buf);
+          buf ^= 1;
+        }
+        epilogue(acc, c_x0, c_y0, c_img, c_n0);
+        if (!more) break;
+      }
+    }
+    return;
+  }
+
   if (loader) {
     item_lane_setup();
     stage(0, 0);
   }
   int buf = 0;
-  for (int w = w_begin;;) {
+  for (;;) {
     bool more = true;
     const int c_x0 = i_tx * 32, c_y0 = i_ty * 16, c_img = i_img, c_n0 = i_g * WR;
     f32x4 acc[8][4];
@@ -196,108 +415,17 @@ k_conv3_ldr16(const u16* __restrict__ src0_, const u16* __restrict__ src1_, int 
       if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the step have landed
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();      // every loader's pieces have landed; every compute wave is done reading the other buffer
-      // the step after this one (every wave keeps the walk: the compute waves need the item's coordinates for their epilogue)
-      int n_cc = cc + 1;
-      bool has_next = true, new_item = false;
-      if (n_cc < nchunk) {
-      } else if (w + 1 < w_end) {
-        ++w;
-        if (++i_g == ngroups) { i_g = 0; if (++i_tx == tiles_x) { i_tx = 0; if (++i_ty == tiles_y) { i_ty = 0; ++i_img; } } }
-        n_cc = 0; new_item = true;
-      } else {      // next ticket: its id was written before this step's barrier; the slot it frees is refilled for the one after
-        const int nt = __builtin_amdgcn_readfirstlane(s_q[qk]);
-        if (nt < ntk) {
-          if (tid == UL_LTHREADS) s_q[qk ^ 1] = ud_take_ticket(ticket);
-          qk ^= 1;
-          w = tk_tab[nt]; w_end = tk_tab[nt + 1];
-          decode(w);
-          n_cc = 0; new_item = true;
-        } else { has_next = false; more = false; }
-      }
-      // (the walk is the same in every lane: say so, or hipcc keeps it -- and the 64-bit source addresses it feeds -- in vector registers,
-      //  which pushed the pooled instantiation into scratch, with a vmcnt(0) behind every reload between two LDS-DMA pieces)
-      i_g = __builtin_amdgcn_readfirstlane(i_g); i_tx = __builtin_amdgcn_readfirstlane(i_tx);
-      i_ty = __builtin_amdgcn_readfirstlane(i_ty); i_img = __builtin_amdgcn_readfirstlane(i_img);
-      w = __builtin_amdgcn_readfirstlane(w); w_end = __builtin_amdgcn_readfirstlane(w_end);
-      n_cc = __builtin_amdgcn_readfirstlane(n_cc);
+      int n_cc; bool has_next, new_item;
+      walk(cc, n_cc, has_next, new_item, more);
       if (loader) {
         if (has_next) {
           if (new_item) item_lane_setup();
           stage(n_cc, buf ^ 1);
         }
-      } else {
-        {
-        const unsigned char* sb = smem + buf * BUFB;
-        const unsigned char* wbp = WRES ? smem + WRES_OFF + cc * 9 * WR * 64 + (woff - UD_INROWS * 64) : sb + woff;
-        // compiler-scheduled form: per column offset the 10 pixel rows, per tap the 4 weight fragments
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          v8 xq[10];
-#pragma unroll
-          for (int s = 0; s < 10; ++s) xq[s] = *(const v8*)(sb + xoff[s & 1][dx] + (s & ~1) * UD_PW * 64);
-#pragma unroll
-          for (int dy = 0; dy < 3; ++dy) {
-            const int tap = dy * 3 + dx;
-            v8 wf[4];
-#pragma unroll
-            for (int n = 0; n < 4; ++n) wf[n] = *(const v8*)(wbp + (tap * WR + n * 16) * 64);
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-#pragma unroll
-              for (int n = 0; n < 4; ++n) acc[m][n] = E16<ET>::mfma(wf[n], xq[m + dy], acc[m][n]);
-          }
-        }
-        }
-      }
+      } else multiply(acc, cc, buf);
       buf ^= 1;
     }
-    if (!loader) {
-      // channel-blocked output: channel c_n0 + 16 lk + 8 h of pixel (gy, gx) is element ((c >> 5) HW + pix) 32 + (c & 31); one
-      // uniform 64-bit base per item and one 32-bit lane offset, the rest of every address is a constant
-      const unsigned HW = (unsigned)(H * W);
-      ET* ob = dst + ((size_t)c_img * Cout + c_n0) * HW;
-      const unsigned lo = (((unsigned)(lk >> 1) * HW + (unsigned)((c_y0 + rg8 * 8) * W + c_x0 + xh * 16 + li)) << 5) + 16u * (lk & 1);
-      ET* pb = pooled;
-      unsigned plo = 0;
-      if (FUSE & UF_POOL) {
-        pb = pooled + ((size_t)c_img * Cout + c_n0) * (HW >> 2);
-        plo = (((unsigned)(lk >> 1) * (HW >> 2) + (unsigned)(((c_y0 + rg8 * 8) >> 1) * (W >> 1) + ((c_x0 + xh * 16 + li) >> 1))) << 5) + 16u * (lk & 1);
-      }
-#pragma unroll
-      for (int mp = 0; mp < 4; ++mp)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          // Rounded in pairs (one v_cvt_pk per two values), then ReLU on the rounded 16-bit values, two per instruction: a negative
-          // bf16 / f16 is a negative int16 (sign bit), so max(bits, 0) as packed int16 is max(x, +0.0) -- rounding is monotonic and keeps
-          // the sign, -0.0 becomes +0.0 either way: the same bits as fmaxf on the f32 accumulators followed by the conversion (NaN aside,
-          // which no layer produces from finite input).  Without ReLU the max is against the smallest int16: the identity.  (fmaxf is two
-          // v_max_f32 per value -- it quiets NaNs first -- and a `relu` flag tested per value a select: 380 instead of 128 instructions.)
-          typedef float f32x2 __attribute__((ext_vector_type(2)));
-          using v2 = typename E16<ET>::v2;
-          const unsigned zsel = relu ? 0u : 0x80008000u;
-          u32x4 ua, ub;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f32x4& ra = acc[2 * mp][2 * h + (i >> 1)];
-            const f32x4& rb = acc[2 * mp + 1][2 * h + (i >> 1)];
-            const f32x2 pa = {ra[2 * (i & 1)], ra[2 * (i & 1) + 1]}, pb2 = {rb[2 * (i & 1)], rb[2 * (i & 1) + 1]};
-            ua[i] = pp_pkmax(__builtin_bit_cast(unsigned, __builtin_convertvector(pa, v2)), zsel);
-            ub[i] = pp_pkmax(__builtin_bit_cast(unsigned, __builtin_convertvector(pb2, v2)), zsel);
-          }
-          const v8 oa = __builtin_bit_cast(v8, ua), ob8 = __builtin_bit_cast(v8, ub);
-          *(v8*)(ob + (lo + (unsigned)((2 * mp) * W * 32 + 8 * h))) = oa;
-          *(v8*)(ob + (lo + (unsigned)((2 * mp + 1) * W * 32 + 8 * h))) = ob8;
-          if (FUSE & UF_POOL) {
-            // 2x2 max on the rounded, ReLU'd values (non-negative: they order like int16; the host fuses the pool behind a ReLU only):
-            // rows inside the lane, columns with lane ^ 1
-            u32x4 pv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pv[i] = pp_pkmax_lane1(pp_pkmax(ua[i], ub[i]));      // (one dword at a time: the batched form's temporaries spilled here)
-            const v8 op = __builtin_bit_cast(v8, pv);
-            if (!(li & 1)) *(v8*)(pb + (plo + (unsigned)(mp * (W >> 1) * 32 + 8 * h))) = op;
-          }
-        }
-    }
+    if (!loader) epilogue(acc, c_x0, c_y0, c_img, c_n0);
     if (!more) break;
   }
 }

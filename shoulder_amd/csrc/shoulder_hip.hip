@@ -182,6 +182,8 @@ struct sh_ctx {
     bool obb_prune = true;     // SHOULDER_OBB_PRUNE=0: every hull-face direction is evaluated
     bool slice_merge = true;   // SHOULDER_SLICE_MERGE=0: one slice set per launch group
     bool side_stream = true;   // SHOULDER_SIDE_STREAM=0: small batches keep the distal branch in the chain
+    bool up_inside = false;    // SHOULDER_UP_INSIDE=1: up1 inside dec1a's loader waves instead of a launch of its own (k_upconv16g).  Off: the network
+                               // alone is 0.07 ms faster with it, the two-lane step 0.1-0.2 ms slower
     int te_early = -1;         // SHOULDER_TE_EARLY=1: the trans-epicondylar part forked beside the lane's UNet; 0: behind the UNet; unset: in front of it
     bool debug = false;        // SH_DEBUG: host-phase timings on stderr
   } sw;
@@ -411,6 +413,7 @@ int sh_ctx_create(int device, void* hip_stream, sh_ctx** out) {
     c->sw.obb_prune = !off("SHOULDER_OBB_PRUNE");
     c->sw.slice_merge = !off("SHOULDER_SLICE_MERGE");
     c->sw.side_stream = !off("SHOULDER_SIDE_STREAM");
+    { const char* e = getenv("SHOULDER_UP_INSIDE"); c->sw.up_inside = e && e[0] == '1'; }
     if (const char* e = getenv("SHOULDER_TE_EARLY")) c->sw.te_early = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1);
     c->sw.debug = getenv("SH_DEBUG") != nullptr;
   }
@@ -1346,7 +1349,8 @@ static int unet_tickets(sh_ctx* c, int total, int nwg, int ngrp, unsigned** tk, 
 // production kernels against).
 template <int EK>
 static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, const u16* src0, const u16* src1, int C0, int C1,
-                           u16* dst, int H, int W, int nimg, int relu, int fuse = 0, ConvFuse fz = ConvFuse{}) {
+                           u16* dst, int H, int W, int nimg, int relu, int fuse = 0, ConvFuse fz = ConvFuse{}, const UpSrc* upsrc = nullptr /*the second
+                           source is up(low), computed by the conv's loader waves (k_unet16_ldr.h): C1 = its channels, 128 low-resolution channels*/) {
   if (H % UN_TH || W % UN_TW) return fail(c, SH_ERR_ARG, "unet: feature map is not a multiple of 16");
   const u16* w = buf<u16>(c, "params_bf16") + L.w_off;
   const float* b = buf<float>(c, "params") + L.b_off;
@@ -1366,10 +1370,15 @@ static int conv_layer16(sh_ctx* c, const char* lname, const sh_ctx::ULayer& L, c
     u16* pl = fuse == UF_POOL ? (u16*)fz.pooled : (u16*)nullptr;
     // weights resident in LDS: one cout group whose packed weights fit behind the two input buffers (32 -> 64 and 64 -> 64 layers)
     const bool wres = L.cout == 64 && ((C0 + C1) / 32) * 64 <= 128;
-    if (fuse == UF_POOL && wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
-    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
-    else if (wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
-    else { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk); }
+    const UpSrc nou{nullptr, nullptr, nullptr};
+    if (upsrc) {
+      if (fuse != 0 || wres || L.cout != 64) return fail(c, SH_ERR_ARG, "unet: an up-convolution inside this conv shape is not built");
+      LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 0, 4>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk, *upsrc);
+    }
+    else if (fuse == UF_POOL && wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk, nou); }
+    else if (fuse == UF_POOL) { LAUNCH(c, lname, (k_conv3_ldr16<EK, UF_POOL, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk, nou); }
+    else if (wres) { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 1>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk, nou); }
+    else { LAUNCH(c, lname, (k_conv3_ldr16<EK, 0, 0>), g, dim3(UD_THREADS), src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, nimg, zp, pl, tk, tk_tab, ntk, nou); }
   } else if (L.taps == 9 && L.cout % 64 == 0) {
     const dim3 g(tiles, L.cout / 64, nimg);
     if (fuse == 0) { LAUNCH(c, lname, (k_conv_mfma16<EK, 9, 4, 0>), g, blk, src0, src1, C0, C1, w, b, dst, H, W, L.cout, relu, fz); }
@@ -1518,6 +1527,17 @@ static int unet_forward16(sh_ctx* c, const float* image, float* logits, int nimg
                                                         zp, tk, tk_tab, ntk));
       }
       return SH_OK;
+    }
+    // level 1 (128 -> 64 channels up, then 64 + 64 -> 64), SHOULDER_UP_INSIDE=1: the up-convolution is computed by dec1a's loader waves
+    // where its halo chunks are needed (k_conv3_ldr16<.., UPL = 4>: ONE cout group, so every chunk is computed once per tile) -- no up1
+    // launch, no up1 tensor
+    const bool up_inside = fused && ch == 128 && L(na).cout == 64 && L(nu).cout == 64 && (2 * w) % 32 == 0 && (2 * h) % 16 == 0 && c->sw.up_inside;
+    if (up_inside) {
+      const UpSrc us{x, buf<u16>(c, "params_bf16") + L(nu).w_off, P + L(nu).b_off};
+      h *= 2; w *= 2; ch /= 2;
+      if ((rc = conv_layer16<EK>(c, ("unet." + na).c_str(), L(na), skip[i], nullptr, ch, ch, y, h, w, nimg, 1, 0, ConvFuse{}, &us)) != SH_OK) return rc;
+      if ((rc = conv_layer16<EK>(c, ("unet." + nb).c_str(), L(nb), y, nullptr, ch, 0, x, h, w, nimg, 1)) != SH_OK) return rc;
+      continue;      // (the level's result is in x again)
     }
     if ((rc = conv_layer16<EK>(c, ("unet." + nu).c_str(), L(nu), x, nullptr, ch, 0, y, h, w, nimg, 0)) != SH_OK) return rc;
     h *= 2; w *= 2; ch /= 2;

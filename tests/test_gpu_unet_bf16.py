@@ -237,3 +237,21 @@ def test_first_kernel_scales_the_raw_image_itself(engine, oracle_bones, name):
     finally:
         engine.set_keep_products(False)
         engine.reset_params()
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_up_convolution_inside_the_decoder_conv_is_bit_identical(engine, name):
+    """SHOULDER_UP_INSIDE=1 (off by default: faster alone, slower inside the two-lane region -- DESIGN.md section 9): up1 computed by the
+    loader waves of dec1a (k_conv3_ldr16<.., UPL = 4>) instead of a launch of its own.  Same arithmetic in the same order as
+    k_upconv16g, so the conv sees the same 16-bit values: logits bit for bit, borders and odd batches included."""
+    from conftest import engine_with_env
+    rng = np.random.default_rng(11)
+    engine.set_params(unet_dtype=DTYPES[name][0])
+    try:
+        with engine_with_env(SHOULDER_UP_INSIDE=1) as alt:
+            alt.set_params(unet_dtype=DTYPES[name][0])
+            for shape in ((5, 256, 256), (3, 512, 512)):
+                img = rng.random(shape, dtype=np.float32)
+                np.testing.assert_array_equal(alt.unet_infer(img), engine.unet_infer(img))
+    finally:
+        engine.set_params(unet_dtype=_lib.UNET_F32)
