@@ -227,7 +227,9 @@ __global__ void k_groove_rows(const double* __restrict__ itr_cs /*[B][600][2][51
 
 // sklearn StandardScaler: mean over rows, population variance, scale = sqrt(var) (1 if ~0)
 __global__ void __launch_bounds__(256)
-k_groove_scale(const double* __restrict__ xraw, const int* __restrict__ npk, double* __restrict__ stats, int B) {
+k_groove_scale(const double* __restrict__ xraw, const int* __restrict__ npk, double* __restrict__ stats, int B,
+               int* __restrict__ slots_out /*[B][SH_GSLOTS]: the occupied peak slots of a humerus in row order*/, int* __restrict__ nslot_out /*[B]*/,
+               float* __restrict__ proba /*[B][SH_GSLOTS]: -1 in the slots that hold no peak*/) {
   // The sums run over the peaks in row order, one after the other (the order the oracle's column reduction uses), so
   // they stay sequential per feature; what is parallel is the staging: the valid rows are compacted into LDS first
   // (five, then four feature columns), the nine lanes then add from LDS instead of waiting on one global load per term.
@@ -251,6 +253,12 @@ k_groove_scale(const double* __restrict__ xraw, const int* __restrict__ npk, dou
   }
   __syncthreads();
   const int P = P_s;
+  // the forest walks the occupied slots only (k_groove_rfc): a lane per SLOT left 60 % of its lanes without a peak -- beside a UNet pass,
+  // where the chain has 32 CUs, the kernel is bound by how many waves are resident, not by one wave's latency
+  for (int p = tid; p < P; p += 256) slots_out[(size_t)b * SH_GSLOTS + p] = slot[p];
+  if (tid == 0) nslot_out[b] = P;
+  for (int s = tid; s < SH_GSLOTS; s += 256)
+    if (s % SH_MAXPEAK >= s_cnt[s / SH_MAXPEAK]) proba[(size_t)b * SH_GSLOTS + s] = -1.0f;
   for (int f0 = 0; f0 < 9; f0 += 5) {
     const int nf = f0 + 5 <= 9 ? 5 : 9 - f0;
     for (int q = tid; q < P * nf; q += 256) { const int p = q / nf, f = q - p * nf; col[f][p] = X[(size_t)slot[p] * 9 + f0 + f]; }
@@ -309,16 +317,16 @@ __global__ void k_rfc_pack(const int* __restrict__ feat, const float* __restrict
 // sh::rfc_proba1 (onnxruntime TreeEnsembleClassifier walk, bicipital_groove.py:178-181) on the packed nodes; the nine
 // scaled features of a lane sit in LDS so that the per-node feature pick is one ds_read
 __global__ void __launch_bounds__(64)
-k_groove_rfc(const double* __restrict__ xraw, const int* __restrict__ npk, const double* __restrict__ stats,
+k_groove_rfc(const double* __restrict__ xraw, const int* __restrict__ slots /*[B][SH_GSLOTS]*/, const int* __restrict__ nslot /*[B]*/, const double* __restrict__ stats,
              const int4* __restrict__ nodes, const int* __restrict__ roots, int n_trees,
              double* __restrict__ xs /*[B][slots][9] scaled*/, float* __restrict__ proba, int B) {
   __shared__ double sx[9][64];
   const int tid = threadIdx.x;
-  int gid = blockIdx.x * blockDim.x + tid;
-  if (gid >= B * SH_GSLOTS) return;
-  int b = gid / SH_GSLOTS, s = gid % SH_GSLOTS;
-  int i = s / SH_MAXPEAK, k = s % SH_MAXPEAK;
-  if (k >= npk[(size_t)b * SH_GROOVE_NROWS + i]) { proba[gid] = -1.0f; return; }
+  // workgroup = 64 consecutive entries of one humerus' list of occupied slots (k_groove_scale); the workgroups beyond a list end at once
+  constexpr int WPB = (SH_GSLOTS + 63) / 64;
+  const int b = blockIdx.x / WPB, p = (blockIdx.x - b * WPB) * 64 + tid;
+  if (b >= B || p >= nslot[b]) return;
+  const int gid = b * SH_GSLOTS + slots[(size_t)b * SH_GSLOTS + p];
   for (int f = 0; f < 9; ++f) {
     const double v = (xraw[(size_t)gid * 9 + f] - stats[(size_t)b * 18 + f]) / stats[(size_t)b * 18 + 9 + f];
     xs[(size_t)gid * 9 + f] = v;

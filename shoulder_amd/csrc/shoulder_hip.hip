@@ -554,6 +554,8 @@ static int alloc_batch(sh_ctx* c) {
   ENS("groove.r0", (size_t)B * SH_GROOVE_NROWS * SH_MPROX * 8, 8);
   ENS("groove.stats", (size_t)B * 18 * 8, 8);
   ENS("groove.proba", (size_t)B * SH_GSLOTS * 4, 4);
+  ENS("groove.slots", (size_t)B * SH_GSLOTS * 4, 4);
+  ENS("groove.nslot", (size_t)B * 4, 4);
   ENS("groove.bg_theta", (size_t)B * 8, 8);
   ENS("groove.local_idx", (size_t)B * SH_GROOVE_NROWS * 4, 4);
   ENS("groove.points_obb", (size_t)B * SH_GROOVE_NROWS * 3 * 8, 8);
@@ -2248,14 +2250,14 @@ static int run_window(sh_ctx* c, uint32_t mask, int prepared_slot) {
            buf<double>(c, "prox.zs"), buf<double>(c, "canal.axis_ct"), ga, buf<double>(c, "groove.xraw"),
            buf<double>(c, "groove.ptheta"), buf<int>(c, "groove.npk"), buf<double>(c, "groove.r0"), buf<int>(c, "err"), B);
     LAUNCH(c, "k_groove_scale", k_groove_scale, dim3(B), dim3(256), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
-           buf<double>(c, "groove.stats"), B);
+           buf<double>(c, "groove.stats"), B, buf<int>(c, "groove.slots"), buf<int>(c, "groove.nslot"), buf<float>(c, "groove.proba"));
     if ((rc = ensure(c, "rfc.nodes", N * 16, 4)) != SH_OK) return rc;
     int4* nodes = (int4*)c->bufs["rfc.nodes"].p;
     if (!c->packed_rfc) {      // once per parameter block (it was a launch of every step's chain: 5 us alone, ~50 us beside a UNet pass)
       LAUNCH(c, "k_rfc_pack", k_rfc_pack, dim3((unsigned)((N + 255) / 256)), dim3(256), feat, thr, ti, fi, lw, nodes, (int)N);
       c->packed_rfc = true;
     }
-    LAUNCH(c, "k_groove_rfc", k_groove_rfc, dim3((B * SH_GSLOTS + 63) / 64), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.npk"),
+    LAUNCH(c, "k_groove_rfc", k_groove_rfc, dim3((unsigned)(B * ((SH_GSLOTS + 63) / 64))), dim3(64), buf<double>(c, "groove.xraw"), buf<int>(c, "groove.slots"), buf<int>(c, "groove.nslot"),
            buf<double>(c, "groove.stats"), nodes, roots, c->rfc_trees, buf<double>(c, "groove.xs"), buf<float>(c, "groove.proba"), B);
     LAUNCH(c, "k_groove_tail", k_groove_tail, dim3(B), dim3(256), buf<double>(c, "groove.ptheta"), buf<float>(c, "groove.proba"), buf<double>(c, "groove.bg_theta"), buf<int>(c, "err"),
            buf<double>(c, "prox.itr_centered_start"), buf<double>(c, "groove.r0"), buf<double>(c, "prox.zs"), buf<double>(c, "prox.centroids"), ga, c->params.groove_deg_window,
