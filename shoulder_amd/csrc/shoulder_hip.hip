@@ -1927,7 +1927,7 @@ again:
   }
   *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   for (int b = 0; b < B; ++b)
-    if (status[b] != 0) { *bad_mesh = b0 + b; return status[b]; }
+    if (status[b] != 0) { *bad_mesh = b0 + b; return status[b] == 1 ? SH_ERR_CAPACITY : status[b]; }      // (1 survives only if the re-sized staging still did not hold a hull)
   return SH_OK;
 }
 
